@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Mints the golden fixtures under tests/golden/ (TEST TOOLING).
+
+Runs in the build container only (needs /root/reference).  The reference's own
+*unmodified* Python modules are imported through tools/ref_shims and driven
+with fixed synthetic inputs; the conv-stack forward (TensorFlow in the
+reference, unavailable here) is supplied by oracle/ffn_oracle.forward.
+
+Outputs (committed):
+  tests/golden/fib25_weights.npz   the reference's shipped FIB-25 checkpoint
+                                   (models/fib25/model.ckpt-27465036) as f32
+                                   arrays keyed by TF variable name
+  tests/golden/ref_movement.npz    movement.get_scored_move_offsets KATs
+  tests/golden/ref_misc.json       storage / segmentation / threshold KATs
+  tests/golden/ref_canvas_*.npz    Canvas.segment_all runs: per-step FoV
+                                   positions + queued moves, final
+                                   segmentation, counters, origins
+
+Usage:  python tools/make_golden.py [--only weights|movement|misc|canvas]
+"""
+
+import argparse
+import json
+import os
+import sys
+
+os.environ['PROTOCOL_BUFFERS_PYTHON_IMPLEMENTATION'] = 'python'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('FFN_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(ROOT, 'tools', 'ref_shims'))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+from scipy.special import logit  # noqa: E402
+
+from ffn.inference import executor as ref_executor  # noqa: E402
+from ffn.inference import inference as ref_inference  # noqa: E402
+from ffn.inference import inference_pb2  # noqa: E402
+from ffn.inference import inference_utils as ref_utils  # noqa: E402
+from ffn.inference import movement as ref_movement  # noqa: E402
+from ffn.inference import seed as ref_seed  # noqa: E402
+from ffn.inference import segmentation as ref_segmentation  # noqa: E402
+from ffn.inference import storage as ref_storage  # noqa: E402
+from ffn.training import model as ref_model  # noqa: E402
+
+from ffn_amd import synthetic  # noqa: E402
+from ffn_amd.training import tf_checkpoint  # noqa: E402
+from oracle import ffn_oracle  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+CKPT = os.path.join(REF, 'models', 'fib25', 'model.ckpt-27465036')
+
+
+def make_weights():
+  v = tf_checkpoint.load_checkpoint(CKPT)
+  keep = {k: a for k, a in v.items() if k.startswith('seed_update/')}
+  np.savez_compressed(os.path.join(GOLD, 'fib25_weights.npz'), **keep)
+  print('weights:', len(keep), 'tensors',
+        sum(a.size for a in keep.values()), 'floats')
+
+
+def make_movement():
+  thr = float(logit(float(np.float32(0.9))))
+  out = {}
+  rng = np.random.RandomState(7)
+  cases = [
+      ('iso', (8, 8, 8), rng.normal(0, 2, (33, 33, 33)).astype(np.float32)),
+      ('const', (8, 8, 8), np.full((33, 33, 33), 3.0, np.float32)),
+      ('aniso', (5, 10, 10), rng.normal(0, 2, (21, 41, 41)).astype(np.float32)),
+      ('below', (8, 8, 8), np.full((33, 33, 33), 1.0, np.float32)),
+  ]
+  for i in range(6):
+    cases.append(('rand%d' % i, (8, 8, 8),
+                  rng.normal(1.5, 1.5, (33, 33, 33)).astype(np.float32)))
+  for name, deltas, pm in cases:
+    res = sorted(
+        ref_movement.get_scored_move_offsets(deltas, pm, threshold=thr),
+        reverse=True)
+    out[name + '_deltas'] = np.array(deltas)
+    out[name + '_map'] = pm
+    out[name + '_scores'] = np.array([r[0] for r in res], np.float32)
+    out[name + '_offsets'] = np.array([r[1] for r in res],
+                                      np.int64).reshape(-1, 3)
+  out['threshold'] = np.float64(thr)
+  np.savez_compressed(os.path.join(GOLD, 'ref_movement.npz'), **out)
+  print('movement KATs:', len(cases))
+
+
+class _FakeCanvas:
+  pass
+
+
+def make_misc():
+  out = {}
+  q = ref_storage.quantize_probability(
+      np.array([0, .001, .5, .6, .95, 1, np.nan]))
+  out['quantize_in'] = [0, .001, .5, .6, .95, 1, 'nan']
+  out['quantize_out'] = [int(x) for x in q]
+  dq = ref_storage.dequantize_probability(np.array([0, 1, 128, 255]))
+  out['dequantize_out'] = [None if np.isnan(x) else float(x) for x in dq]
+  out['reduce_id_bits'] = {
+      str(m): str(ref_segmentation.reduce_id_bits(np.array([0, m])).dtype)
+      for m in (255, 256, 65535, 65536, 70000)
+  }
+  out['subvolume_path'] = ref_storage.subvolume_path('out', (3, 2, 1), 'npz')
+  out['checkpoint_path'] = ref_storage.checkpoint_path('out', (3, 2, 1))
+  out['object_prob_path'] = ref_storage.object_prob_path('out', (3, 2, 1))
+  # Logit-space options as the Canvas stores them (inference.py:189-195).
+  opts = inference_pb2.InferenceOptions()
+  opts.init_activation = 0.95
+  opts.pad_value = 0.05
+  opts.move_threshold = 0.9
+  opts.segment_threshold = 0.6
+  for attr in ('init_activation', 'pad_value', 'move_threshold',
+               'segment_threshold'):
+    setattr(opts, attr, logit(getattr(opts, attr)))
+    out['logit_' + attr] = float(getattr(opts, attr))
+  out['disco_seed_threshold_default'] = float(opts.disco_seed_threshold)
+  out['policy_threshold'] = float(logit(float(np.float32(0.9))))
+  # quantize_pos (movement.py:200-208)
+  pol = ref_movement.FaceMaxMovementPolicy.__new__(
+      ref_movement.FaceMaxMovementPolicy)
+  pol.deltas = np.array([8, 8, 8])
+  pol._start_pos = (100, 100, 100)
+  out['quantize_pos'] = {
+      str(p): [int(v) for v in pol.quantize_pos(p)]
+      for p in [(104, 100, 100), (103, 100, 100), (96, 100, 100),
+                (95, 100, 100), (108, 92, 116)]
+  }
+  # PolicyGrid3d coordinates after the margin filter (seed.py:63-95,411-430).
+  fc = _FakeCanvas()
+  fc.image = np.zeros((50, 56, 60), np.uint8)
+  fc.shape = fc.image.shape
+  fc.margin = np.array([16, 16, 16])
+
+  class _C:  # weakref.proxy needs a weakref-able object
+    pass
+
+  c = _C()
+  c.__dict__.update(fc.__dict__)
+  pol = ref_seed.PolicyGrid3d(c, step=16, offsets=(0, 8))
+  out['grid3d_seeds'] = [[int(v) for v in p] for p in pol]
+  with open(os.path.join(GOLD, 'ref_misc.json'), 'w') as f:
+    json.dump(out, f, indent=1, sort_keys=True)
+  print('misc KATs written')
+
+
+class OracleClient(ref_executor.ExecutorClient):
+  """ExecutorClient (executor.py:85-108) backed by the oracle forward."""
+
+  def __init__(self, blob, depth, log):
+    self.blob = blob
+    self.depth = depth
+    self.log = log
+
+  def start(self):
+    return 0
+
+  def finish(self):
+    pass
+
+  def predict(self, seed, image, fetches):
+    out = ffn_oracle.forward(image, seed, self.blob, self.depth)
+    return {'logits': out[..., None]}
+
+
+def run_reference_canvas(image_f32, blob, depth, fov, deltas, seeds,
+                         min_segment_size=1000):
+  """Drives the reference Canvas exactly as Runner does (runner.py:392-408)."""
+  info = ref_model.ModelInfo(
+      deltas=np.array(deltas[::-1]), pred_mask_size=np.array(fov[::-1]),
+      input_seed_size=np.array(fov[::-1]), input_image_size=np.array(fov[::-1]))
+  request = inference_pb2.InferenceRequest()
+  o = request.inference_options
+  o.init_activation = 0.95
+  o.pad_value = 0.05
+  o.move_threshold = 0.9
+  o.segment_threshold = 0.6
+  o.min_segment_size = min_segment_size
+  o.min_boundary_dist.x = 1
+  o.min_boundary_dist.y = 1
+  o.min_boundary_dist.z = 1
+  counters = ref_utils.Counters()
+  trace = []
+  canvas = ref_inference.Canvas(
+      info, OracleClient(blob, depth, trace), image_f32, o, counters=counters,
+      movement_policy_fn=ref_movement.get_policy_fn(request, info))
+
+  # Record each FoV step: position + the moves the policy queued.
+  orig_update = canvas.movement_policy.update
+
+  def recording_update(prob_map, position):
+    before = len(canvas.movement_policy.scored_coords)
+    orig_update(prob_map, position)
+    new = list(canvas.movement_policy.scored_coords)[before:]
+    trace.append((tuple(int(p) for p in position),
+                  [(float(s), tuple(int(c) for c in xyz)) for s, xyz in new]))
+
+  canvas.movement_policy.update = recording_update
+
+  class FixedSeeds(ref_seed.BaseSeedPolicy):
+
+    def init_coords(self):
+      self.coords = np.array(seeds)
+
+  canvas.segment_all(seed_policy=FixedSeeds)
+  return canvas, trace, counters
+
+
+def make_canvas_case(name, shape, seed, depth_weights, grid_step, grid_offsets,
+                     dilate):
+  vol = synthetic.cells_volume(shape, seed=seed, membrane_dilate=dilate)
+  image = synthetic.normalize(vol)
+  blob, depth = depth_weights
+  fov = (33, 33, 33)
+  deltas = (8, 8, 8)
+  seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16), step=grid_step,
+                                offsets=grid_offsets)
+  canvas, trace, counters = run_reference_canvas(image, blob, depth, fov,
+                                                 deltas, seeds)
+  seg = np.array(canvas.segmentation)
+  steps = np.array([t[0] for t in trace], np.int32).reshape(-1, 3)
+  n_moves = np.array([len(t[1]) for t in trace], np.int32)
+  move_scores = np.array([s for t in trace for s, _ in t[1]], np.float32)
+  move_coords = np.array([c for t in trace for _, c in t[1]],
+                         np.int32).reshape(-1, 3)
+  origins = {
+      int(k): [list(int(x) for x in v.start_zyx), int(v.iters)]
+      for k, v in canvas.origins.items()
+  }
+  cdict = {k: c.value for k, c in counters}
+  keep = {k: v for k, v in cdict.items() if not k.endswith('-time-ms')}
+  np.savez_compressed(
+      os.path.join(GOLD, 'ref_canvas_%s.npz' % name),
+      volume=vol, seeds=seeds, segmentation=seg, seed_logits=np.array(
+          canvas.seed), steps=steps, n_moves=n_moves, move_scores=move_scores,
+      move_coords=move_coords, origins=json.dumps(origins),
+      counters=json.dumps(keep), depth=depth)
+  print(name, 'steps', len(steps), 'segments', len(origins), 'counters', keep)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--only', default='')
+  args = ap.parse_args()
+  os.makedirs(GOLD, exist_ok=True)
+  if args.only in ('', 'weights'):
+    make_weights()
+  if args.only in ('', 'movement'):
+    make_movement()
+  if args.only in ('', 'misc'):
+    make_misc()
+  if args.only in ('', 'canvas'):
+    v = tf_checkpoint.load_checkpoint(CKPT)
+    blob = ffn_oracle.weights_blob(v, 12)
+    make_canvas_case('cells56', (56, 56, 56), 11, (blob, 12), 16, (0, 8), 1)
+    make_canvas_case('cells72', (72, 64, 80), 5, (blob, 12), 16, (0,), 2)
+
+
+if __name__ == '__main__':
+  main()
