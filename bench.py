@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FoV-steps/sec of the flood-filling inference loop.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full FoV step of the hot path on a device-resident canvas:
+gather -> conv0_a -> 23 x (3x3x3, 32->32) MFMA convs -> logit head -> disco ->
+paste-back -> 6-face argmax, plus the Python move-queue bookkeeping that picks
+the next position (Canvas.segment_all -> segment_at -> update_at).
+
+Workload (BASELINE.json configs[1]): single seed stream on ONE synthetic 250^3
+uint8 volume per GPU, depth 12, FoV 33^3, deltas 8, FIB-25 weights
+(tests/golden/fib25_weights.npz), options of configs/inference_training_sample2.
+With N > 1 every rank owns an independent 250^3 volume (weak scaling, no
+data-path collective; one barrier-bracketed timed region, MAX over ranks).
+
+Rank 0 prints ONE JSON line (see the contract in the task description) that also
+carries `roofline` (dominant kernel = conv32, exact-f32 MFMA, HIP-event timed on
+the engine's own stream) and, at N == 1, `cpu_baseline` (the oracle port timed
+on this host's cores over a bounded sample of the same workload).
+"""
+
+import argparse
+import functools
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+FOV = (33, 33, 33)
+DELTAS = (8, 8, 8)
+DEPTH = 12
+FEATURES = 32
+VOXELS = FOV[0] * FOV[1] * FOV[2]
+# Algorithmic FLOPs of ONE conv32 launch at batch 1: dense SAME
+# count 2 * 27 taps * 32 cin * 32 cout per voxel x 35,937 voxels.
+CONV32_FLOPS = 2.0 * 27 * 32 * 32 * VOXELS
+STEP_FLOPS = 2.0 * (2 * 27 * 32 + 23 * 27 * 32 * 32 + 32) * VOXELS
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+
+
+class _Done(Exception):
+  pass
+
+
+def _dist_env():
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  return rank, local_rank, world
+
+
+def make_request():
+  from ffn_amd.inference import request as req_lib
+  r = req_lib.InferenceRequest()
+  r.image_mean = 128
+  r.image_stddev = 33
+  r.model_name = 'convstack_3d.ConvStack3DFFNModel'
+  r.model_args = json.dumps({'depth': DEPTH, 'fov_size': list(FOV[::-1]),
+                             'deltas': list(DELTAS[::-1])})
+  o = r.inference_options
+  o.init_activation = 0.95
+  o.pad_value = 0.05
+  o.move_threshold = 0.9
+  o.segment_threshold = 0.6
+  o.min_segment_size = 1000
+  o.min_boundary_dist.x = 1
+  o.min_boundary_dist.y = 1
+  o.min_boundary_dist.z = 1
+  return r
+
+
+def load_model():
+  from ffn_amd.training.models import convstack_3d
+  model = convstack_3d.ConvStack3DFFNModel(
+      fov_size=list(FOV[::-1]), deltas=list(DELTAS[::-1]), batch_size=1,
+      depth=DEPTH, features=FEATURES)
+  model.load_checkpoint(os.path.join(ROOT, 'tests', 'golden',
+                                     'fib25_weights.npz'))
+  return model
+
+
+def run_gpu(args, rank, local_rank, world):
+  import torch
+  import torch.distributed as dist
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from ffn_amd.inference import seed as seed_lib
+
+  if not torch.cuda.is_available():
+    raise RuntimeError('bench.py needs an MI355X: no CPU fallback exists')
+  torch.cuda.set_device(local_rank)
+  if world > 1:
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  model = load_model()
+  request = make_request()
+  counters = inference_utils.Counters()
+  exe = executor.HipBatchExecutor(executor.ExecutorInterface(), model,
+                                  model.info, None, counters, 1,
+                                  device_id=local_rank)
+  eng = exe.engine
+  if args.conv_variant is not None:
+    eng.set_option('conv_variant', args.conv_variant)
+
+  shape = (args.volume,) * 3
+  if args.workload == 'cells':
+    vol = synthetic.cells_volume(shape, seed=1234 + rank)
+  else:
+    vol = synthetic.noise_volume(shape, seed=rank)
+  image = synthetic.normalize(vol)
+
+  total = args.warmup + args.steps
+  state = {'n': 0, 't0': None, 't1': None, 'vox0': 0, 'vox1': 0}
+
+  class BenchCanvas(inference.DeviceCanvas):
+
+    def update_at(self, pos):
+      if state['n'] == args.warmup:
+        eng.synchronize()
+        barrier()
+        eng.get_profile(reset=True)
+        state['vox0'] = self.counters['voxels-segmented'].value
+        state['t0'] = time.perf_counter()
+      pred = super().update_at(pos)
+      state['n'] += 1
+      if state['n'] == total:
+        eng.synchronize()
+        state['t1_local'] = time.perf_counter()
+        barrier()
+        state['t1'] = time.perf_counter()
+        state['vox1'] = self.counters['voxels-segmented'].value
+        raise _Done()
+      return pred
+
+  canvas = BenchCanvas(model.info, exe.get_client(counters, direct=True), image,
+                       request.inference_options, counters=counters,
+                       movement_policy_fn=movement.get_policy_fn(
+                           request, model.info))
+  eng.set_profiling(1)
+  policy = functools.partial(seed_lib.PolicyGrid3d, step=16,
+                             offsets=(0, 8, 4, 12, 2, 10, 14))
+  try:
+    canvas.segment_all(seed_policy=policy)
+    raise RuntimeError('workload exhausted after %d steps (< warmup+steps = %d)'
+                       % (state['n'], total))
+  except _Done:
+    pass
+
+  conv_ms, conv_launches = eng.get_profile()
+  elapsed = state['t1'] - state['t0']
+  elapsed_local = state['t1_local'] - state['t0']
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  result = {
+      'elapsed': elapsed,
+      'elapsed_local': elapsed_local,
+      'conv_ms': conv_ms,
+      'conv_launches': conv_launches,
+      'voxels': state['vox1'] - state['vox0'],
+      'segments': len(canvas.origins),
+      'canvas': canvas,
+  }
+  if world > 1:
+    dist.barrier()
+  return result
+
+
+def cpu_baseline(args):
+  """Oracle port (plain C conv stack + numpy canvas loop, OpenMP on all host
+  cores) on a bounded sample of the same workload."""
+  from ffn_amd import synthetic
+  from oracle import ffn_oracle
+  with np.load(os.path.join(ROOT, 'tests', 'golden', 'fib25_weights.npz')) as d:
+    blob = ffn_oracle.weights_blob({k: d[k] for k in d.files}, DEPTH)
+  shape = (args.volume,) * 3
+  if args.workload == 'cells':
+    vol = synthetic.cells_volume(shape, seed=1234)
+  else:
+    vol = synthetic.noise_volume(shape, seed=0)
+  image = synthetic.normalize(vol)
+  oc = ffn_oracle.OracleCanvas(image, blob, DEPTH, FOV, DELTAS,
+                               ffn_oracle.Options())
+  budget_s = args.cpu_seconds
+  max_steps = args.cpu_steps
+
+  class _Stop(Exception):
+    pass
+
+  t0 = [None]
+  inner = oc.update_at
+  n = [0]
+
+  def timed_update(pos):
+    if n[0] == 1:  # first step = warmup (OpenMP spin-up, page faults)
+      t0[0] = time.perf_counter()
+    out = inner(pos)
+    n[0] += 1
+    if n[0] > 1 and (n[0] - 1 >= max_steps or
+                     time.perf_counter() - t0[0] > budget_s):
+      raise _Stop()
+    return out
+
+  oc.update_at = timed_update
+  seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))
+  try:
+    oc.segment_all(seeds)
+  except _Stop:
+    pass
+  steps = n[0] - 1
+  dt = time.perf_counter() - t0[0]
+  return {
+      'value': round(steps / dt, 3),
+      'unit': 'FoV-steps/s',
+      'cores': os.cpu_count(),
+      'kind': 'port',
+      'sample': ('first %d FoV steps of the same %s %d^3 workload through '
+                 'oracle/ (C conv stack, OpenMP, + numpy canvas loop), %.1f s'
+                 % (steps, args.workload, args.volume, dt)),
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=1500)
+  ap.add_argument('--warmup', type=int, default=100)
+  ap.add_argument('--volume', type=int, default=250)
+  ap.add_argument('--workload', choices=['cells', 'noise'], default='cells')
+  ap.add_argument('--conv-variant', type=int, default=None)
+  ap.add_argument('--cpu-seconds', type=float, default=15.0)
+  ap.add_argument('--cpu-steps', type=int, default=60)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+
+  rank, local_rank, world = _dist_env()
+  if world != args.gpus:
+    if args.gpus != 1 or world != 1:
+      raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.'
+                       'distributed.run --nproc-per-node %d' %
+                       (args.gpus, world, args.gpus))
+
+  res = run_gpu(args, rank, local_rank, world)
+  if rank != 0:
+    return
+
+  steps_per_s = world * args.steps / res['elapsed']
+  avg_conv_ms = res['conv_ms'] / max(res['conv_launches'], 1)
+  achieved = CONV32_FLOPS / (avg_conv_ms * 1e-3) / 1e12 if avg_conv_ms else 0.0
+  out = {
+      'metric': 'FoV-steps/sec (flood-filling inference loop, 250^3 volume)',
+      'value': round(steps_per_s, 2),
+      'unit': 'FoV-steps/s',
+      'n_gpus': world,
+      'steps': args.steps,
+      'warmup': args.warmup,
+      'ms_per_step': round(1e3 * res['elapsed'] / args.steps, 4),
+      'higher_is_better': True,
+      'scaling': 'weak',
+      'vs_baseline': None,
+      'dtype': 'f32',
+      'data': 'synthetic',
+      'config': {
+          'workload': ('configs[1] single-seed single-GPU: depth=12 fov=33^3 '
+                       'deltas=8, synthetic %s %d^3 uint8 volume per GPU, '
+                       'FIB-25 weights, device-resident canvas, batch 1'
+                       % (args.workload, args.volume)),
+          'volume': [args.volume] * 3,
+          'parallelism': 'independent volume per rank (no data-path collective)',
+      },
+      'voxels_segmented_per_s': round(world * res['voxels'] / res['elapsed'], 1),
+      'step_gflop': round(STEP_FLOPS / 1e9, 3),
+      'end_to_end_tflops': round(steps_per_s * STEP_FLOPS / 1e12, 3),
+      'roofline': {
+          'bound': 'mfma',
+          'kernel': 'conv32 (3x3x3 32->32 implicit GEMM, v_mfma_f32_16x16x4_f32)',
+          'achieved': round(achieved, 3),
+          'peak': PEAK_F32_MFMA_TFLOPS,
+          'unit': 'TFLOP/s',
+          'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+          'traffic': None,
+          'avg_launch_us': round(avg_conv_ms * 1e3, 3),
+          'launches': int(res['conv_launches']),
+          'flops_per_launch': CONV32_FLOPS,
+      },
+  }
+  if world == 1 and not args.no_cpu_baseline:
+    out['cpu_baseline'] = cpu_baseline(args)
+  print(json.dumps(out))
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,148 @@
+"""ctypes binding of libffn_hip.so (the C-ABI in include/ffn_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, every
+entry point raises.  The oracle under oracle/ is test infrastructure and is
+never imported from here.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libffn_hip.so')
+HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'ffn_hip.h')
+
+MAX_CANDIDATES = 16
+
+
+class FFNHipError(RuntimeError):
+  """Raised for any non-zero return code of the C-ABI."""
+
+
+class StepParams(ctypes.Structure):
+  _fields_ = [('pad_value', ctypes.c_float),
+              ('move_threshold', ctypes.c_float),
+              ('disco_seed_threshold', ctypes.c_float)]
+
+
+class StepRequest(ctypes.Structure):
+  _fields_ = [('pos', ctypes.c_int32 * 3),
+              ('start_pos', ctypes.c_int32 * 3),
+              ('num_candidates', ctypes.c_int32),
+              ('candidates', (ctypes.c_int32 * 3) * MAX_CANDIDATES)]
+
+
+class StepResult(ctypes.Structure):
+  _fields_ = [('face_score', ctypes.c_float * 6),
+              ('face_index', ctypes.c_int32 * 6),
+              ('face_seg', ctypes.c_int32 * 6),
+              ('start_logit', ctypes.c_float),
+              ('num_above_move', ctypes.c_uint32),
+              ('disco_applied', ctypes.c_int32),
+              ('cand_seed', ctypes.c_float * MAX_CANDIDATES),
+              ('cand_seg', ctypes.c_int32 * MAX_CANDIDATES)]
+
+
+class CommitCounts(ctypes.Structure):
+  _fields_ = [('raw_segmented_voxels', ctypes.c_int64),
+              ('actual_segmented_voxels', ctypes.c_int64),
+              ('num_overlapped_ids', ctypes.c_int32)]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_I3 = ctypes.POINTER(ctypes.c_int32)
+
+# name -> (restype, argtypes); every symbol include/ffn_hip.h declares.
+SIGNATURES = {
+    'ffn_abi_version': (_I, []),
+    'ffn_last_error': (ctypes.c_char_p, []),
+    'ffn_engine_weight_count': (ctypes.c_size_t, [_I, _I]),
+    'ffn_engine_create': (_I, [_I, _I3, _I3, _I, _I, _I,
+                               ctypes.POINTER(_P)]),
+    'ffn_engine_destroy': (None, [_P]),
+    'ffn_engine_set_weights': (_I, [_P, _P, ctypes.c_size_t]),
+    'ffn_engine_set_option': (_I, [_P, ctypes.c_char_p, _I]),
+    'ffn_engine_set_profiling': (_I, [_P, _I]),
+    'ffn_engine_get_profile': (_I, [_P, ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_int64), _I]),
+    'ffn_engine_synchronize': (_I, [_P]),
+    'ffn_predict': (_I, [_P, _I, _P, _P, _P]),
+    'ffn_forward_resident': (_I, [_P, _I, _I]),
+    'ffn_canvas_create': (_I, [_P, _P, _I3, ctypes.POINTER(_P)]),
+    'ffn_canvas_destroy': (None, [_P]),
+    'ffn_canvas_init_seed': (_I, [_P, _I3, ctypes.c_float]),
+    'ffn_canvas_step': (_I, [_P, _I, ctypes.POINTER(_P),
+                             ctypes.POINTER(StepRequest),
+                             ctypes.POINTER(StepParams),
+                             ctypes.POINTER(StepResult)]),
+    'ffn_canvas_read_points': (_I, [_P, _I, _P, _P, _P]),
+    'ffn_canvas_write_seg_points': (_I, [_P, _I, _P, _P]),
+    'ffn_canvas_any_segmented': (_I, [_P, _I3, _I3,
+                                      ctypes.POINTER(ctypes.c_int32)]),
+    'ffn_canvas_commit_count': (_I, [_P, _I3, _I3, ctypes.c_float,
+                                     ctypes.c_int32,
+                                     ctypes.POINTER(CommitCounts),
+                                     ctypes.c_int32, _P, _P]),
+    'ffn_canvas_commit_assign': (_I, [_P, _I3, _I3, ctypes.c_float,
+                                      ctypes.c_int32]),
+    'ffn_canvas_read_seed': (_I, [_P, _I3, _I3, _P]),
+    'ffn_canvas_read_segmentation': (_I, [_P, _I3, _I3, _P]),
+    'ffn_canvas_write_seed': (_I, [_P, _I3, _I3, _P]),
+    'ffn_canvas_write_segmentation': (_I, [_P, _I3, _I3, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(force: bool = False) -> str:
+  """Compiles csrc/ffn_hip.hip for gfx950 into csrc/libffn_hip.so (in-tree)."""
+  src = os.path.join(CSRC, 'ffn_hip.hip')
+  deps = [src, os.path.join(CSRC, 'ffn_kernels.h'), HEADER]
+  if (not force and os.path.exists(LIB_PATH) and
+      all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+    return LIB_PATH
+  hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+  if not os.path.exists(hipcc):
+    hipcc = 'hipcc'
+  cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared',
+         '-fPIC', '-o', LIB_PATH, src]
+  subprocess.check_call(cmd, cwd=CSRC)
+  return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+  """Loads the HIP library; raises (never falls back) if it is unavailable."""
+  global _lib
+  with _lock:
+    if _lib is not None:
+      return _lib
+    if not os.path.exists(LIB_PATH):
+      raise FFNHipError(
+          '%s not found: build it with `python -c "import __graft_entry__ as g;'
+          ' g.build()"` (hipcc --offload-arch=gfx950). There is no CPU '
+          'fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+      fn = getattr(lib, name)  # AttributeError if the symbol is missing
+      fn.restype = res
+      fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+  if rc != 0:
+    msg = load().ffn_last_error()
+    raise FFNHipError('libffn_hip error %d: %s' %
+                      (rc, msg.decode('utf-8', 'replace') if msg else '?'))
+
+
+def i3(values):
+  return (ctypes.c_int32 * 3)(*[int(v) for v in values])

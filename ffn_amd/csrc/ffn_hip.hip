@@ -1,0 +1,912 @@
+// libffn_hip.so -- host side of the C-ABI declared in include/ffn_hip.h.
+//
+// One engine = one GPU + one HIP stream + the conv-stack weights + staging and
+// activation buffers for up to max_batch concurrent fields of view.  Canvases
+// (image / seed / segmentation of a whole subvolume) are device resident.
+// The reference interfaces each entry point replaces are cited in the header.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ffn_kernels.h"
+
+using namespace ffn;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                        \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess)                                                    \
+      return fail(FFN_ERR_HIP, "%s failed: %s (%s:%d)", #expr,               \
+                  hipGetErrorString(_e), __FILE__, __LINE__);                \
+  } while (0)
+
+}  // namespace
+
+struct ffn_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Geom g{};
+  int depth = 0;
+  int max_batch = 0;
+  bool weights_set = false;
+
+  float* act_base = nullptr;  // 2 activation buffers (T, X) x max_batch
+  float* bufT = nullptr;      // logical origins
+  float* bufX = nullptr;
+  float* bufXR = nullptr;     // relu(X) (pipelined variant only)
+  uint32_t* validbits = nullptr;
+  int conv_variant = 1;       // 0 = conv32_kernel (simple), 1 = conv32p_kernel
+  float* in_image = nullptr;
+  float* in_seed = nullptr;
+  float* logits = nullptr;
+  unsigned* count = nullptr;
+  uint8_t* valid = nullptr;
+  float* weights = nullptr;  // one allocation; layout below
+  size_t w0a_off = 0, b0a_off = 0, wl_off = 0;
+  std::vector<size_t> wpack_off, bias_off;  // 2*depth-1 entries (conv0_b ..)
+
+  StepItem* d_items = nullptr;
+  StepItem* h_items = nullptr;
+  ffn_step_result* d_results = nullptr;
+  ffn_step_result* h_results = nullptr;
+
+  void* d_scratch = nullptr;
+  void* h_scratch = nullptr;
+  size_t scratch_bytes = 0;
+
+  int prof_mode = 0;
+  std::vector<hipEvent_t> events;
+  int events_used = 0;
+  double conv_ms = 0.0;
+  int64_t conv_launches = 0;
+  size_t lds_bytes = 0;
+};
+
+struct ffn_canvas {
+  ffn_engine* engine = nullptr;
+  float* image = nullptr;
+  float* seed = nullptr;
+  int32_t* seg = nullptr;
+  int cz = 0, cy = 0, cx = 0;
+  size_t nvox = 0;
+};
+
+namespace {
+
+int ensure_scratch(ffn_engine* e, size_t bytes) {
+  if (bytes <= e->scratch_bytes) return FFN_OK;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->d_scratch) HIP_TRY(hipFree(e->d_scratch));
+  if (e->h_scratch) HIP_TRY(hipHostFree(e->h_scratch));
+  e->d_scratch = e->h_scratch = nullptr;
+  e->scratch_bytes = 0;
+  size_t want = std::max<size_t>(bytes, 1 << 20);
+  HIP_TRY(hipMalloc(&e->d_scratch, want));
+  HIP_TRY(hipHostMalloc(&e->h_scratch, want, hipHostMallocDefault));
+  e->scratch_bytes = want;
+  return FFN_OK;
+}
+
+template <bool RI, bool RO, bool SK>
+int set_lds_attr(size_t bytes) {
+  HIP_TRY(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&conv32_kernel<RI, RO, SK>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return FFN_OK;
+}
+
+template <bool RO, bool SK, bool DU>
+int set_lds_attr_p(size_t bytes) {
+  HIP_TRY(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&conv32p_kernel<RO, SK, DU>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return FFN_OK;
+}
+
+// Flush the per-launch event pairs recorded since the last flush.
+int flush_events(ffn_engine* e) {
+  if (e->events_used == 0) return FFN_OK;
+  HIP_TRY(hipEventSynchronize(e->events[e->events_used - 1]));
+  for (int k = 0; k + 1 < e->events_used; k += 2) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->events[k], e->events[k + 1]));
+    e->conv_ms += ms;
+    e->conv_launches += 1;
+  }
+  e->events_used = 0;
+  return FFN_OK;
+}
+
+template <bool RI, bool RO, bool SK>
+int launch_conv32(ffn_engine* e, int n, const float* in, float* out,
+                  const float* skip, int layer) {
+  ConvArgs a;
+  a.in = in;
+  a.out = out;
+  a.skip = skip;
+  a.wpack = e->weights + e->wpack_off[layer];
+  a.bias = e->weights + e->bias_off[layer];
+  a.valid = e->valid;
+  a.act_stride = e->g.act_stride;
+  a.XS = e->g.XS;
+  a.plane = e->g.plane;
+  a.R = e->g.R;
+  a.nchunks = e->g.nchunks;
+  const bool prof = e->prof_mode == 1;
+  if (prof) {
+    if (e->events_used + 2 > (int)e->events.size()) {
+      int rc = flush_events(e);
+      if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  }
+  hipLaunchKernelGGL((conv32_kernel<RI, RO, SK>), dim3(n * e->g.nchunks),
+                     dim3(kConvThreads), e->lds_bytes, e->stream, a);
+  if (prof) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  return FFN_OK;
+}
+
+template <bool RO, bool SK, bool DU>
+int launch_conv32p(ffn_engine* e, int n, const float* in, float* out,
+                   float* out_relu, const float* skip, int layer) {
+  ConvPArgs a;
+  a.in = in;
+  a.out = out;
+  a.out_relu = out_relu;
+  a.skip = skip;
+  a.wpack = e->weights + e->wpack_off[layer];
+  a.bias = e->weights + e->bias_off[layer];
+  a.validbits = e->validbits;
+  a.act_stride = e->g.act_stride;
+  a.XS = e->g.XS;
+  a.plane = e->g.plane;
+  a.R = e->g.R;
+  a.nchunks = e->g.nchunks;
+  a.total_slots = n * e->g.nchunks;
+  a.slots_per_xcd = (a.total_slots + 7) / 8;
+  const bool prof = e->prof_mode == 1;
+  if (prof) {
+    if (e->events_used + 2 > (int)e->events.size()) {
+      int rc = flush_events(e);
+      if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  }
+  hipLaunchKernelGGL((conv32p_kernel<RO, SK, DU>), dim3(8 * a.slots_per_xcd),
+                     dim3(kConvThreads), e->lds_bytes, e->stream, a);
+  if (prof) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  return FFN_OK;
+}
+
+// in_image / in_seed (dense staging) -> logits (+ count of logits >= move_thr)
+int run_stack(ffn_engine* e, int n, float pad_value, float move_thr) {
+  const Geom& g = e->g;
+  const float* W = e->weights;
+  hipLaunchKernelGGL(conv0a_kernel, dim3((g.npos + 255) / 256, n), dim3(256), 0,
+                     e->stream, e->in_image, e->in_seed, pad_value,
+                     W + e->w0a_off, W + e->b0a_off, e->bufT, g);
+  int rc;
+  const float* head_in;
+  if (e->conv_variant == 0) {
+    rc = launch_conv32<false, false, false>(e, n, e->bufT, e->bufX, nullptr, 0);
+    if (rc) return rc;
+    for (int i = 1; i < e->depth; ++i) {
+      rc = launch_conv32<true, true, false>(e, n, e->bufX, e->bufT, nullptr,
+                                            2 * i - 1);
+      if (rc) return rc;
+      rc = launch_conv32<false, false, true>(e, n, e->bufT, e->bufX, e->bufX,
+                                             2 * i);
+      if (rc) return rc;
+    }
+    head_in = e->bufX;
+  } else {
+    // T is already post-ReLU (conv0_a / conv_a apply it); X raw + XR = relu(X)
+    rc = launch_conv32p<false, false, true>(e, n, e->bufT, e->bufX, e->bufXR,
+                                            nullptr, 0);
+    if (rc) return rc;
+    for (int i = 1; i < e->depth; ++i) {
+      rc = launch_conv32p<true, false, false>(e, n, e->bufXR, e->bufT, nullptr,
+                                              nullptr, 2 * i - 1);
+      if (rc) return rc;
+      rc = launch_conv32p<false, true, true>(e, n, e->bufT, e->bufX, e->bufXR,
+                                             e->bufX, 2 * i);
+      if (rc) return rc;
+    }
+    head_in = e->bufXR;
+  }
+  HIP_TRY(hipMemsetAsync(e->count, 0, sizeof(unsigned) * n, e->stream));
+  hipLaunchKernelGGL(head_kernel, dim3((g.V * 8 + 255) / 256, n), dim3(256), 0,
+                     e->stream, head_in, e->in_seed, pad_value, W + e->wl_off,
+                     move_thr, e->logits, e->count, g);
+  HIP_TRY(hipGetLastError());
+  return FFN_OK;
+}
+
+Box make_box(const ffn_canvas* c, const int32_t lo[3], const int32_t hi[3],
+             long* total) {
+  Box b;
+  for (int k = 0; k < 3; ++k) {
+    b.lo[k] = lo[k];
+    b.n[k] = hi[k] - lo[k];
+  }
+  b.cy = c->cy;
+  b.cx = c->cx;
+  *total = (long)b.n[0] * b.n[1] * b.n[2];
+  return b;
+}
+
+int check_box(const ffn_canvas* c, const int32_t lo[3], const int32_t hi[3]) {
+  const int dims[3] = {c->cz, c->cy, c->cx};
+  for (int k = 0; k < 3; ++k)
+    if (lo[k] < 0 || hi[k] > dims[k] || hi[k] < lo[k])
+      return fail(FFN_ERR_ARG, "box [%d,%d) out of canvas axis %d (size %d)",
+                  lo[k], hi[k], k, dims[k]);
+  return FFN_OK;
+}
+
+int grid_for(long total, int block = 256) {
+  long g = (total + block - 1) / block;
+  return (int)std::max<long>(1, std::min<long>(g, 2048));
+}
+
+}  // namespace
+
+extern "C" {
+
+int ffn_abi_version(void) { return 1; }
+
+const char* ffn_last_error(void) { return g_error.c_str(); }
+
+size_t ffn_engine_weight_count(int depth, int features) {
+  const size_t F = (size_t)features;
+  return 27 * 2 * F + F + (size_t)(2 * depth - 1) * (27 * F * F + F) + F + 1;
+}
+
+int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
+                      const int32_t deltas_zyx[3], int depth, int features,
+                      int max_batch, ffn_engine** out) {
+  if (!out || !fov_zyx || !deltas_zyx) return fail(FFN_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (features != kFeatures)
+    return fail(FFN_ERR_ARG, "features must be %d (got %d)", kFeatures, features);
+  if (depth < 1 || max_batch < 1)
+    return fail(FFN_ERR_ARG, "depth and max_batch must be >= 1");
+  for (int k = 0; k < 3; ++k) {
+    if (fov_zyx[k] < 3 || fov_zyx[k] % 2 == 0)
+      return fail(FFN_ERR_ARG, "fov must be odd and >= 3 per axis");
+    if (deltas_zyx[k] < 0 || 2 * deltas_zyx[k] + 1 > fov_zyx[k])
+      return fail(FFN_ERR_ARG, "deltas do not fit inside the fov");
+  }
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev)
+    return fail(FFN_ERR_ARG, "device %d not present (%d visible)", device_id, ndev);
+  HIP_TRY(hipSetDevice(device_id));
+
+  ffn_engine* e = new ffn_engine();
+  e->device = device_id;
+  e->depth = depth;
+  e->max_batch = max_batch;
+  Geom& g = e->g;
+  g.fz = fov_zyx[0];
+  g.fy = fov_zyx[1];
+  g.fx = fov_zyx[2];
+  g.dz = deltas_zyx[0];
+  g.dy = deltas_zyx[1];
+  g.dx = deltas_zyx[2];
+  g.XS = g.fx + 1;
+  g.plane = (g.fy + 1) * g.XS;
+  g.npos = g.fz * g.plane;
+  g.guard = g.plane + g.XS + 1;
+  g.nchunks = (g.npos + kChunk - 1) / kChunk;
+  g.V = g.fz * g.fy * g.fx;
+  g.R = kChunk + 2 * (g.XS + 1);
+  const long positions = (long)g.guard + (long)g.nchunks * kChunk + g.guard;
+  g.act_stride = positions * kFeatures;
+  e->lds_bytes = (size_t)3 * g.R * kFeatures * sizeof(float);
+  if (e->lds_bytes > 160 * 1024) {
+    delete e;
+    return fail(FFN_ERR_ARG, "fov too wide for the LDS-staged conv (%zu B)",
+                e->lds_bytes);
+  }
+
+#define E_TRY(expr)                                                          \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      int _rc = fail(FFN_ERR_HIP, "%s failed: %s (%s:%d)", #expr,            \
+                     hipGetErrorString(_e), __FILE__, __LINE__);             \
+      ffn_engine_destroy(e);                                                 \
+      return _rc;                                                            \
+    }                                                                        \
+  } while (0)
+
+  E_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  const size_t act_bytes = (size_t)3 * max_batch * g.act_stride * sizeof(float);
+  E_TRY(hipMalloc(&e->act_base, act_bytes));
+  E_TRY(hipMemset(e->act_base, 0, act_bytes));
+  e->bufT = e->act_base + (size_t)g.guard * kFeatures;
+  e->bufX = e->bufT + (size_t)max_batch * g.act_stride;
+  e->bufXR = e->bufX + (size_t)max_batch * g.act_stride;
+  const size_t vbytes = (size_t)max_batch * g.V * sizeof(float);
+  E_TRY(hipMalloc(&e->in_image, vbytes));
+  E_TRY(hipMalloc(&e->in_seed, vbytes));
+  E_TRY(hipMalloc(&e->logits, vbytes));
+  E_TRY(hipMemset(e->in_image, 0, vbytes));
+  E_TRY(hipMemset(e->in_seed, 0, vbytes));
+  E_TRY(hipMalloc(&e->count, sizeof(unsigned) * max_batch));
+  E_TRY(hipMalloc(&e->d_items, sizeof(StepItem) * max_batch));
+  E_TRY(hipHostMalloc(&e->h_items, sizeof(StepItem) * max_batch,
+                      hipHostMallocDefault));
+  E_TRY(hipMalloc(&e->d_results, sizeof(ffn_step_result) * max_batch));
+  E_TRY(hipHostMalloc(&e->h_results, sizeof(ffn_step_result) * max_batch,
+                      hipHostMallocDefault));
+
+  // validity table of the padded-flat layout
+  {
+    std::vector<uint8_t> v((size_t)g.nchunks * kChunk, 0);
+    for (int p = 0; p < g.npos; ++p) {
+      const int rem = p % g.plane;
+      v[p] = (rem / g.XS < g.fy && rem % g.XS < g.fx) ? 1 : 0;
+    }
+    E_TRY(hipMalloc(&e->valid, v.size()));
+    E_TRY(hipMemcpy(e->valid, v.data(), v.size(), hipMemcpyHostToDevice));
+    std::vector<uint32_t> bits((size_t)g.nchunks * 5, 0u);
+    for (size_t p = 0; p < v.size(); ++p)
+      if (v[p]) bits[(p / kChunk) * 5 + ((p % kChunk) >> 5)] |= 1u << (p & 31);
+    static_assert(kChunk == 160, "validbits layout assumes 5 words per chunk");
+    E_TRY(hipMalloc(&e->validbits, bits.size() * sizeof(uint32_t)));
+    E_TRY(hipMemcpy(e->validbits, bits.data(), bits.size() * sizeof(uint32_t),
+                    hipMemcpyHostToDevice));
+  }
+
+  // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)
+  // [wl 32 + 1]
+  {
+    size_t off = 0;
+    e->w0a_off = off;
+    off += 27 * 2 * kFeatures;
+    e->b0a_off = off;
+    off += kFeatures;
+    for (int l = 0; l < 2 * depth - 1; ++l) {
+      e->wpack_off.push_back(off);
+      off += 27 * kFeatures * kFeatures;
+      e->bias_off.push_back(off);
+      off += kFeatures;
+    }
+    e->wl_off = off;
+    off += kFeatures + 1;
+    off = (off + 3) & ~(size_t)3;
+    E_TRY(hipMalloc(&e->weights, off * sizeof(float)));
+  }
+
+  e->events.resize(2 * 64);
+  for (auto& ev : e->events) E_TRY(hipEventCreate(&ev));
+
+  {
+    int rc = set_lds_attr<false, false, false>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr<true, true, false>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr<false, false, true>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<true, false, false>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, true, true>(e->lds_bytes);
+    if (rc) {
+      ffn_engine_destroy(e);
+      return rc;
+    }
+  }
+#undef E_TRY
+  *out = e;
+  return FFN_OK;
+}
+
+void ffn_engine_destroy(ffn_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (auto& ev : e->events)
+    if (ev) (void)hipEventDestroy(ev);
+  (void)hipFree(e->act_base);
+  (void)hipFree(e->in_image);
+  (void)hipFree(e->in_seed);
+  (void)hipFree(e->logits);
+  (void)hipFree(e->count);
+  (void)hipFree(e->valid);
+  (void)hipFree(e->validbits);
+  (void)hipFree(e->weights);
+  (void)hipFree(e->d_items);
+  (void)hipFree(e->d_results);
+  (void)hipFree(e->d_scratch);
+  if (e->h_items) (void)hipHostFree(e->h_items);
+  if (e->h_results) (void)hipHostFree(e->h_results);
+  if (e->h_scratch) (void)hipHostFree(e->h_scratch);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
+  if (!e || !blob) return fail(FFN_ERR_ARG, "null argument");
+  const size_t want = ffn_engine_weight_count(e->depth, kFeatures);
+  if (count != want)
+    return fail(FFN_ERR_ARG, "weight blob has %zu floats, expected %zu", count,
+                want);
+  HIP_TRY(hipSetDevice(e->device));
+  const int F = kFeatures;
+  std::vector<float> host(e->wl_off + F + 1 + 3, 0.0f);
+  const float* src = blob;
+  // conv0_a: [27][2][32] + bias, used as stored
+  std::memcpy(&host[e->w0a_off], src, sizeof(float) * 27 * 2 * F);
+  src += 27 * 2 * F;
+  std::memcpy(&host[e->b0a_off], src, sizeof(float) * F);
+  src += F;
+  // 32->32 convs: repack W[tap][ci][co] for the MFMA B operand:
+  //   wpack[tap][nhalf][h][lane = 16*g + j][s] = W[tap][16h + 4g + s][16*nhalf + j]
+  for (int l = 0; l < 2 * e->depth - 1; ++l) {
+    float* wp = &host[e->wpack_off[l]];
+    for (int tap = 0; tap < 27; ++tap)
+      for (int nh = 0; nh < 2; ++nh)
+        for (int h = 0; h < 2; ++h)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int s = 0; s < 4; ++s) {
+              const int gq = lane >> 4, j = lane & 15;
+              const int ci = 16 * h + 4 * gq + s, co = 16 * nh + j;
+              wp[((((size_t)tap * 2 + nh) * 2 + h) * 64 + lane) * 4 + s] =
+                  src[((size_t)tap * F + ci) * F + co];
+            }
+    src += 27 * F * F;
+    std::memcpy(&host[e->bias_off[l]], src, sizeof(float) * F);
+    src += F;
+  }
+  std::memcpy(&host[e->wl_off], src, sizeof(float) * (F + 1));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(e->weights, host.data(),
+                    sizeof(float) * (e->wl_off + F + 1), hipMemcpyHostToDevice));
+  e->weights_set = true;
+  return FFN_OK;
+}
+
+int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
+                float* logits_out) {
+  if (!e || !seed || !image || !logits_out) return fail(FFN_ERR_ARG, "null argument");
+  if (n < 1 || n > e->max_batch)
+    return fail(FFN_ERR_ARG, "batch %d outside [1, %d]", n, e->max_batch);
+  if (!e->weights_set) return fail(FFN_ERR_STATE, "weights not set");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t bytes = (size_t)n * e->g.V * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(e->in_seed, seed, bytes, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->in_image, image, bytes, hipMemcpyHostToDevice, e->stream));
+  // NaNs in a caller-provided seed stay NaN (the reference would feed them to TF).
+  int rc = run_stack(e, n, std::nanf(""), INFINITY);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(logits_out, e->logits, bytes, hipMemcpyDeviceToHost,
+                         e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return FFN_OK;
+}
+
+int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
+  if (!e) return fail(FFN_ERR_ARG, "null argument");
+  if (n < 1 || n > e->max_batch)
+    return fail(FFN_ERR_ARG, "batch %d outside [1, %d]", n, e->max_batch);
+  if (!e->weights_set) return fail(FFN_ERR_STATE, "weights not set");
+  HIP_TRY(hipSetDevice(e->device));
+  for (int r = 0; r < repeats; ++r) {
+    int rc = run_stack(e, n, std::nanf(""), INFINITY);
+    if (rc) return rc;
+  }
+  return FFN_OK;
+}
+
+int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
+  if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
+  if (std::strcmp(name, "conv_variant") == 0) {
+    if (value != 0 && value != 1) return fail(FFN_ERR_ARG, "conv_variant must be 0 or 1");
+    e->conv_variant = value;
+    return FFN_OK;
+  }
+  return fail(FFN_ERR_ARG, "unknown option '%s'", name);
+}
+
+int ffn_engine_synchronize(ffn_engine* e) {
+  if (!e) return fail(FFN_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return FFN_OK;
+}
+
+int ffn_engine_set_profiling(ffn_engine* e, int mode) {
+  if (!e) return fail(FFN_ERR_ARG, "null argument");
+  if (mode != 0 && mode != 1) return fail(FFN_ERR_ARG, "mode must be 0 or 1");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = flush_events(e);
+  if (rc) return rc;
+  e->prof_mode = mode;
+  return FFN_OK;
+}
+
+int ffn_engine_get_profile(ffn_engine* e, double* conv_ms_total,
+                           int64_t* conv_launches, int reset) {
+  if (!e) return fail(FFN_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = flush_events(e);
+  if (rc) return rc;
+  if (conv_ms_total) *conv_ms_total = e->conv_ms;
+  if (conv_launches) *conv_launches = e->conv_launches;
+  if (reset) {
+    e->conv_ms = 0.0;
+    e->conv_launches = 0;
+  }
+  return FFN_OK;
+}
+
+/* ------------------------------- canvas ---------------------------------- */
+
+int ffn_canvas_create(ffn_engine* e, const float* image_f32,
+                      const int32_t shape_zyx[3], ffn_canvas** out) {
+  if (!e || !image_f32 || !shape_zyx || !out) return fail(FFN_ERR_ARG, "null argument");
+  *out = nullptr;
+  for (int k = 0; k < 3; ++k)
+    if (shape_zyx[k] < 1) return fail(FFN_ERR_ARG, "bad canvas shape");
+  HIP_TRY(hipSetDevice(e->device));
+  ffn_canvas* c = new ffn_canvas();
+  c->engine = e;
+  c->cz = shape_zyx[0];
+  c->cy = shape_zyx[1];
+  c->cx = shape_zyx[2];
+  c->nvox = (size_t)c->cz * c->cy * c->cx;
+  hipError_t err = hipMalloc(&c->image, c->nvox * sizeof(float));
+  if (err == hipSuccess) err = hipMalloc(&c->seed, c->nvox * sizeof(float));
+  if (err == hipSuccess) err = hipMalloc(&c->seg, c->nvox * sizeof(int32_t));
+  if (err == hipSuccess)
+    err = hipMemcpy(c->image, image_f32, c->nvox * sizeof(float),
+                    hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemset(c->seg, 0, c->nvox * sizeof(int32_t));
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, e->stream,
+                       reinterpret_cast<uint32_t*>(c->seed), 0x7fc00000u, c->nvox);
+    err = hipStreamSynchronize(e->stream);
+  }
+  if (err != hipSuccess) {
+    int rc = fail(FFN_ERR_HIP, "canvas allocation failed: %s", hipGetErrorString(err));
+    ffn_canvas_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return FFN_OK;
+}
+
+void ffn_canvas_destroy(ffn_canvas* c) {
+  if (!c) return;
+  if (c->engine) {
+    (void)hipSetDevice(c->engine->device);
+    (void)hipStreamSynchronize(c->engine->stream);
+  }
+  (void)hipFree(c->image);
+  (void)hipFree(c->seed);
+  (void)hipFree(c->seg);
+  delete c;
+}
+
+int ffn_canvas_init_seed(ffn_canvas* c, const int32_t pos[3], float value) {
+  if (!c || !pos) return fail(FFN_ERR_ARG, "null argument");
+  if (pos[0] < 0 || pos[0] >= c->cz || pos[1] < 0 || pos[1] >= c->cy ||
+      pos[2] < 0 || pos[2] >= c->cx)
+    return fail(FFN_ERR_ARG, "seed position outside the canvas");
+  ffn_engine* e = c->engine;
+  HIP_TRY(hipSetDevice(e->device));
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, e->stream,
+                     reinterpret_cast<uint32_t*>(c->seed), 0x7fc00000u, c->nvox);
+  const size_t ci = ((size_t)pos[0] * c->cy + pos[1]) * c->cx + pos[2];
+  hipLaunchKernelGGL(set_seed_point_kernel, dim3(1), dim3(1), 0, e->stream,
+                     c->seed, ci, value);
+  HIP_TRY(hipGetLastError());
+  return FFN_OK;
+}
+
+int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
+                    const ffn_step_request* requests,
+                    const ffn_step_params* params, ffn_step_result* results) {
+  if (!e || !canvases || !requests || !params || !results)
+    return fail(FFN_ERR_ARG, "null argument");
+  if (n < 1 || n > e->max_batch)
+    return fail(FFN_ERR_ARG, "batch %d outside [1, %d]", n, e->max_batch);
+  if (!e->weights_set) return fail(FFN_ERR_STATE, "weights not set");
+  const Geom& g = e->g;
+  for (int k = 0; k < n; ++k) {
+    const ffn_canvas* c = canvases[k];
+    if (!c || c->engine != e) return fail(FFN_ERR_ARG, "canvas %d not of this engine", k);
+    const ffn_step_request& r = requests[k];
+    const int half[3] = {g.fz / 2, g.fy / 2, g.fx / 2};
+    const int dims[3] = {c->cz, c->cy, c->cx};
+    for (int a = 0; a < 3; ++a)
+      if (r.pos[a] - half[a] < 0 || r.pos[a] + half[a] >= dims[a])
+        return fail(FFN_ERR_ARG, "FoV at (%d,%d,%d) leaves the canvas", r.pos[0],
+                    r.pos[1], r.pos[2]);
+    if (r.num_candidates < 0 || r.num_candidates > FFN_MAX_CANDIDATES)
+      return fail(FFN_ERR_ARG, "num_candidates out of range");
+    for (int k2 = 0; k2 < k; ++k2)
+      if (canvases[k2] == c)
+        return fail(FFN_ERR_ARG, "canvas appears twice in one batch");
+    StepItem& it = e->h_items[k];
+    it.image = c->image;
+    it.seed = c->seed;
+    it.seg = c->seg;
+    it.cz = c->cz;
+    it.cy = c->cy;
+    it.cx = c->cx;
+    it.req = r;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->d_items, e->h_items, sizeof(StepItem) * n,
+                         hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(gather_kernel, dim3(36, n), dim3(256), 0, e->stream,
+                     e->d_items, g, e->in_image, e->in_seed);
+  int rc = run_stack(e, n, params->pad_value, params->move_threshold);
+  if (rc) return rc;
+  hipLaunchKernelGGL(paste_kernel, dim3(19, n), dim3(512), 0, e->stream,
+                     e->d_items, g, e->logits, e->in_seed, e->count,
+                     params->move_threshold, params->disco_seed_threshold,
+                     e->d_results);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(e->h_results, e->d_results, sizeof(ffn_step_result) * n,
+                         hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::memcpy(results, e->h_results, sizeof(ffn_step_result) * n);
+  return FFN_OK;
+}
+
+int ffn_canvas_read_points(ffn_canvas* c, int n, const int32_t* pos,
+                           float* seed_out, int32_t* seg_out) {
+  if (!c || !pos || !seed_out || !seg_out) return fail(FFN_ERR_ARG, "null argument");
+  if (n < 1) return FFN_OK;
+  ffn_engine* e = c->engine;
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t pb = sizeof(int32_t) * 3 * n;
+  const size_t pbr = (pb + 15) & ~(size_t)15;
+  int rc = ensure_scratch(e, pbr + 8 * (size_t)n);
+  if (rc) return rc;
+  char* hs = static_cast<char*>(e->h_scratch);
+  char* ds = static_cast<char*>(e->d_scratch);
+  std::memcpy(hs, pos, pb);
+  HIP_TRY(hipMemcpyAsync(ds, hs, pb, hipMemcpyHostToDevice, e->stream));
+  float* d_seed = reinterpret_cast<float*>(ds + pbr);
+  int32_t* d_seg = reinterpret_cast<int32_t*>(ds + pbr + 4 * (size_t)n);
+  hipLaunchKernelGGL(points_read_kernel, dim3((n + 63) / 64), dim3(64), 0,
+                     e->stream, c->seed, c->seg, c->cz, c->cy, c->cx, n,
+                     reinterpret_cast<const int32_t*>(ds), d_seed, d_seg);
+  HIP_TRY(hipMemcpyAsync(hs + pbr, ds + pbr, 8 * (size_t)n, hipMemcpyDeviceToHost,
+                         e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::memcpy(seed_out, hs + pbr, 4 * (size_t)n);
+  std::memcpy(seg_out, hs + pbr + 4 * (size_t)n, 4 * (size_t)n);
+  return FFN_OK;
+}
+
+int ffn_canvas_write_seg_points(ffn_canvas* c, int n, const int32_t* pos,
+                                const int32_t* values) {
+  if (!c || !pos || !values) return fail(FFN_ERR_ARG, "null argument");
+  if (n < 1) return FFN_OK;
+  for (int k = 0; k < n; ++k)
+    if (pos[3 * k] < 0 || pos[3 * k] >= c->cz || pos[3 * k + 1] < 0 ||
+        pos[3 * k + 1] >= c->cy || pos[3 * k + 2] < 0 || pos[3 * k + 2] >= c->cx)
+      return fail(FFN_ERR_ARG, "point %d outside the canvas", k);
+  ffn_engine* e = c->engine;
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t pb = sizeof(int32_t) * 3 * n;
+  const size_t pbr = (pb + 15) & ~(size_t)15;
+  int rc = ensure_scratch(e, pbr + 4 * (size_t)n);
+  if (rc) return rc;
+  char* hs = static_cast<char*>(e->h_scratch);
+  char* ds = static_cast<char*>(e->d_scratch);
+  std::memcpy(hs, pos, pb);
+  std::memcpy(hs + pbr, values, 4 * (size_t)n);
+  HIP_TRY(hipMemcpyAsync(ds, hs, pbr + 4 * (size_t)n, hipMemcpyHostToDevice,
+                         e->stream));
+  hipLaunchKernelGGL(points_write_seg_kernel, dim3((n + 63) / 64), dim3(64), 0,
+                     e->stream, c->seg, c->cy, c->cx, n,
+                     reinterpret_cast<const int32_t*>(ds),
+                     reinterpret_cast<const int32_t*>(ds + pbr));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return FFN_OK;
+}
+
+int ffn_canvas_any_segmented(ffn_canvas* c, const int32_t lo[3],
+                             const int32_t hi[3], int32_t* out) {
+  if (!c || !lo || !hi || !out) return fail(FFN_ERR_ARG, "null argument");
+  // numpy slicing clips to the array bounds (inference.py:575-578)
+  int32_t l[3], h[3];
+  const int dims[3] = {c->cz, c->cy, c->cx};
+  for (int k = 0; k < 3; ++k) {
+    l[k] = std::max(lo[k], 0);
+    h[k] = std::min(hi[k], dims[k]);
+    if (h[k] <= l[k]) {
+      *out = 0;
+      return FFN_OK;
+    }
+  }
+  ffn_engine* e = c->engine;
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = ensure_scratch(e, 16);
+  if (rc) return rc;
+  long total;
+  Box b = make_box(c, l, h, &total);
+  HIP_TRY(hipMemsetAsync(e->d_scratch, 0, 4, e->stream));
+  hipLaunchKernelGGL(any_segmented_kernel, dim3(grid_for(total)), dim3(256), 0,
+                     e->stream, c->seg, b, total,
+                     static_cast<int32_t*>(e->d_scratch));
+  HIP_TRY(hipMemcpyAsync(e->h_scratch, e->d_scratch, 4, hipMemcpyDeviceToHost,
+                         e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *out = *static_cast<int32_t*>(e->h_scratch);
+  return FFN_OK;
+}
+
+int ffn_canvas_commit_count(ffn_canvas* c, const int32_t lo[3],
+                            const int32_t hi[3], float segment_threshold,
+                            int32_t max_existing_id, ffn_commit_counts* counts,
+                            int32_t max_overlaps, int32_t* overlap_ids,
+                            int64_t* overlap_counts) {
+  if (!c || !lo || !hi || !counts) return fail(FFN_ERR_ARG, "null argument");
+  int rc = check_box(c, lo, hi);
+  if (rc) return rc;
+  if (max_existing_id < 0) max_existing_id = 0;
+  ffn_engine* e = c->engine;
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t hist_n = (size_t)max_existing_id + 1;
+  const size_t bytes = 16 + hist_n * sizeof(unsigned);
+  rc = ensure_scratch(e, bytes);
+  if (rc) return rc;
+  long total;
+  Box b = make_box(c, lo, hi, &total);
+  HIP_TRY(hipMemsetAsync(e->d_scratch, 0, bytes, e->stream));
+  auto* d_counts = static_cast<unsigned long long*>(e->d_scratch);
+  auto* d_hist = reinterpret_cast<unsigned*>(static_cast<char*>(e->d_scratch) + 16);
+  if (total > 0)
+    hipLaunchKernelGGL(commit_count_kernel, dim3(grid_for(total)), dim3(256), 0,
+                       e->stream, c->seed, c->seg, b, total, segment_threshold,
+                       max_existing_id, d_counts, d_hist);
+  HIP_TRY(hipMemcpyAsync(e->h_scratch, e->d_scratch, bytes, hipMemcpyDeviceToHost,
+                         e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const auto* hc = static_cast<const unsigned long long*>(e->h_scratch);
+  const auto* hh = reinterpret_cast<const unsigned*>(
+      static_cast<const char*>(e->h_scratch) + 16);
+  counts->raw_segmented_voxels = (int64_t)hc[0];
+  counts->actual_segmented_voxels = (int64_t)hc[1];
+  int nover = 0;
+  for (size_t id = 1; id < hist_n; ++id) {
+    if (hh[id]) {
+      if (nover < max_overlaps && overlap_ids && overlap_counts) {
+        overlap_ids[nover] = (int32_t)id;
+        overlap_counts[nover] = (int64_t)hh[id];
+      }
+      ++nover;
+    }
+  }
+  counts->num_overlapped_ids = nover;
+  return FFN_OK;
+}
+
+int ffn_canvas_commit_assign(ffn_canvas* c, const int32_t lo[3],
+                             const int32_t hi[3], float segment_threshold,
+                             int32_t segment_id) {
+  if (!c || !lo || !hi) return fail(FFN_ERR_ARG, "null argument");
+  int rc = check_box(c, lo, hi);
+  if (rc) return rc;
+  ffn_engine* e = c->engine;
+  HIP_TRY(hipSetDevice(e->device));
+  long total;
+  Box b = make_box(c, lo, hi, &total);
+  if (total > 0)
+    hipLaunchKernelGGL(commit_assign_kernel, dim3(grid_for(total)), dim3(256), 0,
+                       e->stream, c->seed, c->seg, b, total, segment_threshold,
+                       segment_id);
+  HIP_TRY(hipGetLastError());
+  return FFN_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <typename T>
+int box_read(ffn_canvas* c, const T* vol, const int32_t lo[3], const int32_t hi[3],
+             T* dst) {
+  if (!c || !lo || !hi || !dst) return fail(FFN_ERR_ARG, "null argument");
+  int rc = check_box(c, lo, hi);
+  if (rc) return rc;
+  ffn_engine* e = c->engine;
+  HIP_TRY(hipSetDevice(e->device));
+  long total;
+  Box b = make_box(c, lo, hi, &total);
+  if (total == 0) return FFN_OK;
+  if (total == (long)c->nvox) {  // whole volume: straight copy
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(dst, vol, sizeof(T) * total, hipMemcpyDeviceToHost));
+    return FFN_OK;
+  }
+  rc = ensure_scratch(e, sizeof(T) * total);
+  if (rc) return rc;
+  hipLaunchKernelGGL((box_read_kernel<T>), dim3(grid_for(total)), dim3(256), 0,
+                     e->stream, vol, b, total, static_cast<T*>(e->d_scratch));
+  HIP_TRY(hipMemcpyAsync(e->h_scratch, e->d_scratch, sizeof(T) * total,
+                         hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::memcpy(dst, e->h_scratch, sizeof(T) * total);
+  return FFN_OK;
+}
+
+template <typename T>
+int box_write(ffn_canvas* c, T* vol, const int32_t lo[3], const int32_t hi[3],
+              const T* src) {
+  if (!c || !lo || !hi || !src) return fail(FFN_ERR_ARG, "null argument");
+  int rc = check_box(c, lo, hi);
+  if (rc) return rc;
+  ffn_engine* e = c->engine;
+  HIP_TRY(hipSetDevice(e->device));
+  long total;
+  Box b = make_box(c, lo, hi, &total);
+  if (total == 0) return FFN_OK;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (total == (long)c->nvox) {
+    HIP_TRY(hipMemcpy(vol, src, sizeof(T) * total, hipMemcpyHostToDevice));
+    return FFN_OK;
+  }
+  rc = ensure_scratch(e, sizeof(T) * total);
+  if (rc) return rc;
+  std::memcpy(e->h_scratch, src, sizeof(T) * total);
+  HIP_TRY(hipMemcpyAsync(e->d_scratch, e->h_scratch, sizeof(T) * total,
+                         hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL((box_write_kernel<T>), dim3(grid_for(total)), dim3(256), 0,
+                     e->stream, vol, b, total,
+                     static_cast<const T*>(e->d_scratch));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return FFN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ffn_canvas_read_seed(ffn_canvas* c, const int32_t lo[3], const int32_t hi[3],
+                         float* dst) {
+  return box_read<float>(c, c ? c->seed : nullptr, lo, hi, dst);
+}
+
+int ffn_canvas_read_segmentation(ffn_canvas* c, const int32_t lo[3],
+                                 const int32_t hi[3], int32_t* dst) {
+  return box_read<int32_t>(c, c ? c->seg : nullptr, lo, hi, dst);
+}
+
+int ffn_canvas_write_seed(ffn_canvas* c, const int32_t lo[3], const int32_t hi[3],
+                          const float* src) {
+  return box_write<float>(c, c ? c->seed : nullptr, lo, hi, src);
+}
+
+int ffn_canvas_write_segmentation(ffn_canvas* c, const int32_t lo[3],
+                                  const int32_t hi[3], const int32_t* src) {
+  return box_write<int32_t>(c, c ? c->seg : nullptr, lo, hi, src);
+}
+
+}  // extern "C"

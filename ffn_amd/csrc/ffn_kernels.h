@@ -1,0 +1,746 @@
+// Device kernels of the MI355X (gfx950 / CDNA4) FFN field-of-view engine.
+//
+// Written for gfx950 only: 64-wide wavefronts, v_mfma_f32_16x16x4_f32 (exact f32
+// MFMA, bitwise an fmaf chain), 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+//
+// Activation layout in HBM ("padded flat", channels last):
+//   position p = z*plane + y*XS + x,  XS = fx+1, plane = (fy+1)*XS
+//   one zero column (x = fx) and one zero row (y = fy) are shared between
+//   neighbouring rows / planes, and a zero guard of plane+XS+1 positions sits
+//   in front of and behind the FoV, so EVERY 3x3x3 tap of EVERY position is a
+//   plain constant offset  dz*plane + dy*XS + dx  -- the SAME zero padding of
+//   tf_slim.convolution3d (reference convstack_3d.py:28-31) without a single
+//   bounds test in the inner loop.  Invalid (padding) positions are never
+//   written, so they stay zero for the lifetime of the engine.
+//   Each position holds 32 channels = 128 B = one cache line.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ffn_hip.h"
+
+namespace ffn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFeatures = 32;
+constexpr int kChunk = 160;          // output positions per workgroup
+constexpr int kTile = 16;            // positions per MFMA M-tile
+constexpr int kTilesPerWave = 5;     // 2 tile groups x 5 tiles = 10 tiles = kChunk
+constexpr int kConvThreads = 256;    // 4 waves: (nhalf, tile group)
+
+struct Geom {
+  int fz, fy, fx;      // FoV (zyx)
+  int dz, dy, dx;      // deltas (zyx)
+  int XS, plane;       // padded strides (positions)
+  int npos;            // fz * plane
+  int guard;           // plane + XS + 1
+  int nchunks;         // ceil(npos / kChunk)
+  int V;               // fz*fy*fx
+  int R;               // LDS rows per dz segment = kChunk + 2*(XS+1)
+  long act_stride;     // floats per FoV activation buffer
+};
+
+// Per-FoV step descriptor read by the gather / paste kernels.
+struct StepItem {
+  const float* image;
+  float* seed;
+  const int32_t* seg;
+  int cz, cy, cx;
+  ffn_step_request req;
+};
+
+// ---------------------------------------------------------------------------
+// gather: canvas image/seed FoV -> dense staging  (reference inference.py:348-354,
+// 399-405).  NaN ("never visited") is kept; consumers substitute pad_value.
+// ---------------------------------------------------------------------------
+__global__ void gather_kernel(const StepItem* __restrict__ items, Geom g,
+                              float* __restrict__ in_image,
+                              float* __restrict__ in_seed) {
+  const StepItem& it = items[blockIdx.y];
+  const int z0 = it.req.pos[0] - g.fz / 2;
+  const int y0 = it.req.pos[1] - g.fy / 2;
+  const int x0 = it.req.pos[2] - g.fx / 2;
+  const size_t base = (size_t)blockIdx.y * g.V;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < g.V;
+       v += gridDim.x * blockDim.x) {
+    const int x = v % g.fx;
+    const int t = v / g.fx;
+    const int y = t % g.fy;
+    const int z = t / g.fy;
+    const size_t ci = ((size_t)(z0 + z) * it.cy + (y0 + y)) * it.cx + (x0 + x);
+    in_image[base + v] = it.image[ci];
+    in_seed[base + v] = it.seed[ci];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// conv0_a: concat(image, seed) -> 3x3x3 conv 2->32 + bias + ReLU
+// (reference convstack_3d.py:38,86).  K = 54 only: VALU, weights through the
+// scalar cache (wave-uniform addresses).  One thread per padded position.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv0a_kernel(
+    const float* __restrict__ in_image, const float* __restrict__ in_seed,
+    float pad_value, const float* __restrict__ w /*[27][2][32]*/,
+    const float* __restrict__ bias, float* __restrict__ out, Geom g) {
+  const int item = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= g.npos) return;
+  const int z = p / g.plane;
+  const int rem = p - z * g.plane;
+  const int y = rem / g.XS;
+  const int x = rem - y * g.XS;
+  if (y >= g.fy || x >= g.fx) return;  // shared halo row / column: stays zero
+  const float* img = in_image + (size_t)item * g.V;
+  const float* sd = in_seed + (size_t)item * g.V;
+
+  float acc[kFeatures];
+#pragma unroll
+  for (int c = 0; c < kFeatures; ++c) acc[c] = 0.0f;
+
+#pragma unroll 1
+  for (int kz = 0; kz < 3; ++kz) {
+    const int zz = z + kz - 1;
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = x + kx - 1;
+        float a0 = 0.0f, a1 = 0.0f;
+        if (zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy && xx >= 0 &&
+            xx < g.fx) {
+          const int v = (zz * g.fy + yy) * g.fx + xx;
+          a0 = img[v];
+          a1 = sd[v];
+          if (a1 != a1) a1 = pad_value;  // NaN -> pad (inference.py:406-407)
+        }
+        const float* wt = w + ((kz * 3 + ky) * 3 + kx) * 2 * kFeatures;
+#pragma unroll
+        for (int c = 0; c < kFeatures; ++c) {
+          acc[c] = __builtin_fmaf(a0, wt[c], acc[c]);
+          acc[c] = __builtin_fmaf(a1, wt[kFeatures + c], acc[c]);
+        }
+      }
+    }
+  }
+  float* o = out + (size_t)item * g.act_stride + (size_t)p * kFeatures;
+#pragma unroll
+  for (int c = 0; c < kFeatures; c += 4) {
+    float4 v;
+    v.x = fmaxf(acc[c + 0] + bias[c + 0], 0.0f);
+    v.y = fmaxf(acc[c + 1] + bias[c + 1], 0.0f);
+    v.z = fmaxf(acc[c + 2] + bias[c + 2], 0.0f);
+    v.w = fmaxf(acc[c + 3] + bias[c + 3], 0.0f);
+    *reinterpret_cast<float4*>(o + c) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// conv32: 3x3x3 conv 32->32 as an implicit GEMM on the exact-f32 MFMA
+// (reference convstack_3d.py:39,45-47; 23 of the 24 convs of a depth-12 stack,
+// 99.7 % of the FLOPs).
+//
+//   M = positions (16 per MFMA tile), N = 32 couts (two halves of 16),
+//   K = 27 taps x 32 cin  (8 k-steps of 4 per tap).
+//
+// Workgroup = 4 waves = one chunk of 160 consecutive padded positions.
+//   wave w: nhalf = w & 1 (which 16 couts), tile group = w >> 1 (which 5 tiles)
+//   -> 5 independent accumulator chains per wave (f32x4 each): the 40-cycle
+//      dependent latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle
+//      issue rate.
+// Operands:
+//   A (activations): the chunk plus its halo (3 dz-segments of R rows x 128 B)
+//      is staged ONCE into LDS (ReLU fused into the staging when RELU_IN); the
+//      16-byte quads of a row are XOR-swizzled with (row & 7) so that the
+//      ds_read_b128 of 16 consecutive rows is bank-conflict free for every tap
+//      offset.  One b128 read yields the A operand of 4 k-steps (K is
+//      permuted so that lane group g owns channels 16h+4g..+3).
+//   B (weights): host-packed so that each lane's 8 values per tap are two
+//      coalesced 16-byte global loads; streamed L2 -> registers one tap ahead
+//      (no LDS, no barrier in the main loop).
+// ---------------------------------------------------------------------------
+struct ConvArgs {
+  const float* in;     // logical origin of item 0
+  float* out;
+  const float* skip;   // may alias out (in-place residual add)
+  const float* wpack;  // [27][2][2][64][4]
+  const float* bias;   // [32]
+  const uint8_t* valid;  // [nchunks * kChunk]
+  long act_stride;
+  int XS, plane, R, nchunks;
+};
+
+template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP>
+__global__ __launch_bounds__(kConvThreads) void conv32_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int item = blockIdx.x / a.nchunks;
+  const int chunk = blockIdx.x - item * a.nchunks;
+  const int m0 = chunk * kChunk;
+  const float* src = a.in + (size_t)item * a.act_stride;
+
+  // ---- stage chunk + halo into LDS (3 dz segments) ----
+  const int R = a.R;
+  const int nf4 = R * 8;
+#pragma unroll 1
+  for (int seg = 0; seg < 3; ++seg) {
+    const long p0 = (long)m0 - (a.XS + 1) + (long)(seg - 1) * a.plane;
+    const float* s = src + p0 * kFeatures;
+    const int row0 = seg * R;
+#pragma unroll 4
+    for (int e = tid; e < nf4; e += kConvThreads) {
+      const int r = e >> 3, q = e & 7;
+      float4 v = *reinterpret_cast<const float4*>(s + (size_t)e * 4);
+      if (RELU_IN) {
+        v.x = fmaxf(v.x, 0.0f);
+        v.y = fmaxf(v.y, 0.0f);
+        v.z = fmaxf(v.z, 0.0f);
+        v.w = fmaxf(v.w, 0.0f);
+      }
+      const int row = row0 + r;
+      *reinterpret_cast<float4*>(lds + row * 32 + ((q ^ (row & 7)) << 2)) = v;
+    }
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nhalf = wave & 1;
+  const int tgrp = wave >> 1;
+  const int i = lane & 15;
+  const int grp = lane >> 4;
+
+  f32x4 acc[kTilesPerWave];
+#pragma unroll
+  for (int t = 0; t < kTilesPerWave; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int rbase = (a.XS + 1) + tgrp * kTilesPerWave * kTile + i;
+  const f32x4* wp =
+      reinterpret_cast<const f32x4*>(a.wpack) + nhalf * 128 + lane;
+
+  f32x4 b0 = wp[0], b1 = wp[64];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) {
+    f32x4 nb0 = b0, nb1 = b1;
+    if (tap + 1 < 27) {
+      nb0 = wp[(tap + 1) * 256];
+      nb1 = wp[(tap + 1) * 256 + 64];
+    }
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    const int tapoff = kz * R + (ky - 1) * a.XS + (kx - 1);
+    f32x4 a0[kTilesPerWave], a1[kTilesPerWave];
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t) {
+      const int row = rbase + t * kTile + tapoff;
+      const int ad = row * 32 + ((grp ^ (row & 7)) << 2);
+      a0[t] = *reinterpret_cast<const f32x4*>(lds + ad);
+      a1[t] = *reinterpret_cast<const f32x4*>(lds + (ad ^ 16));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int t = 0; t < kTilesPerWave; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t][s], b0[s], acc[t],
+                                                      0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int t = 0; t < kTilesPerWave; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][s], b1[s], acc[t],
+                                                      0, 0, 0);
+    }
+    b0 = nb0;
+    b1 = nb1;
+  }
+
+  // ---- epilogue: D[row = grp*4 + r][col = i] -> out[pos][16*nhalf + i] ----
+  const int co = nhalf * 16 + i;
+  const float bv = a.bias[co];
+  float* dst = a.out + (size_t)item * a.act_stride;
+  const float* skp = ADD_SKIP ? a.skip + (size_t)item * a.act_stride : nullptr;
+#pragma unroll
+  for (int t = 0; t < kTilesPerWave; ++t) {
+    const int pbase = m0 + (tgrp * kTilesPerWave + t) * kTile + grp * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = pbase + r;
+      if (a.valid[p]) {
+        float v = acc[t][r] + bv;
+        if (RELU_OUT) v = fmaxf(v, 0.0f);
+        if (ADD_SKIP) v += skp[(size_t)p * kFeatures + co];
+        dst[(size_t)p * kFeatures + co] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// conv32p: the software-pipelined production variant of conv32.
+//
+// Same math and operand layout as conv32_kernel, plus:
+//  * inputs are PRE-ACTIVATED: conv0_b / conv_b epilogues store both the raw
+//    residual stream X (needed by the skip add) and relu(X) (DUAL_OUT), so the
+//    staging is a pure copy with all loads in flight at once (24 x 16 B per
+//    lane) instead of 4-deep load -> max -> ds_write rounds;
+//  * explicit double-buffered A fragments (LDS -> VGPR one half-tap ahead) and a
+//    3-deep B ring (L2 -> VGPR two half-taps = 1280 MFMA-cycles ahead), pinned
+//    with sched_barrier so the 20 MFMAs of a half-tap never wait on the
+//    ds_read / global_load issued for the next one;
+//  * XCD-aware block -> chunk mapping: block b runs on XCD b % 8, so XCD k gets
+//    the contiguous chunk range [k*q, (k+1)*q): the 4.3x halo re-reads of
+//    neighbouring chunks hit the same 4 MiB L2 instead of crossing the fabric;
+//  * the padding-position mask comes from 5 scalar dwords per chunk.
+// ---------------------------------------------------------------------------
+struct ConvPArgs {
+  const float* in;       // pre-activated input, logical origin of item 0
+  float* out;            // RELU_OUT ? relu(conv) : conv (+ skip)
+  float* out_relu;       // DUAL_OUT: relu(out)
+  const float* skip;     // may alias out
+  const float* wpack;    // [27][2][2][64][4]
+  const float* bias;     // [32]
+  const uint32_t* validbits;  // [nchunks][5]
+  long act_stride;
+  int XS, plane, R, nchunks;
+  int total_slots, slots_per_xcd;
+};
+
+#define FFN_MFMA20(AC, BC)                                                    \
+  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                          \
+    _Pragma("unroll") for (int t_ = 0; t_ < kTilesPerWave; ++t_) acc[t_] =    \
+        __builtin_amdgcn_mfma_f32_16x16x4f32(AC[t_][s_], BC[s_], acc[t_], 0,  \
+                                             0, 0);                           \
+  }
+
+template <bool RELU_OUT, bool ADD_SKIP, bool DUAL_OUT>
+__global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
+  if (gc >= a.total_slots) return;
+  const int item = gc / a.nchunks;
+  const int chunk = gc - item * a.nchunks;
+  const int m0 = chunk * kChunk;
+  const float* src = a.in + (size_t)item * a.act_stride;
+  const int R = a.R;
+
+  // ---- stage chunk + halo: all loads first, then all LDS writes ----
+  // Host guarantees 7*256 <= R*8 <= 8*256 (31 <= XS <= 47): slots k < 7 need no
+  // bounds test, only the last one does.
+  {
+    const int nf4 = R * 8;
+    f32x4 v[3][8];
+#pragma unroll
+    for (int seg = 0; seg < 3; ++seg) {
+      const long p0 = (long)m0 - (a.XS + 1) + (long)(seg - 1) * a.plane;
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) v[seg][k] = s4[tid + k * kConvThreads];
+      const int e7 = tid + 7 * kConvThreads;
+      v[seg][7] = s4[e7 < nf4 ? e7 : tid];  // clamp: always a legal address
+    }
+#pragma unroll
+    for (int seg = 0; seg < 3; ++seg) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = tid + k * kConvThreads;
+        if (k < 7 || e < nf4) {
+          const int row = seg * R + (e >> 3);
+          const int q = e & 7;
+          *reinterpret_cast<f32x4*>(lds + row * 32 + ((q ^ (row & 7)) << 2)) =
+              v[seg][k];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nhalf = wave & 1;
+  const int tgrp = wave >> 1;
+  const int i = lane & 15;
+  const int grp = lane >> 4;
+
+  f32x4 acc[kTilesPerWave];
+#pragma unroll
+  for (int t = 0; t < kTilesPerWave; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int rbase = (a.XS + 1) + tgrp * kTilesPerWave * kTile + i;
+  const f32x4* wp =
+      reinterpret_cast<const f32x4*>(a.wpack) + nhalf * 128 + lane;
+
+  // half-tap ht = 2*tap + h: A = 5 x ds_read_b128, B = 1 x global_load_dwordx4
+  auto loadA = [&](int ht, f32x4(&dst)[kTilesPerWave]) {
+    const int tap = ht >> 1, h = ht & 1;
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    const int row = rbase + kz * R + (ky - 1) * a.XS + (kx - 1);
+    const int ad = (row * 32 + ((grp ^ (row & 7)) << 2)) ^ (h << 4);
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t)
+      dst[t] = *reinterpret_cast<const f32x4*>(lds + ad + t * (kTile * 32));
+  };
+  auto loadB = [&](int ht) -> f32x4 {
+    return wp[(ht >> 1) * 256 + (ht & 1) * 64];
+  };
+
+  f32x4 A0[kTilesPerWave], A1[kTilesPerWave];
+  f32x4 B0, B1, B2;
+  loadA(0, A0);
+  B0 = loadB(0);
+  B1 = loadB(1);
+
+#define FFN_STEP(K, ACUR, ANEXT, BCUR, BNEXT2)        \
+  if ((K) + 1 < 54) loadA((K) + 1, ANEXT);            \
+  if ((K) + 2 < 54) BNEXT2 = loadB((K) + 2);          \
+  __builtin_amdgcn_sched_barrier(0);                  \
+  FFN_MFMA20(ACUR, BCUR)                              \
+  __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+  for (int ht = 0; ht < 54; ht += 6) {
+    FFN_STEP(ht + 0, A0, A1, B0, B2)
+    FFN_STEP(ht + 1, A1, A0, B1, B0)
+    FFN_STEP(ht + 2, A0, A1, B2, B1)
+    FFN_STEP(ht + 3, A1, A0, B0, B2)
+    FFN_STEP(ht + 4, A0, A1, B1, B0)
+    FFN_STEP(ht + 5, A1, A0, B2, B1)
+  }
+#undef FFN_STEP
+
+  // ---- epilogue: D[row = grp*4 + r][col = i] -> out[pos][16*nhalf + i] ----
+  const int co = nhalf * 16 + i;
+  const float bv = a.bias[co];
+  const size_t ibase = (size_t)item * a.act_stride;
+  const uint32_t* vb = a.validbits + chunk * 5;
+#pragma unroll
+  for (int t = 0; t < kTilesPerWave; ++t) {
+    const int tile = tgrp * kTilesPerWave + t;       // wave-uniform
+    const uint32_t word = vb[tile >> 1];             // scalar load
+    const int bit0 = (tile & 1) * 16 + grp * 4;
+    const size_t pbase = (size_t)(m0 + tile * kTile + grp * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if ((word >> (bit0 + r)) & 1u) {
+        const size_t o = ibase + (pbase + r) * kFeatures + co;
+        float v = acc[t][r] + bv;
+        if (RELU_OUT) v = v > 0.0f ? v : 0.0f;
+        if (ADD_SKIP) v += a.skip[o];
+        a.out[o] = v;
+        if (DUAL_OUT) a.out_relu[o] = v > 0.0f ? v : 0.0f;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// head: ReLU -> 1x1x1 conv 32->1 + bias; logits = seed + update
+// (reference convstack_3d.py:51-54,91-94; model.py:168-183) and the count of
+// logits >= move_threshold that the disco test needs (inference.py:428-431).
+// 8 lanes per voxel: one coalesced 128-B line per voxel, xor-shuffle reduce.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(
+    const float* __restrict__ X, const float* __restrict__ in_seed,
+    float pad_value, const float* __restrict__ wl /*[32] + bias*/,
+    float move_thr, float* __restrict__ logits, unsigned* __restrict__ count,
+    Geom g) {
+  const int item = blockIdx.y;
+  const int sub = threadIdx.x & 7;
+  const int v = (blockIdx.x * 256 + threadIdx.x) >> 3;
+  float partial = 0.0f;
+  const bool live = v < g.V;
+  if (live) {
+    const int x = v % g.fx;
+    const int t = v / g.fx;
+    const int y = t % g.fy;
+    const int z = t / g.fy;
+    const size_t p = (size_t)z * g.plane + y * g.XS + x;
+    const float4 a = *reinterpret_cast<const float4*>(
+        X + (size_t)item * g.act_stride + p * kFeatures + sub * 4);
+    const float4 w4 = *reinterpret_cast<const float4*>(wl + sub * 4);
+    // max(0, .) is idempotent, so this is correct for raw and pre-activated X
+    partial = fmaxf(a.x, 0.f) * w4.x;
+    partial = __builtin_fmaf(fmaxf(a.y, 0.f), w4.y, partial);
+    partial = __builtin_fmaf(fmaxf(a.z, 0.f), w4.z, partial);
+    partial = __builtin_fmaf(fmaxf(a.w, 0.f), w4.w, partial);
+  }
+  partial += __shfl_xor(partial, 1);
+  partial += __shfl_xor(partial, 2);
+  partial += __shfl_xor(partial, 4);
+  unsigned above = 0;
+  if (live && sub == 0) {
+    float s = in_seed[(size_t)item * g.V + v];
+    if (s != s) s = pad_value;
+    const float lg = s + (partial + wl[kFeatures]);
+    logits[(size_t)item * g.V + v] = lg;
+    above = lg >= move_thr ? 1u : 0u;
+  }
+  // wavefront reduction of the count, one atomic per wave
+  const unsigned long long m = __ballot(above != 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&count[item], (unsigned)__popcll(m));
+}
+
+// ---------------------------------------------------------------------------
+// paste: disco bias + write-back into the canvas seed (inference.py:416-439),
+// 6-face max/argmax for the movement policy (movement.py:67-100), and the point
+// reads the host queue needs next (inference.py:325,341,503).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float post_disco(float lg, float old, bool disco) {
+  // mask = (old < logit(0.5) == 0) & (logits > old); NaN old -> false.
+  return (disco && old < 0.0f && lg > old) ? old : lg;
+}
+
+__device__ __forceinline__ bool disco_on(unsigned cnt, int V, float thr) {
+  // np.mean(bool array) is an f64 division; the threshold is an f32 proto field.
+  return thr >= 0.0f && ((double)cnt / (double)V) > (double)thr;
+}
+
+__global__ __launch_bounds__(512) void paste_kernel(
+    const StepItem* __restrict__ items, Geom g, const float* __restrict__ logits,
+    const float* __restrict__ in_seed, const unsigned* __restrict__ count,
+    float move_thr, float disco_thr, ffn_step_result* __restrict__ results) {
+  const int item = blockIdx.y;
+  const StepItem& it = items[item];
+  const unsigned cnt = count[item];
+  const bool disco = disco_on(cnt, g.V, disco_thr);
+  const float* lg = logits + (size_t)item * g.V;
+  const float* old = in_seed + (size_t)item * g.V;
+  const int z0 = it.req.pos[0] - g.fz / 2;
+  const int y0 = it.req.pos[1] - g.fy / 2;
+  const int x0 = it.req.pos[2] - g.fx / 2;
+
+  if (blockIdx.x + 1 < gridDim.x) {
+    const int nb = gridDim.x - 1;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < g.V;
+         v += nb * blockDim.x) {
+      const int x = v % g.fx;
+      const int t = v / g.fx;
+      const int y = t % g.fy;
+      const int z = t / g.fy;
+      const size_t ci =
+          ((size_t)(z0 + z) * it.cy + (y0 + y)) * it.cx + (x0 + x);
+      it.seed[ci] = post_disco(lg[v], old[v], disco);
+    }
+    return;
+  }
+
+  // ---- last block: wave 0..5 = faces, wave 6 = start + candidates ----
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  ffn_step_result& res = results[item];
+  if (wave < 6) {
+    const int axis = wave >> 1;
+    const int sign = (wave & 1) ? 1 : -1;
+    const int cz = g.fz / 2, cy = g.fy / 2, cx = g.fx / 2;
+    // face rows / cols = the two non-fixed axes in zyx order (selects, not
+    // runtime-indexed arrays: those would live in scratch memory)
+    const int nr = axis == 0 ? 2 * g.dy + 1 : 2 * g.dz + 1;
+    const int nc = axis == 2 ? 2 * g.dy + 1 : 2 * g.dx + 1;
+    float best = -__builtin_inff();
+    int besti = 0x7fffffff;
+    bool any = false;
+    for (int e = lane; e < nr * nc; e += 64) {
+      const int fi = e / nc, fj = e - fi * nc;
+      const int z = axis == 0 ? cz + sign * g.dz : cz - g.dz + fi;
+      const int y = axis == 1 ? cy + sign * g.dy
+                              : (axis == 0 ? cy - g.dy + fi : cy - g.dy + fj);
+      const int x = axis == 2 ? cx + sign * g.dx : cx - g.dx + fj;
+      const int v = (z * g.fy + y) * g.fx + x;
+      const float val = post_disco(lg[v], old[v], disco);
+      if (!any || val > best) {  // strict >: first occurrence wins
+        best = val;
+        besti = e;
+        any = true;
+      }
+    }
+    if (!any) {
+      best = -__builtin_inff();
+      besti = 0x7fffffff;
+    }
+    // wavefront argmax reduction, ties -> smaller flat index (np.argmax order)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off);
+      const int oi = __shfl_xor(besti, off);
+      if (ob > best || (ob == best && oi < besti)) {
+        best = ob;
+        besti = oi;
+      }
+    }
+    if (lane == 0) {
+      res.face_score[wave] = best;
+      res.face_index[wave] = besti;
+      int sg = 0;
+      if (besti != 0x7fffffff) {
+        const int fi = besti / nc, fj = besti - fi * nc;
+        const int z = axis == 0 ? cz + sign * g.dz : cz - g.dz + fi;
+        const int y = axis == 1 ? cy + sign * g.dy
+                                : (axis == 0 ? cy - g.dy + fi : cy - g.dy + fj);
+        const int x = axis == 2 ? cx + sign * g.dx : cx - g.dx + fj;
+        sg = it.seg[((size_t)(z0 + z) * it.cy + (y0 + y)) * it.cx + (x0 + x)];
+      }
+      res.face_seg[wave] = sg;
+    }
+  } else if (wave == 6) {
+    // point reads: inside the FoV -> value being pasted by the other blocks of
+    // this launch (recomputed here, so no read-after-write race); outside ->
+    // the canvas, which this launch does not touch there.
+    const int n = it.req.num_candidates;
+    if (lane <= n && lane <= FFN_MAX_CANDIDATES) {
+      const int32_t* q = lane == 0 ? it.req.start_pos : it.req.candidates[lane - 1];
+      const int z = q[0], y = q[1], x = q[2];
+      float sv = __builtin_nanf("");
+      int gv = 0;
+      if (z >= 0 && z < it.cz && y >= 0 && y < it.cy && x >= 0 && x < it.cx) {
+        const int lz = z - z0, ly = y - y0, lx = x - x0;
+        const size_t ci = ((size_t)z * it.cy + y) * it.cx + x;
+        if (lz >= 0 && lz < g.fz && ly >= 0 && ly < g.fy && lx >= 0 &&
+            lx < g.fx) {
+          const int v = (lz * g.fy + ly) * g.fx + lx;
+          sv = post_disco(lg[v], old[v], disco);
+        } else {
+          sv = it.seed[ci];
+        }
+        gv = it.seg[ci];
+      }
+      if (lane == 0) {
+        res.start_logit = sv;
+        res.num_above_move = cnt;
+        res.disco_applied = disco ? 1 : 0;
+      } else {
+        res.cand_seed[lane - 1] = sv;
+        res.cand_seg[lane - 1] = gv;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Canvas utility kernels (integer / byte work, HBM-bound).
+// ---------------------------------------------------------------------------
+struct Box {
+  int lo[3];
+  int n[3];      // extent
+  int cy, cx;    // canvas strides
+};
+
+__device__ __forceinline__ size_t box_index(const Box& b, long e) {
+  const int x = e % b.n[2];
+  const long t = e / b.n[2];
+  const int y = t % b.n[1];
+  const int z = t / b.n[1];
+  return ((size_t)(b.lo[0] + z) * b.cy + (b.lo[1] + y)) * b.cx + (b.lo[2] + x);
+}
+
+template <typename T>
+__global__ void box_read_kernel(const T* __restrict__ vol, Box b, long total,
+                                T* __restrict__ dst) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x)
+    dst[e] = vol[box_index(b, e)];
+}
+
+template <typename T>
+__global__ void box_write_kernel(T* __restrict__ vol, Box b, long total,
+                                 const T* __restrict__ src) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x)
+    vol[box_index(b, e)] = src[e];
+}
+
+__global__ void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, size_t n) {
+  // 16-byte stores, grid-stride: the per-seed "seed.clear()" (storage.py:69-71).
+  const size_t n4 = n / 4;
+  uint4 vv = make_uint4(v, v, v, v);
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n4;
+       e += (size_t)gridDim.x * blockDim.x)
+    reinterpret_cast<uint4*>(p)[e] = vv;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = v;
+}
+
+__global__ void points_read_kernel(const float* __restrict__ seed,
+                                   const int32_t* __restrict__ seg, int cz,
+                                   int cy, int cx, int n,
+                                   const int32_t* __restrict__ pos,
+                                   float* __restrict__ seed_out,
+                                   int32_t* __restrict__ seg_out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int z = pos[3 * k], y = pos[3 * k + 1], x = pos[3 * k + 2];
+  if (z < 0 || z >= cz || y < 0 || y >= cy || x < 0 || x >= cx) {
+    seed_out[k] = __builtin_nanf("");
+    seg_out[k] = 0;
+    return;
+  }
+  const size_t ci = ((size_t)z * cy + y) * cx + x;
+  seed_out[k] = seed[ci];
+  seg_out[k] = seg[ci];
+}
+
+__global__ void points_write_seg_kernel(int32_t* __restrict__ seg, int cy, int cx,
+                                        int n, const int32_t* __restrict__ pos,
+                                        const int32_t* __restrict__ val) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  seg[((size_t)pos[3 * k] * cy + pos[3 * k + 1]) * cx + pos[3 * k + 2]] = val[k];
+}
+
+__global__ void set_seed_point_kernel(float* __restrict__ seed, size_t ci,
+                                      float value) {
+  seed[ci] = value;
+}
+
+__global__ void any_segmented_kernel(const int32_t* __restrict__ seg, Box b,
+                                     long total, int32_t* __restrict__ out) {
+  int hit = 0;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x)
+    hit |= seg[box_index(b, e)] > 0;
+  if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(out, 1);
+}
+
+// counts[0] = raw, counts[1] = actual; hist[id] += 1 for overlapped ids > 0.
+__global__ void commit_count_kernel(const float* __restrict__ seed,
+                                    const int32_t* __restrict__ seg, Box b,
+                                    long total, float thr, int32_t max_id,
+                                    unsigned long long* __restrict__ counts,
+                                    unsigned* __restrict__ hist) {
+  unsigned raw = 0, act = 0;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const size_t ci = box_index(b, e);
+    if (seed[ci] >= thr) {  // NaN -> false
+      ++raw;
+      const int32_t s = seg[ci];
+      if (s <= 0) {
+        ++act;
+      } else if (s <= max_id) {
+        atomicAdd(&hist[s], 1u);
+      }
+    }
+  }
+  // wavefront reduction, then one atomic per wave
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    raw += __shfl_xor(raw, off);
+    act += __shfl_xor(act, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (raw) atomicAdd(&counts[0], (unsigned long long)raw);
+    if (act) atomicAdd(&counts[1], (unsigned long long)act);
+  }
+}
+
+__global__ void commit_assign_kernel(const float* __restrict__ seed,
+                                     int32_t* __restrict__ seg, Box b, long total,
+                                     float thr, int32_t sid) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const size_t ci = box_index(b, e);
+    if (seed[ci] >= thr && seg[ci] <= 0) seg[ci] = sid;
+  }
+}
+
+}  // namespace ffn

@@ -1,0 +1,242 @@
+"""Python handles over the C-ABI objects (ffn_engine / ffn_canvas).
+
+Thin, allocation-free wrappers: every method is one ctypes call into
+libffn_hip.so.  torch is not involved -- device memory belongs to the library.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import (CommitCounts, StepParams, StepRequest, StepResult, check, i3)
+
+
+def _f32(a):
+  return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class HipEngine:
+  """One GPU + one stream + the conv-stack weights (include/ffn_hip.h)."""
+
+  def __init__(self, fov_zyx, deltas_zyx, depth: int, features: int = 32,
+               max_batch: int = 1, device_id: int = 0):
+    self._lib = _lib.load()
+    self._h = ctypes.c_void_p()
+    self.fov_zyx = tuple(int(v) for v in fov_zyx)
+    self.deltas_zyx = tuple(int(v) for v in deltas_zyx)
+    self.depth = int(depth)
+    self.features = int(features)
+    self.max_batch = int(max_batch)
+    self.device_id = int(device_id)
+    check(self._lib.ffn_engine_create(self.device_id, i3(self.fov_zyx),
+                                      i3(self.deltas_zyx), self.depth,
+                                      self.features, self.max_batch,
+                                      ctypes.byref(self._h)))
+    self._canvas_arr = (ctypes.c_void_p * self.max_batch)()
+    self._req_arr = (StepRequest * self.max_batch)()
+    self._res_arr = (StepResult * self.max_batch)()
+
+  @classmethod
+  def from_model(cls, model, max_batch: int = 1, device_id: int = 0):
+    """Builds an engine from a ConvStack3DFFNModel (xyz geometry -> zyx)."""
+    info = model.info
+    if not (np.array_equal(info.pred_mask_size, info.input_seed_size) and
+            np.array_equal(info.pred_mask_size, info.input_image_size)):
+      raise ValueError('pred/seed/image sizes must be equal for the conv stack')
+    eng = cls(tuple(int(v) for v in info.pred_mask_size[::-1]),
+              tuple(int(v) for v in info.deltas[::-1]), model.depth,
+              model.features, max_batch, device_id)
+    eng.set_weights(model.weights_blob())
+    return eng
+
+  def close(self):
+    if self._h:
+      self._lib.ffn_engine_destroy(self._h)
+      self._h = ctypes.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint:disable=broad-except
+      pass
+
+  # -- setup -----------------------------------------------------------------
+  def set_weights(self, blob: np.ndarray):
+    blob = _f32(blob).ravel()
+    check(self._lib.ffn_engine_set_weights(self._h, blob.ctypes.data,
+                                           blob.size))
+
+  def set_option(self, name: str, value: int):
+    check(self._lib.ffn_engine_set_option(self._h, name.encode(), int(value)))
+
+  def set_profiling(self, mode: int):
+    check(self._lib.ffn_engine_set_profiling(self._h, int(mode)))
+
+  def get_profile(self, reset: bool = False):
+    ms = ctypes.c_double()
+    n = ctypes.c_int64()
+    check(self._lib.ffn_engine_get_profile(self._h, ctypes.byref(ms),
+                                           ctypes.byref(n), int(reset)))
+    return ms.value, n.value
+
+  def synchronize(self):
+    check(self._lib.ffn_engine_synchronize(self._h))
+
+  # -- stateless predict (ExecutorClient.predict) ------------------------------
+  def predict(self, seed: np.ndarray, image: np.ndarray) -> np.ndarray:
+    """seed, image: [n, z, y, x] f32 -> logits [n, z, y, x] f32."""
+    seed = _f32(seed)
+    image = _f32(image)
+    if seed.shape != image.shape or seed.shape[1:] != self.fov_zyx:
+      raise ValueError('predict expects [n,%d,%d,%d] arrays, got %r / %r' %
+                       (self.fov_zyx + (seed.shape, image.shape)))
+    out = np.empty_like(seed)
+    check(self._lib.ffn_predict(self._h, seed.shape[0], seed.ctypes.data,
+                                image.ctypes.data, out.ctypes.data))
+    return out
+
+  def forward_resident(self, n: int = 1, repeats: int = 1):
+    check(self._lib.ffn_forward_resident(self._h, n, repeats))
+
+  # -- device canvases -----------------------------------------------------------
+  def create_canvas(self, image_f32: np.ndarray) -> 'DeviceCanvasHandle':
+    return DeviceCanvasHandle(self, image_f32)
+
+  def step(self, canvases: Sequence['DeviceCanvasHandle'],
+           requests: Sequence[StepRequest], params: StepParams):
+    """One FoV step for each canvas; returns the internal StepResult array
+    (valid until the next call)."""
+    n = len(canvases)
+    for k in range(n):
+      self._canvas_arr[k] = canvases[k]._h
+      ctypes.pointer(self._req_arr[k])[0] = requests[k]
+    check(self._lib.ffn_canvas_step(self._h, n, self._canvas_arr,
+                                    self._req_arr, ctypes.byref(params),
+                                    self._res_arr))
+    return self._res_arr
+
+  def step1(self, canvas: 'DeviceCanvasHandle', request: StepRequest,
+            params: StepParams) -> StepResult:
+    """Single-canvas fast path: no per-call copies of the request."""
+    self._canvas_arr[0] = canvas._h
+    check(self._lib.ffn_canvas_step(self._h, 1, self._canvas_arr,
+                                    ctypes.byref(request), ctypes.byref(params),
+                                    self._res_arr))
+    return self._res_arr[0]
+
+
+class DeviceCanvasHandle:
+  """image / seed / segmentation of one subvolume, resident in HBM."""
+
+  def __init__(self, engine: HipEngine, image_f32: np.ndarray):
+    self.engine = engine
+    self._lib = engine._lib
+    self._h = ctypes.c_void_p()
+    image_f32 = _f32(image_f32)
+    if image_f32.ndim != 3:
+      raise ValueError('image must be 3d (z, y, x)')
+    self.shape = tuple(int(s) for s in image_f32.shape)
+    check(self._lib.ffn_canvas_create(engine._h, image_f32.ctypes.data,
+                                      i3(self.shape), ctypes.byref(self._h)))
+    self._pt = (ctypes.c_int32 * 3)()
+    self._pt_seed = ctypes.c_float()
+    self._pt_seg = ctypes.c_int32()
+
+  def close(self):
+    if self._h:
+      self._lib.ffn_canvas_destroy(self._h)
+      self._h = ctypes.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint:disable=broad-except
+      pass
+
+  def init_seed(self, pos, value: float):
+    check(self._lib.ffn_canvas_init_seed(self._h, i3(pos), float(value)))
+
+  def read_point(self, pos):
+    """(seed[pos], segmentation[pos]); out-of-canvas -> (nan, 0)."""
+    self._pt[0], self._pt[1], self._pt[2] = int(pos[0]), int(pos[1]), int(pos[2])
+    check(self._lib.ffn_canvas_read_points(
+        self._h, 1, ctypes.addressof(self._pt), ctypes.addressof(self._pt_seed),
+        ctypes.addressof(self._pt_seg)))
+    return self._pt_seed.value, self._pt_seg.value
+
+  def read_points(self, pos: np.ndarray):
+    pos = np.ascontiguousarray(pos, dtype=np.int32).reshape(-1, 3)
+    seed = np.empty(len(pos), np.float32)
+    seg = np.empty(len(pos), np.int32)
+    if len(pos):
+      check(self._lib.ffn_canvas_read_points(self._h, len(pos), pos.ctypes.data,
+                                             seed.ctypes.data, seg.ctypes.data))
+    return seed, seg
+
+  def write_seg_points(self, pos: np.ndarray, values: np.ndarray):
+    pos = np.ascontiguousarray(pos, dtype=np.int32).reshape(-1, 3)
+    values = np.ascontiguousarray(values, dtype=np.int32).ravel()
+    assert len(pos) == len(values)
+    if len(pos):
+      check(self._lib.ffn_canvas_write_seg_points(
+          self._h, len(pos), pos.ctypes.data, values.ctypes.data))
+
+  def any_segmented(self, lo, hi) -> bool:
+    out = ctypes.c_int32()
+    check(self._lib.ffn_canvas_any_segmented(self._h, i3(lo), i3(hi),
+                                             ctypes.byref(out)))
+    return bool(out.value)
+
+  def commit_count(self, lo, hi, segment_threshold: float, max_existing_id: int):
+    counts = CommitCounts()
+    cap = max(int(max_existing_id), 1)
+    ids = np.zeros(cap, np.int32)
+    cnts = np.zeros(cap, np.int64)
+    check(self._lib.ffn_canvas_commit_count(
+        self._h, i3(lo), i3(hi), float(segment_threshold),
+        int(max_existing_id), ctypes.byref(counts), cap, ids.ctypes.data,
+        cnts.ctypes.data))
+    n = counts.num_overlapped_ids
+    return (int(counts.raw_segmented_voxels),
+            int(counts.actual_segmented_voxels), ids[:n].copy(),
+            cnts[:n].copy())
+
+  def commit_assign(self, lo, hi, segment_threshold: float, segment_id: int):
+    check(self._lib.ffn_canvas_commit_assign(self._h, i3(lo), i3(hi),
+                                             float(segment_threshold),
+                                             int(segment_id)))
+
+  def _box(self, lo, hi):
+    lo = [int(v) for v in lo]
+    hi = [int(v) for v in hi]
+    return lo, hi, tuple(h - l for l, h in zip(lo, hi))
+
+  def read_seed(self, lo=None, hi=None) -> np.ndarray:
+    lo, hi, shp = self._box(lo or (0, 0, 0), hi or self.shape)
+    out = np.empty(shp, np.float32)
+    check(self._lib.ffn_canvas_read_seed(self._h, i3(lo), i3(hi),
+                                         out.ctypes.data))
+    return out
+
+  def read_segmentation(self, lo=None, hi=None) -> np.ndarray:
+    lo, hi, shp = self._box(lo or (0, 0, 0), hi or self.shape)
+    out = np.empty(shp, np.int32)
+    check(self._lib.ffn_canvas_read_segmentation(self._h, i3(lo), i3(hi),
+                                                 out.ctypes.data))
+    return out
+
+  def write_seed(self, lo, hi, src: np.ndarray):
+    lo, hi, shp = self._box(lo, hi)
+    src = np.ascontiguousarray(np.broadcast_to(src, shp), dtype=np.float32)
+    check(self._lib.ffn_canvas_write_seed(self._h, i3(lo), i3(hi),
+                                          src.ctypes.data))
+
+  def write_segmentation(self, lo, hi, src: np.ndarray):
+    lo, hi, shp = self._box(lo, hi)
+    src = np.ascontiguousarray(np.broadcast_to(src, shp), dtype=np.int32)
+    check(self._lib.ffn_canvas_write_segmentation(self._h, i3(lo), i3(hi),
+                                                  src.ctypes.data))

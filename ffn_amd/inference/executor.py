@@ -1,0 +1,463 @@
+"""Client/server executor boundary -- the drop-in plug-in API of the FoV loop.
+
+Mirror of reference ffn/inference/executor.py: `ExecutorInterface` (:46-82),
+`ExecutorClient` (:85-108), `ThreadingExecutorClient` (:111-139),
+`BatchExecutor` (:142-204), `ThreadingBatchExecutor` (:207-340).  Same queue
+protocol ('exit' | int register/deregister | request tuple), same fail-fast
+behaviour, same counters.  What changes is what sits behind it:
+
+* `HipBatchExecutor` replaces TF `session.run` with libffn_hip.so.  It serves two
+  request kinds on the same queue:
+    - `predict(seed, image, fetches)`: the reference's stateless contract (works
+      with an unmodified reference `Canvas`);
+    - `step(canvas_handle, request)`: one FoV step on a device-resident canvas
+      (gather -> conv stack -> disco -> paste -> face argmax on the GPU); steps of
+      different canvases are batched into one `ffn_canvas_step` call.
+* Unlike the reference, a partially filled batch is NOT padded with stale slots
+  (reference executor.py:308-323 always runs the full batch).
+* `HipBatchExecutor.get_client(..., direct=True)` returns a `DirectHipClient`
+  that calls the engine in the caller's thread (no queue hop): the right choice
+  for a single canvas, where the reference's thread hop is pure overhead.
+"""
+
+from __future__ import annotations
+
+import _thread
+import ctypes
+import logging
+import os
+import queue
+import threading
+import time
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .. import engine as hip_engine
+from ..training import model as ffn_model
+from . import inference_utils
+from .errors import TerminationException
+from .inference_utils import timer_counter
+
+
+class ExecutorInterface:
+  """Owns the communication channels between clients and the server."""
+
+  def __init__(self):
+    self.lock = threading.Lock()
+    self.outputs = {}  # client_id -> Queue
+    # Protocol: 'exit' | N >= 0 register | N < 0 deregister client -N-1 |
+    # (client_id, seed, image, fetches) | ('step', client_id, handle, request)
+    self._input_queue = queue.Queue()
+    self.exit_request = threading.Event()
+
+  def queue_put(self, x):
+    if self.exit_request.is_set():
+      raise TerminationException()
+    return self._input_queue.put(x)
+
+  def queue_get(self, **kwargs):
+    return self._input_queue.get(**kwargs)
+
+  def get_output(self, client_id: int, timeout: int = 0):
+    while True:
+      try:
+        return self.outputs[client_id].get(timeout=timeout)
+      except queue.Empty:
+        if self.exit_request.is_set():
+          raise TerminationException()  # pylint:disable=raise-missing-from
+
+
+class ExecutorClient:
+  """Client interface for the FFN executor."""
+
+  def __init__(self, counters: inference_utils.Counters,
+               interface: Optional[ExecutorInterface]):
+    self._client_id = None
+    self.counters = counters
+    self._interface = interface
+
+  def start(self) -> int:
+    raise NotImplementedError()
+
+  def finish(self):
+    raise NotImplementedError()
+
+  def predict(self, seed: np.ndarray, image: np.ndarray,
+              fetches: Sequence[str]) -> dict:
+    raise NotImplementedError()
+
+
+class ThreadingExecutorClient(ExecutorClient):
+  """Client interface for a same-process executor."""
+
+  def start(self) -> int:
+    with self._interface.lock:
+      if not self._interface.outputs:
+        client_id = 0
+      else:
+        client_id = max(self._interface.outputs.keys()) + 1
+      self._interface.outputs[client_id] = queue.Queue()
+    self._interface.queue_put(client_id)
+    self._client_id = client_id
+    return client_id
+
+  def finish(self):
+    if self._client_id is None:
+      return
+    with self._interface.lock:
+      del self._interface.outputs[self._client_id]
+    self._interface.queue_put(-1 - self._client_id)
+    self._client_id = None
+
+  def predict(self, seed, image, fetches):
+    assert self._client_id is not None
+    self._interface.queue_put((self._client_id, seed, image, fetches))
+    with timer_counter(self.counters, 'client-wait'):
+      return self._interface.get_output(self._client_id, timeout=1)
+
+
+class BatchExecutor:
+  """Base class for FFN executors: owns the model and accelerator resources."""
+
+  def __init__(self, interface: ExecutorInterface, model,
+               model_info: ffn_model.ModelInfo, session,
+               counters: inference_utils.Counters, batch_size: int):
+    self._interface = interface
+    self.session = session
+    self.model = model
+    self.counters = counters
+    self.batch_size = batch_size
+    self.active_clients = 0
+    self.registered_clients = set()
+    self._input_seed_size = np.array(model_info.input_seed_size[::-1]).tolist()
+    self._input_image_size = np.array(
+        model_info.input_image_size[::-1]).tolist()
+    self._pred_size = np.array(model_info.pred_mask_size[::-1]).tolist()
+    self._initialize_model()
+
+  def __del__(self):
+    try:
+      self.stop_server()
+    except Exception:  # pylint:disable=broad-except
+      pass
+
+  def start_server(self):
+    raise NotImplementedError()
+
+  def stop_server(self):
+    raise NotImplementedError()
+
+  def get_client(self, subvol_counters):
+    return ThreadingExecutorClient(subvol_counters, self._interface)
+
+  def _initialize_model(self):
+    pass
+
+  def _run_executor(self):
+    raise NotImplementedError()
+
+  def _run_executor_log_exceptions(self):
+    """Runs the executor loop; on failure the whole process is taken down
+    (reference executor.py:187-200)."""
+    try:
+      self._run_executor()
+    except Exception as e:  # pylint:disable=broad-except
+      logging.exception(e)
+      self._interface.exit_request.set()
+      _thread.interrupt_main()
+      time.sleep(10)
+      os._exit(1)  # pylint:disable=protected-access
+
+  @property
+  def num_devices(self):
+    return 1
+
+
+class ThreadingBatchExecutor(BatchExecutor):
+  """Thread-based server: N client threads -> 1 server thread -> batched call.
+
+  Subclasses implement `_schedule_batch(client_ids, fetches)` reading
+  `self.input_seed` / `self.input_image` ([B, z, y, x, 1] f32).
+  """
+
+  def __init__(self, interface, model, model_info, session, counters,
+               batch_size: int, expected_clients: int = 1):
+    super().__init__(interface, model, model_info, session, counters,
+                     batch_size)
+    self.total_clients = 0
+    self.expected_clients = expected_clients
+    self.input_seed = np.zeros([batch_size] + self._input_seed_size + [1],
+                               dtype=np.float32)
+    self.input_image = np.zeros([batch_size] + self._input_image_size + [1],
+                                dtype=np.float32)
+    self.th_executor = None
+
+  def start_server(self):
+    if self.th_executor is None:
+      self.th_executor = threading.Thread(
+          target=self._run_executor_log_exceptions, daemon=True)
+      self._interface.exit_request.clear()
+      self.th_executor.start()
+
+  def stop_server(self):
+    if self.th_executor is None:
+      return
+    logging.info('Requesting executor shutdown.')
+    try:
+      self._interface.queue_put('exit')
+    except TerminationException:
+      pass
+    self._interface.exit_request.set()
+    self.th_executor.join()
+    self.th_executor = None
+    logging.info('Executor shutdown complete.')
+
+  def _handle_control(self, data) -> bool:
+    """Processes register / deregister messages; returns True if handled."""
+    if isinstance(data, int):
+      client_id = data
+      if client_id >= 0:
+        self.registered_clients.add(client_id)
+        self.total_clients += 1
+        self.active_clients += 1
+        logging.info('client %d starting', client_id)
+      else:
+        try:
+          self.registered_clients.remove(-client_id - 1)
+          logging.info('client %d terminating', -client_id - 1)
+          self.active_clients -= 1
+        except KeyError:
+          logging.warning('client %d not known or already terminated',
+                          -client_id - 1)
+      return True
+    return False
+
+  def _run_executor(self):
+    """Main loop of the server thread (reference executor.py:266-311)."""
+    logging.info('Executor starting, batch_size=%d.', self.batch_size)
+    fetches = None
+    while self.active_clients or self.total_clients < self.expected_clients:
+      self.counters.get('executor-clients',
+                        cumulative=False).Set(self.active_clients)
+      with timer_counter(self.counters, 'executor-input'):
+        ready = []
+        while (len(ready) < min(self.active_clients, self.batch_size) or
+               not self.active_clients):
+          try:
+            data = self._interface.queue_get(timeout=5)
+          except queue.Empty:
+            continue
+          if isinstance(data, str) and data == 'exit':
+            logging.info('Executor shut down requested.')
+            return
+          if self._handle_control(data):
+            continue
+          client_id, seed, image, fetches = data
+          l = len(ready)
+          self.input_seed[l, ..., 0] = seed
+          self.input_image[l, ..., 0] = image
+          ready.append(client_id)
+      if ready:
+        self._schedule_batch(ready, fetches)
+    logging.info('Executor terminating.')
+
+  def _schedule_batch(self, client_ids: Sequence[int], fetches: Sequence[str]):
+    raise NotImplementedError()
+
+  def _deliver(self, client_ids, rows):
+    with timer_counter(self.counters, 'executor-output'):
+      with self._interface.lock:
+        for client_id, row in zip(client_ids, rows):
+          try:
+            self._interface.outputs[client_id].put(row)
+          except KeyError:
+            pass  # client deregistered while inference was running
+
+
+# ---------------------------------------------------------------------------
+# MI355X executor
+# ---------------------------------------------------------------------------
+
+
+class HipExecutorClient(ThreadingExecutorClient):
+  """Queue-based client that can also run device-resident canvas steps."""
+
+  def __init__(self, counters, interface, executor: 'HipBatchExecutor'):
+    super().__init__(counters, interface)
+    self._executor = executor
+
+  @property
+  def engine(self) -> hip_engine.HipEngine:
+    return self._executor.engine
+
+  def create_canvas(self, image_f32: np.ndarray):
+    with self._executor.engine_lock:
+      return self._executor.engine.create_canvas(image_f32)
+
+  def canvas_call(self, fn, *args, **kwargs):
+    """Runs a (rare) canvas utility call serialised against the server."""
+    with self._executor.engine_lock:
+      return fn(*args, **kwargs)
+
+  def step(self, handle, request, params):
+    """One FoV step on a device canvas, batched with other clients' steps."""
+    assert self._client_id is not None
+    self._interface.queue_put(('step', self._client_id, handle, request, params))
+    with timer_counter(self.counters, 'client-wait'):
+      return self._interface.get_output(self._client_id, timeout=1)
+
+
+class DirectHipClient(ExecutorClient):
+  """In-thread client: calls the engine directly, no queue / thread hop.
+
+  For one canvas per GPU the reference's client->server->client hop (two thread
+  switches per FoV step) is pure overhead; this client keeps the same
+  `predict` contract and adds `step` for device canvases.
+  """
+
+  def __init__(self, counters, executor: 'HipBatchExecutor'):
+    super().__init__(counters, None)
+    self._executor = executor
+    self._next_id = 0
+
+  @property
+  def engine(self) -> hip_engine.HipEngine:
+    return self._executor.engine
+
+  def start(self) -> int:
+    self._client_id = self._executor.allocate_direct_id()
+    return self._client_id
+
+  def finish(self):
+    self._client_id = None
+
+  def predict(self, seed, image, fetches):
+    del fetches
+    with self._executor.engine_lock:
+      out = self._executor.engine.predict(seed[None], image[None])
+    return {'logits': out[0][..., None]}
+
+  def create_canvas(self, image_f32):
+    with self._executor.engine_lock:
+      return self._executor.engine.create_canvas(image_f32)
+
+  def canvas_call(self, fn, *args, **kwargs):
+    with self._executor.engine_lock:
+      return fn(*args, **kwargs)
+
+  def step(self, handle, request, params):
+    with self._executor.engine_lock:
+      return self._executor.engine.step1(handle, request, params)
+
+
+class HipBatchExecutor(ThreadingBatchExecutor):
+  """BatchExecutor backed by libffn_hip.so (one MI355X).
+
+  Constructor signature follows the reference's BatchExecutor
+  (`interface, model, model_info, session, counters, batch_size`); `session`
+  is unused and may be None.  `model` must be a ConvStack3DFFNModel with
+  weights loaded.
+  """
+
+  def __init__(self, interface, model, model_info, session, counters,
+               batch_size: int, expected_clients: int = 1, device_id: int = 0):
+    self._device_id = device_id
+    self.engine_lock = threading.RLock()
+    self._direct_ids = 0
+    super().__init__(interface, model, model_info, session, counters,
+                     batch_size, expected_clients)
+
+  def _initialize_model(self):
+    self.engine = hip_engine.HipEngine.from_model(
+        self.model, max_batch=self.batch_size, device_id=self._device_id)
+
+  def allocate_direct_id(self) -> int:
+    with self.engine_lock:
+      self._direct_ids += 1
+      return 1_000_000 + self._direct_ids
+
+  def get_client(self, subvol_counters, direct: bool = False):
+    if direct:
+      return DirectHipClient(subvol_counters, self)
+    return HipExecutorClient(subvol_counters, self._interface, self)
+
+  def _run_executor(self):
+    """Server loop handling both `predict` tuples and `step` requests."""
+    logging.info('HIP executor starting, batch_size=%d.', self.batch_size)
+    while self.active_clients or self.total_clients < self.expected_clients:
+      self.counters.get('executor-clients',
+                        cumulative=False).Set(self.active_clients)
+      with timer_counter(self.counters, 'executor-input'):
+        predicts = []   # client ids, rows already copied into input_* arrays
+        steps = []      # (client_id, handle, request, params)
+        fetches = None
+        while (len(predicts) + len(steps) <
+               min(self.active_clients, self.batch_size) or
+               not self.active_clients):
+          try:
+            data = self._interface.queue_get(timeout=5)
+          except queue.Empty:
+            continue
+          if isinstance(data, str) and data == 'exit':
+            logging.info('Executor shut down requested.')
+            return
+          if self._handle_control(data):
+            continue
+          if data[0] == 'step':
+            steps.append(data[1:])
+          else:
+            client_id, seed, image, fetches = data
+            l = len(predicts)
+            self.input_seed[l, ..., 0] = seed
+            self.input_image[l, ..., 0] = image
+            predicts.append(client_id)
+      if predicts:
+        self._schedule_batch(predicts, fetches)
+      if steps:
+        self._schedule_steps(steps)
+    logging.info('Executor terminating.')
+
+  def _fail(self, e):
+    logging.exception(e)
+    self._interface.exit_request.set()
+    _thread.interrupt_main()
+    raise e
+
+  def _schedule_batch(self, client_ids, fetches):
+    """Stateless predict for len(client_ids) FoVs (no stale padding slots)."""
+    del fetches
+    n = len(client_ids)
+    with timer_counter(self.counters, 'executor-inference'):
+      try:
+        with self.engine_lock:
+          out = self.engine.predict(self.input_seed[:n, ..., 0],
+                                    self.input_image[:n, ..., 0])
+      except Exception as e:  # pylint:disable=broad-except
+        self._fail(e)
+    self._deliver(client_ids, [{'logits': out[i][..., None]} for i in range(n)])
+
+  def _schedule_steps(self, steps):
+    """Batched device-canvas steps; all steps of one batch share `params`."""
+    with timer_counter(self.counters, 'executor-inference'):
+      try:
+        results = []
+        # group by identical params object values (normally a single group)
+        pending = list(steps)
+        while pending:
+          p0 = pending[0][3]
+          key = (p0.pad_value, p0.move_threshold, p0.disco_seed_threshold)
+          group = [s for s in pending
+                   if (s[3].pad_value, s[3].move_threshold,
+                       s[3].disco_seed_threshold) == key]
+          pending = [s for s in pending if s not in group]
+          with self.engine_lock:
+            res = self.engine.step([s[1] for s in group],
+                                   [s[2] for s in group], p0)
+            for k, s in enumerate(group):
+              r = hip_engine.StepResult()
+              ctypes.pointer(r)[0] = res[k]
+              results.append((s[0], r))
+      except Exception as e:  # pylint:disable=broad-except
+        self._fail(e)
+    self._deliver([c for c, _ in results], [r for _, r in results])

@@ -1,0 +1,759 @@
+"""The FoV inference loop: `Canvas` (mirror of reference ffn/inference/inference.py).
+
+Two implementations share the reference's public surface (`is_valid_pos`,
+`predict`, `update_at`, `init_seed`, `segment_at`, `segment_all`,
+`save_checkpoint`, `restore_checkpoint`, `seed`, `segmentation`, `origins`,
+`overlaps`, `counters`):
+
+* `Canvas` keeps its state in host numpy arrays and calls
+  `exec_client.predict(seed, image, ['logits'])` once per step -- the
+  reference's literal contract (inference.py:356-441), usable with ANY
+  ExecutorClient (the stateless `ffn_predict` path of HipBatchExecutor, or a
+  test double).
+* `DeviceCanvas` keeps image / seed / segmentation resident in HBM
+  (libffn_hip.so `ffn_canvas_*`).  One C call per FoV step does gather -> conv
+  stack -> disco -> paste-back -> 6-face argmax on the GPU and returns ~30
+  scalars; the BFS move queue, the seed iteration and the accept/reject logic of
+  segments stay in Python exactly as in the reference.
+
+`make_canvas(...)` picks `DeviceCanvas` when the client can host device
+canvases (`create_canvas` + `step`), else `Canvas`.
+"""
+
+from __future__ import annotations
+
+import logging
+import os
+import threading
+import time
+
+import numpy as np
+from scipy.special import expit
+from scipy.special import logit
+
+from .. import _lib
+from ..training import model as ffn_model
+from . import executor
+from . import movement
+from . import seed as seed_lib
+from . import storage
+from .inference_utils import Counters
+from .inference_utils import TimedIter
+from .inference_utils import timer_counter
+from .request import InferenceOptions
+
+MSEC_IN_SEC = 1000
+MAX_SELF_CONSISTENT_ITERS = 32
+
+
+def _logit_options(options) -> InferenceOptions:
+  """Copies `options` and converts the four probability fields to logits,
+  rounded to f32 like the reference's proto fields (inference.py:187-195)."""
+  out = InferenceOptions()
+  out.CopyFrom(options)
+  for attr in ('init_activation', 'pad_value', 'move_threshold',
+               'segment_threshold'):
+    setattr(out, attr, logit(getattr(out, attr)))
+  return out
+
+
+class Canvas:
+  """Tracks state of the inference progress and results within a subvolume."""
+
+  io_lock = threading.Lock()
+
+  def __init__(self, model_info: ffn_model.ModelInfo,
+               exec_client: executor.ExecutorClient, image, options,
+               voxel_size_zyx=(1, 1, 1), counters=None, restrictor=None,
+               movement_policy_fn=None, keep_history=False,
+               checkpoint_path=None, checkpoint_interval_sec=0,
+               corner_zyx=None, storage_cls=storage.NumpyArray,
+               keep_probability_maps=False):
+    self.image = image
+    self._exec_client = exec_client
+    self._exec_client_id = None
+    self.voxel_size_zyx = voxel_size_zyx
+    self.options = _logit_options(options)
+    self.counters = counters if counters is not None else Counters()
+    self.checkpoint_interval_sec = checkpoint_interval_sec
+    self.checkpoint_path = checkpoint_path
+    self.checkpoint_last = time.time()
+    self._keep_history = keep_history
+    self.corner_zyx = corner_zyx
+    self.shape = tuple(image.shape)
+    self.restrictor = (movement.MovementRestrictor()
+                       if restrictor is None else restrictor)
+
+    # zyx
+    self._pred_size = np.array(model_info.pred_mask_size[::-1])
+    self._input_seed_size = np.array(model_info.input_seed_size[::-1])
+    self._input_image_size = np.array(model_info.input_image_size[::-1])
+    self.margin = self._input_image_size // 2
+    self._pred_delta = (self._input_seed_size - self._pred_size) // 2
+    assert np.all(self._pred_delta >= 0)
+    self._margin_t = tuple(int(v) for v in self.margin)
+
+    self.keep_probability_maps = keep_probability_maps
+    self._alloc_state(storage_cls)
+
+    self.global_to_local_ids = {}
+    self.local_to_global_ids = {}
+    self.seed_policy = None
+    self._seed_policy_state = None
+    self._max_id = 0
+    self.origins = {}
+    self.overlaps = {}
+    self.reset_seed_per_segment = True
+
+    if movement_policy_fn is None:
+      self.movement_policy = movement.FaceMaxMovementPolicy(
+          self, deltas=model_info.deltas[::-1],
+          score_threshold=self.options.move_threshold)
+    else:
+      self.movement_policy = movement_policy_fn(self)
+
+    self._hosts = []
+    self.history = []
+    self.history_deleted = []
+    self.reset_state((0, 0, 0))
+    self.t_last_predict = None
+    self.log_info('Constructed canvas with corner %s (zyx) and shape %s',
+                  self.corner_zyx, self.shape)
+
+  # -- state allocation (overridden by DeviceCanvas) ---------------------------
+  def _alloc_state(self, storage_cls):
+    self.seed = storage_cls(shape=self.shape, dtype=np.float32,
+                            default_value=np.nan)
+    self.segmentation = storage_cls(shape=self.shape, dtype=np.int32)
+    if self.keep_probability_maps:
+      self.seg_prob = storage_cls(shape=self.shape, dtype=np.uint8)
+    else:
+      self.seg_prob = None
+
+  # -- executor registration -----------------------------------------------------
+  def _register_client(self):
+    if self._exec_client_id is None:
+      self._exec_client_id = self._exec_client.start()
+      logging.info('Registered as client %d.', self._exec_client_id)
+
+  def _deregister_client(self):
+    if self._exec_client_id is not None:
+      logging.info('Deregistering client %d', self._exec_client_id)
+      self._exec_client.finish()
+      self._exec_client_id = None
+
+  def __del__(self):
+    try:
+      self._deregister_client()
+    except Exception:  # pylint:disable=broad-except
+      pass
+
+  def local_id(self, segment_id: int):
+    return self.global_to_local_ids.get(segment_id, segment_id)
+
+  def reset_state(self, start_pos, reset_extents=True):
+    """Prepares the canvas for a new inference run (inference.py:291-310)."""
+    self.movement_policy.reset_state(start_pos)
+    self.history = []
+    self.history_deleted = []
+    if reset_extents:
+      self._min_pos = np.array(start_pos)
+      self._max_pos = np.array(start_pos)
+    self._register_client()
+
+  # -- validity --------------------------------------------------------------------
+  def _in_bounds(self, pos) -> bool:
+    m = self._margin_t
+    s = self.shape
+    return (pos[0] - m[0] >= 0 and pos[0] + m[0] < s[0] and
+            pos[1] - m[1] >= 0 and pos[1] + m[1] < s[1] and
+            pos[2] - m[2] >= 0 and pos[2] + m[2] < s[2])
+
+  def is_valid_pos(self, pos, ignore_move_threshold=False) -> bool:
+    """True if segmentation should be attempted at `pos` (inference.py:312-346)."""
+    if not ignore_move_threshold:
+      if self.seed[pos] < self.options.move_threshold:
+        self.counters['skip_threshold'].Increment()
+        return False
+    if not self._in_bounds(pos):
+      self.counters['skip_invalid_pos'].Increment()
+      return False
+    if self.segmentation[pos] > 0:
+      self.counters['skip_invalid_pos'].Increment()
+      return False
+    return True
+
+  # -- one FoV step ----------------------------------------------------------------
+  def _get_image(self, pos) -> np.ndarray:
+    start = np.array(pos) - self.margin
+    end = start + self._input_image_size
+    return self.image[tuple(slice(s, e) for s, e in zip(start, end))]
+
+  def predict(self, pos, logit_seed: np.ndarray) -> np.ndarray:
+    """Runs a single step of FFN prediction (inference.py:356-384)."""
+    with timer_counter(self.counters, 'predict'):
+      with timer_counter(self.counters, 'get-image'):
+        img = self._get_image(pos)
+      if self.t_last_predict is not None:
+        delta_t = time.time() - self.t_last_predict
+        self.counters['inference-not-predict-ms'].IncrementBy(
+            delta_t * MSEC_IN_SEC)
+      with timer_counter(self.counters, 'inference'):
+        fetches = self._exec_client.predict(logit_seed, img, ['logits'])
+      self.t_last_predict = time.time()
+    logits = fetches.pop('logits')
+    return logits[..., 0]
+
+  def update_at(self, pos):
+    """Updates the object mask prediction at `pos` (inference.py:386-441)."""
+    with timer_counter(self.counters, 'update_at'):
+      off = self._input_seed_size // 2
+      start = np.array(pos) - off
+      end = start + self._input_seed_size
+      logit_seed = np.array(
+          self.seed[tuple(slice(s, e) for s, e in zip(start, end))])
+      init_prediction = np.isnan(logit_seed)
+      logit_seed[init_prediction] = np.float32(self.options.pad_value)
+
+      logits = self.predict(pos, logit_seed)
+      start += self._pred_delta
+      end = start + self._pred_size
+      sel = tuple(slice(s, e) for s, e in zip(start, end))
+
+      # Disco bias: never reverse a disconnectedness prediction.
+      if self.options.disco_seed_threshold >= 0:
+        th_max = logit(0.5)
+        old_seed = self.seed[sel]
+        if self._keep_history:
+          self.history_deleted.append(
+              np.sum((old_seed >= logit(0.8)) & (logits < th_max)))
+        if (np.mean(logits >= self.options.move_threshold) >
+            self.options.disco_seed_threshold):
+          with np.errstate(invalid='ignore'):
+            mask = (old_seed < th_max) & (logits > old_seed)
+          logits[mask] = old_seed[mask]
+      self.seed[sel] = logits
+    return logits
+
+  def init_seed(self, pos):
+    """Reinitialises the object mask with a seed (inference.py:443-450)."""
+    self.seed.clear()
+    self.seed[pos] = self.options.init_activation
+
+  def get_next_segment_id(self) -> int:
+    self._max_id += 1
+    while self._max_id in self.origins:
+      self._max_id += 1
+    return self._max_id
+
+  def _start_logit(self, start_pos):
+    return self.seed[start_pos]
+
+  def segment_at(self, start_pos, dynamic_image=None, vis_update_every=10,
+                 vis_fixed_z=False, partial_segment_iters=0):
+    """Runs FFN segmentation from `start_pos` (inference.py:460-533)."""
+    del dynamic_image, vis_update_every, vis_fixed_z  # notebook-only in the ref
+    start_pos = tuple(int(v) for v in start_pos)
+    if not partial_segment_iters:
+      if self.reset_seed_per_segment:
+        self.init_seed(start_pos)
+      self.reset_state(start_pos, reset_extents=self.reset_seed_per_segment)
+      if not self.movement_policy:
+        item = (self.movement_policy.score_threshold * 2, start_pos)
+        self.movement_policy.append(item)
+
+    num_iters = partial_segment_iters
+    with timer_counter(self.counters, 'segment_at-loop'):
+      for pos in self.movement_policy:
+        if self._start_logit(start_pos) < self.options.move_threshold:
+          self.counters['seed_got_too_weak'].Increment()
+          break
+        if not self.restrictor.is_valid_pos(pos):
+          self.counters['skip_restriced_pos'].Increment()
+          continue
+        pred = self.update_at(pos)
+        self._min_pos = np.minimum(self._min_pos, pos)
+        self._max_pos = np.maximum(self._max_pos, pos)
+        num_iters += 1
+        with timer_counter(self.counters, 'movement_policy'):
+          self._policy_update(pred, pos)
+        if self._keep_history:
+          self.history.append(pos)
+        self._maybe_save_checkpoint(partial_segment_iters=num_iters)
+    return num_iters
+
+  def _policy_update(self, pred, pos):
+    self.movement_policy.update(pred, pos)
+
+  def log_info(self, string: str, *args, **kwargs):
+    logging.info('[cl %s] ' + string, self._exec_client_id, *args, **kwargs)
+
+  # -- segment bookkeeping hooks (overridden by DeviceCanvas) -------------------------
+  def _seg_point(self, pos) -> int:
+    return int(self.segmentation[pos])
+
+  def _mark_excluded(self, pos):
+    if self.segmentation[pos] == 0:
+      self.segmentation[pos] = -1
+
+  def _too_close(self, pos, mbd) -> bool:
+    low = np.array(pos) - mbd
+    high = np.array(pos) + mbd + 1
+    sel = tuple(slice(max(int(s), 0), int(e)) for s, e in zip(low, high))
+    if np.any(self.segmentation[sel] > 0):
+      self.segmentation[pos] = -1
+      return True
+    return False
+
+  def _commit(self, sel_lo, sel_hi, pos):
+    """mask/overlap/assign of one finished object (inference.py:614-661).
+
+    Returns (raw, actual, overlapped_ids, counts, sid or None)."""
+    sel = tuple(slice(l, h) for l, h in zip(sel_lo, sel_hi))
+    mask = self.seed[sel] >= self.options.segment_threshold
+    raw = int(np.sum(mask))
+    overlapped_ids, counts = np.unique(self.segmentation[sel][mask],
+                                       return_counts=True)
+    valid = overlapped_ids > 0
+    overlapped_ids = overlapped_ids[valid]
+    counts = counts[valid]
+    mask &= self.segmentation[sel] <= 0
+    actual = int(np.sum(mask))
+    if actual < self.options.min_segment_size:
+      return raw, actual, overlapped_ids, counts, None
+    sid = self.get_next_segment_id()
+    self.segmentation[sel][mask] = sid
+    if self.keep_probability_maps:
+      self.seg_prob[sel][mask] = storage.quantize_probability(
+          expit(self.seed[sel][mask]))
+    return raw, actual, overlapped_ids, counts, sid
+
+  def segment_all(self, seed_policy=seed_lib.PolicyPeaks,
+                  partial_segment_iters=0):
+    """Segments the input image from every seed (inference.py:538-683)."""
+    self.seed_policy = seed_policy(self)
+    if self._seed_policy_state is not None:
+      self.seed_policy.set_state(self._seed_policy_state)
+      self._seed_policy_state = None
+
+    with timer_counter(self.counters, 'segment_all'):
+      mbd = self.options.min_boundary_dist
+      mbd = np.array([mbd.z, mbd.y, mbd.x])
+
+      for pos in TimedIter(self.seed_policy, self.counters, 'seed-policy'):
+        if not (self.is_valid_pos(pos, ignore_move_threshold=True) and
+                self.restrictor.is_valid_pos(pos) and
+                self.restrictor.is_valid_seed(pos)):
+          assert not partial_segment_iters
+          continue
+        if not partial_segment_iters:
+          self._maybe_save_checkpoint(partial_segment_iters=0)
+
+        if self._too_close(pos, mbd):
+          assert not partial_segment_iters
+          continue
+
+        self.log_info('Starting segmentation at %r (zyx)', pos)
+        seg_start = time.time()
+        num_iters = self.segment_at(
+            pos, partial_segment_iters=partial_segment_iters)
+        partial_segment_iters = 0
+        t_seg = time.time() - seg_start
+
+        if num_iters <= 0:
+          self.counters['invalid-other-time-ms'].IncrementBy(
+              t_seg * MSEC_IN_SEC)
+          self.log_info('Failed: num iters was %d', num_iters)
+          continue
+
+        if self._start_logit(pos) < self.options.move_threshold:
+          self._mark_excluded(pos)
+          self.log_info('Failed: weak seed')
+          self.counters['invalid-weak-time-ms'].IncrementBy(
+              t_seg * MSEC_IN_SEC)
+          continue
+
+        # Bounding box of the area the FFN actually changed.
+        half = self._pred_size // 2
+        lo = [max(int(s), 0) for s in self._min_pos - half]
+        hi = [min(int(e) + 1, d)
+              for e, d in zip(self._max_pos + half, self.shape)]
+        raw, actual, overlapped_ids, counts, sid = self._commit(lo, hi, pos)
+
+        if sid is None:
+          self._mark_excluded(pos)
+          self.log_info('Failed: too small: %d', actual)
+          self.counters['invalid-small-time-ms'].IncrementBy(
+              t_seg * MSEC_IN_SEC)
+          continue
+
+        self.counters['voxels-segmented'].IncrementBy(actual)
+        self.counters['voxels-overlapping'].IncrementBy(raw - actual)
+        self.log_info('Created supervoxel:%d  seed(zyx):%s  size:%d  iters:%d',
+                      self._max_id, pos, actual, num_iters)
+        self.overlaps[self._max_id] = np.array([overlapped_ids, counts])
+        self.origins[self._max_id] = storage.OriginInfo(pos, num_iters, t_seg)
+        self.counters['valid-time-ms'].IncrementBy(t_seg * MSEC_IN_SEC)
+        self._maybe_save_checkpoint(partial_segment_iters=0)
+
+    self.log_info('Segmentation done.')
+    self._deregister_client()
+
+  # -- initial segmentation / checkpoints -------------------------------------------------
+  def _set_segmentation(self, seg: np.ndarray):
+    self.segmentation[:] = seg
+
+  def _set_seed(self, seed: np.ndarray):
+    self.seed[:] = seed
+
+  def init_segmentation_from_volume(self, volume, corner, end,
+                                    align_and_crop=None):
+    """Starts from an existing segmentation (inference.py:685-726)."""
+    init_seg = volume[:, corner[0]:end[0], corner[1]:end[1], corner[2]:end[2]]
+    init_seg = np.asarray(init_seg[0, ...])
+    ids = np.unique(init_seg)
+    new = np.arange(len(ids))
+    if len(ids) and ids[0] != 0:
+      new = new + 1
+    self.global_to_local_ids = {int(k): int(v) for k, v in zip(ids, new)}
+    self.local_to_global_ids = {
+        v: k for k, v in self.global_to_local_ids.items()}
+    init_seg = new[np.searchsorted(ids, init_seg)].astype(np.int32)
+    if align_and_crop is not None:
+      init_seg = align_and_crop(init_seg)
+    self._set_segmentation(init_seg)
+    if self.keep_probability_maps:
+      self.seg_prob[np.asarray(self.segmentation) > 0] = (
+          storage.quantize_probability(np.array([1.0])))
+    self._max_id = int(np.max(init_seg)) if init_seg.size else 0
+
+  def restore_checkpoint(self, path: str) -> int:
+    """Restores state from a checkpoint (inference.py:728-778)."""
+    self.log_info('Restoring inference checkpoint: %s', path)
+    with open(path, 'rb') as f:
+      data = np.load(f, allow_pickle=True)
+      self._set_segmentation(data['segmentation'])
+      self._set_seed(data['seed'])
+      if self.keep_probability_maps:
+        self.seg_prob[:] = data['seg_qprob']
+      self.history_deleted = list(data['history_deleted'])
+      self.history = list(data['history'])
+      self.origins = data['origins'].item()
+      if 'overlaps' in data:
+        self.overlaps = data['overlaps'].item()
+      seg = data['segmentation']
+      self.counters['voxels-segmented'].Set(int(np.sum(seg != 0)))
+      self._max_id = int(np.max(seg))
+      self._min_pos = data['min_pos']
+      self._max_pos = data['max_pos']
+      self.movement_policy.restore_state(data['movement_policy'])
+      self._seed_policy_state = data['seed_policy_state']
+      self.counters.loads(data['counters'].item())
+      partial = (int(data['partial_segment_iters'])
+                 if 'partial_segment_iters' in data else 0)
+      if 'hosts' in data:
+        self._hosts = list(data['hosts'])
+    self.log_info('Inference checkpoint restored.')
+    return partial
+
+  def save_checkpoint(self, path: str, partial_segment_iters: int):
+    """Saves an inference checkpoint (inference.py:780-821)."""
+    self.log_info('Saving inference checkpoint to %s.', path)
+    with timer_counter(self.counters, 'save_checkpoint'):
+      os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+      with storage.atomic_file(path) as fd:
+        seed_policy_state = None
+        if self.seed_policy is not None:
+          seed_policy_state = self.seed_policy.get_state(
+              partial_segment_iters > 0)
+        aux = {}
+        if self.keep_probability_maps:
+          aux['seg_qprob'] = np.asarray(self.seg_prob)
+        np.savez_compressed(
+            fd,
+            movement_policy=np.asarray(self.movement_policy.get_state(),
+                                       dtype=object),
+            segmentation=np.asarray(self.segmentation),
+            seed=np.asarray(self.seed),
+            origins=self.origins,
+            overlaps=self.overlaps,
+            min_pos=self._min_pos,
+            max_pos=self._max_pos,
+            history=np.array(self.history),
+            history_deleted=np.array(self.history_deleted),
+            seed_policy_state=np.asarray(seed_policy_state, dtype=object),
+            counters=self.counters.dumps(),
+            partial_segment_iters=partial_segment_iters,
+            hosts=self._hosts,
+            **aux)
+    self.log_info('Inference checkpoint saved.')
+
+  def _maybe_save_checkpoint(self, partial_segment_iters=0):
+    if self.checkpoint_path is None or self.checkpoint_interval_sec <= 0:
+      return
+    if time.time() - self.checkpoint_last < self.checkpoint_interval_sec:
+      return
+    with Canvas.io_lock:
+      self.save_checkpoint(self.checkpoint_path,
+                           partial_segment_iters=partial_segment_iters)
+    self.checkpoint_last = time.time()
+
+
+# ---------------------------------------------------------------------------
+# Device-resident canvas
+# ---------------------------------------------------------------------------
+
+
+class _DeviceArray:
+  """ndarray-like view of one device-resident canvas volume.
+
+  Supports what the Canvas surface and downstream code use: point reads
+  `arr[(z, y, x)]`, box reads / writes with slices, `clear()`, `np.asarray`.
+  """
+
+  def __init__(self, canvas: 'DeviceCanvas', which: str):
+    self._c = canvas
+    self._which = which
+    self.shape = canvas.shape
+    self.dtype = np.dtype(np.float32 if which == 'seed' else np.int32)
+    self.ndim = 3
+
+  def _box(self, key):
+    if key is Ellipsis:
+      key = (slice(None),) * 3
+    if not isinstance(key, tuple):
+      key = (key,)
+    key = tuple(key) + (slice(None),) * (3 - len(key))
+    lo, hi, squeeze = [], [], []
+    for k, n in zip(key, self.shape):
+      if isinstance(k, slice):
+        s, e, st = k.indices(n)
+        if st != 1:
+          raise IndexError('device arrays support unit-stride slices only')
+        lo.append(s)
+        hi.append(max(e, s))
+        squeeze.append(False)
+      else:
+        k = int(k)
+        if k < 0:
+          k += n
+        lo.append(k)
+        hi.append(k + 1)
+        squeeze.append(True)
+    return lo, hi, squeeze
+
+  def __getitem__(self, key):
+    if (isinstance(key, tuple) and len(key) == 3 and
+        not any(isinstance(k, slice) for k in key)):
+      sv, gv = self._c._read_point(key)
+      return np.float32(sv) if self._which == 'seed' else np.int32(gv)
+    lo, hi, squeeze = self._box(key)
+    h = self._c._handle
+    fn = h.read_seed if self._which == 'seed' else h.read_segmentation
+    out = self._c._call(fn, lo, hi)
+    idx = tuple(0 if s else slice(None) for s in squeeze)
+    return out[idx]
+
+  def __setitem__(self, key, value):
+    self._c._invalidate_cache()
+    lo, hi, _ = self._box(key)
+    h = self._c._handle
+    if self._which == 'seed':
+      self._c._call(h.write_seed, lo, hi, np.asarray(value, np.float32))
+    else:
+      self._c._call(h.write_segmentation, lo, hi, np.asarray(value, np.int32))
+
+  def clear(self):
+    default = np.nan if self._which == 'seed' else 0
+    self[...] = np.full((), default, self.dtype)
+
+  def __array__(self, dtype=None, copy=None):
+    arr = self[...]
+    return arr if dtype is None else arr.astype(dtype)
+
+  def __len__(self):
+    return self.shape[0]
+
+
+class DeviceCanvas(Canvas):
+  """Canvas whose image / seed / segmentation live in HBM for its lifetime."""
+
+  #: number of queue-head positions whose post-step values ride along with a step
+  PREFETCH = _lib.MAX_CANDIDATES
+
+  def __init__(self, model_info, exec_client, image, options, **kwargs):
+    if not (hasattr(exec_client, 'create_canvas') and
+            hasattr(exec_client, 'step')):
+      raise TypeError('DeviceCanvas needs an executor client that can host '
+                      'device canvases (HipBatchExecutor.get_client)')
+    kwargs.pop('storage_cls', None)
+    self._handle = None
+    self._cache = {}
+    self._cached_start = None
+    self._step_req = _lib.StepRequest()
+    self._step_params = _lib.StepParams()
+    if kwargs.get('keep_history'):
+      raise NotImplementedError('keep_history needs host-resident logits')
+    super().__init__(model_info, exec_client, image, options, **kwargs)
+    if np.any(self._pred_delta != 0):
+      raise NotImplementedError('pred size must equal seed size')
+    self._step_params.pad_value = self.options.pad_value
+    self._step_params.move_threshold = self.options.move_threshold
+    self._step_params.disco_seed_threshold = self.options.disco_seed_threshold
+    self._fast_policy = (
+        type(self.movement_policy) is movement.FaceMaxMovementPolicy)
+
+  def _alloc_state(self, storage_cls):
+    del storage_cls
+    image = np.ascontiguousarray(self.image, dtype=np.float32)
+    self._handle = self._exec_client.create_canvas(image)
+    self.seed = _DeviceArray(self, 'seed')
+    self.segmentation = _DeviceArray(self, 'seg')
+    if self.keep_probability_maps:
+      self.seg_prob = storage.NumpyArray(shape=self.shape, dtype=np.uint8)
+    else:
+      self.seg_prob = None
+
+  def _call(self, fn, *args, **kwargs):
+    return self._exec_client.canvas_call(fn, *args, **kwargs)
+
+  def close(self):
+    if self._handle is not None:
+      self._call(self._handle.close)
+      self._handle = None
+
+  # -- cached point reads ------------------------------------------------------------
+  def _invalidate_cache(self):
+    self._cache = {}
+    self._cached_start = None
+
+  def _read_point(self, pos):
+    pos = (int(pos[0]), int(pos[1]), int(pos[2]))
+    hit = self._cache.get(pos)
+    if hit is not None:
+      return hit
+    val = self._call(self._handle.read_point, pos)
+    self._cache[pos] = val
+    return val
+
+  def is_valid_pos(self, pos, ignore_move_threshold=False) -> bool:
+    if not ignore_move_threshold:
+      if self._read_point(pos)[0] < self.options.move_threshold:
+        self.counters['skip_threshold'].Increment()
+        return False
+    if not self._in_bounds(pos):
+      self.counters['skip_invalid_pos'].Increment()
+      return False
+    if self._read_point(pos)[1] > 0:
+      self.counters['skip_invalid_pos'].Increment()
+      return False
+    return True
+
+  def _start_logit(self, start_pos):
+    if self._cached_start is not None and self._cached_start[0] == start_pos:
+      return self._cached_start[1]
+    return self._read_point(start_pos)[0]
+
+  # -- one FoV step: a single C call ---------------------------------------------------
+  def update_at(self, pos):
+    """gather -> conv stack -> disco -> paste -> face argmax on the GPU."""
+    with timer_counter(self.counters, 'update_at'):
+      req = self._step_req
+      req.pos[0], req.pos[1], req.pos[2] = pos
+      sp = self.movement_policy._start_pos if self._fast_policy else pos
+      req.start_pos[0], req.start_pos[1], req.start_pos[2] = sp
+      cands = (self.movement_policy.peek_candidates(self.PREFETCH)
+               if self._fast_policy else [])
+      req.num_candidates = len(cands)
+      for k, c in enumerate(cands):
+        rc = req.candidates[k]
+        rc[0], rc[1], rc[2] = c
+
+      if self.t_last_predict is not None:
+        self.counters['inference-not-predict-ms'].IncrementBy(
+            (time.time() - self.t_last_predict) * MSEC_IN_SEC)
+      with timer_counter(self.counters, 'inference'):
+        res = self._exec_client.step(self._handle, req, self._step_params)
+      self.t_last_predict = time.time()
+      self.counters['predict-calls'].Increment()
+
+      # Post-step values of the queue head: valid until the next mutation.
+      cache = {}
+      cs, cg = res.cand_seed, res.cand_seg
+      for k, c in enumerate(cands):
+        cache[tuple(c)] = (cs[k], cg[k])
+      self._cache = cache
+      self._cached_start = (tuple(sp), res.start_logit)
+      handle = self._handle
+      half = self._margin_t
+      lo = (pos[0] - half[0], pos[1] - half[1], pos[2] - half[2])
+      hi = (pos[0] + half[0] + 1, pos[1] + half[1] + 1, pos[2] + half[2] + 1)
+      pred = movement.FacePrediction(
+          list(res.face_score), list(res.face_index), list(res.face_seg),
+          tuple(int(v) for v in self._pred_size),
+          read_fn=lambda: self._call(handle.read_seed, lo, hi))
+    return pred
+
+  def _policy_update(self, pred, pos):
+    new = self.movement_policy.update(pred, pos)
+    if new:
+      # Freshly queued moves: their seed logit is the face maximum just written
+      # by the paste kernel, and the kernel also returned segmentation[] there.
+      for coord, score, seg in new:
+        self._cache.setdefault(coord, (score, seg))
+
+  def init_seed(self, pos):
+    self._invalidate_cache()
+    self._call(self._handle.init_seed, pos, self.options.init_activation)
+    self._cached_start = (tuple(int(v) for v in pos),
+                          float(np.float32(self.options.init_activation)))
+
+  # -- segment bookkeeping on the device -------------------------------------------------
+  def _seg_point(self, pos) -> int:
+    return int(self._read_point(pos)[1])
+
+  def _mark_excluded(self, pos):
+    if self._seg_point(pos) == 0:
+      self._invalidate_cache()
+      self._call(self._handle.write_seg_points, [pos], [-1])
+
+  def _too_close(self, pos, mbd) -> bool:
+    low = [int(p - m) for p, m in zip(pos, mbd)]
+    high = [int(p + m + 1) for p, m in zip(pos, mbd)]
+    if self._call(self._handle.any_segmented, low, high):
+      self._invalidate_cache()
+      self._call(self._handle.write_seg_points, [pos], [-1])
+      return True
+    return False
+
+  def _commit(self, sel_lo, sel_hi, pos):
+    thr = self.options.segment_threshold
+    max_existing = max(self._max_id, max(self.origins) if self.origins else 0)
+    raw, actual, ids, counts = self._call(self._handle.commit_count, sel_lo,
+                                          sel_hi, thr, max_existing)
+    if actual < self.options.min_segment_size:
+      return raw, actual, ids, counts, None
+    sid = self.get_next_segment_id()
+    if self.keep_probability_maps:
+      sel = tuple(slice(l, h) for l, h in zip(sel_lo, sel_hi))
+      seed = self._call(self._handle.read_seed, sel_lo, sel_hi)
+      seg = self._call(self._handle.read_segmentation, sel_lo, sel_hi)
+      mask = (seed >= thr) & (seg <= 0)
+      self.seg_prob[sel][mask] = storage.quantize_probability(
+          expit(seed[mask]))
+    self._invalidate_cache()
+    self._call(self._handle.commit_assign, sel_lo, sel_hi, thr, sid)
+    return raw, actual, ids, counts, sid
+
+  def _set_segmentation(self, seg):
+    self.segmentation[...] = np.asarray(seg, np.int32)
+
+  def _set_seed(self, seed):
+    self.seed[...] = np.asarray(seed, np.float32)
+
+
+def make_canvas(model_info, exec_client, image, options, **kwargs) -> Canvas:
+  """DeviceCanvas if the client can host device canvases, else host Canvas."""
+  if hasattr(exec_client, 'create_canvas') and hasattr(exec_client, 'step'):
+    return DeviceCanvas(model_info, exec_client, image, options, **kwargs)
+  return Canvas(model_info, exec_client, image, options, **kwargs)

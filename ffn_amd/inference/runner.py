@@ -1,0 +1,280 @@
+"""`Runner`: orchestration of FFN inference runs on one MI355X.
+
+Mirror of reference ffn/inference/runner.py (`start` :165-216, `make_canvas`
+:307-414, `get_seed_policy` :416-431, `save_segmentation` :433-482, `run`
+:484-544).  The TF session / graph / Saver of `_init_tf_model` (:116-163) are
+replaced by `_init_hip_model`: a `ConvStack3DFFNModel` carrying the checkpoint
+weights and a `HipBatchExecutor` that owns the GPU.
+
+Reference defects NOT inherited: `run` no longer reads
+`partial_segment_iters` unbound on a fresh run (:518-533); `save_segmentation`
+writes the probability map only when the canvas tracks one (:480 passes None).
+"""
+
+from __future__ import annotations
+
+import copy
+import functools
+import json
+import logging
+import os
+from typing import Optional
+
+import numpy as np
+
+from ..training import model as ffn_model
+from ..training.import_util import import_symbol
+from . import align
+from . import executor
+from . import inference
+from . import inference_utils
+from . import movement
+from . import seed
+from . import storage
+from .inference_utils import timer_counter
+
+
+class Runner:
+  """Helper for managing FFN inference runs."""
+
+  ALL_MASKED = 1
+
+  def __init__(self, device_id: int = 0):
+    self.counters = inference_utils.Counters()
+    self.executor = None
+    self._exec_interface = executor.ExecutorInterface()
+    self.canvases = {}
+    self.device_id = device_id
+    self.request = None
+    self._model_info: Optional[ffn_model.ModelInfo] = None
+    self._image_volume = None
+    self.init_seg_volume = None
+    self._aligner = align.Aligner()
+    self._direct = True
+
+  def __del__(self):
+    try:
+      self.stop_executor()
+    except Exception:  # pylint:disable=broad-except
+      pass
+
+  def stop_executor(self):
+    """Shuts down the executor; no-op when none is active."""
+    if self.executor is not None:
+      try:
+        self.executor.stop_server()
+      except executor.TerminationException:
+        pass
+      self.executor = None
+
+  def _get_model_class(self, model_name: str):
+    return import_symbol(model_name)
+
+  def _init_hip_model(self, request, batch_size: int):
+    """Builds the model description, loads weights, creates the executor."""
+    model_class = self._get_model_class(request.model_name)
+    args = json.loads(request.model_args) if request.model_args else {}
+    args['batch_size'] = batch_size
+    model = model_class(**args)
+    self._model_info = model.info
+    with timer_counter(self.counters, 'restore-checkpoint'):
+      if request.model_checkpoint_path:
+        model.load_checkpoint(request.model_checkpoint_path)
+      elif model.variables is None:
+        raise ValueError('model_checkpoint_path is required')
+    self.executor = executor.HipBatchExecutor(
+        self._exec_interface, model, model.info, None, self.counters,
+        batch_size, device_id=self.device_id)
+    return model
+
+  def start(self, request, batch_size: int = 1, session=None, direct=None,
+            image_volume=None):
+    """Opens input volumes and initialises the FFN engine.
+
+    Args:
+      request: InferenceRequest
+      batch_size: max number of FoVs evaluated per engine call
+      session: ignored (kept for signature compatibility with the reference)
+      direct: None -> in-thread client when batch_size == 1 (no queue hop),
+        else the reference's client/server threads; True / False to force
+      image_volume: optional array-like overriding request.image
+    """
+    del session
+    request = copy.deepcopy(request)
+    self.request = request
+    assert self.request.segmentation_output_dir
+    os.makedirs(request.segmentation_output_dir, exist_ok=True)
+
+    self.stop_executor()
+    self._init_hip_model(request, batch_size)
+    self._direct = (batch_size == 1) if direct is None else bool(direct)
+
+    with timer_counter(self.counters, 'volstore-open'):
+      if image_volume is not None:
+        self._image_volume = image_volume
+      else:
+        self._image_volume = storage.decorated_volume(request.image)
+      assert self._image_volume is not None
+      if request.HasField('init_segmentation'):
+        self.init_seg_volume = storage.decorated_volume(
+            request.init_segmentation)
+      else:
+        self.init_seg_volume = None
+      if (request.HasField('shift_mask') and
+          request.shift_mask.which_volume() is not None):
+        raise NotImplementedError('shift masks are out of scope (SURVEY 8a16)')
+      alignment_options = request.alignment_options
+      if alignment_options.type != alignment_options.NO_ALIGNMENT:
+        raise NotImplementedError('Only NO_ALIGNMENT is implemented')
+      self._aligner = align.Aligner()
+
+    if not self._direct:
+      self.executor.start_server()
+
+  def make_restrictor(self, corner, subvol_size, image, alignment):
+    """Masks are not on the hot path (all-pass restrictor)."""
+    del corner, subvol_size, image, alignment
+    return None
+
+  def make_canvas(self, corner, subvol_size, **canvas_kwargs):
+    """Builds the Canvas for a subvolume (reference runner.py:307-414)."""
+    subvol_counters = self.counters.get_sub_counters()
+    with timer_counter(subvol_counters, 'load-image'):
+      logging.info('Process subvolume: %r', corner)
+      alignment = self._aligner.generate_alignment(corner, subvol_size)
+      dst_corner, dst_size = alignment.expand_bounds(corner, subvol_size,
+                                                     forward=True)
+      src_corner, src_size = alignment.expand_bounds(dst_corner, dst_size,
+                                                     forward=False)
+      src_corner, src_size = storage.clip_subvolume_to_bounds(
+          src_corner, src_size, self._image_volume)
+
+      def get_data_3d(volume, start_zyx, size_zyx):
+        slc = tuple(slice(int(s), int(s + n))
+                    for s, n in zip(start_zyx, size_zyx))
+        if volume.ndim == 4:
+          slc = np.index_exp[0:1] + slc
+        data = np.asarray(volume[slc])
+        if data.ndim == 4:
+          data = data.squeeze(axis=0)
+        return data
+
+      src_image = get_data_3d(self._image_volume, src_corner, src_size)
+
+      def align_and_crop(image):
+        return alignment.align_and_crop(src_corner, image, dst_corner, dst_size,
+                                        forward=True)
+
+      image = align_and_crop(src_image)
+      logging.info('Image data loaded, shape: %r.', image.shape)
+
+    restrictor = self.make_restrictor(dst_corner, dst_size, image, alignment)
+    if restrictor == self.ALL_MASKED:
+      return None, None
+
+    # (u8 -> f32 - mean) / stddev in f32, exactly as reference runner.py:383-385.
+    image = (image.astype(np.float32) -
+             self.request.image_mean) / self.request.image_stddev
+
+    exc = self.executor
+    if exc is None:
+      raise executor.TerminationException
+
+    canvas = inference.make_canvas(
+        self._model_info,
+        exc.get_client(subvol_counters, direct=self._direct),
+        image,
+        self.request.inference_options,
+        counters=subvol_counters,
+        restrictor=restrictor,
+        movement_policy_fn=movement.get_policy_fn(self.request,
+                                                  self._model_info),
+        checkpoint_path=storage.checkpoint_path(
+            self.request.segmentation_output_dir, corner),
+        checkpoint_interval_sec=self.request.checkpoint_interval,
+        corner_zyx=dst_corner,
+        **canvas_kwargs)
+
+    if self.request.HasField('init_segmentation'):
+      end = np.array(src_corner) + np.array(src_size)
+      canvas.init_segmentation_from_volume(self.init_seg_volume, src_corner,
+                                           end, align_and_crop)
+    return canvas, alignment
+
+  def get_seed_policy(self, corner, subvol_size):
+    """Seed policy factory (reference runner.py:416-431)."""
+    policy_cls = getattr(seed, self.request.seed_policy)
+    kwargs = {'corner': corner, 'subvol_size': subvol_size}
+    if self.request.seed_policy_args:
+      kwargs.update(json.loads(self.request.seed_policy_args))
+    return functools.partial(policy_cls, **kwargs)
+
+  def save_segmentation(self, canvas, alignment, target_path, prob_path):
+    """Saves segmentation (+ probability map) (reference runner.py:433-482)."""
+
+    def unalign_image(im3d):
+      if alignment is None or im3d is None:
+        return im3d
+      return alignment.align_and_crop(canvas.corner_zyx, im3d,
+                                      alignment.corner, alignment.size,
+                                      forward=False)
+
+    def unalign_origins(origins, canvas_corner):
+      out_origins = dict()
+      for key, value in origins.items():
+        zyx = np.array(value.start_zyx) + canvas_corner
+        zyx = alignment.transform(zyx[:, np.newaxis], forward=False).squeeze()
+        zyx = zyx - canvas_corner
+        out_origins[key] = value._replace(
+            start_zyx=tuple(int(v) for v in zyx))
+      return out_origins
+
+    seg = np.array(np.asarray(canvas.segmentation))
+    seg[seg < 0] = 0  # remove the -1 "excluded" markers
+    corner = np.array(canvas.corner_zyx if canvas.corner_zyx is not None else
+                      (0, 0, 0))
+    storage.save_subvolume(
+        unalign_image(seg), unalign_origins(canvas.origins, corner),
+        target_path, request=self.request.SerializeToString(),
+        counters=canvas.counters.dumps(), overlaps=canvas.overlaps)
+    if canvas.seg_prob is not None:
+      prob = unalign_image(np.asarray(canvas.seg_prob))
+      with storage.atomic_file(prob_path) as fd:
+        np.savez_compressed(fd, qprob=prob)
+
+  def run(self, corner, subvol_size, reset_counters=True, **canvas_kwargs):
+    """Runs FFN inference over a subvolume (reference runner.py:484-544)."""
+    if reset_counters:
+      self.counters.reset()
+    corner = tuple(int(c) for c in corner)
+    subvol_size = tuple(int(s) for s in subvol_size)
+    out_dir = self.request.segmentation_output_dir
+    seg_path = storage.segmentation_path(out_dir, corner)
+    prob_path = storage.object_prob_path(out_dir, corner)
+    cpoint_path = storage.checkpoint_path(out_dir, corner)
+    if os.path.exists(seg_path):
+      return None
+
+    canvas, alignment = self.make_canvas(corner, subvol_size, **canvas_kwargs)
+    if canvas is None:
+      return None
+
+    partial_segment_iters = 0
+    if os.path.exists(cpoint_path):
+      partial_segment_iters = canvas.restore_checkpoint(cpoint_path)
+
+    if self.request.alignment_options.save_raw:
+      image_path = storage.subvolume_path(out_dir, corner, 'align')
+      with storage.atomic_file(image_path) as fd:
+        np.savez_compressed(fd, im=canvas.image)
+
+    self.canvases[corner] = canvas
+    canvas.segment_all(seed_policy=self.get_seed_policy(corner, subvol_size),
+                       partial_segment_iters=partial_segment_iters)
+    self.save_segmentation(canvas, alignment, seg_path, prob_path)
+    del self.canvases[corner]
+    try:
+      os.remove(cpoint_path)
+    except OSError:
+      pass
+    return canvas

@@ -1,0 +1,226 @@
+"""Storage helpers of the inference path (mirror of reference ffn/inference/storage.py).
+
+`NumpyArray` (:55-71), `decorated_volume` (:74-112), `atomic_file` (:116-134),
+probability (de)quantisation (:137-151), `save_subvolume` (:154-171), path
+helpers (:174-233), `clip_subvolume_to_bounds`, `load_segmentation`.
+Output files are byte-compatible with the reference (`seg-*.npz` with keys
+segmentation / origins / request / counters / overlaps; `.prob` with `qprob`).
+
+Volume sources: the reference reads HDF5 / TensorStore / VolumeStore.  This
+image has neither h5py nor tensorstore, so `decorated_volume` additionally
+accepts `npy: "path.npy"` (memory-mapped) and uses h5py only if importable.
+"""
+
+from __future__ import annotations
+
+import collections
+from contextlib import contextmanager
+import glob
+import json
+import os
+import re
+import tempfile
+
+import numpy as np
+
+from . import segmentation
+
+OriginInfo = collections.namedtuple('OriginInfo',
+                                    ['start_zyx', 'iters', 'walltime_sec'])
+
+
+class NumpyArray(np.ndarray):
+  """ndarray with a `clear` method (dense in-memory canvas storage)."""
+
+  def __new__(cls, default_value=0, **kwargs):
+    ret = super().__new__(cls, **kwargs)
+    ret.default_value = default_value
+    return ret
+
+  def __init__(self, *args, **kwargs):
+    del args, kwargs
+    self.clear()
+
+  def __array_finalize__(self, obj):
+    self.default_value = getattr(obj, 'default_value', 0)
+
+  def clear(self):
+    self[...] = self.default_value
+
+
+def decorated_volume(settings, **kwargs):
+  """DecoratedVolume -> array-like with __getitem__, shape, ndim in (3, 4)."""
+  del kwargs
+  which = settings.which_volume()
+  if which == 'npy':
+    volume = np.load(settings.npy, mmap_mode='r')
+  elif which == 'hdf5':
+    path = settings.hdf5.split(':')
+    if len(path) != 2:
+      raise ValueError('hdf5 volume_path should be specified as file_path:'
+                       'hdf5_internal_dataset_path.  Got: ' + settings.hdf5)
+    try:
+      import h5py  # pylint:disable=g-import-not-at-top
+    except ImportError as e:
+      raise NotImplementedError(
+          'h5py is not available in this environment; convert the volume to '
+          '.npy and use `image { npy: "..." }`') from e
+    volume = h5py.File(path[0], 'r')[path[1]]
+  elif which == 'tensorstore':
+    raise NotImplementedError('tensorstore is not available.')
+  elif which == 'volinfo':
+    raise NotImplementedError('VolumeStore operations not available.')
+  else:
+    raise ValueError('A volume_path must be set.')
+  if volume.ndim not in (3, 4):
+    raise ValueError('Volume must be 3d or 4d.')
+  return volume
+
+
+@contextmanager
+def atomic_file(path, mode='w+b'):
+  """Atomically saves data to `path` (write to temp, then rename)."""
+  d = os.path.dirname(os.path.abspath(path))
+  os.makedirs(d, exist_ok=True)
+  with tempfile.NamedTemporaryFile(mode=mode, dir=d, delete=False) as tmp:
+    try:
+      yield tmp
+      tmp.flush()
+    except BaseException:
+      tmp.close()
+      os.unlink(tmp.name)
+      raise
+  os.replace(tmp.name, path)
+
+
+def quantize_probability(prob: np.ndarray) -> np.ndarray:
+  """Quantises a probability map into bytes; 0 = NaN (never predicted)."""
+  ret = np.digitize(prob, np.linspace(0.0, 1.0, 255))
+  ret[np.isnan(prob)] = 0
+  return ret.astype(np.uint8)
+
+
+def dequantize_probability(prob: np.ndarray) -> np.ndarray:
+  dq = 1.0 / 255
+  ret = ((prob - 0.5) * dq).astype(np.float32)
+  ret[prob == 0] = np.nan
+  return ret
+
+
+def save_subvolume(labels, origins, output_path, **misc_items):
+  """Saves an FFN subvolume as .npz (ids reduced to the minimal uint type)."""
+  seg = segmentation.reduce_id_bits(labels)
+  os.makedirs(os.path.dirname(os.path.abspath(output_path)), exist_ok=True)
+  with atomic_file(output_path) as fd:
+    np.savez_compressed(fd, segmentation=seg, origins=origins, **misc_items)
+
+
+def legacy_subvolume_path(output_dir, corner, suffix):
+  return os.path.join(
+      output_dir, 'seg-%s.%s' % ('_'.join([str(x) for x in corner[::-1]]),
+                                 suffix))
+
+
+def subvolume_path(output_dir, corner, suffix):
+  """<dir>/<x>/<y>/seg-<x>_<y>_<z>.<suffix> for a (z, y, x) corner."""
+  return os.path.join(
+      output_dir, str(corner[2]), str(corner[1]),
+      'seg-%s.%s' % ('_'.join([str(x) for x in corner[::-1]]), suffix))
+
+
+def get_corner_from_path(path):
+  match = re.search(r'(\d+)_(\d+)_(\d+).npz', os.path.basename(path))
+  if match is None:
+    raise ValueError('Unrecognized path: %s' % path)
+  coord = tuple([int(x) for x in match.groups()])
+  return coord[::-1]
+
+
+def get_existing_corners(segmentation_dir):
+  corners = []
+  for path in glob.glob(os.path.join(segmentation_dir, 'seg-*_*_*.npz')):
+    corners.append(get_corner_from_path(path))
+  for path in glob.glob(os.path.join(segmentation_dir, '*/*/seg-*_*_*.npz')):
+    corners.append(get_corner_from_path(path))
+  return corners
+
+
+def checkpoint_path(output_dir, corner):
+  return subvolume_path(output_dir, corner, 'cpoint')
+
+
+def segmentation_path(output_dir, corner):
+  return subvolume_path(output_dir, corner, 'npz')
+
+
+def object_prob_path(output_dir, corner):
+  return subvolume_path(output_dir, corner, 'prob')
+
+
+def legacy_segmentation_path(output_dir, corner):
+  return legacy_subvolume_path(output_dir, corner, 'npz')
+
+
+def legacy_object_prob_path(output_dir, corner):
+  return legacy_subvolume_path(output_dir, corner, 'prob')
+
+
+def get_existing_subvolume_path(segmentation_dir, corner, allow_cpoint=False):
+  """Returns the path of an existing result (or checkpoint) for `corner`."""
+  target_path = segmentation_path(segmentation_dir, corner)
+  if os.path.exists(target_path):
+    return target_path
+  target_path = legacy_segmentation_path(segmentation_dir, corner)
+  if os.path.exists(target_path):
+    return target_path
+  if allow_cpoint:
+    target_path = checkpoint_path(segmentation_dir, corner)
+    if os.path.exists(target_path):
+      return target_path
+  return None
+
+
+def clip_subvolume_to_bounds(corner, size, volume):
+  """Clips a (z, y, x) box to the bounds of `volume` (3d or 4d czyx)."""
+  volume_size = np.array(volume.shape[-3:])
+  corner = np.array(corner)
+  size = np.array(size)
+  start = np.maximum(corner, 0)
+  end = np.minimum(corner + size, volume_size)
+  return start, np.maximum(end - start, 0)
+
+
+def load_origins(segmentation_dir, corner):
+  target_path = get_existing_subvolume_path(segmentation_dir, corner, False)
+  if target_path is None:
+    raise ValueError('Segmentation not found: %s, %s' %
+                     (segmentation_dir, corner))
+  with np.load(target_path, allow_pickle=True) as data:
+    return data['origins'].item()
+
+
+def load_segmentation(segmentation_dir, corner, allow_cpoint=False,
+                      threshold=None, split_cc=True, min_size=0):
+  """Loads a saved segmentation subvolume (reference storage.py:414-488)."""
+  del split_cc  # CC splitting is a "next" row
+  target_path = get_existing_subvolume_path(segmentation_dir, corner,
+                                            allow_cpoint)
+  if target_path is None:
+    raise ValueError('Segmentation not found, %s, %r' %
+                     (segmentation_dir, corner))
+  with np.load(target_path, allow_pickle=True) as data:
+    seg = data['segmentation'].astype(np.uint64)
+    origins = data['origins'].item()
+    output = seg
+    if threshold is not None and threshold > 0:
+      prob_path = object_prob_path(segmentation_dir, corner)
+      with np.load(prob_path) as pdata:
+        prob = dequantize_probability(pdata['qprob'])
+      output = np.where(prob >= threshold, seg, 0).astype(np.uint64)
+    if min_size:
+      segmentation.clear_dust(output, min_size=min_size)
+  return output, origins
+
+
+def dump_json(obj) -> str:
+  return json.dumps(obj, sort_keys=True)

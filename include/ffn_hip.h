@@ -1,0 +1,178 @@
+/*
+ * libffn_hip.so -- C-ABI of the MI355X (gfx950) flood-filling inference engine.
+ *
+ * This is the drop-in boundary for the ONE hot path this repository replaces:
+ * the FFN field-of-view loop of google/ffn.  Every entry point below names the
+ * reference interface (file:line, relative to the google/ffn checkout) whose
+ * work it takes over.  The reference is pure Python; its FFI for this path is a
+ * ctypes binding (see INTEGRATION.md for the stub a maintainer would add to
+ * ffn/inference/executor.py).
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a
+ * negative FFN_ERR_* code (no exceptions cross the ABI); the caller owns all
+ * host buffers, the library owns all device memory; one HIP stream per engine;
+ * calls on one engine (and on canvases created from it) must be serialised by
+ * the caller (the executor's server thread); coordinates are (z, y, x).
+ */
+#ifndef FFN_HIP_H_
+#define FFN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFN_OK 0
+#define FFN_ERR_ARG (-1)     /* invalid argument / unsupported geometry      */
+#define FFN_ERR_HIP (-2)     /* HIP runtime failure (see ffn_last_error)     */
+#define FFN_ERR_STATE (-3)   /* call order violated (e.g. weights not set)   */
+
+#define FFN_MAX_CANDIDATES 16
+
+typedef struct ffn_engine ffn_engine;
+typedef struct ffn_canvas ffn_canvas;
+
+/* Thresholds of one FoV step, already in logit space, exactly the f32-rounded
+ * values Canvas.__init__ stores (ffn/inference/inference.py:189-195). */
+typedef struct ffn_step_params {
+  float pad_value;             /* NaN -> pad substitution  (inference.py:406-407) */
+  float move_threshold;        /* disco mean test + counters (inference.py:429)   */
+  float disco_seed_threshold;  /* < 0 disables the disco bias (inference.py:416)  */
+} ffn_step_params;
+
+/* One FoV step request (one entry per canvas in a batched call). */
+typedef struct ffn_step_request {
+  int32_t pos[3];        /* FoV centre (z, y, x)                               */
+  int32_t start_pos[3];  /* segment origin: its logit is returned for the
+                            "seed got too weak" test (inference.py:503-505)    */
+  int32_t num_candidates;                      /* <= FFN_MAX_CANDIDATES        */
+  int32_t candidates[FFN_MAX_CANDIDATES][3];   /* queue-head positions whose
+                            post-step seed logit / segment id are wanted
+                            (Canvas.is_valid_pos, inference.py:325,341)        */
+} ffn_step_request;
+
+/* Everything the Python movement policy needs from one FoV step. */
+typedef struct ffn_step_result {
+  float   face_score[6];  /* max over each face of the +-delta cuboid, order
+                             (z-,z+,y-,y+,x-,x+)  (movement.py:67-87)          */
+  int32_t face_index[6];  /* first-occurrence C-order argmax inside the face   */
+  int32_t face_seg[6];    /* segmentation[] at each face maximum (the validity
+                             test of a freshly queued move, inference.py:341)  */
+  float   start_logit;    /* seed[start_pos] after the paste                   */
+  uint32_t num_above_move;/* #(logits >= move_threshold) before disco          */
+  int32_t disco_applied;  /* 1 if the disco mask was applied                   */
+  float   cand_seed[FFN_MAX_CANDIDATES];  /* seed[candidate] after the paste   */
+  int32_t cand_seg[FFN_MAX_CANDIDATES];   /* segmentation[candidate]           */
+} ffn_step_result;
+
+/* Result of the per-segment commit reduction (inference.py:614-646). */
+typedef struct ffn_commit_counts {
+  int64_t raw_segmented_voxels;     /* sum(seed[sel] >= segment_threshold)      */
+  int64_t actual_segmented_voxels;  /* ... and segmentation[sel] <= 0           */
+  int32_t num_overlapped_ids;       /* distinct ids > 0 under the raw mask      */
+} ffn_commit_counts;
+
+/* ---- lifecycle -----------------------------------------------------------
+ * Replaces model construction in Runner._init_tf_model
+ * (ffn/inference/runner.py:116-163) and ConvStack3DFFNModel.__init__ /
+ * define_tf_graph (ffn/training/models/convstack_3d.py:68-95).
+ * features must be 32 (the MFMA kernel's N); depth >= 1; fov odd per axis. */
+int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
+                      const int32_t deltas_zyx[3], int depth, int features,
+                      int max_batch, ffn_engine** out);
+void ffn_engine_destroy(ffn_engine* engine);
+
+/* Replaces tf.train.Saver().restore (runner.py:98-111).  `blob` holds the TF
+ * variables in graph order, each tensor exactly as TensorFlow stores it:
+ *   conv0_a W[3][3][3][2][F] b[F], conv0_b W[3][3][3][F][F] b[F],
+ *   conv{i}_a W b, conv{i}_b W b  (i = 1..depth-1), conv_lom W[F] b[1].     */
+int ffn_engine_set_weights(ffn_engine* engine, const float* blob, size_t count);
+size_t ffn_engine_weight_count(int depth, int features);
+
+/* ---- stateless step == ExecutorClient.predict ----------------------------
+ * Replaces BatchExecutor._schedule_batch -> session.run
+ * (ffn/inference/executor.py:313-340): logits = seed + conv_stack(image,seed).
+ * seed, image, logits_out: host arrays [n][fz][fy][fx] f32, n <= max_batch.   */
+int ffn_predict(ffn_engine* engine, int n, const float* seed,
+                const float* image, float* logits_out);
+
+/* Conv stack only, on whatever FoVs are resident in the engine's staging
+ * buffers (no host traffic) -- the kernel-only leg of bench.py. */
+int ffn_forward_resident(ffn_engine* engine, int n, int repeats);
+
+/* ---- device-resident canvas ---------------------------------------------
+ * Replaces the numpy state of Canvas (inference.py:224-232): image f32
+ * (already normalised as runner.py:383-385), seed f32 (NaN = unvisited),
+ * segmentation i32, all kept in HBM for the whole subvolume. */
+int ffn_canvas_create(ffn_engine* engine, const float* image_f32,
+                      const int32_t shape_zyx[3], ffn_canvas** out);
+void ffn_canvas_destroy(ffn_canvas* canvas);
+
+/* Canvas.init_seed (inference.py:443-450): seed[:] = NaN; seed[pos] = value. */
+int ffn_canvas_init_seed(ffn_canvas* canvas, const int32_t pos[3], float value);
+
+/* Canvas.update_at + FaceMaxMovementPolicy scoring for n canvases at once
+ * (inference.py:386-441, movement.py:42-100): gather -> conv stack -> disco ->
+ * paste-back -> 6-face argmax, entirely on the GPU. */
+int ffn_canvas_step(ffn_engine* engine, int n, ffn_canvas* const* canvases,
+                    const ffn_step_request* requests,
+                    const ffn_step_params* params, ffn_step_result* results);
+
+/* Point reads used by Canvas.is_valid_pos (inference.py:312-346). */
+int ffn_canvas_read_points(ffn_canvas* canvas, int n, const int32_t* pos_zyx,
+                           float* seed_out, int32_t* seg_out);
+/* segmentation[pos] = value (the -1 "excluded" markers, inference.py:579,604). */
+int ffn_canvas_write_seg_points(ffn_canvas* canvas, int n,
+                                const int32_t* pos_zyx, const int32_t* values);
+/* np.any(segmentation[lo:hi] > 0) -- min_boundary_dist test (inference.py:573-581). */
+int ffn_canvas_any_segmented(ffn_canvas* canvas, const int32_t lo[3],
+                             const int32_t hi[3], int32_t* out);
+
+/* Segment commit (inference.py:614-646), in two calls so Python keeps the
+ * accept/reject decision: count, then (if accepted) assign `segment_id`.
+ * overlap_ids/overlap_counts receive up to `max_overlaps` (id, count) pairs in
+ * ascending id order (np.unique semantics, ids > 0 only). */
+int ffn_canvas_commit_count(ffn_canvas* canvas, const int32_t lo[3],
+                            const int32_t hi[3], float segment_threshold,
+                            int32_t max_existing_id, ffn_commit_counts* counts,
+                            int32_t max_overlaps, int32_t* overlap_ids,
+                            int64_t* overlap_counts);
+int ffn_canvas_commit_assign(ffn_canvas* canvas, const int32_t lo[3],
+                             const int32_t hi[3], float segment_threshold,
+                             int32_t segment_id);
+
+/* Box transfers between the canvas and host arrays ([hi-lo] C-order):
+ * checkpoint/restore and final save (inference.py:728-821, runner.py:433-482). */
+int ffn_canvas_read_seed(ffn_canvas* canvas, const int32_t lo[3],
+                         const int32_t hi[3], float* dst);
+int ffn_canvas_read_segmentation(ffn_canvas* canvas, const int32_t lo[3],
+                                 const int32_t hi[3], int32_t* dst);
+int ffn_canvas_write_seed(ffn_canvas* canvas, const int32_t lo[3],
+                          const int32_t hi[3], const float* src);
+int ffn_canvas_write_segmentation(ffn_canvas* canvas, const int32_t lo[3],
+                                  const int32_t hi[3], const int32_t* src);
+
+/* ---- measurement ----------------------------------------------------------
+ * HIP-event timing of the dominant kernel (the 32->32 3x3x3 MFMA conv) on the
+ * engine's own stream.  mode 0 = off, 1 = one event pair per conv launch. */
+int ffn_engine_set_profiling(ffn_engine* engine, int mode);
+int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
+                           int64_t* conv_launches, int reset);
+/* Tuning / A-B switches.  "conv_variant": 0 = simple MFMA conv, 1 = software-
+ * pipelined MFMA conv (default).  Results are identical up to f32 summation
+ * order. */
+int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
+/* Blocks until all work queued on the engine's stream has finished. */
+int ffn_engine_synchronize(ffn_engine* engine);
+
+/* Thread-local description of the last error. */
+const char* ffn_last_error(void);
+/* ABI version of this header. */
+int ffn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFN_HIP_H_ */

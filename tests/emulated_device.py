@@ -1,0 +1,148 @@
+"""TEST DOUBLE for the device side of the C-ABI (numpy + the oracle forward).
+
+Lets the CPU-only test-suite exercise the *host* logic of `DeviceCanvas`
+(candidate prefetch, value caches, commit protocol) without a GPU.  It
+restates, in numpy, what `ffn_canvas_step` / `ffn_canvas_commit_*` etc. are
+specified to return (include/ffn_hip.h).  Never imported by the product.
+"""
+
+import numpy as np
+
+from ffn_amd import _lib
+from ffn_amd.inference import executor
+from oracle import ffn_oracle
+
+
+class EmulatedHandle:
+
+  def __init__(self, image):
+    self.image = np.array(image, np.float32)
+    self.shape = self.image.shape
+    self.seed = np.full(self.shape, np.nan, np.float32)
+    self.seg = np.zeros(self.shape, np.int32)
+    self.point_reads = 0
+
+  def close(self):
+    pass
+
+  def init_seed(self, pos, value):
+    self.seed[...] = np.nan
+    self.seed[tuple(pos)] = value
+
+  def read_point(self, pos):
+    self.point_reads += 1
+    pos = tuple(int(p) for p in pos)
+    if any(p < 0 or p >= s for p, s in zip(pos, self.shape)):
+      return float('nan'), 0
+    return float(self.seed[pos]), int(self.seg[pos])
+
+  def write_seg_points(self, pos, values):
+    for p, v in zip(pos, values):
+      self.seg[tuple(int(x) for x in p)] = v
+
+  def any_segmented(self, lo, hi):
+    sel = tuple(slice(max(l, 0), h) for l, h in zip(lo, hi))
+    return bool(np.any(self.seg[sel] > 0))
+
+  def commit_count(self, lo, hi, thr, max_existing_id):
+    sel = tuple(slice(l, h) for l, h in zip(lo, hi))
+    mask = self.seed[sel] >= np.float32(thr)
+    raw = int(mask.sum())
+    ids, counts = np.unique(self.seg[sel][mask], return_counts=True)
+    keep = ids > 0
+    actual = int((mask & (self.seg[sel] <= 0)).sum())
+    return raw, actual, ids[keep].astype(np.int32), counts[keep].astype(np.int64)
+
+  def commit_assign(self, lo, hi, thr, sid):
+    sel = tuple(slice(l, h) for l, h in zip(lo, hi))
+    mask = (self.seed[sel] >= np.float32(thr)) & (self.seg[sel] <= 0)
+    self.seg[sel][mask] = sid
+
+  def read_seed(self, lo=None, hi=None):
+    lo = lo or (0, 0, 0)
+    hi = hi or self.shape
+    return np.array(self.seed[tuple(slice(l, h) for l, h in zip(lo, hi))])
+
+  def read_segmentation(self, lo=None, hi=None):
+    lo = lo or (0, 0, 0)
+    hi = hi or self.shape
+    return np.array(self.seg[tuple(slice(l, h) for l, h in zip(lo, hi))])
+
+  def write_seed(self, lo, hi, src):
+    self.seed[tuple(slice(l, h) for l, h in zip(lo, hi))] = src
+
+  def write_segmentation(self, lo, hi, src):
+    self.seg[tuple(slice(l, h) for l, h in zip(lo, hi))] = src
+
+
+class EmulatedDeviceClient(executor.ExecutorClient):
+  """ExecutorClient with the device-canvas surface, computed on the CPU."""
+
+  def __init__(self, counters, blob, depth, fov_zyx, deltas_zyx):
+    super().__init__(counters, None)
+    self.blob = blob
+    self.depth = depth
+    self.fov = np.array(fov_zyx)
+    self.deltas = np.array(deltas_zyx)
+    self.steps = 0
+
+  def start(self):
+    self._client_id = 0
+    return 0
+
+  def finish(self):
+    self._client_id = None
+
+  def predict(self, seed, image, fetches):
+    out = ffn_oracle.forward(image, seed, self.blob, self.depth)
+    return {'logits': out[..., None]}
+
+  def create_canvas(self, image):
+    return EmulatedHandle(image)
+
+  def canvas_call(self, fn, *args, **kwargs):
+    return fn(*args, **kwargs)
+
+  def step(self, h, req, params):
+    self.steps += 1
+    pos = np.array(list(req.pos))
+    start = pos - self.fov // 2
+    sel = tuple(slice(s, s + f) for s, f in zip(start, self.fov))
+    old = np.array(h.seed[sel])
+    seed_in = old.copy()
+    seed_in[np.isnan(seed_in)] = np.float32(params.pad_value)
+    logits = ffn_oracle.forward(h.image[sel], seed_in, self.blob, self.depth)
+    cnt = int(np.sum(logits >= np.float32(params.move_threshold)))
+    disco = (params.disco_seed_threshold >= 0 and
+             cnt / logits.size > params.disco_seed_threshold)
+    if disco:
+      with np.errstate(invalid='ignore'):
+        mask = (old < 0) & (logits > old)
+      logits[mask] = old[mask]
+    h.seed[sel] = logits
+    res = _lib.StepResult()
+    scores, idx = ffn_oracle.face_maxima(self.deltas, logits)
+    c = self.fov // 2
+    k = 0
+    for axis in range(3):
+      others = [a for a in range(3) if a != axis]
+      for sign in (-1, 1):
+        res.face_score[k] = scores[k]
+        res.face_index[k] = idx[k]
+        ncols = 2 * self.deltas[others[1]] + 1
+        fi, fj = divmod(int(idx[k]), int(ncols))
+        rel = [0, 0, 0]
+        rel[axis] = sign * self.deltas[axis]
+        rel[others[0]] = fi - self.deltas[others[0]]
+        rel[others[1]] = fj - self.deltas[others[1]]
+        coord = tuple(int(p + r) for p, r in zip(pos, rel))
+        res.face_seg[k] = int(h.seg[coord])
+        k += 1
+    res.start_logit = h.seed[tuple(req.start_pos)]
+    res.num_above_move = cnt
+    res.disco_applied = int(disco)
+    for k in range(req.num_candidates):
+      cpos = tuple(req.candidates[k])
+      res.cand_seed[k] = h.seed[cpos]
+      res.cand_seg[k] = h.seg[cpos]
+    return res

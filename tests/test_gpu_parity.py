@@ -1,0 +1,349 @@
+"""GPU parity tests: the HIP path (through the C-ABI) vs the CPU oracle.
+
+Tolerance for float logits: |delta| <= 1e-4 absolute per FoV step (f32 path;
+BASELINE.md section 4; observed ~1e-5).  Integer / index work (face argmax,
+segment ids, queue trajectory, commit counts) must be bit-exact.
+"""
+
+import functools
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def engine(fib25_model):
+  from ffn_amd import engine as hip_engine
+  eng = hip_engine.HipEngine.from_model(fib25_model, max_batch=4, device_id=0)
+  yield eng
+  eng.close()
+
+
+def _fov_inputs(rng, n=1):
+  from oracle import ffn_oracle
+  img = ((rng.randint(0, 256, (n, 33, 33, 33)).astype(np.float32)) - 128) / 33
+  seed = np.full((n, 33, 33, 33), ffn_oracle.f32_logit(0.05), np.float32)
+  seed[:, 16, 16, 16] = ffn_oracle.f32_logit(0.95)
+  seed[:, 10:20, 12:22, 8:30] += rng.normal(0, 1.5, (n, 10, 10, 22)).astype(
+      np.float32)
+  return img, seed
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+def test_predict_matches_oracle(engine, fib25_blob, variant):
+  from oracle import ffn_oracle
+  engine.set_option('conv_variant', variant)
+  rng = np.random.RandomState(42)
+  img, seed = _fov_inputs(rng, 1)
+  got = engine.predict(seed, img)
+  want = ffn_oracle.forward(img, seed, fib25_blob, 12)
+  assert got.shape == want.shape
+  assert np.abs(got - want).max() <= TOL
+  engine.set_option('conv_variant', 1)
+
+
+def test_predict_batch_and_ragged(engine, fib25_blob):
+  from oracle import ffn_oracle
+  rng = np.random.RandomState(7)
+  img, seed = _fov_inputs(rng, 4)
+  want = ffn_oracle.forward(img, seed, fib25_blob, 12)
+  got4 = engine.predict(seed, img)
+  assert np.abs(got4 - want).max() <= TOL
+  # ragged batch (3 of 4 slots) and batch-1 give the same rows, bit for bit
+  got3 = engine.predict(seed[:3], img[:3])
+  assert np.array_equal(got3, got4[:3])
+  got1 = engine.predict(seed[2:3], img[2:3])
+  assert np.array_equal(got1[0], got4[2])
+
+
+def test_predict_is_deterministic_and_variants_agree(engine):
+  rng = np.random.RandomState(3)
+  img, seed = _fov_inputs(rng, 2)
+  a = engine.predict(seed, img)
+  b = engine.predict(seed, img)
+  assert np.array_equal(a, b)
+  engine.set_option('conv_variant', 0)
+  c = engine.predict(seed, img)
+  engine.set_option('conv_variant', 1)
+  assert np.abs(a - c).max() <= 2e-5
+
+
+def test_predict_nan_seed_propagates_like_reference(engine):
+  # The stateless contract feeds the seed as given (the Canvas substitutes NaN
+  # before calling predict); a NaN must not be silently replaced.
+  rng = np.random.RandomState(5)
+  img, seed = _fov_inputs(rng, 1)
+  seed[0, 0, 0, 0] = np.nan
+  out = engine.predict(seed, img)
+  assert np.isnan(out[0, 0, 0, 0])
+
+
+def test_layerwise_random_weights_other_depth(fib25_model):
+  """depth 3 / random weights: exercises conv0_b and one residual module."""
+  from ffn_amd import engine as hip_engine
+  from ffn_amd.training.models import convstack_3d
+  from oracle import ffn_oracle
+  variables = ffn_oracle.random_weights(3, seed=11, stddev=0.08)
+  m = convstack_3d.ConvStack3DFFNModel(fov_size=[33, 33, 33],
+                                       deltas=[8, 8, 8], depth=3)
+  m.set_variables(variables)
+  eng = hip_engine.HipEngine.from_model(m, max_batch=1)
+  rng = np.random.RandomState(1)
+  img, seed = _fov_inputs(rng, 1)
+  got = eng.predict(seed, img)
+  want = ffn_oracle.forward(img, seed, ffn_oracle.weights_blob(variables, 3), 3)
+  assert np.abs(got - want).max() <= TOL
+  eng.close()
+
+
+def test_anisotropic_fov(fib25_model):
+  """C5 geometry: fov zyx (21, 41, 41), deltas (5, 10, 10), random weights."""
+  from ffn_amd import engine as hip_engine
+  from ffn_amd.training.models import convstack_3d
+  from oracle import ffn_oracle
+  variables = ffn_oracle.random_weights(2, seed=5, stddev=0.08)
+  m = convstack_3d.ConvStack3DFFNModel(fov_size=[41, 41, 21],
+                                       deltas=[10, 10, 5], depth=2)
+  m.set_variables(variables)
+  eng = hip_engine.HipEngine.from_model(m, max_batch=1)
+  rng = np.random.RandomState(2)
+  img = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
+  seed = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
+  blob = ffn_oracle.weights_blob(variables, 2)
+  for variant in (0, 1):
+    eng.set_option('conv_variant', variant)
+    got = eng.predict(seed, img)
+    want = ffn_oracle.forward(img, seed, blob, 2)
+    assert np.abs(got - want).max() <= TOL, variant
+  eng.close()
+
+
+def test_canvas_step_matches_oracle(engine, fib25_blob):
+  """gather + conv + disco + paste + faces + point reads on the device."""
+  from ffn_amd import _lib
+  from ffn_amd import synthetic
+  from oracle import ffn_oracle
+  vol = synthetic.normalize(synthetic.cells_volume((64, 60, 72), seed=9))
+  canvas = engine.create_canvas(vol)
+  oc = ffn_oracle.OracleCanvas(vol, fib25_blob, 12, (33, 33, 33), (8, 8, 8),
+                               ffn_oracle.Options())
+  start = (30, 30, 36)
+  canvas.init_seed(start, oc.init_activation)
+  oc.seed[start] = oc.init_activation
+  params = _lib.StepParams(oc.pad_value, oc.move_threshold,
+                           oc.disco_seed_threshold)
+  positions = [start, (30, 30, 44), (38, 30, 36), (30, 22, 36), (30, 30, 44)]
+  cands = [(30, 30, 44), (38, 30, 36), (20, 20, 20), (47, 43, 55)]
+  for pos in positions:
+    req = _lib.StepRequest()
+    req.pos[:] = pos
+    req.start_pos[:] = start
+    req.num_candidates = len(cands)
+    for k, c in enumerate(cands):
+      req.candidates[k][:] = c
+    res = engine.step1(canvas, req, params)
+    logits = oc.update_at(pos)
+    scores, idx = ffn_oracle.face_maxima((8, 8, 8), logits)
+    assert np.allclose(list(res.face_score), scores, atol=TOL)
+    assert list(res.face_index) == [int(i) for i in idx]
+    assert abs(res.start_logit - oc.seed[start]) <= TOL
+    for k, c in enumerate(cands):
+      a, b = res.cand_seed[k], oc.seed[c]
+      assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= TOL
+      assert res.cand_seg[k] == 0
+    got = canvas.read_seed()
+    assert np.array_equal(np.isnan(got), np.isnan(oc.seed))
+    assert np.nanmax(np.abs(got - oc.seed)) <= TOL
+  canvas.close()
+
+
+def test_canvas_utilities_bit_exact(engine):
+  """point / box / commit kernels are integer work: exact."""
+  from ffn_amd import synthetic
+  rng = np.random.RandomState(0)
+  shape = (40, 37, 45)
+  canvas = engine.create_canvas(rng.normal(0, 1, shape).astype(np.float32))
+  seed = rng.normal(0, 2, shape).astype(np.float32)
+  seed[rng.rand(*shape) < 0.3] = np.nan
+  seg = rng.randint(-1, 6, shape).astype(np.int32)
+  canvas.write_seed((0, 0, 0), shape, seed)
+  canvas.write_segmentation((0, 0, 0), shape, seg)
+  assert np.array_equal(canvas.read_seed(), seed, equal_nan=True)
+  assert np.array_equal(canvas.read_segmentation(), seg)
+  lo, hi = (3, 5, 7), (33, 30, 41)
+  sel = tuple(slice(l, h) for l, h in zip(lo, hi))
+  assert np.array_equal(canvas.read_seed(lo, hi), seed[sel], equal_nan=True)
+  assert np.array_equal(canvas.read_segmentation(lo, hi), seg[sel])
+  # commit count
+  thr = 0.4054652154
+  raw, actual, ids, counts = canvas.commit_count(lo, hi, thr, 5)
+  mask = seed[sel] >= np.float32(thr)
+  assert raw == int(mask.sum())
+  assert actual == int((mask & (seg[sel] <= 0)).sum())
+  uid, ucnt = np.unique(seg[sel][mask], return_counts=True)
+  keep = uid > 0
+  assert list(ids) == list(uid[keep]) and list(counts) == list(ucnt[keep])
+  canvas.commit_assign(lo, hi, thr, 77)
+  want = seg.copy()
+  want[sel][mask & (seg[sel] <= 0)] = 77
+  assert np.array_equal(canvas.read_segmentation(), want)
+  # any_segmented / points
+  assert canvas.any_segmented((0, 0, 0), (3, 3, 3)) == bool(
+      np.any(want[:3, :3, :3] > 0))
+  pts = rng.randint(0, 37, (50, 3))
+  s, g = canvas.read_points(pts)
+  assert np.array_equal(s, seed[tuple(pts.T)], equal_nan=True)
+  assert np.array_equal(g, want[tuple(pts.T)])
+  canvas.write_seg_points(pts[:5], [-1] * 5)
+  assert all(canvas.read_point(p)[1] == -1 for p in pts[:5])
+  # init_seed: everything NaN except the seed voxel
+  canvas.init_seed((20, 20, 20), 2.9444387)
+  out = canvas.read_seed()
+  assert np.isnan(out).sum() == out.size - 1
+  assert out[20, 20, 20] == np.float32(2.9444387)
+  canvas.close()
+
+
+@pytest.mark.parametrize('name', ['cells56', 'cells72'])
+def test_device_canvas_reproduces_reference_run(fib25_model, name):
+  """Full Canvas.segment_all on the GPU vs the fixture minted by the
+  reference's own Python (tools/make_golden.py): identical FoV trajectory,
+  segment ids and counters; seed logits within tolerance."""
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from ffn_amd.inference import seed as seed_lib
+  import bench
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_%s.npz' % name))
+  request = bench.make_request()
+  counters = inference_utils.Counters()
+  exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
+                                  fib25_model.info, None, counters, 1)
+  image = synthetic.normalize(g['volume'])
+  steps = []
+
+  class Rec(inference.DeviceCanvas):
+
+    def update_at(self, pos):
+      steps.append(tuple(pos))
+      return super().update_at(pos)
+
+  canvas = Rec(fib25_model.info, exe.get_client(counters, direct=True), image,
+               request.inference_options, counters=counters,
+               movement_policy_fn=movement.get_policy_fn(request,
+                                                         fib25_model.info))
+  canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                   coords=g['seeds']))
+  assert np.array_equal(np.array(steps).reshape(-1, 3), g['steps'])
+  assert np.array_equal(np.asarray(canvas.segmentation), g['segmentation'])
+  got_seed = np.asarray(canvas.seed)
+  assert np.array_equal(np.isnan(got_seed), np.isnan(g['seed_logits']))
+  assert np.nanmax(np.abs(got_seed - g['seed_logits'])) <= TOL
+  ref_counters = json.loads(str(g['counters']))
+  for key in ('update_at-calls', 'voxels-segmented', 'voxels-overlapping',
+              'skip_invalid_pos', 'skip_threshold', 'seed_got_too_weak',
+              'segment_at-loop-calls', 'seed-policy-calls'):
+    if key in ref_counters:
+      assert counters[key].value == ref_counters[key], key
+  origins = json.loads(str(g['origins']))
+  assert {int(k): [list(v.start_zyx), v.iters]
+          for k, v in canvas.origins.items()} == {
+              int(k): v for k, v in origins.items()}
+  canvas.close()
+
+
+def test_reference_style_host_canvas_through_threaded_executor(fib25_model):
+  """The literal plug-in boundary: host Canvas + client/server threads +
+  stateless ffn_predict (what an unmodified reference Canvas would use)."""
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from ffn_amd.inference import seed as seed_lib
+  import bench
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells56.npz'))
+  request = bench.make_request()
+  counters = inference_utils.Counters()
+  iface = executor.ExecutorInterface()
+  exe = executor.HipBatchExecutor(iface, fib25_model, fib25_model.info, None,
+                                  counters, 1)
+  exe.start_server()
+  client = executor.ThreadingExecutorClient(counters, iface)
+  canvas = inference.Canvas(fib25_model.info, client,
+                            synthetic.normalize(g['volume']),
+                            request.inference_options, counters=counters,
+                            movement_policy_fn=movement.get_policy_fn(
+                                request, fib25_model.info))
+  canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                   coords=g['seeds']))
+  exe.stop_server()
+  assert np.array_equal(np.asarray(canvas.segmentation), g['segmentation'])
+  assert counters['update_at-calls'].value == len(g['steps'])
+
+
+def test_full_size_properties_250(fib25_model):
+  """BASELINE size (250^3): size-independent properties instead of the oracle:
+  (1) re-running the same segment gives the identical trajectory/mask
+  (determinism), (2) the paste only touches the FoV box, (3) the device commit
+  counts equal a host recount of the downloaded arrays."""
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  import bench
+  request = bench.make_request()
+  counters = inference_utils.Counters()
+  exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
+                                  fib25_model.info, None, counters, 1)
+  vol = synthetic.cells_volume((250, 250, 250), seed=1234)
+  canvas = inference.DeviceCanvas(
+      fib25_model.info, exe.get_client(counters, direct=True),
+      synthetic.normalize(vol), request.inference_options, counters=counters,
+      movement_policy_fn=movement.get_policy_fn(request, fib25_model.info))
+  start = (120, 120, 120)
+  runs = []
+  for _ in range(2):
+    steps = []
+    orig = canvas.update_at
+
+    def rec(pos, _o=orig, _s=steps):
+      _s.append(tuple(pos))
+      if len(_s) > 60:
+        raise StopIteration
+      return _o(pos)
+
+    canvas.update_at = rec
+    try:
+      canvas.segment_at(start)
+    except StopIteration:
+      pass
+    canvas.update_at = orig
+    runs.append((list(steps), canvas._handle.read_seed()))
+  assert runs[0][0] == runs[1][0]
+  assert np.array_equal(runs[0][1], runs[1][1], equal_nan=True)
+  seed = runs[1][1]
+  touched = ~np.isnan(seed)
+  pts = np.array(runs[1][0][:-1] if len(runs[1][0]) > 60 else runs[1][0])
+  lo = np.maximum(pts.min(0) - 16, 0)
+  hi = pts.max(0) + 17
+  outside = touched.copy()
+  outside[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = False
+  assert not outside.any()
+  thr = canvas.options.segment_threshold
+  raw, actual, ids, counts = canvas._handle.commit_count(
+      [int(v) for v in lo], [int(min(h, 250)) for h in hi], thr, 0)
+  assert raw == int(np.sum(seed >= np.float32(thr)))
+  assert actual == raw and len(ids) == 0
+  canvas.close()

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Kernel-only timing of the conv stack (no host traffic, no Python per step).
+
+  python tools/gpu_microbench.py [--batch 1 4 32] [--repeats 50]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from ffn_amd import engine as hip_engine  # noqa: E402
+from ffn_amd.training.models import convstack_3d  # noqa: E402
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--batch', type=int, nargs='+', default=[1, 2, 4, 8, 32])
+  ap.add_argument('--repeats', type=int, default=50)
+  args = ap.parse_args()
+  model = convstack_3d.ConvStack3DFFNModel(fov_size=[33, 33, 33],
+                                           deltas=[8, 8, 8], depth=12)
+  model.load_checkpoint(os.path.join(ROOT, 'tests/golden/fib25_weights.npz'))
+  maxb = max(args.batch)
+  eng = hip_engine.HipEngine.from_model(model, max_batch=maxb)
+  rng = np.random.RandomState(0)
+  img = rng.normal(0, 1, (maxb, 33, 33, 33)).astype(np.float32)
+  seed = rng.normal(0, 1, (maxb, 33, 33, 33)).astype(np.float32)
+  eng.predict(seed, img)  # fills the staging buffers
+  flop = 2.0 * (2 * 27 * 32 + 23 * 27 * 32 * 32 + 32) * 33**3
+  for variant in (0, 1):
+    eng.set_option('conv_variant', variant)
+    for b in args.batch:
+      eng.forward_resident(b, 3)
+      eng.synchronize()
+      t0 = time.perf_counter()
+      eng.forward_resident(b, args.repeats)
+      eng.synchronize()
+      dt = (time.perf_counter() - t0) / args.repeats
+      eng.set_profiling(1)
+      eng.get_profile(reset=True)
+      eng.forward_resident(b, 10)
+      ms, n = eng.get_profile(reset=True)
+      eng.set_profiling(0)
+      print('variant %d batch %2d: %8.1f us/stack  %8.1f FoV/s  %6.2f TFLOP/s '
+            ' conv32 avg %.2f us (%d launches, %.1f TF/s in-kernel)' %
+            (variant, b, dt * 1e6, b / dt, b * flop / dt / 1e12,
+             ms / n * 1e3, n, b * 2.0 * 27 * 32 * 32 * 33**3 / (ms / n * 1e-3) / 1e12))
+  eng.close()
+
+
+if __name__ == '__main__':
+  main()
