@@ -116,6 +116,8 @@ def run_gpu(args, rank, local_rank, world):
   eng = exe.engine
   if args.conv_variant is not None:
     eng.set_option('conv_variant', args.conv_variant)
+  if args.sync_mode is not None:
+    eng.set_option('sync_mode', args.sync_mode)
 
   shape = (args.volume,) * 3
   if args.workload == 'cells':
@@ -151,6 +153,9 @@ def run_gpu(args, rank, local_rank, world):
                        request.inference_options, counters=counters,
                        movement_policy_fn=movement.get_policy_fn(
                            request, model.info))
+  # HIP-event pairs around every conv32 launch of 1 FoV step in
+  # `profile_every` (sampling keeps the event overhead out of `value`).
+  eng.set_option('profile_every', args.profile_every)
   eng.set_profiling(1)
   policy = functools.partial(seed_lib.PolicyGrid3d, step=16,
                              offsets=(0, 8, 4, 12, 2, 10, 14))
@@ -168,7 +173,9 @@ def run_gpu(args, rank, local_rank, world):
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+  cvals = {k: c.value for k, c in counters}
   result = {
+      'counters': cvals,
       'elapsed': elapsed,
       'elapsed_local': elapsed_local,
       'conv_ms': conv_ms,
@@ -183,56 +190,99 @@ def run_gpu(args, rank, local_rank, world):
 
 
 def cpu_baseline(args):
-  """Oracle port (plain C conv stack + numpy canvas loop, OpenMP on all host
-  cores) on a bounded sample of the same workload."""
+  """Oracle port on a bounded sample of the same workload, on this host's cores.
+
+  Two restatements of the conv stack are timed on the first FoV steps of the
+  same volume / seeds / options through the oracle's numpy canvas loop: the
+  plain-C OpenMP one (best of a few thread counts) and the torch-CPU / oneDNN
+  one (the stand-in for the reference's TF CPU path).
+  The faster is reported as `value`."""
   from ffn_amd import synthetic
   from oracle import ffn_oracle
   with np.load(os.path.join(ROOT, 'tests', 'golden', 'fib25_weights.npz')) as d:
-    blob = ffn_oracle.weights_blob({k: d[k] for k in d.files}, DEPTH)
+    variables = {k: d[k] for k in d.files}
+  blob = ffn_oracle.weights_blob(variables, DEPTH)
   shape = (args.volume,) * 3
   if args.workload == 'cells':
     vol = synthetic.cells_volume(shape, seed=1234)
   else:
     vol = synthetic.noise_volume(shape, seed=0)
   image = synthetic.normalize(vol)
-  oc = ffn_oracle.OracleCanvas(image, blob, DEPTH, FOV, DELTAS,
-                               ffn_oracle.Options())
-  budget_s = args.cpu_seconds
-  max_steps = args.cpu_steps
+  seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))
+  ncpu = os.cpu_count() or 1
 
   class _Stop(Exception):
     pass
 
-  t0 = [None]
-  inner = oc.update_at
-  n = [0]
+  def run(forward_fn, budget_s, max_steps):
+    oc = ffn_oracle.OracleCanvas(image, blob, DEPTH, FOV, DELTAS,
+                                 ffn_oracle.Options())
+    oc.forward_fn = forward_fn
+    t0 = [None]
+    inner = oc.update_at
+    n = [0]
 
-  def timed_update(pos):
-    if n[0] == 1:  # first step = warmup (OpenMP spin-up, page faults)
-      t0[0] = time.perf_counter()
-    out = inner(pos)
-    n[0] += 1
-    if n[0] > 1 and (n[0] - 1 >= max_steps or
-                     time.perf_counter() - t0[0] > budget_s):
-      raise _Stop()
-    return out
+    def timed_update(pos):
+      if n[0] == 1:  # first step = warm-up (thread spin-up, page faults)
+        t0[0] = time.perf_counter()
+      out = inner(pos)
+      n[0] += 1
+      if n[0] > 1 and (n[0] - 1 >= max_steps or
+                       time.perf_counter() - t0[0] > budget_s):
+        raise _Stop()
+      return out
 
-  oc.update_at = timed_update
-  seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))
+    oc.update_at = timed_update
+    try:
+      oc.segment_all(seeds)
+    except _Stop:
+      pass
+    steps = n[0] - 1
+    dt = time.perf_counter() - t0[0]
+    return steps / dt, steps, dt
+
+  results = {}
+  # plain-C oracle: pick the best OpenMP thread count with a short probe
+  best_thr, best_rate = None, 0.0
+  for thr in sorted({ncpu, max(ncpu // 2, 1), min(64, ncpu), min(32, ncpu),
+                     min(16, ncpu)}, reverse=True):
+    ffn_oracle.set_threads(thr)
+    rate, _, _ = run(None, 1.5, 4)
+    if rate > best_rate:
+      best_thr, best_rate = thr, rate
+  ffn_oracle.set_threads(best_thr)
+  rate_c, steps_c, dt_c = run(None, args.cpu_seconds / 2, args.cpu_steps)
+  results['c_oracle'] = (rate_c, steps_c, dt_c, best_thr)
   try:
-    oc.segment_all(seeds)
-  except _Stop:
+    import torch
+    best_t, best_rate = None, 0.0
+    for thr in sorted({ncpu, min(64, ncpu), min(32, ncpu), min(16, ncpu)},
+                      reverse=True):
+      fn = functools.partial(ffn_oracle.forward_torch, variables=variables,
+                             depth=DEPTH, threads=thr)
+      rate, _, _ = run(fn, 1.5, 4)
+      if rate > best_rate:
+        best_t, best_rate = thr, rate
+    fn = functools.partial(ffn_oracle.forward_torch, variables=variables,
+                           depth=DEPTH, threads=best_t)
+    rate_t, steps_t, dt_t = run(fn, args.cpu_seconds / 2, args.cpu_steps)
+    results['torch_onednn'] = (rate_t, steps_t, dt_t, best_t)
+  except ImportError:
     pass
-  steps = n[0] - 1
-  dt = time.perf_counter() - t0[0]
+  name = max(results, key=lambda k: results[k][0])
+  rate, steps, dt, thr = results[name]
   return {
-      'value': round(steps / dt, 3),
+      'value': round(rate, 3),
       'unit': 'FoV-steps/s',
-      'cores': os.cpu_count(),
+      'cores': int(thr),
+      'host_cores': ncpu,
       'kind': 'port',
-      'sample': ('first %d FoV steps of the same %s %d^3 workload through '
-                 'oracle/ (C conv stack, OpenMP, + numpy canvas loop), %.1f s'
-                 % (steps, args.workload, args.volume, dt)),
+      'implementation': name,
+      'all': {k: round(v[0], 3) for k, v in results.items()},
+      'sample': ('first %d FoV steps of the same %s %d^3 workload (same seeds, '
+                 'options, weights) through the oracle canvas loop with the %s '
+                 'conv stack on %d threads, %.1f s'
+                 % (steps, args.workload, args.volume, name, thr, dt)),
   }
 
 
@@ -244,6 +294,8 @@ def main():
   ap.add_argument('--volume', type=int, default=250)
   ap.add_argument('--workload', choices=['cells', 'noise'], default='cells')
   ap.add_argument('--conv-variant', type=int, default=None)
+  ap.add_argument('--profile-every', type=int, default=8)
+  ap.add_argument('--sync-mode', type=int, default=None)
   ap.add_argument('--cpu-seconds', type=float, default=15.0)
   ap.add_argument('--cpu-steps', type=int, default=60)
   ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -285,6 +337,17 @@ def main():
           'parallelism': 'independent volume per rank (no data-path collective)',
       },
       'voxels_segmented_per_s': round(world * res['voxels'] / res['elapsed'], 1),
+      'host_breakdown_us_per_step': {
+          'c_abi_step_call': round(1e3 * res['counters'].get(
+              'inference-time-ms', 0) / max(res['counters'].get(
+                  'inference-calls', 1), 1), 1),
+          'update_at': round(1e3 * res['counters'].get(
+              'update_at-time-ms', 0) / max(res['counters'].get(
+                  'update_at-calls', 1), 1), 1),
+          'movement_policy': round(1e3 * res['counters'].get(
+              'movement_policy-time-ms', 0) / max(res['counters'].get(
+                  'movement_policy-calls', 1), 1), 1),
+      },
       'step_gflop': round(STEP_FLOPS / 1e9, 3),
       'end_to_end_tflops': round(steps_per_s * STEP_FLOPS / 1e12, 3),
       'roofline': {

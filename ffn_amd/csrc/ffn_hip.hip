@@ -21,6 +21,8 @@ using namespace ffn;
 
 namespace {
 
+constexpr int kHeadBlocks = 281;  // head kernel grid.x (4 sweeps of 32 voxels x 281)
+
 thread_local std::string g_error;
 
 int fail(int code, const char* fmt, ...) {
@@ -57,8 +59,9 @@ struct ffn_engine {
   float* bufXR = nullptr;     // relu(X) (pipelined variant only)
   uint32_t* validbits = nullptr;
   int conv_variant = 1;       // 0 = conv32_kernel (simple), 1 = conv32p_kernel
-  float* in_image = nullptr;
-  float* in_seed = nullptr;
+  float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
+  float* up_seed = nullptr;
+  float* seed_raw = nullptr;  // raw (NaN-preserving) seed FoV of the current step
   float* logits = nullptr;
   unsigned* count = nullptr;
   uint8_t* valid = nullptr;
@@ -68,8 +71,10 @@ struct ffn_engine {
 
   StepItem* d_items = nullptr;
   StepItem* h_items = nullptr;
-  ffn_step_result* d_results = nullptr;
-  ffn_step_result* h_results = nullptr;
+  ffn_step_result* h_results = nullptr;  // pinned; written by the paste kernel
+  unsigned* h_seq = nullptr;             // pinned per-item completion flags
+  unsigned step_id = 0;
+  int sync_mode = 1;  // 0 = hipStreamSynchronize, 1 = poll h_seq (then sync)
 
   void* d_scratch = nullptr;
   void* h_scratch = nullptr;
@@ -81,6 +86,11 @@ struct ffn_engine {
   double conv_ms = 0.0;
   int64_t conv_launches = 0;
   size_t lds_bytes = 0;
+  std::vector<ffn_canvas*> canvases;  // live canvases created from this engine
+  int prof_every = 1;                 // profile 1 of every N run_stack calls
+  long stack_calls = 0;
+  bool prof_now = false;
+  int ablate = 0;                     // debug: skip phases of the conv kernel
 };
 
 struct ffn_canvas {
@@ -116,10 +126,10 @@ int set_lds_attr(size_t bytes) {
   return FFN_OK;
 }
 
-template <bool RO, bool SK, bool DU>
+template <bool RO, bool SK, bool DU, int ABL = 0>
 int set_lds_attr_p(size_t bytes) {
   HIP_TRY(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv32p_kernel<RO, SK, DU>),
+      reinterpret_cast<const void*>(&conv32p_kernel<RO, SK, DU, ABL>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return FFN_OK;
 }
@@ -153,7 +163,7 @@ int launch_conv32(ffn_engine* e, int n, const float* in, float* out,
   a.plane = e->g.plane;
   a.R = e->g.R;
   a.nchunks = e->g.nchunks;
-  const bool prof = e->prof_mode == 1;
+  const bool prof = e->prof_now;
   if (prof) {
     if (e->events_used + 2 > (int)e->events.size()) {
       int rc = flush_events(e);
@@ -185,7 +195,7 @@ int launch_conv32p(ffn_engine* e, int n, const float* in, float* out,
   a.nchunks = e->g.nchunks;
   a.total_slots = n * e->g.nchunks;
   a.slots_per_xcd = (a.total_slots + 7) / 8;
-  const bool prof = e->prof_mode == 1;
+  const bool prof = e->prof_now;
   if (prof) {
     if (e->events_used + 2 > (int)e->events.size()) {
       int rc = flush_events(e);
@@ -193,19 +203,45 @@ int launch_conv32p(ffn_engine* e, int n, const float* in, float* out,
     }
     HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   }
-  hipLaunchKernelGGL((conv32p_kernel<RO, SK, DU>), dim3(8 * a.slots_per_xcd),
-                     dim3(kConvThreads), e->lds_bytes, e->stream, a);
+  const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
+  if (RO == false && SK == true && DU == true && e->ablate != 0) {
+    // debug ablations exist for the conv_b instantiation only
+    switch (e->ablate) {
+#define FFN_ABL_CASE(N)                                                     \
+  case N:                                                                   \
+    hipLaunchKernelGGL((conv32p_kernel<false, true, true, N>), grid, block, \
+                       e->lds_bytes, e->stream, a);                         \
+    break;
+      FFN_ABL_CASE(1)
+      FFN_ABL_CASE(2)
+      FFN_ABL_CASE(4)
+      FFN_ABL_CASE(5)
+      FFN_ABL_CASE(6)
+      FFN_ABL_CASE(7)
+#undef FFN_ABL_CASE
+      default:
+        return fail(FFN_ERR_ARG, "unsupported ablate mask %d", e->ablate);
+    }
+  } else {
+    hipLaunchKernelGGL((conv32p_kernel<RO, SK, DU>), grid, block, e->lds_bytes,
+                       e->stream, a);
+  }
   if (prof) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   return FFN_OK;
 }
 
-// in_image / in_seed (dense staging) -> logits (+ count of logits >= move_thr)
-int run_stack(ffn_engine* e, int n, float pad_value, float move_thr) {
+// FoVs described by `si` -> logits (+ count of logits >= move_thr, + seed_raw)
+int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
+              float move_thr) {
   const Geom& g = e->g;
+  e->prof_now = e->prof_mode == 1 && (e->stack_calls % e->prof_every) == 0;
+  e->stack_calls++;
   const float* W = e->weights;
-  hipLaunchKernelGGL(conv0a_kernel, dim3((g.npos + 255) / 256, n), dim3(256), 0,
-                     e->stream, e->in_image, e->in_seed, pad_value,
-                     W + e->w0a_off, W + e->b0a_off, e->bufT, g);
+  const int tz = (g.fz + kC0Z - 1) / kC0Z, ty = (g.fy + kC0Y - 1) / kC0Y,
+            tx = (g.fx + kC0X - 1) / kC0X;
+  hipLaunchKernelGGL(conv0a_kernel, dim3(tz * ty * tx, n), dim3(256), 0,
+                     e->stream, si, pad_value, W + e->w0a_off, W + e->b0a_off,
+                     e->bufT, e->seed_raw, g, ty, tx);
   int rc;
   const float* head_in;
   if (e->conv_variant == 0) {
@@ -235,11 +271,36 @@ int run_stack(ffn_engine* e, int n, float pad_value, float move_thr) {
     }
     head_in = e->bufXR;
   }
-  HIP_TRY(hipMemsetAsync(e->count, 0, sizeof(unsigned) * n, e->stream));
-  hipLaunchKernelGGL(head_kernel, dim3((g.V * 8 + 255) / 256, n), dim3(256), 0,
-                     e->stream, head_in, e->in_seed, pad_value, W + e->wl_off,
-                     move_thr, e->logits, e->count, g);
+  hipLaunchKernelGGL(head_kernel, dim3(kHeadBlocks, n), dim3(256), 0, e->stream, head_in,
+                     e->seed_raw, pad_value, W + e->wl_off, move_thr, e->logits,
+                     e->count, g);
   HIP_TRY(hipGetLastError());
+  return FFN_OK;
+}
+
+// Step descriptors for the dense uploaded FoVs (predict / forward_resident):
+// each FoV is its own FoV-sized "canvas" centred on its middle voxel.
+int dense_items(ffn_engine* e, int n, StepItems* si) {
+  const Geom& g = e->g;
+  for (int k = 0; k < n; ++k) {
+    StepItem& it = e->h_items[k];
+    std::memset(&it, 0, sizeof(it));
+    it.image = e->up_image + (size_t)k * g.V;
+    it.seed = e->up_seed + (size_t)k * g.V;
+    it.seg = nullptr;
+    it.cz = g.fz;
+    it.cy = g.fy;
+    it.cx = g.fx;
+    it.req.pos[0] = g.fz / 2;
+    it.req.pos[1] = g.fy / 2;
+    it.req.pos[2] = g.fx / 2;
+  }
+  si->items = e->d_items;
+  si->use_inline = n == 1;
+  si->inline_item = e->h_items[0];
+  if (n > 1)
+    HIP_TRY(hipMemcpyAsync(e->d_items, e->h_items, sizeof(StepItem) * n,
+                           hipMemcpyHostToDevice, e->stream));
   return FFN_OK;
 }
 
@@ -254,6 +315,12 @@ Box make_box(const ffn_canvas* c, const int32_t lo[3], const int32_t hi[3],
   b.cx = c->cx;
   *total = (long)b.n[0] * b.n[1] * b.n[2];
   return b;
+}
+
+int check_canvas(const ffn_canvas* c) {
+  if (!c) return fail(FFN_ERR_ARG, "null canvas");
+  if (!c->engine) return fail(FFN_ERR_STATE, "canvas outlived its engine");
+  return FFN_OK;
 }
 
 int check_box(const ffn_canvas* c, const int32_t lo[3], const int32_t hi[3]) {
@@ -350,18 +417,21 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   e->bufX = e->bufT + (size_t)max_batch * g.act_stride;
   e->bufXR = e->bufX + (size_t)max_batch * g.act_stride;
   const size_t vbytes = (size_t)max_batch * g.V * sizeof(float);
-  E_TRY(hipMalloc(&e->in_image, vbytes));
-  E_TRY(hipMalloc(&e->in_seed, vbytes));
+  E_TRY(hipMalloc(&e->up_image, vbytes));
+  E_TRY(hipMalloc(&e->up_seed, vbytes));
+  E_TRY(hipMalloc(&e->seed_raw, vbytes));
   E_TRY(hipMalloc(&e->logits, vbytes));
-  E_TRY(hipMemset(e->in_image, 0, vbytes));
-  E_TRY(hipMemset(e->in_seed, 0, vbytes));
-  E_TRY(hipMalloc(&e->count, sizeof(unsigned) * max_batch));
+  E_TRY(hipMemset(e->up_image, 0, vbytes));
+  E_TRY(hipMemset(e->up_seed, 0, vbytes));
+  E_TRY(hipMalloc(&e->count, sizeof(unsigned) * max_batch * kHeadBlocks));
   E_TRY(hipMalloc(&e->d_items, sizeof(StepItem) * max_batch));
   E_TRY(hipHostMalloc(&e->h_items, sizeof(StepItem) * max_batch,
                       hipHostMallocDefault));
-  E_TRY(hipMalloc(&e->d_results, sizeof(ffn_step_result) * max_batch));
   E_TRY(hipHostMalloc(&e->h_results, sizeof(ffn_step_result) * max_batch,
                       hipHostMallocDefault));
+  E_TRY(hipHostMalloc(&e->h_seq, sizeof(unsigned) * max_batch,
+                      hipHostMallocDefault));
+  std::memset(e->h_seq, 0, sizeof(unsigned) * max_batch);
 
   // validity table of the padded-flat layout
   {
@@ -411,6 +481,12 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<true, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<false, true, true>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, true, true, 1>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, true, true, 2>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, true, true, 4>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, true, true, 5>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, true, true, 6>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, true, true, 7>(e->lds_bytes);
     if (rc) {
       ffn_engine_destroy(e);
       return rc;
@@ -425,21 +501,33 @@ void ffn_engine_destroy(ffn_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  // Orphan the canvases still alive: their device memory goes with the engine;
+  // ffn_canvas_destroy on an orphan only frees the host struct.
+  for (ffn_canvas* c : e->canvases) {
+    (void)hipFree(c->image);
+    (void)hipFree(c->seed);
+    (void)hipFree(c->seg);
+    c->image = c->seed = nullptr;
+    c->seg = nullptr;
+    c->engine = nullptr;
+  }
+  e->canvases.clear();
   for (auto& ev : e->events)
     if (ev) (void)hipEventDestroy(ev);
   (void)hipFree(e->act_base);
-  (void)hipFree(e->in_image);
-  (void)hipFree(e->in_seed);
+  (void)hipFree(e->up_image);
+  (void)hipFree(e->up_seed);
+  (void)hipFree(e->seed_raw);
   (void)hipFree(e->logits);
   (void)hipFree(e->count);
   (void)hipFree(e->valid);
   (void)hipFree(e->validbits);
   (void)hipFree(e->weights);
   (void)hipFree(e->d_items);
-  (void)hipFree(e->d_results);
   (void)hipFree(e->d_scratch);
   if (e->h_items) (void)hipHostFree(e->h_items);
   if (e->h_results) (void)hipHostFree(e->h_results);
+  if (e->h_seq) (void)hipHostFree(e->h_seq);
   if (e->h_scratch) (void)hipHostFree(e->h_scratch);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -494,10 +582,13 @@ int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
   if (!e->weights_set) return fail(FFN_ERR_STATE, "weights not set");
   HIP_TRY(hipSetDevice(e->device));
   const size_t bytes = (size_t)n * e->g.V * sizeof(float);
-  HIP_TRY(hipMemcpyAsync(e->in_seed, seed, bytes, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->in_image, image, bytes, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->up_seed, seed, bytes, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->up_image, image, bytes, hipMemcpyHostToDevice, e->stream));
+  StepItems si;
+  int rc = dense_items(e, n, &si);
+  if (rc) return rc;
   // NaNs in a caller-provided seed stay NaN (the reference would feed them to TF).
-  int rc = run_stack(e, n, std::nanf(""), INFINITY);
+  rc = run_stack(e, n, si, std::nanf(""), INFINITY);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(logits_out, e->logits, bytes, hipMemcpyDeviceToHost,
                          e->stream));
@@ -511,8 +602,11 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
     return fail(FFN_ERR_ARG, "batch %d outside [1, %d]", n, e->max_batch);
   if (!e->weights_set) return fail(FFN_ERR_STATE, "weights not set");
   HIP_TRY(hipSetDevice(e->device));
+  StepItems si;
+  int rc = dense_items(e, n, &si);
+  if (rc) return rc;
   for (int r = 0; r < repeats; ++r) {
-    int rc = run_stack(e, n, std::nanf(""), INFINITY);
+    rc = run_stack(e, n, si, std::nanf(""), INFINITY);
     if (rc) return rc;
   }
   return FFN_OK;
@@ -523,6 +617,20 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (std::strcmp(name, "conv_variant") == 0) {
     if (value != 0 && value != 1) return fail(FFN_ERR_ARG, "conv_variant must be 0 or 1");
     e->conv_variant = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "profile_every") == 0) {
+    if (value < 1) return fail(FFN_ERR_ARG, "profile_every must be >= 1");
+    e->prof_every = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "sync_mode") == 0) {
+    if (value != 0 && value != 1) return fail(FFN_ERR_ARG, "sync_mode must be 0 or 1");
+    e->sync_mode = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "ablate") == 0) {
+    e->ablate = value;
     return FFN_OK;
   }
   return fail(FFN_ERR_ARG, "unknown option '%s'", name);
@@ -592,6 +700,7 @@ int ffn_canvas_create(ffn_engine* e, const float* image_f32,
     ffn_canvas_destroy(c);
     return rc;
   }
+  e->canvases.push_back(c);
   *out = c;
   return FFN_OK;
 }
@@ -599,12 +708,15 @@ int ffn_canvas_create(ffn_engine* e, const float* image_f32,
 void ffn_canvas_destroy(ffn_canvas* c) {
   if (!c) return;
   if (c->engine) {
-    (void)hipSetDevice(c->engine->device);
-    (void)hipStreamSynchronize(c->engine->stream);
+    ffn_engine* e = c->engine;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    e->canvases.erase(std::remove(e->canvases.begin(), e->canvases.end(), c),
+                      e->canvases.end());
+    (void)hipFree(c->image);
+    (void)hipFree(c->seed);
+    (void)hipFree(c->seg);
   }
-  (void)hipFree(c->image);
-  (void)hipFree(c->seed);
-  (void)hipFree(c->seg);
   delete c;
 }
 
@@ -614,6 +726,7 @@ int ffn_canvas_init_seed(ffn_canvas* c, const int32_t pos[3], float value) {
       pos[2] < 0 || pos[2] >= c->cx)
     return fail(FFN_ERR_ARG, "seed position outside the canvas");
   ffn_engine* e = c->engine;
+  if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
   hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, e->stream,
                      reinterpret_cast<uint32_t*>(c->seed), 0x7fc00000u, c->nvox);
@@ -658,20 +771,47 @@ int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
     it.req = r;
   }
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemcpyAsync(e->d_items, e->h_items, sizeof(StepItem) * n,
-                         hipMemcpyHostToDevice, e->stream));
-  hipLaunchKernelGGL(gather_kernel, dim3(36, n), dim3(256), 0, e->stream,
-                     e->d_items, g, e->in_image, e->in_seed);
-  int rc = run_stack(e, n, params->pad_value, params->move_threshold);
+  StepItems si;
+  si.items = e->d_items;
+  si.use_inline = n == 1;
+  si.inline_item = e->h_items[0];
+  if (n > 1)
+    HIP_TRY(hipMemcpyAsync(e->d_items, e->h_items, sizeof(StepItem) * n,
+                           hipMemcpyHostToDevice, e->stream));
+  int rc = run_stack(e, n, si, params->pad_value, params->move_threshold);
   if (rc) return rc;
-  hipLaunchKernelGGL(paste_kernel, dim3(19, n), dim3(512), 0, e->stream,
-                     e->d_items, g, e->logits, e->in_seed, e->count,
-                     params->move_threshold, params->disco_seed_threshold,
-                     e->d_results);
+  const unsigned step_id = ++e->step_id ? e->step_id : ++e->step_id;  // never 0
+  hipLaunchKernelGGL(paste_kernel, dim3(72, n), dim3(512), 0, e->stream, si, g,
+                     e->logits, e->seed_raw, e->count, kHeadBlocks,
+                     params->move_threshold,
+                     params->disco_seed_threshold, e->h_results, e->h_seq,
+                     step_id);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(e->h_results, e->d_results, sizeof(ffn_step_result) * n,
-                         hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->sync_mode == 1) {
+    // Poll the completion flags the paste kernel raises in pinned memory: lower
+    // wake-up latency than a blocking stream synchronise.  Bounded spin, then
+    // fall back to the stream so that device faults still surface as errors.
+    volatile unsigned* seq = e->h_seq;
+    bool done = false;
+    for (long spin = 0; spin < 200000000L && !done; ++spin) {
+      done = true;
+      for (int k = 0; k < n; ++k)
+        if (__atomic_load_n(&seq[k], __ATOMIC_ACQUIRE) != step_id) done = false;
+      if (!done && (spin & 0xfff) == 0xfff &&
+          hipStreamQuery(e->stream) == hipSuccess) {
+        done = true;  // stream drained: flags must be set (or the kernel died)
+      }
+    }
+    if (!done) HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int k = 0; k < n; ++k)
+      if (__atomic_load_n(&seq[k], __ATOMIC_ACQUIRE) != step_id) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (__atomic_load_n(&seq[k], __ATOMIC_ACQUIRE) != step_id)
+          return fail(FFN_ERR_HIP, "step %u did not complete", step_id);
+      }
+  } else {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   std::memcpy(results, e->h_results, sizeof(ffn_step_result) * n);
   return FFN_OK;
 }
@@ -681,6 +821,7 @@ int ffn_canvas_read_points(ffn_canvas* c, int n, const int32_t* pos,
   if (!c || !pos || !seed_out || !seg_out) return fail(FFN_ERR_ARG, "null argument");
   if (n < 1) return FFN_OK;
   ffn_engine* e = c->engine;
+  if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
   const size_t pb = sizeof(int32_t) * 3 * n;
   const size_t pbr = (pb + 15) & ~(size_t)15;
@@ -712,6 +853,7 @@ int ffn_canvas_write_seg_points(ffn_canvas* c, int n, const int32_t* pos,
         pos[3 * k + 1] >= c->cy || pos[3 * k + 2] < 0 || pos[3 * k + 2] >= c->cx)
       return fail(FFN_ERR_ARG, "point %d outside the canvas", k);
   ffn_engine* e = c->engine;
+  if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
   const size_t pb = sizeof(int32_t) * 3 * n;
   const size_t pbr = (pb + 15) & ~(size_t)15;
@@ -746,6 +888,7 @@ int ffn_canvas_any_segmented(ffn_canvas* c, const int32_t lo[3],
     }
   }
   ffn_engine* e = c->engine;
+  if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
   int rc = ensure_scratch(e, 16);
   if (rc) return rc;
@@ -772,6 +915,7 @@ int ffn_canvas_commit_count(ffn_canvas* c, const int32_t lo[3],
   if (rc) return rc;
   if (max_existing_id < 0) max_existing_id = 0;
   ffn_engine* e = c->engine;
+  if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
   const size_t hist_n = (size_t)max_existing_id + 1;
   const size_t bytes = 16 + hist_n * sizeof(unsigned);
@@ -815,6 +959,7 @@ int ffn_canvas_commit_assign(ffn_canvas* c, const int32_t lo[3],
   int rc = check_box(c, lo, hi);
   if (rc) return rc;
   ffn_engine* e = c->engine;
+  if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
   long total;
   Box b = make_box(c, lo, hi, &total);
@@ -837,6 +982,7 @@ int box_read(ffn_canvas* c, const T* vol, const int32_t lo[3], const int32_t hi[
   int rc = check_box(c, lo, hi);
   if (rc) return rc;
   ffn_engine* e = c->engine;
+  if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
   long total;
   Box b = make_box(c, lo, hi, &total);
@@ -864,6 +1010,7 @@ int box_write(ffn_canvas* c, T* vol, const int32_t lo[3], const int32_t hi[3],
   int rc = check_box(c, lo, hi);
   if (rc) return rc;
   ffn_engine* e = c->engine;
+  if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
   long total;
   Box b = make_box(c, lo, hi, &total);

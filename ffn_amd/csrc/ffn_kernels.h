@@ -52,88 +52,96 @@ struct StepItem {
 };
 
 // ---------------------------------------------------------------------------
-// gather: canvas image/seed FoV -> dense staging  (reference inference.py:348-354,
-// 399-405).  NaN ("never visited") is kept; consumers substitute pad_value.
+// conv0a: gather + concat(image, seed) -> 3x3x3 conv 2->32 + bias + ReLU
+// (reference inference.py:348-354,399-407; convstack_3d.py:38,86).
+//
+// Reads the FoV straight out of the canvas volumes (or, for the stateless
+// predict path, out of the uploaded dense FoV treated as a FoV-sized canvas),
+// substitutes pad_value for NaN ("never visited") seed voxels, and also writes
+// the raw (NaN-preserving) seed FoV to `seed_raw`, which the head (seed + update)
+// and the paste kernel (disco mask) need later.  K = 54 only: VALU.
+// One block = a 4x8x8 tile of positions: the tile + halo is staged once in LDS
+// (one canvas read per input voxel), every thread then computes all 32 output
+// channels of its position with the weights coming through the scalar cache.
 // ---------------------------------------------------------------------------
-__global__ void gather_kernel(const StepItem* __restrict__ items, Geom g,
-                              float* __restrict__ in_image,
-                              float* __restrict__ in_seed) {
-  const StepItem& it = items[blockIdx.y];
+struct StepItems {
+  const StepItem* items;  // device array (batched path)
+  StepItem inline_item;   // kernarg copy (single-canvas fast path)
+  int use_inline;
+};
+
+constexpr int kC0Z = 4, kC0Y = 8, kC0X = 8;  // conv0a output tile per block
+
+__global__ __launch_bounds__(256) void conv0a_kernel(
+    StepItems si, float pad_value, const float* __restrict__ w /*[27][2][32]*/,
+    const float* __restrict__ bias, float* __restrict__ out,
+    float* __restrict__ seed_raw, Geom g, int tiles_y, int tiles_x) {
+  // input tile + 1-voxel halo, (image, seed) interleaved
+  constexpr int HZ = kC0Z + 2, HY = kC0Y + 2, HX = kC0X + 2;
+  __shared__ float2 tile[HZ * HY * HX];
+  const int item = blockIdx.y;
+  const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
+  int b = blockIdx.x;
+  const int tx = b % tiles_x;
+  b /= tiles_x;
+  const int ty = b % tiles_y;
+  const int tz = b / tiles_y;
+  const int oz = tz * kC0Z, oy = ty * kC0Y, ox = tx * kC0X;  // FoV coords
   const int z0 = it.req.pos[0] - g.fz / 2;
   const int y0 = it.req.pos[1] - g.fy / 2;
   const int x0 = it.req.pos[2] - g.fx / 2;
-  const size_t base = (size_t)blockIdx.y * g.V;
-  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < g.V;
-       v += gridDim.x * blockDim.x) {
-    const int x = v % g.fx;
-    const int t = v / g.fx;
-    const int y = t % g.fy;
-    const int z = t / g.fy;
-    const size_t ci = ((size_t)(z0 + z) * it.cy + (y0 + y)) * it.cx + (x0 + x);
-    in_image[base + v] = it.image[ci];
-    in_seed[base + v] = it.seed[ci];
-  }
-}
 
-// ---------------------------------------------------------------------------
-// conv0_a: concat(image, seed) -> 3x3x3 conv 2->32 + bias + ReLU
-// (reference convstack_3d.py:38,86).  K = 54 only: VALU, weights through the
-// scalar cache (wave-uniform addresses).  One thread per padded position.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv0a_kernel(
-    const float* __restrict__ in_image, const float* __restrict__ in_seed,
-    float pad_value, const float* __restrict__ w /*[27][2][32]*/,
-    const float* __restrict__ bias, float* __restrict__ out, Geom g) {
-  const int item = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= g.npos) return;
-  const int z = p / g.plane;
-  const int rem = p - z * g.plane;
-  const int y = rem / g.XS;
-  const int x = rem - y * g.XS;
-  if (y >= g.fy || x >= g.fx) return;  // shared halo row / column: stays zero
-  const float* img = in_image + (size_t)item * g.V;
-  const float* sd = in_seed + (size_t)item * g.V;
+  for (int e = threadIdx.x; e < HZ * HY * HX; e += 256) {
+    const int hx = e % HX;
+    const int t = e / HX;
+    const int hy = t % HY;
+    const int hz = t / HY;
+    const int zz = oz + hz - 1, yy = oy + hy - 1, xx = ox + hx - 1;
+    float2 v = make_float2(0.0f, 0.0f);  // SAME zero padding outside the FoV
+    if (zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy && xx >= 0 && xx < g.fx) {
+      const size_t ci =
+          ((size_t)(z0 + zz) * it.cy + (y0 + yy)) * it.cx + (x0 + xx);
+      v.x = it.image[ci];
+      v.y = it.seed[ci];
+      if (hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y && hx >= 1 &&
+          hx <= kC0X)  // interior voxel: keep the raw seed (NaN preserved)
+        seed_raw[(size_t)item * g.V + ((size_t)zz * g.fy + yy) * g.fx + xx] = v.y;
+      if (v.y != v.y) v.y = pad_value;  // NaN -> pad (inference.py:406-407)
+    }
+    tile[e] = v;
+  }
+  __syncthreads();
+
+  const int lx = threadIdx.x % kC0X;
+  const int ly = (threadIdx.x / kC0X) % kC0Y;
+  const int lz = threadIdx.x / (kC0X * kC0Y);
+  const int z = oz + lz, y = oy + ly, x = ox + lx;
+  if (z >= g.fz || y >= g.fy || x >= g.fx) return;
 
   float acc[kFeatures];
 #pragma unroll
-  for (int c = 0; c < kFeatures; ++c) acc[c] = 0.0f;
-
-#pragma unroll 1
-  for (int kz = 0; kz < 3; ++kz) {
-    const int zz = z + kz - 1;
-#pragma unroll 1
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yy = y + ky - 1;
+  for (int c = 0; c < kFeatures; ++c) acc[c] = bias[c];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int xx = x + kx - 1;
-        float a0 = 0.0f, a1 = 0.0f;
-        if (zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy && xx >= 0 &&
-            xx < g.fx) {
-          const int v = (zz * g.fy + yy) * g.fx + xx;
-          a0 = img[v];
-          a1 = sd[v];
-          if (a1 != a1) a1 = pad_value;  // NaN -> pad (inference.py:406-407)
-        }
-        const float* wt = w + ((kz * 3 + ky) * 3 + kx) * 2 * kFeatures;
+  for (int tap = 0; tap < 27; ++tap) {
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    const float2 a = tile[((lz + kz) * HY + (ly + ky)) * HX + (lx + kx)];
+    const float* wt = w + tap * 2 * kFeatures;  // wave-uniform: scalar loads
 #pragma unroll
-        for (int c = 0; c < kFeatures; ++c) {
-          acc[c] = __builtin_fmaf(a0, wt[c], acc[c]);
-          acc[c] = __builtin_fmaf(a1, wt[kFeatures + c], acc[c]);
-        }
-      }
+    for (int c = 0; c < kFeatures; ++c) {
+      acc[c] = __builtin_fmaf(a.x, wt[c], acc[c]);
+      acc[c] = __builtin_fmaf(a.y, wt[kFeatures + c], acc[c]);
     }
   }
-  float* o = out + (size_t)item * g.act_stride + (size_t)p * kFeatures;
+  const size_t p = (size_t)z * g.plane + (size_t)y * g.XS + x;
+  float* o = out + (size_t)item * g.act_stride + p * kFeatures;
 #pragma unroll
   for (int c = 0; c < kFeatures; c += 4) {
-    float4 v;
-    v.x = fmaxf(acc[c + 0] + bias[c + 0], 0.0f);
-    v.y = fmaxf(acc[c + 1] + bias[c + 1], 0.0f);
-    v.z = fmaxf(acc[c + 2] + bias[c + 2], 0.0f);
-    v.w = fmaxf(acc[c + 3] + bias[c + 3], 0.0f);
-    *reinterpret_cast<float4*>(o + c) = v;
+    f32x4 v;
+    v[0] = fmaxf(acc[c + 0], 0.0f);
+    v[1] = fmaxf(acc[c + 1], 0.0f);
+    v[2] = fmaxf(acc[c + 2], 0.0f);
+    v[3] = fmaxf(acc[c + 3], 0.0f);
+    *reinterpret_cast<f32x4*>(o + c) = v;
   }
 }
 
@@ -314,7 +322,9 @@ struct ConvPArgs {
                                              0, 0);                           \
   }
 
-template <bool RELU_OUT, bool ADD_SKIP, bool DUAL_OUT>
+// ABL (debug ablation, 0 in production): 1 = no staging loads, 2 = no MFMA
+// loop, 4 = no epilogue memory traffic.
+template <bool RELU_OUT, bool ADD_SKIP, bool DUAL_OUT, int ABL = 0>
 __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -337,9 +347,12 @@ __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
       const long p0 = (long)m0 - (a.XS + 1) + (long)(seg - 1) * a.plane;
       const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
 #pragma unroll
-      for (int k = 0; k < 7; ++k) v[seg][k] = s4[tid + k * kConvThreads];
+      for (int k = 0; k < 7; ++k)
+        v[seg][k] = (ABL & 1) ? f32x4{1.f, 2.f, 3.f, 4.f}
+                              : s4[tid + k * kConvThreads];
       const int e7 = tid + 7 * kConvThreads;
-      v[seg][7] = s4[e7 < nf4 ? e7 : tid];  // clamp: always a legal address
+      v[seg][7] = (ABL & 1) ? f32x4{1.f, 2.f, 3.f, 4.f}
+                            : s4[e7 < nf4 ? e7 : tid];  // clamp: legal address
     }
 #pragma unroll
     for (int seg = 0; seg < 3; ++seg) {
@@ -356,6 +369,32 @@ __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
     }
   }
   __syncthreads();
+
+  // Residual input of this thread's 5 output pieces, fetched now so that its
+  // latency hides under the MFMA loop (all chunk positions are inside the
+  // allocation; padding positions are simply never stored).
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + (tid & 7) * 4);
+  f32x4 skipv[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (ADD_SKIP && !(ABL & 4)) {
+    const f32x4* sp = reinterpret_cast<const f32x4*>(
+        a.skip + (size_t)item * a.act_stride +
+        ((size_t)m0 + (tid >> 3)) * kFeatures + (tid & 7) * 4);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) skipv[k] = sp[(size_t)k * 32 * (kFeatures / 4)];
+  }
+
+  // padding-position mask of this chunk: 5 scalar words, fetched up front
+  uint32_t vbw[5];
+  {
+    const uint32_t* vb = a.validbits + chunk * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      vbw[k] = __builtin_amdgcn_readfirstlane(vb[k]);
+      asm volatile("" ::"s"(vbw[k]));
+    }
+  }
 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -400,7 +439,7 @@ __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
   __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
-  for (int ht = 0; ht < 54; ht += 6) {
+  for (int ht = 0; ht < ((ABL & 2) ? 0 : 54); ht += 6) {
     FFN_STEP(ht + 0, A0, A1, B0, B2)
     FFN_STEP(ht + 1, A1, A0, B1, B0)
     FFN_STEP(ht + 2, A0, A1, B2, B1)
@@ -410,26 +449,63 @@ __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
   }
 #undef FFN_STEP
 
-  // ---- epilogue: D[row = grp*4 + r][col = i] -> out[pos][16*nhalf + i] ----
-  const int co = nhalf * 16 + i;
-  const float bv = a.bias[co];
-  const size_t ibase = (size_t)item * a.act_stride;
-  const uint32_t* vb = a.validbits + chunk * 5;
+  if (ABL & 4) {
 #pragma unroll
-  for (int t = 0; t < kTilesPerWave; ++t) {
-    const int tile = tgrp * kTilesPerWave + t;       // wave-uniform
-    const uint32_t word = vb[tile >> 1];             // scalar load
-    const int bit0 = (tile & 1) * 16 + grp * 4;
-    const size_t pbase = (size_t)(m0 + tile * kTile + grp * 4);
+    for (int t = 0; t < kTilesPerWave; ++t) asm volatile("" ::"v"(acc[t]));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if ((word >> (bit0 + r)) & 1u) {
-        const size_t o = ibase + (pbase + r) * kFeatures + co;
-        float v = acc[t][r] + bv;
-        if (RELU_OUT) v = v > 0.0f ? v : 0.0f;
-        if (ADD_SKIP) v += a.skip[o];
-        a.out[o] = v;
-        if (DUAL_OUT) a.out_relu[o] = v > 0.0f ? v : 0.0f;
+    for (int k = 0; k < 5; ++k) asm volatile("" ::"v"(skipv[k]));
+    return;
+  }
+  // ---- epilogue: transpose the accumulators through LDS so that every global
+  // access is a coalesced 16-byte piece of a 128-byte position row ----
+  // D[row = grp*4 + r][col = i] of tile t -> stage[pos = tile*16 + row][co]
+  __syncthreads();  // every wave is done reading the A tiles
+  {
+    const int co = nhalf * 16 + i;
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t) {
+      const int prow = (tgrp * kTilesPerWave + t) * kTile + grp * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[(prow + r) * 32 + co] = acc[t][r];
+    }
+  }
+  __syncthreads();
+  {
+    const int q = tid & 7;          // channel quad, constant per thread
+    const int prow0 = tid >> 3;     // 32 positions per sweep, 5 sweeps
+    // Branch-free stores through buffer descriptors: a padding position gets an
+    // out-of-range offset and the hardware drops the store (a per-position
+    // branch would make hipcc drain vmcnt(0) -- i.e. wait for the previous
+    // stores -- at every join).
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned nbytes = (unsigned)a.nchunks * kChunk * kFeatures * 4u;
+    float* obase = a.out + (size_t)item * a.act_stride;
+    float* rbase_ = DUAL_OUT ? a.out_relu + (size_t)item * a.act_stride : obase;
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(obase, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_relu =
+        __builtin_amdgcn_make_buffer_rsrc(rbase_, 0, nbytes, 0x00020000);
+    const unsigned off0 = ((unsigned)(m0 + prow0) * kFeatures + q * 4) * 4u;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const bool ok = (vbw[k] >> prow0) & 1u;
+      f32x4 v = *reinterpret_cast<const f32x4*>(lds + (prow0 + k * 32) * 32 +
+                                                q * 4);
+      v += b4;
+      if (RELU_OUT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+      }
+      if (ADD_SKIP) v += skipv[k];
+      const unsigned off = ok ? off0 + (unsigned)k * 32u * kFeatures * 4u
+                              : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                             rs_out, off, 0, 0);
+      if (DUAL_OUT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_relu, off, 0, 0);
       }
     }
   }
@@ -444,42 +520,52 @@ __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
 __global__ __launch_bounds__(256) void head_kernel(
     const float* __restrict__ X, const float* __restrict__ in_seed,
     float pad_value, const float* __restrict__ wl /*[32] + bias*/,
-    float move_thr, float* __restrict__ logits, unsigned* __restrict__ count,
-    Geom g) {
+    float move_thr, float* __restrict__ logits,
+    unsigned* __restrict__ block_count /*[n][gridDim.x]*/, Geom g) {
+  __shared__ unsigned wave_cnt[4];
   const int item = blockIdx.y;
   const int sub = threadIdx.x & 7;
-  const int v = (blockIdx.x * 256 + threadIdx.x) >> 3;
-  float partial = 0.0f;
-  const bool live = v < g.V;
-  if (live) {
-    const int x = v % g.fx;
-    const int t = v / g.fx;
-    const int y = t % g.fy;
-    const int z = t / g.fy;
-    const size_t p = (size_t)z * g.plane + y * g.XS + x;
-    const float4 a = *reinterpret_cast<const float4*>(
-        X + (size_t)item * g.act_stride + p * kFeatures + sub * 4);
-    const float4 w4 = *reinterpret_cast<const float4*>(wl + sub * 4);
-    // max(0, .) is idempotent, so this is correct for raw and pre-activated X
-    partial = fmaxf(a.x, 0.f) * w4.x;
-    partial = __builtin_fmaf(fmaxf(a.y, 0.f), w4.y, partial);
-    partial = __builtin_fmaf(fmaxf(a.z, 0.f), w4.z, partial);
-    partial = __builtin_fmaf(fmaxf(a.w, 0.f), w4.w, partial);
+  const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + sub * 4);
+  const float bias = wl[kFeatures];
+  unsigned mine = 0;
+  for (int v0 = blockIdx.x * 32; v0 < g.V; v0 += gridDim.x * 32) {
+    const int v = v0 + (threadIdx.x >> 3);
+    float partial = 0.0f;
+    const bool live = v < g.V;
+    if (live) {
+      const int x = v % g.fx;
+      const int t = v / g.fx;
+      const int y = t % g.fy;
+      const int z = t / g.fy;
+      const size_t p = (size_t)z * g.plane + y * g.XS + x;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(
+          X + (size_t)item * g.act_stride + p * kFeatures + sub * 4);
+      // max(0, .) is idempotent: correct for raw and pre-activated X
+      partial = fmaxf(a[0], 0.f) * w4[0];
+      partial = __builtin_fmaf(fmaxf(a[1], 0.f), w4[1], partial);
+      partial = __builtin_fmaf(fmaxf(a[2], 0.f), w4[2], partial);
+      partial = __builtin_fmaf(fmaxf(a[3], 0.f), w4[3], partial);
+    }
+    partial += __shfl_xor(partial, 1);
+    partial += __shfl_xor(partial, 2);
+    partial += __shfl_xor(partial, 4);
+    bool above = false;
+    if (live && sub == 0) {
+      float s = in_seed[(size_t)item * g.V + v];
+      if (s != s) s = pad_value;
+      const float lg = s + (partial + bias);
+      logits[(size_t)item * g.V + v] = lg;
+      above = lg >= move_thr;
+    }
+    mine += (unsigned)__popcll(__ballot(above));  // wave-uniform
   }
-  partial += __shfl_xor(partial, 1);
-  partial += __shfl_xor(partial, 2);
-  partial += __shfl_xor(partial, 4);
-  unsigned above = 0;
-  if (live && sub == 0) {
-    float s = in_seed[(size_t)item * g.V + v];
-    if (s != s) s = pad_value;
-    const float lg = s + (partial + wl[kFeatures]);
-    logits[(size_t)item * g.V + v] = lg;
-    above = lg >= move_thr ? 1u : 0u;
-  }
-  // wavefront reduction of the count, one atomic per wave
-  const unsigned long long m = __ballot(above != 0);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&count[item], (unsigned)__popcll(m));
+  // per-block partial count; the paste kernel sums them (no atomics on one hot
+  // address: those serialise at ~12 ns each, and no counter to zero per step)
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    block_count[item * gridDim.x + blockIdx.x] =
+        wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
 // ---------------------------------------------------------------------------
@@ -498,12 +584,25 @@ __device__ __forceinline__ bool disco_on(unsigned cnt, int V, float thr) {
 }
 
 __global__ __launch_bounds__(512) void paste_kernel(
-    const StepItem* __restrict__ items, Geom g, const float* __restrict__ logits,
-    const float* __restrict__ in_seed, const unsigned* __restrict__ count,
-    float move_thr, float disco_thr, ffn_step_result* __restrict__ results) {
+    StepItems si, Geom g, const float* __restrict__ logits,
+    const float* __restrict__ in_seed,
+    const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
+    float disco_thr, ffn_step_result* __restrict__ results,
+    unsigned* __restrict__ seq, unsigned step_id) {
+  __shared__ unsigned s_cnt[8];
   const int item = blockIdx.y;
-  const StepItem& it = items[item];
-  const unsigned cnt = count[item];
+  const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
+  // total #(logits >= move_thr): sum of the head kernel's per-block partials
+  unsigned part = 0;
+  for (int e = threadIdx.x; e < head_blocks; e += blockDim.x)
+    part += block_count[item * head_blocks + e];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = part;
+  __syncthreads();
+  unsigned cnt = 0;
+#pragma unroll
+  for (int wv = 0; wv < 8; ++wv) cnt += s_cnt[wv];
   const bool disco = disco_on(cnt, g.V, disco_thr);
   const float* lg = logits + (size_t)item * g.V;
   const float* old = in_seed + (size_t)item * g.V;
@@ -615,6 +714,13 @@ __global__ __launch_bounds__(512) void paste_kernel(
       }
     }
   }
+  // Publish: results live in pinned host memory; make them visible system-wide,
+  // then raise the per-item sequence flag the host may be polling.
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&seq[item], step_id, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------

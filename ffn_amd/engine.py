@@ -6,8 +6,10 @@ libffn_hip.so.  torch is not involved -- device memory belongs to the library.
 
 from __future__ import annotations
 
+import atexit
 import ctypes
 from typing import Sequence
+import weakref
 
 import numpy as np
 
@@ -17,6 +19,20 @@ from ._lib import (CommitCounts, StepParams, StepRequest, StepResult, check, i3)
 
 def _f32(a):
   return np.ascontiguousarray(a, dtype=np.float32)
+
+
+_LIVE_ENGINES = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all_engines():
+  # Release device objects while the HIP runtime is still alive, instead of
+  # leaving it to arbitrary-order __del__ calls at interpreter teardown.
+  for eng in list(_LIVE_ENGINES):
+    try:
+      eng.close()
+    except Exception:  # pylint:disable=broad-except
+      pass
 
 
 class HipEngine:
@@ -39,6 +55,8 @@ class HipEngine:
     self._canvas_arr = (ctypes.c_void_p * self.max_batch)()
     self._req_arr = (StepRequest * self.max_batch)()
     self._res_arr = (StepResult * self.max_batch)()
+    self._canvases = weakref.WeakSet()
+    _LIVE_ENGINES.add(self)
 
   @classmethod
   def from_model(cls, model, max_batch: int = 1, device_id: int = 0):
@@ -55,6 +73,8 @@ class HipEngine:
 
   def close(self):
     if self._h:
+      for c in list(self._canvases):
+        c.close()
       self._lib.ffn_engine_destroy(self._h)
       self._h = ctypes.c_void_p()
 
@@ -145,6 +165,7 @@ class DeviceCanvasHandle:
     self._pt = (ctypes.c_int32 * 3)()
     self._pt_seed = ctypes.c_float()
     self._pt_seg = ctypes.c_int32()
+    engine._canvases.add(self)
 
   def close(self):
     if self._h:

@@ -590,6 +590,7 @@ class DeviceCanvas(Canvas):
     self._handle = None
     self._cache = {}
     self._cached_start = None
+    self._hot = [0, 0.0, 0.0, 0.0, 0, 0.0]
     self._step_req = _lib.StepRequest()
     self._step_params = _lib.StepParams()
     if kwargs.get('keep_history'):
@@ -600,6 +601,7 @@ class DeviceCanvas(Canvas):
     self._step_params.pad_value = self.options.pad_value
     self._step_params.move_threshold = self.options.move_threshold
     self._step_params.disco_seed_threshold = self.options.disco_seed_threshold
+    self._pred_size_t = tuple(int(v) for v in self._pred_size)
     self._fast_policy = (
         type(self.movement_policy) is movement.FaceMaxMovementPolicy)
 
@@ -655,44 +657,124 @@ class DeviceCanvas(Canvas):
     return self._read_point(start_pos)[0]
 
   # -- one FoV step: a single C call ---------------------------------------------------
+  def _flush_hot(self):
+    """Adds the per-step tallies kept in plain Python numbers to the counters."""
+    h = self._hot
+    if not h[0]:
+      return
+    c = self.counters
+    c['update_at-calls'].IncrementBy(h[0])
+    c['inference-calls'].IncrementBy(h[0])
+    c['predict-calls'].IncrementBy(h[0])
+    c['update_at-time-ms'].IncrementBy(h[1] * MSEC_IN_SEC)
+    c['inference-time-ms'].IncrementBy(h[2] * MSEC_IN_SEC)
+    c['inference-not-predict-ms'].IncrementBy(h[3] * MSEC_IN_SEC)
+    if h[4]:
+      c['movement_policy-calls'].IncrementBy(h[4])
+      c['movement_policy-time-ms'].IncrementBy(h[5] * MSEC_IN_SEC)
+    self._hot = [0, 0.0, 0.0, 0.0, 0, 0.0]
+
   def update_at(self, pos):
     """gather -> conv stack -> disco -> paste -> face argmax on the GPU."""
-    with timer_counter(self.counters, 'update_at'):
-      req = self._step_req
-      req.pos[0], req.pos[1], req.pos[2] = pos
-      sp = self.movement_policy._start_pos if self._fast_policy else pos
-      req.start_pos[0], req.start_pos[1], req.start_pos[2] = sp
-      cands = (self.movement_policy.peek_candidates(self.PREFETCH)
-               if self._fast_policy else [])
-      req.num_candidates = len(cands)
-      for k, c in enumerate(cands):
-        rc = req.candidates[k]
-        rc[0], rc[1], rc[2] = c
+    t_start = time.time()
+    hot = self._hot
+    req = self._step_req
+    rp = req.pos
+    rp[0], rp[1], rp[2] = pos
+    if self._fast_policy:
+      policy = self.movement_policy
+      sp = policy._start_pos
+      cands = policy.peek_candidates(self.PREFETCH)
+    else:
+      sp = pos
+      cands = ()
+    rs = req.start_pos
+    rs[0], rs[1], rs[2] = sp
+    req.num_candidates = len(cands)
+    rcs = req.candidates
+    for k, c in enumerate(cands):
+      rc = rcs[k]
+      rc[0], rc[1], rc[2] = c
 
-      if self.t_last_predict is not None:
-        self.counters['inference-not-predict-ms'].IncrementBy(
-            (time.time() - self.t_last_predict) * MSEC_IN_SEC)
-      with timer_counter(self.counters, 'inference'):
-        res = self._exec_client.step(self._handle, req, self._step_params)
-      self.t_last_predict = time.time()
-      self.counters['predict-calls'].Increment()
+    t_call = time.time()
+    if self.t_last_predict is not None:
+      hot[3] += t_call - self.t_last_predict
+    res = self._exec_client.step(self._handle, req, self._step_params)
+    t_done = time.time()
+    self.t_last_predict = t_done
+    hot[2] += t_done - t_call
 
-      # Post-step values of the queue head: valid until the next mutation.
-      cache = {}
-      cs, cg = res.cand_seed, res.cand_seg
-      for k, c in enumerate(cands):
-        cache[tuple(c)] = (cs[k], cg[k])
-      self._cache = cache
-      self._cached_start = (tuple(sp), res.start_logit)
-      handle = self._handle
+    # Post-step values of the queue head: valid until the next mutation.
+    cs, cg = res.cand_seed, res.cand_seg
+    self._cache = {c: (cs[k], cg[k]) for k, c in enumerate(cands)}
+    self._cached_start = (sp, res.start_logit)
+    pred = movement.FacePrediction(
+        list(res.face_score), list(res.face_index), list(res.face_seg),
+        self._pred_size_t, read_fn=self._make_reader(pos))
+    hot[0] += 1
+    hot[1] += time.time() - t_start
+    return pred
+
+  def segment_at(self, start_pos, dynamic_image=None, vis_update_every=10,
+                 vis_fixed_z=False, partial_segment_iters=0):
+    """Same loop as Canvas.segment_at (reference inference.py:460-533), with
+    the per-step tallies kept in plain Python numbers."""
+    del dynamic_image, vis_update_every, vis_fixed_z
+    start_pos = tuple(int(v) for v in start_pos)
+    if not partial_segment_iters:
+      if self.reset_seed_per_segment:
+        self.init_seed(start_pos)
+      self.reset_state(start_pos, reset_extents=self.reset_seed_per_segment)
+      if not self.movement_policy:
+        self.movement_policy.append(
+            (self.movement_policy.score_threshold * 2, start_pos))
+    num_iters = partial_segment_iters
+    mn = [int(v) for v in self._min_pos]
+    mx = [int(v) for v in self._max_pos]
+    thr = self.options.move_threshold
+    restrict = (None if getattr(self.restrictor, 'is_trivial', False) else
+                self.restrictor)
+    hot = self._hot
+    checkpointing = (self.checkpoint_path is not None and
+                     self.checkpoint_interval_sec > 0)
+    with timer_counter(self.counters, 'segment_at-loop'):
+      try:
+        for pos in self.movement_policy:
+          if self._start_logit(start_pos) < thr:
+            self.counters['seed_got_too_weak'].Increment()
+            break
+          if restrict is not None and not restrict.is_valid_pos(pos):
+            self.counters['skip_restriced_pos'].Increment()
+            continue
+          pred = self.update_at(pos)
+          for a in (0, 1, 2):
+            if pos[a] < mn[a]:
+              mn[a] = pos[a]
+            if pos[a] > mx[a]:
+              mx[a] = pos[a]
+          num_iters += 1
+          t0 = time.time()
+          self._policy_update(pred, pos)
+          hot[4] += 1
+          hot[5] += time.time() - t0
+          if checkpointing:
+            self._min_pos = np.array(mn)
+            self._max_pos = np.array(mx)
+            self._flush_hot()
+            self._maybe_save_checkpoint(partial_segment_iters=num_iters)
+      finally:
+        self._min_pos = np.array(mn)
+        self._max_pos = np.array(mx)
+        self._flush_hot()
+    return num_iters
+
+  def _make_reader(self, pos):
+    def read():
       half = self._margin_t
       lo = (pos[0] - half[0], pos[1] - half[1], pos[2] - half[2])
       hi = (pos[0] + half[0] + 1, pos[1] + half[1] + 1, pos[2] + half[2] + 1)
-      pred = movement.FacePrediction(
-          list(res.face_score), list(res.face_index), list(res.face_seg),
-          tuple(int(v) for v in self._pred_size),
-          read_fn=lambda: self._call(handle.read_seed, lo, hi))
-    return pred
+      return self._call(self._handle.read_seed, lo, hi)
+    return read
 
   def _policy_update(self, pred, pos):
     new = self.movement_policy.update(pred, pos)

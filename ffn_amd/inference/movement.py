@@ -143,7 +143,14 @@ class BaseMovementPolicy:
 
 
 class FaceMaxMovementPolicy(BaseMovementPolicy):
-  """Selects candidates from maxima on prediction cuboid faces."""
+  """Selects candidates from maxima on prediction cuboid faces.
+
+  Same queue semantics as the reference (FIFO deque, quantised visited set,
+  descending (score, coord) insertion order).  Internally every queue entry also
+  carries its quantised position -- computed once at append time instead of at
+  every scan -- and `get_state` / `restore_state` convert to / from the
+  reference's (score, coord) layout so checkpoints stay interchangeable.
+  """
 
   def __init__(self, canvas, deltas=(4, 8, 8), score_threshold=0.9):
     self.done_rounded_coords = set()
@@ -154,6 +161,14 @@ class FaceMaxMovementPolicy(BaseMovementPolicy):
     self._d = tuple(int(v) for v in self.deltas)
     self._dh = tuple(v // 2 for v in self._d)
     self._dm = tuple(max(v, 1) for v in self._d)
+    # per face (axis z,y,x; sign -,+): axis, signed offset, deltas of the two
+    # in-face axes, number of face columns
+    self._faces = []
+    for axis in range(3):
+      others = [a for a in range(3) if a != axis]
+      for sign in (-1, 1):
+        self._faces.append((axis, sign * self._d[axis], self._d[others[0]],
+                            self._d[others[1]], 2 * self._d[others[1]] + 1))
 
   def reset_state(self, start_pos):
     self.scored_coords = deque([])
@@ -161,27 +176,33 @@ class FaceMaxMovementPolicy(BaseMovementPolicy):
     self._start_pos = tuple(int(v) for v in start_pos)
 
   def get_state(self):
-    return [(self.scored_coords, self.done_rounded_coords, self._start_pos)]
+    queue = deque((s, list(c)) for s, c, _ in self.scored_coords)
+    return [(queue, self.done_rounded_coords, self._start_pos)]
 
   def restore_state(self, state):
-    self.scored_coords, self.done_rounded_coords, self._start_pos = state[0]
-    self.scored_coords = deque(self.scored_coords)
-    self.done_rounded_coords = set(
-        tuple(int(v) for v in q) for q in self.done_rounded_coords)
-    self._start_pos = tuple(int(v) for v in self._start_pos)
+    queue, done, start = state[0]
+    self._start_pos = tuple(int(v) for v in start)
+    self.done_rounded_coords = set(tuple(int(v) for v in q) for q in done)
+    self.scored_coords = deque([])
+    for score, coord in queue:
+      self.append((score, coord))
+
+  def append(self, item):
+    coord = tuple(int(v) for v in item[1])
+    self.scored_coords.append((item[0], coord, self.quantize_pos(coord)))
 
   def __next__(self):
     """Pops positions from the queue until a valid one is found."""
-    while self.scored_coords:
-      _, coord = self.scored_coords.popleft()
-      coord = tuple(coord)
-      if self.quantize_pos(coord) in self.done_rounded_coords:
+    sc = self.scored_coords
+    done = self.done_rounded_coords
+    is_valid = self.canvas.is_valid_pos
+    while sc:
+      _, coord, q = sc.popleft()
+      if q in done:
         continue
-      if self.canvas.is_valid_pos(coord):
-        break
-    else:
-      raise StopIteration()
-    return tuple(coord)
+      if is_valid(coord):
+        return coord
+    raise StopIteration()
 
   def quantize_pos(self, pos):
     """Quantises symmetrically to a grid downsampled by deltas
@@ -192,13 +213,19 @@ class FaceMaxMovementPolicy(BaseMovementPolicy):
             (int(pos[2]) - s[2] + self._dh[2]) // self._dm[2])
 
   def peek_candidates(self, limit):
-    """First `limit` queued coordinates not yet visited (queue order)."""
-    out = []
+    """First `limit` queued coordinates not yet visited, in queue order.
+
+    Already-visited entries at the head are dropped for good: `__next__` would
+    skip them anyway, without side effects."""
+    sc = self.scored_coords
     done = self.done_rounded_coords
-    for _, coord in self.scored_coords:
-      if self.quantize_pos(coord) in done:
+    while sc and sc[0][2] in done:
+      sc.popleft()
+    out = []
+    for entry in sc:
+      if entry[2] in done:
         continue
-      out.append(coord)
+      out.append(entry[1])
       if len(out) >= limit:
         break
     return out
@@ -207,21 +234,44 @@ class FaceMaxMovementPolicy(BaseMovementPolicy):
     """Adds movements to the queue for the cuboid face maxima of `prob_map`."""
     self.done_rounded_coords.add(self.quantize_pos(position))
     if isinstance(prob_map, FacePrediction):
-      moves = prob_map.scored_move_offsets(self._d, self.score_threshold)
-      moves.sort(key=lambda m: (m[0], m[1]), reverse=True)
+      thr = self.score_threshold
+      fs, fi_, fg = prob_map.face_score, prob_map.face_index, prob_map.face_seg
+      moves = []
+      for k, (axis, off, d_row, d_col, ncols) in enumerate(self._faces):
+        if off == 0:
+          continue
+        score = fs[k]
+        if score < thr:
+          continue
+        fi, fj = divmod(fi_[k], ncols)
+        if axis == 0:
+          rel = (off, fi - d_row, fj - d_col)
+        elif axis == 1:
+          rel = (fi - d_row, off, fj - d_col)
+        else:
+          rel = (fi - d_row, fj - d_col, off)
+        moves.append((score, rel, fg[k]))
+      if len(moves) > 1:
+        # duplicates of the same (score, offset) are dropped (movement.py:98-100)
+        uniq = {}
+        for mv in moves:
+          uniq.setdefault((mv[0], mv[1]), mv)
+        moves = sorted(uniq.values(), key=lambda mv: (mv[0], mv[1]),
+                       reverse=True)
       new = []
+      pz, py, px = position
+      qp = self.quantize_pos
+      sc = self.scored_coords
       for score, rel, seg in moves:
-        coord = (rel[0] + position[0], rel[1] + position[1],
-                 rel[2] + position[2])
-        self.scored_coords.append((score, coord))
+        coord = (rel[0] + pz, rel[1] + py, rel[2] + px)
+        sc.append((score, coord, qp(coord)))
         new.append((coord, score, seg))
       return new
     scored = sorted(
         get_scored_move_offsets(self.deltas, prob_map,
                                 threshold=self.score_threshold), reverse=True)
     for score, rel in scored:
-      coord = [rel[i] + position[i] for i in range(3)]
-      self.scored_coords.append((score, coord))
+      self.append((score, [rel[i] + position[i] for i in range(3)]))
     return None
 
 

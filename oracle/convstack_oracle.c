@@ -30,6 +30,9 @@
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define MAXF 64
 
@@ -174,4 +177,16 @@ done:
 size_t ffn_oracle_weight_count(int depth, int features) {
   size_t F = (size_t)features;
   return 27 * 2 * F + F + (size_t)(2 * depth - 1) * (27 * F * F + F) + F + 1;
+}
+
+/* Number of OpenMP threads used by the convs (0 = leave unchanged).  Returns the
+ * current maximum. */
+int ffn_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
 }

@@ -50,8 +50,15 @@ def _lib():
     ]
     lib.ffn_oracle_weight_count.restype = ctypes.c_size_t
     lib.ffn_oracle_weight_count.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.ffn_oracle_set_threads.restype = ctypes.c_int
+    lib.ffn_oracle_set_threads.argtypes = [ctypes.c_int]
     _LIB = lib
   return _LIB
+
+
+def set_threads(n=0):
+  """Sets / queries the OpenMP thread count of the C conv stack."""
+  return _lib().ffn_oracle_set_threads(int(n))
 
 
 # ---------------------------------------------------------------------------
@@ -138,6 +145,47 @@ def forward(image, seed, blob, depth, features=32, stop_after=-1):
     raise RuntimeError('ffn_oracle_forward failed: %d' % rc)
   if stop_after >= 0:
     return act
+  return out[0] if squeeze else out
+
+
+def forward_torch(image, seed, variables, depth, threads=None):
+  """The same forward pass restated on torch-CPU (oneDNN conv3d, f32): an
+  independent implementation used to cross-check `forward` and as the stronger
+  CPU baseline (BASELINE.md section 3 names it as the stand-in for the
+  reference's TF CPU path, TensorFlow being unavailable)."""
+  import torch
+  import torch.nn.functional as F
+  if threads:
+    torch.set_num_threads(int(threads))
+  image = np.asarray(image, np.float32)
+  seed = np.asarray(seed, np.float32)
+  squeeze = image.ndim == 3
+  if squeeze:
+    image, seed = image[None], seed[None]
+  cache = variables.setdefault('__torch__', {})
+
+  def wb(name):
+    if name not in cache:
+      w = torch.from_numpy(np.ascontiguousarray(
+          variables['seed_update/%s/weights' % name])).permute(4, 3, 0, 1, 2)
+      b = torch.from_numpy(np.ascontiguousarray(
+          variables['seed_update/%s/biases' % name]))
+      cache[name] = (w.contiguous(), b)
+    return cache[name]
+
+  with torch.no_grad():
+    s = torch.from_numpy(seed)
+    x = torch.stack([torch.from_numpy(image), s], dim=1)
+    net = torch.relu(F.conv3d(x, *wb('conv0_a'), padding=1))
+    net = F.conv3d(net, *wb('conv0_b'), padding=1)
+    for i in range(1, depth):
+      skip = net
+      net = torch.relu(net)
+      net = torch.relu(F.conv3d(net, *wb('conv%d_a' % i), padding=1))
+      net = F.conv3d(net, *wb('conv%d_b' % i), padding=1) + skip
+    net = torch.relu(net)
+    out = s + F.conv3d(net, *wb('conv_lom'))[:, 0]
+  out = out.numpy()
   return out[0] if squeeze else out
 
 

@@ -50,6 +50,25 @@ def main():
             ' conv32 avg %.2f us (%d launches, %.1f TF/s in-kernel)' %
             (variant, b, dt * 1e6, b / dt, b * flop / dt / 1e12,
              ms / n * 1e3, n, b * 2.0 * 27 * 32 * 32 * 33**3 / (ms / n * 1e-3) / 1e12))
+  # phase ablation of the pipelined conv_b kernel (11 of the 23 convs per stack)
+  eng.set_option('conv_variant', 1)
+  print('ablation (conv_b launches only; 1=no staging loads 2=no MFMA loop '
+        '4=no epilogue traffic):')
+  for b in (1, 8):
+    base = None
+    for mask in (0, 1, 2, 4, 5, 6, 7):
+      eng.set_option('ablate', mask)
+      eng.forward_resident(b, 3)
+      eng.synchronize()
+      t0 = time.perf_counter()
+      eng.forward_resident(b, args.repeats)
+      eng.synchronize()
+      dt = (time.perf_counter() - t0) / args.repeats
+      if mask == 0:
+        base = dt
+      print('  batch %d ablate %d: %8.1f us/stack  -> conv_b delta %+.2f us/launch'
+            % (b, mask, dt * 1e6, (dt - base) * 1e6 / 11))
+    eng.set_option('ablate', 0)
   eng.close()
 
 
