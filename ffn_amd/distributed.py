@@ -1,0 +1,144 @@
+"""Multi-GPU: sub-box sharding and the final segmentation merge over RCCL.
+
+The FoV loop has no exchange step: the reference's unit of parallelism is the
+subvolume ("embarrassingly parallel ... does not contain support for workload
+distribution", reference doc/manual.md:107-117), and seeds inside one canvas
+are strictly sequential (inference.py:341,573-581).  So one process per GPU
+(torch.distributed, backend "nccl" = RCCL over xGMI) each segments its own
+overlapping sub-boxes with NO data-path collective; the only communication is
+the final assembly of one global label volume:
+
+  1. all_gather of each rank's max local id  -> exclusive-scan id offsets
+     (an 8-int collective);
+  2. every rank writes its sub-boxes' *core* regions (the part of each sub-box
+     it owns) with globally offset ids into a zero-filled full-volume int32
+     array and the ranks `all_reduce(MAX)` it -- cores are disjoint, so MAX is
+     a union.  (north_star asks for exactly this all-reduce; at 1024^3 int32 =
+     4.3 GB a ring all-reduce is ~49 ms on xGMI, negligible against minutes of
+     segmentation.  An all_gather of owned slabs would be ~3.5 ms; see
+     DESIGN.md.)
+
+Reconciliation of objects that cross a cut (overlap-zone consensus /
+union-find) is not implemented in the reference either
+(doc/manual.md:119-127) and is a "next" row.
+
+The tiler mirrors the semantics of the reference's
+`OrderlyOverlappingCalculator` (ffn/utils/bounding_box.py:250-412): sub-boxes
+of a fixed size with a fixed overlap, clipped to the outer box, enumerated in
+z-major order.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+@dataclasses.dataclass(frozen=True)
+class SubBox:
+  """A sub-box (zyx) and the core region it owns inside the outer volume."""
+  index: int
+  corner: Tuple[int, int, int]
+  size: Tuple[int, int, int]
+  core_lo: Tuple[int, int, int]   # absolute coordinates
+  core_hi: Tuple[int, int, int]   # exclusive
+
+
+def tile_volume(shape_zyx: Sequence[int], sub_size_zyx: Sequence[int],
+                overlap_zyx: Sequence[int]) -> List[SubBox]:
+  """Overlapping sub-boxes covering `shape`; cores partition the volume.
+
+  Consecutive sub-boxes along an axis start `sub_size - overlap` apart; the
+  last one is clipped to the volume.  The core of a sub-box extends to the
+  middle of each overlap zone, so cores tile the volume exactly once.
+  """
+  starts_per_axis = []
+  for n, s, o in zip(shape_zyx, sub_size_zyx, overlap_zyx):
+    if s <= o:
+      raise ValueError('sub-box size must exceed the overlap')
+    step = s - o
+    starts = [0]
+    while starts[-1] + s < n:
+      starts.append(starts[-1] + step)
+    starts_per_axis.append(starts)
+  boxes = []
+  idx = 0
+  for z0 in starts_per_axis[0]:
+    for y0 in starts_per_axis[1]:
+      for x0 in starts_per_axis[2]:
+        corner = (z0, y0, x0)
+        size, lo, hi = [], [], []
+        for a, (c, n, s, o) in enumerate(zip(corner, shape_zyx, sub_size_zyx,
+                                             overlap_zyx)):
+          e = min(c + s, n)
+          size.append(e - c)
+          starts = starts_per_axis[a]
+          k = starts.index(c)
+          lo.append(0 if k == 0 else c + o // 2)
+          hi.append(n if k == len(starts) - 1 else starts[k + 1] + o // 2)
+        boxes.append(SubBox(idx, corner, tuple(size), tuple(lo), tuple(hi)))
+        idx += 1
+  return boxes
+
+
+def assign_round_robin(boxes: Sequence[SubBox], rank: int,
+                       world: int) -> List[SubBox]:
+  """Static dealing of sub-boxes to ranks (deterministic, no communication)."""
+  return [b for b in boxes if b.index % world == rank]
+
+
+def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
+                        device=None):
+  """Assembles one global int32 label volume from per-rank sub-box results.
+
+  Args:
+    local_results: list of (SubBox, segmentation ndarray of SubBox.size) that
+      this rank produced; ids are local to each sub-box, 0 = background.
+    shape_zyx: outer volume shape
+    rank, world: torch.distributed rank / world size (world == 1: no
+      collective at all)
+    device: torch device for the collective buffers ('cuda:k' with the nccl
+      backend, 'cpu' with gloo)
+
+  Returns:
+    (global int32 ndarray, list of per-sub-box id offsets of this rank)
+  """
+  import torch
+  import torch.distributed as dist
+
+  # 1. global id space: offsets by exclusive scan over (rank, sub-box) order
+  local_max = [int(seg.max()) if seg.size else 0 for _, seg in local_results]
+  my_total = int(sum(local_max))
+  if world > 1:
+    t = torch.tensor([my_total], dtype=torch.int64, device=device)
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    totals = [int(g.item()) for g in gathered]
+  else:
+    totals = [my_total]
+  base = int(sum(totals[:rank]))
+  offsets = []
+  for m in local_max:
+    offsets.append(base)
+    base += m
+  if sum(totals) >= 2**31:
+    raise OverflowError('global id space exceeds int32')
+
+  # 2. owned cores into a zero-filled volume, then union by all_reduce(MAX)
+  out = np.zeros(tuple(shape_zyx), dtype=np.int32)
+  for (box, seg), off in zip(local_results, offsets):
+    lo = [c - b for c, b in zip(box.core_lo, box.corner)]
+    hi = [c - b for c, b in zip(box.core_hi, box.corner)]
+    core = seg[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].astype(np.int32)
+    core = np.where(core > 0, core + off, 0).astype(np.int32)
+    out[box.core_lo[0]:box.core_hi[0], box.core_lo[1]:box.core_hi[1],
+        box.core_lo[2]:box.core_hi[2]] = core
+  if world > 1:
+    t = torch.from_numpy(out)
+    if device is not None and str(device) != 'cpu':
+      t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out = t.cpu().numpy()
+  return out, offsets

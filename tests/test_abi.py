@@ -1,0 +1,66 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol that
+include/ffn_hip.h declares; entry points fail loudly, never fall back."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from ffn_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+  with open(os.path.join(ROOT, 'include', 'ffn_hip.h')) as f:
+    text = f.read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(ffn_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+  assert os.path.exists(_lib.LIB_PATH), 'build with __graft_entry__.build()'
+  lib = ctypes.CDLL(_lib.LIB_PATH)
+  declared = _declared_symbols()
+  assert len(declared) >= 25
+  for name in declared:
+    assert hasattr(lib, name), 'missing export: %s' % name
+  assert set(declared) == set(_lib.SIGNATURES), (
+      set(declared) ^ set(_lib.SIGNATURES))
+
+
+def test_abi_version_and_weight_count():
+  lib = _lib.load()
+  assert lib.ffn_abi_version() == 1
+  assert lib.ffn_engine_weight_count(12, 32) == 638433
+  assert lib.ffn_engine_weight_count(18, 32) == 27 * 2 * 32 + 32 + 35 * (
+      27 * 32 * 32 + 32) + 33
+
+
+def test_no_cpu_fallback_without_gpu():
+  """Without a GPU the product path raises; it never routes to the oracle."""
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  from ffn_amd import engine
+  with pytest.raises(_lib.FFNHipError):
+    engine.HipEngine((33, 33, 33), (8, 8, 8), 12)
+
+
+def test_product_never_imports_the_oracle():
+  import ast
+  pkg = os.path.join(ROOT, 'ffn_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for fn in files:
+      if not fn.endswith('.py'):
+        continue
+      with open(os.path.join(dirpath, fn)) as f:
+        tree = ast.parse(f.read())
+      for node in ast.walk(tree):
+        names = []
+        if isinstance(node, ast.Import):
+          names = [a.name for a in node.names]
+        elif isinstance(node, ast.ImportFrom):
+          names = [node.module or '']
+        assert not any(n.split('.')[0] == 'oracle' for n in names), (fn, names)

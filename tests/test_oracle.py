@@ -1,0 +1,130 @@
+"""The oracle against (a) the fixtures minted by the reference's own Python
+(tools/make_golden.py) and (b) an independent torch implementation."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ffn_oracle
+from tests.conftest import GOLDEN
+
+
+def test_forward_matches_torch_f32_and_f64(fib25_variables, fib25_blob):
+  import torch
+  import torch.nn.functional as F
+  rng = np.random.RandomState(0)
+  img = ((rng.randint(0, 256, (33, 33, 33)).astype(np.float32)) - 128) / 33
+  seed = np.full((33, 33, 33), ffn_oracle.f32_logit(0.05), np.float32)
+  seed[16, 16, 16] = ffn_oracle.f32_logit(0.95)
+  got = ffn_oracle.forward(img, seed, fib25_blob, 12)
+  want32 = ffn_oracle.forward_torch(img, seed, dict(fib25_variables), 12)
+  assert np.abs(got - want32).max() <= 2e-5
+
+  def ref64():
+    x = torch.tensor(np.stack([img, seed])[None], dtype=torch.float64)
+
+    def conv(x, name, relu):
+      w = torch.tensor(fib25_variables['seed_update/%s/weights' % name],
+                       dtype=torch.float64).permute(4, 3, 0, 1, 2)
+      b = torch.tensor(fib25_variables['seed_update/%s/biases' % name],
+                       dtype=torch.float64)
+      y = F.conv3d(x, w, b, padding=1 if w.shape[-1] == 3 else 0)
+      return torch.relu(y) if relu else y
+
+    n = conv(x, 'conv0_a', True)
+    n = conv(n, 'conv0_b', False)
+    for i in range(1, 12):
+      s = n
+      n = conv(torch.relu(n), 'conv%d_a' % i, True)
+      n = conv(n, 'conv%d_b' % i, False) + s
+    return seed + conv(torch.relu(n), 'conv_lom', False)[0, 0].numpy()
+
+  assert np.abs(got - ref64()).max() <= 2e-5
+
+
+def test_forward_batch_and_small_depth():
+  rng = np.random.RandomState(1)
+  variables = ffn_oracle.random_weights(2, seed=3, stddev=0.1)
+  blob = ffn_oracle.weights_blob(variables, 2)
+  img = rng.normal(0, 1, (3, 9, 11, 13)).astype(np.float32)
+  seed = rng.normal(0, 1, (3, 9, 11, 13)).astype(np.float32)
+  got = ffn_oracle.forward(img, seed, blob, 2)
+  for k in range(3):
+    assert np.array_equal(got[k], ffn_oracle.forward(img[k], seed[k], blob, 2))
+  want = ffn_oracle.forward_torch(img, seed, variables, 2)
+  assert np.abs(got - want).max() <= 1e-5
+  act = ffn_oracle.forward(img, seed, blob, 2, stop_after=0)
+  assert act.shape == (9, 11, 13, 32) and act.min() >= 0.0
+
+
+def test_move_scoring_matches_reference_kats():
+  g = np.load(os.path.join(GOLDEN, 'ref_movement.npz'))
+  thr = float(g['threshold'])
+  names = sorted({k[:-len('_map')] for k in g.files if k.endswith('_map')})
+  assert len(names) >= 10
+  for name in names:
+    res = sorted(ffn_oracle.scored_move_offsets(g[name + '_deltas'],
+                                                g[name + '_map'], thr),
+                 reverse=True)
+    assert [r[1] for r in res] == [tuple(o) for o in g[name + '_offsets']], name
+    assert np.array_equal(np.array([r[0] for r in res], np.float32),
+                          g[name + '_scores']), name
+  # the constant map pins first-occurrence tie breaking + de-duplication
+  assert len(g['const_offsets']) == 4
+  assert len(g['below_offsets']) == 0
+
+
+def test_misc_kats():
+  with open(os.path.join(GOLDEN, 'ref_misc.json')) as f:
+    k = json.load(f)
+  q = ffn_oracle.quantize_probability(
+      np.array([0, .001, .5, .6, .95, 1, np.nan]))
+  assert [int(x) for x in q] == k['quantize_out']
+  for m, dt in k['reduce_id_bits'].items():
+    assert str(ffn_oracle.reduce_id_bits(np.array([0, int(m)])).dtype) == dt
+  for name in ('init_activation', 'pad_value', 'move_threshold',
+               'segment_threshold'):
+    p = {'init_activation': 0.95, 'pad_value': 0.05, 'move_threshold': 0.9,
+         'segment_threshold': 0.6}[name]
+    assert ffn_oracle.f32_logit(p) == k['logit_' + name]
+  seeds = ffn_oracle.grid_seeds((50, 56, 60), (16, 16, 16), 16, (0, 8))
+  assert [list(map(int, s)) for s in seeds] == k['grid3d_seeds']
+  oc = ffn_oracle.OracleCanvas(np.zeros((40, 40, 40), np.float32), None, 12,
+                               (33, 33, 33), (8, 8, 8), ffn_oracle.Options())
+  for p, qv in k['quantize_pos'].items():
+    pos = tuple(int(v) for v in p.strip('()').split(','))
+    assert list(oc._quantize(pos, (100, 100, 100))) == qv
+  assert oc.policy_threshold == k['policy_threshold']
+
+
+@pytest.mark.parametrize('name', ['cells56', 'cells72'])
+def test_oracle_canvas_reproduces_reference_run(fib25_blob, name):
+  """OracleCanvas.segment_all == the reference's Canvas.segment_all, step for
+  step (positions, queued moves, segment ids, counters)."""
+  from ffn_amd import synthetic
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_%s.npz' % name))
+  oc = ffn_oracle.OracleCanvas(synthetic.normalize(g['volume']), fib25_blob,
+                               12, (33, 33, 33), (8, 8, 8),
+                               ffn_oracle.Options())
+  oc.segment_all(g['seeds'])
+  assert np.array_equal(np.array([t[0] for t in oc.trace]).reshape(-1, 3),
+                        g['steps'])
+  assert np.array_equal(np.array([len(t[1]) for t in oc.trace]), g['n_moves'])
+  coords = np.array([[p + o for p, o in zip(t[0], off)]
+                     for t in oc.trace for _, off in t[1]]).reshape(-1, 3)
+  assert np.array_equal(coords, g['move_coords'])
+  assert np.array_equal(
+      np.array([s for t in oc.trace for s, _ in t[1]], np.float32),
+      g['move_scores'])
+  assert np.array_equal(oc.segmentation, g['segmentation'])
+  assert np.array_equal(oc.seed, g['seed_logits'], equal_nan=True)
+  ref = json.loads(str(g['counters']))
+  for key in ('update_at-calls', 'voxels-segmented', 'voxels-overlapping',
+              'skip_invalid_pos', 'skip_threshold', 'seed_got_too_weak'):
+    if key in ref:
+      assert oc.counters[key] == ref[key], key
+  origins = json.loads(str(g['origins']))
+  assert {int(k): [list(v[0]), v[1]] for k, v in oc.origins.items()} == {
+      int(k): v for k, v in origins.items()}
