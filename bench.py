@@ -315,6 +315,15 @@ def main():
   steps_per_s = world * args.steps / res['elapsed']
   avg_conv_ms = res['conv_ms'] / max(res['conv_launches'], 1)
   achieved = CONV32_FLOPS / (avg_conv_ms * 1e-3) / 1e12 if avg_conv_ms else 0.0
+  # HBM traffic of the conv kernel cannot be counted from inside this process
+  # (PMC counters need rocprofv3): it is taken from the committed PMC profile of
+  # this same command, when present.
+  traffic = None
+  try:
+    with open(os.path.join(ROOT, 'profiles', 'conv32_pmc_traffic.json')) as f:
+      traffic = json.load(f)['traffic_bytes_per_launch']
+  except (OSError, KeyError, ValueError):
+    pass
   out = {
       'metric': 'FoV-steps/sec (flood-filling inference loop, 250^3 volume)',
       'value': round(steps_per_s, 2),
@@ -357,7 +366,7 @@ def main():
           'peak': PEAK_F32_MFMA_TFLOPS,
           'unit': 'TFLOP/s',
           'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-          'traffic': None,
+          'traffic': traffic,
           'avg_launch_us': round(avg_conv_ms * 1e3, 3),
           'launches': int(res['conv_launches']),
           'flops_per_launch': CONV32_FLOPS,

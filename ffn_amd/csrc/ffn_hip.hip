@@ -56,7 +56,6 @@ struct ffn_engine {
   float* act_base = nullptr;  // 2 activation buffers (T, X) x max_batch
   float* bufT = nullptr;      // logical origins
   float* bufX = nullptr;
-  float* bufXR = nullptr;     // relu(X) (pipelined variant only)
   uint32_t* validbits = nullptr;
   int conv_variant = 1;       // 0 = conv32_kernel (simple), 1 = conv32p_kernel
   float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
@@ -126,10 +125,10 @@ int set_lds_attr(size_t bytes) {
   return FFN_OK;
 }
 
-template <bool RO, bool SK, bool DU, int ABL = 0>
+template <bool RI, bool RO, bool SK, int ABL = 0>
 int set_lds_attr_p(size_t bytes) {
   HIP_TRY(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv32p_kernel<RO, SK, DU, ABL>),
+      reinterpret_cast<const void*>(&conv32p_kernel<RI, RO, SK, ABL>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return FFN_OK;
 }
@@ -177,13 +176,12 @@ int launch_conv32(ffn_engine* e, int n, const float* in, float* out,
   return FFN_OK;
 }
 
-template <bool RO, bool SK, bool DU>
+template <bool RI, bool RO, bool SK>
 int launch_conv32p(ffn_engine* e, int n, const float* in, float* out,
-                   float* out_relu, const float* skip, int layer) {
+                   const float* skip, int layer) {
   ConvPArgs a;
   a.in = in;
   a.out = out;
-  a.out_relu = out_relu;
   a.skip = skip;
   a.wpack = e->weights + e->wpack_off[layer];
   a.bias = e->weights + e->bias_off[layer];
@@ -204,12 +202,12 @@ int launch_conv32p(ffn_engine* e, int n, const float* in, float* out,
     HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   }
   const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
-  if (RO == false && SK == true && DU == true && e->ablate != 0) {
+  if (RI == false && RO == false && SK == true && e->ablate != 0) {
     // debug ablations exist for the conv_b instantiation only
     switch (e->ablate) {
 #define FFN_ABL_CASE(N)                                                     \
   case N:                                                                   \
-    hipLaunchKernelGGL((conv32p_kernel<false, true, true, N>), grid, block, \
+    hipLaunchKernelGGL((conv32p_kernel<false, false, true, N>), grid, block, \
                        e->lds_bytes, e->stream, a);                         \
     break;
       FFN_ABL_CASE(1)
@@ -223,7 +221,7 @@ int launch_conv32p(ffn_engine* e, int n, const float* in, float* out,
         return fail(FFN_ERR_ARG, "unsupported ablate mask %d", e->ablate);
     }
   } else {
-    hipLaunchKernelGGL((conv32p_kernel<RO, SK, DU>), grid, block, e->lds_bytes,
+    hipLaunchKernelGGL((conv32p_kernel<RI, RO, SK>), grid, block, e->lds_bytes,
                        e->stream, a);
   }
   if (prof) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
@@ -239,7 +237,7 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   const float* W = e->weights;
   const int tz = (g.fz + kC0Z - 1) / kC0Z, ty = (g.fy + kC0Y - 1) / kC0Y,
             tx = (g.fx + kC0X - 1) / kC0X;
-  hipLaunchKernelGGL(conv0a_kernel, dim3(tz * ty * tx, n), dim3(256), 0,
+  hipLaunchKernelGGL(conv0a_kernel, dim3(tz * ty * tx, n), dim3(kC0Threads), 0,
                      e->stream, si, pad_value, W + e->w0a_off, W + e->b0a_off,
                      e->bufT, e->seed_raw, g, ty, tx);
   int rc;
@@ -257,19 +255,18 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     }
     head_in = e->bufX;
   } else {
-    // T is already post-ReLU (conv0_a / conv_a apply it); X raw + XR = relu(X)
-    rc = launch_conv32p<false, false, true>(e, n, e->bufT, e->bufX, e->bufXR,
-                                            nullptr, 0);
+    // T is post-ReLU (conv0_a / conv_a apply it); X is the raw residual stream
+    rc = launch_conv32p<false, false, false>(e, n, e->bufT, e->bufX, nullptr, 0);
     if (rc) return rc;
     for (int i = 1; i < e->depth; ++i) {
-      rc = launch_conv32p<true, false, false>(e, n, e->bufXR, e->bufT, nullptr,
-                                              nullptr, 2 * i - 1);
+      rc = launch_conv32p<true, true, false>(e, n, e->bufX, e->bufT, nullptr,
+                                             2 * i - 1);
       if (rc) return rc;
-      rc = launch_conv32p<false, true, true>(e, n, e->bufT, e->bufX, e->bufXR,
-                                             e->bufX, 2 * i);
+      rc = launch_conv32p<false, false, true>(e, n, e->bufT, e->bufX, e->bufX,
+                                              2 * i);
       if (rc) return rc;
     }
-    head_in = e->bufXR;
+    head_in = e->bufX;
   }
   hipLaunchKernelGGL(head_kernel, dim3(kHeadBlocks, n), dim3(256), 0, e->stream, head_in,
                      e->seed_raw, pad_value, W + e->wl_off, move_thr, e->logits,
@@ -410,12 +407,11 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   } while (0)
 
   E_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  const size_t act_bytes = (size_t)3 * max_batch * g.act_stride * sizeof(float);
+  const size_t act_bytes = (size_t)2 * max_batch * g.act_stride * sizeof(float);
   E_TRY(hipMalloc(&e->act_base, act_bytes));
   E_TRY(hipMemset(e->act_base, 0, act_bytes));
   e->bufT = e->act_base + (size_t)g.guard * kFeatures;
   e->bufX = e->bufT + (size_t)max_batch * g.act_stride;
-  e->bufXR = e->bufX + (size_t)max_batch * g.act_stride;
   const size_t vbytes = (size_t)max_batch * g.V * sizeof(float);
   E_TRY(hipMalloc(&e->up_image, vbytes));
   E_TRY(hipMalloc(&e->up_seed, vbytes));
@@ -478,15 +474,15 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     int rc = set_lds_attr<false, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr<false, false, true>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, false, false>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<true, false, false>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, true, true>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, true, true, 1>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, true, true, 2>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, true, true, 4>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, true, true, 5>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, true, true, 6>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, true, true, 7>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, false, true, 1>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, false, true, 2>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, false, true, 4>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, false, true, 5>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, false, true, 6>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_p<false, false, true, 7>(e->lds_bytes);
     if (rc) {
       ffn_engine_destroy(e);
       return rc;
@@ -781,11 +777,13 @@ int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
   int rc = run_stack(e, n, si, params->pad_value, params->move_threshold);
   if (rc) return rc;
   const unsigned step_id = ++e->step_id ? e->step_id : ++e->step_id;  // never 0
-  hipLaunchKernelGGL(paste_kernel, dim3(72, n), dim3(512), 0, e->stream, si, g,
+  hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, kHeadBlocks,
-                     params->move_threshold,
-                     params->disco_seed_threshold, e->h_results, e->h_seq,
-                     step_id);
+                     params->move_threshold, params->disco_seed_threshold,
+                     e->h_results, e->h_seq, step_id);
+  hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
+                     e->logits, e->seed_raw, e->count, kHeadBlocks,
+                     params->disco_seed_threshold);
   HIP_TRY(hipGetLastError());
   if (e->sync_mode == 1) {
     // Poll the completion flags the paste kernel raises in pinned memory: lower

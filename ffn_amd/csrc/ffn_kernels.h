@@ -71,14 +71,16 @@ struct StepItems {
 };
 
 constexpr int kC0Z = 4, kC0Y = 8, kC0X = 8;  // conv0a output tile per block
+constexpr int kC0Threads = 512;               // 256 positions x 2 cout halves
 
-__global__ __launch_bounds__(256) void conv0a_kernel(
+__global__ __launch_bounds__(kC0Threads) void conv0a_kernel(
     StepItems si, float pad_value, const float* __restrict__ w /*[27][2][32]*/,
     const float* __restrict__ bias, float* __restrict__ out,
     float* __restrict__ seed_raw, Geom g, int tiles_y, int tiles_x) {
-  // input tile + 1-voxel halo, (image, seed) interleaved
+  // input tile + 1-voxel halo, (image, seed) interleaved; weights for broadcast
   constexpr int HZ = kC0Z + 2, HY = kC0Y + 2, HX = kC0X + 2;
   __shared__ float2 tile[HZ * HY * HX];
+  __shared__ __attribute__((aligned(16))) float wl[27 * 2 * kFeatures];
   const int item = blockIdx.y;
   const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
   int b = blockIdx.x;
@@ -91,7 +93,9 @@ __global__ __launch_bounds__(256) void conv0a_kernel(
   const int y0 = it.req.pos[1] - g.fy / 2;
   const int x0 = it.req.pos[2] - g.fx / 2;
 
-  for (int e = threadIdx.x; e < HZ * HY * HX; e += 256) {
+  for (int e = threadIdx.x; e < 27 * 2 * kFeatures / 4; e += kC0Threads)
+    reinterpret_cast<f32x4*>(wl)[e] = reinterpret_cast<const f32x4*>(w)[e];
+  for (int e = threadIdx.x; e < HZ * HY * HX; e += kC0Threads) {
     const int hx = e % HX;
     const int t = e / HX;
     const int hy = t % HY;
@@ -112,36 +116,43 @@ __global__ __launch_bounds__(256) void conv0a_kernel(
   }
   __syncthreads();
 
-  const int lx = threadIdx.x % kC0X;
-  const int ly = (threadIdx.x / kC0X) % kC0Y;
-  const int lz = threadIdx.x / (kC0X * kC0Y);
+  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // couts
+  const int lp = threadIdx.x & 255;
+  const int lx = lp % kC0X;
+  const int ly = (lp / kC0X) % kC0Y;
+  const int lz = lp / (kC0X * kC0Y);
   const int z = oz + lz, y = oy + ly, x = ox + lx;
   if (z >= g.fz || y >= g.fy || x >= g.fx) return;
 
-  float acc[kFeatures];
+  f32x4 acc[4];
 #pragma unroll
-  for (int c = 0; c < kFeatures; ++c) acc[c] = bias[c];
+  for (int c = 0; c < 4; ++c)
+    acc[c] = *reinterpret_cast<const f32x4*>(bias + half * 16 + c * 4);
 #pragma unroll
   for (int tap = 0; tap < 27; ++tap) {
     const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
     const float2 a = tile[((lz + kz) * HY + (ly + ky)) * HX + (lx + kx)];
-    const float* wt = w + tap * 2 * kFeatures;  // wave-uniform: scalar loads
+    const f32x4* wt =
+        reinterpret_cast<const f32x4*>(wl + tap * 2 * kFeatures + half * 16);
 #pragma unroll
-    for (int c = 0; c < kFeatures; ++c) {
-      acc[c] = __builtin_fmaf(a.x, wt[c], acc[c]);
-      acc[c] = __builtin_fmaf(a.y, wt[kFeatures + c], acc[c]);
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 w0 = wt[c];                  // wave-uniform address: broadcast
+      const f32x4 w1 = wt[kFeatures / 4 + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[c][j] = __builtin_fmaf(a.x, w0[j], acc[c][j]);
+        acc[c][j] = __builtin_fmaf(a.y, w1[j], acc[c][j]);
+      }
     }
   }
   const size_t p = (size_t)z * g.plane + (size_t)y * g.XS + x;
-  float* o = out + (size_t)item * g.act_stride + p * kFeatures;
+  float* o = out + (size_t)item * g.act_stride + p * kFeatures + half * 16;
 #pragma unroll
-  for (int c = 0; c < kFeatures; c += 4) {
+  for (int c = 0; c < 4; ++c) {
     f32x4 v;
-    v[0] = fmaxf(acc[c + 0], 0.0f);
-    v[1] = fmaxf(acc[c + 1], 0.0f);
-    v[2] = fmaxf(acc[c + 2], 0.0f);
-    v[3] = fmaxf(acc[c + 3], 0.0f);
-    *reinterpret_cast<f32x4*>(o + c) = v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[c][j], 0.0f);
+    *reinterpret_cast<f32x4*>(o + c * 4) = v;
   }
 }
 
@@ -289,10 +300,9 @@ __global__ __launch_bounds__(kConvThreads) void conv32_kernel(ConvArgs a) {
 // conv32p: the software-pipelined production variant of conv32.
 //
 // Same math and operand layout as conv32_kernel, plus:
-//  * inputs are PRE-ACTIVATED: conv0_b / conv_b epilogues store both the raw
-//    residual stream X (needed by the skip add) and relu(X) (DUAL_OUT), so the
-//    staging is a pure copy with all loads in flight at once (24 x 16 B per
-//    lane) instead of 4-deep load -> max -> ds_write rounds;
+//  * staging has all 24 x 16-B loads per lane in flight at once (then the ReLU
+//    in front of conv_a on the registers, then the LDS writes) instead of 4-deep
+//    load -> max -> ds_write rounds;
 //  * explicit double-buffered A fragments (LDS -> VGPR one half-tap ahead) and a
 //    3-deep B ring (L2 -> VGPR two half-taps = 1280 MFMA-cycles ahead), pinned
 //    with sched_barrier so the 20 MFMAs of a half-tap never wait on the
@@ -305,7 +315,6 @@ __global__ __launch_bounds__(kConvThreads) void conv32_kernel(ConvArgs a) {
 struct ConvPArgs {
   const float* in;       // pre-activated input, logical origin of item 0
   float* out;            // RELU_OUT ? relu(conv) : conv (+ skip)
-  float* out_relu;       // DUAL_OUT: relu(out)
   const float* skip;     // may alias out
   const float* wpack;    // [27][2][2][64][4]
   const float* bias;     // [32]
@@ -324,7 +333,7 @@ struct ConvPArgs {
 
 // ABL (debug ablation, 0 in production): 1 = no staging loads, 2 = no MFMA
 // loop, 4 = no epilogue memory traffic.
-template <bool RELU_OUT, bool ADD_SKIP, bool DUAL_OUT, int ABL = 0>
+template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int ABL = 0>
 __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -353,6 +362,15 @@ __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
       const int e7 = tid + 7 * kConvThreads;
       v[seg][7] = (ABL & 1) ? f32x4{1.f, 2.f, 3.f, 4.f}
                             : s4[e7 < nf4 ? e7 : tid];  // clamp: legal address
+    }
+    if (RELU_IN) {  // tf.nn.relu in front of conv_a (convstack_3d.py:44)
+#pragma unroll
+      for (int seg = 0; seg < 3; ++seg)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            v[seg][k][c] = v[seg][k][c] > 0.0f ? v[seg][k][c] : 0.0f;
     }
 #pragma unroll
     for (int seg = 0; seg < 3; ++seg) {
@@ -480,11 +498,8 @@ __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const unsigned nbytes = (unsigned)a.nchunks * kChunk * kFeatures * 4u;
     float* obase = a.out + (size_t)item * a.act_stride;
-    float* rbase_ = DUAL_OUT ? a.out_relu + (size_t)item * a.act_stride : obase;
     const __amdgpu_buffer_rsrc_t rs_out =
         __builtin_amdgcn_make_buffer_rsrc(obase, 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_relu =
-        __builtin_amdgcn_make_buffer_rsrc(rbase_, 0, nbytes, 0x00020000);
     const unsigned off0 = ((unsigned)(m0 + prow0) * kFeatures + q * 4) * 4u;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -501,12 +516,6 @@ __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
                               : 0x80000000u;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
                                              rs_out, off, 0, 0);
-      if (DUAL_OUT) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                               rs_relu, off, 0, 0);
-      }
     }
   }
 }
@@ -583,15 +592,9 @@ __device__ __forceinline__ bool disco_on(unsigned cnt, int V, float thr) {
   return thr >= 0.0f && ((double)cnt / (double)V) > (double)thr;
 }
 
-__global__ __launch_bounds__(512) void paste_kernel(
-    StepItems si, Geom g, const float* __restrict__ logits,
-    const float* __restrict__ in_seed,
-    const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
-    float disco_thr, ffn_step_result* __restrict__ results,
-    unsigned* __restrict__ seq, unsigned step_id) {
-  __shared__ unsigned s_cnt[8];
-  const int item = blockIdx.y;
-  const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
+__device__ __forceinline__ unsigned sum_block_counts(
+    const unsigned* __restrict__ block_count, int head_blocks, int item,
+    unsigned* s_cnt /* [blockDim.x / 64] shared */) {
   // total #(logits >= move_thr): sum of the head kernel's per-block partials
   unsigned part = 0;
   for (int e = threadIdx.x; e < head_blocks; e += blockDim.x)
@@ -601,34 +604,37 @@ __global__ __launch_bounds__(512) void paste_kernel(
   if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = part;
   __syncthreads();
   unsigned cnt = 0;
-#pragma unroll
-  for (int wv = 0; wv < 8; ++wv) cnt += s_cnt[wv];
+  for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) cnt += s_cnt[wv];
+  return cnt;
+}
+
+// faces: everything the HOST waits for after a step -- six face max/argmax
+// (movement.py:67-100), the point reads of the queue head (inference.py:325,
+// 341,503) and the completion flag.  One block per item, launched BEFORE the
+// canvas write-back so that the host's queue bookkeeping overlaps the paste.
+// Values inside the FoV are recomputed from (logits, old seed) exactly as the
+// paste kernel will write them; values outside come from the canvas, which this
+// step does not modify there.
+__global__ __launch_bounds__(512) void faces_kernel(
+    StepItems si, Geom g, const float* __restrict__ logits,
+    const float* __restrict__ in_seed,
+    const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
+    float disco_thr, ffn_step_result* __restrict__ results,
+    unsigned* __restrict__ seq, unsigned step_id) {
+  __shared__ unsigned s_cnt[8];
+  __shared__ ffn_step_result s_res;
+  const int item = blockIdx.x;
+  const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
+  const unsigned cnt = sum_block_counts(block_count, head_blocks, item, s_cnt);
   const bool disco = disco_on(cnt, g.V, disco_thr);
   const float* lg = logits + (size_t)item * g.V;
   const float* old = in_seed + (size_t)item * g.V;
   const int z0 = it.req.pos[0] - g.fz / 2;
   const int y0 = it.req.pos[1] - g.fy / 2;
   const int x0 = it.req.pos[2] - g.fx / 2;
-
-  if (blockIdx.x + 1 < gridDim.x) {
-    const int nb = gridDim.x - 1;
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < g.V;
-         v += nb * blockDim.x) {
-      const int x = v % g.fx;
-      const int t = v / g.fx;
-      const int y = t % g.fy;
-      const int z = t / g.fy;
-      const size_t ci =
-          ((size_t)(z0 + z) * it.cy + (y0 + y)) * it.cx + (x0 + x);
-      it.seed[ci] = post_disco(lg[v], old[v], disco);
-    }
-    return;
-  }
-
-  // ---- last block: wave 0..5 = faces, wave 6 = start + candidates ----
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  ffn_step_result& res = results[item];
+
   if (wave < 6) {
     const int axis = wave >> 1;
     const int sign = (wave & 1) ? 1 : -1;
@@ -637,21 +643,38 @@ __global__ __launch_bounds__(512) void paste_kernel(
     // runtime-indexed arrays: those would live in scratch memory)
     const int nr = axis == 0 ? 2 * g.dy + 1 : 2 * g.dz + 1;
     const int nc = axis == 2 ? 2 * g.dy + 1 : 2 * g.dx + 1;
-    float best = -__builtin_inff();
-    int besti = 0x7fffffff;
-    bool any = false;
-    for (int e = lane; e < nr * nc; e += 64) {
+    const int total = nr * nc;
+    auto dense_index = [&](int e) {
       const int fi = e / nc, fj = e - fi * nc;
       const int z = axis == 0 ? cz + sign * g.dz : cz - g.dz + fi;
       const int y = axis == 1 ? cy + sign * g.dy
                               : (axis == 0 ? cy - g.dy + fi : cy - g.dy + fj);
       const int x = axis == 2 ? cx + sign * g.dx : cx - g.dx + fj;
-      const int v = (z * g.fy + y) * g.fx + x;
-      const float val = post_disco(lg[v], old[v], disco);
-      if (!any || val > best) {  // strict >: first occurrence wins
-        best = val;
-        besti = e;
-        any = true;
+      return (z * g.fy + y) * g.fx + x;
+    };
+    float best = -__builtin_inff();
+    int besti = 0x7fffffff;
+    bool any = false;
+    for (int base = 0; base < total; base += 8 * 64) {
+      float a[8], b[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {  // all loads of the sweep in flight at once
+        const int e = base + k * 64 + lane;
+        const int v = dense_index(e < total ? e : 0);
+        a[k] = lg[v];
+        b[k] = old[v];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = base + k * 64 + lane;
+        if (e < total) {
+          const float val = post_disco(a[k], b[k], disco);
+          if (!any || val > best) {  // strict >: first occurrence wins
+            best = val;
+            besti = e;
+            any = true;
+          }
+        }
       }
     }
     if (!any) {
@@ -669,8 +692,8 @@ __global__ __launch_bounds__(512) void paste_kernel(
       }
     }
     if (lane == 0) {
-      res.face_score[wave] = best;
-      res.face_index[wave] = besti;
+      s_res.face_score[wave] = best;
+      s_res.face_index[wave] = besti;
       int sg = 0;
       if (besti != 0x7fffffff) {
         const int fi = besti / nc, fj = besti - fi * nc;
@@ -680,12 +703,9 @@ __global__ __launch_bounds__(512) void paste_kernel(
         const int x = axis == 2 ? cx + sign * g.dx : cx - g.dx + fj;
         sg = it.seg[((size_t)(z0 + z) * it.cy + (y0 + y)) * it.cx + (x0 + x)];
       }
-      res.face_seg[wave] = sg;
+      s_res.face_seg[wave] = sg;
     }
   } else if (wave == 6) {
-    // point reads: inside the FoV -> value being pasted by the other blocks of
-    // this launch (recomputed here, so no read-after-write race); outside ->
-    // the canvas, which this launch does not touch there.
     const int n = it.req.num_candidates;
     if (lane <= n && lane <= FFN_MAX_CANDIDATES) {
       const int32_t* q = lane == 0 ? it.req.start_pos : it.req.candidates[lane - 1];
@@ -705,22 +725,55 @@ __global__ __launch_bounds__(512) void paste_kernel(
         gv = it.seg[ci];
       }
       if (lane == 0) {
-        res.start_logit = sv;
-        res.num_above_move = cnt;
-        res.disco_applied = disco ? 1 : 0;
+        s_res.start_logit = sv;
+        s_res.num_above_move = cnt;
+        s_res.disco_applied = disco ? 1 : 0;
       } else {
-        res.cand_seed[lane - 1] = sv;
-        res.cand_seg[lane - 1] = gv;
+        s_res.cand_seed[lane - 1] = sv;
+        s_res.cand_seg[lane - 1] = gv;
       }
     }
   }
-  // Publish: results live in pinned host memory; make them visible system-wide,
-  // then raise the per-item sequence flag the host may be polling.
-  __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0)
-    __hip_atomic_store(&seq[item], step_id, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
+  // Publish from ONE wave: copy the record into pinned host memory, make it
+  // visible system-wide, then raise the item's sequence flag the host polls.
+  if (wave == 0) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_res);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&results[item]);
+    for (int k = lane; k < (int)(sizeof(ffn_step_result) / 4); k += 64)
+      dst[k] = src[k];
+    __threadfence_system();
+    if (lane == 0)
+      __hip_atomic_store(&seq[item], step_id, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// paste: disco bias + write-back into the canvas seed (inference.py:416-439).
+__global__ __launch_bounds__(512) void paste_kernel(
+    StepItems si, Geom g, const float* __restrict__ logits,
+    const float* __restrict__ in_seed,
+    const unsigned* __restrict__ block_count, int head_blocks,
+    float disco_thr) {
+  __shared__ unsigned s_cnt[8];
+  const int item = blockIdx.y;
+  const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
+  const unsigned cnt = sum_block_counts(block_count, head_blocks, item, s_cnt);
+  const bool disco = disco_on(cnt, g.V, disco_thr);
+  const float* lg = logits + (size_t)item * g.V;
+  const float* old = in_seed + (size_t)item * g.V;
+  const int z0 = it.req.pos[0] - g.fz / 2;
+  const int y0 = it.req.pos[1] - g.fy / 2;
+  const int x0 = it.req.pos[2] - g.fx / 2;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < g.V;
+       v += gridDim.x * blockDim.x) {
+    const int x = v % g.fx;
+    const int t = v / g.fx;
+    const int y = t % g.fy;
+    const int z = t / g.fy;
+    const size_t ci = ((size_t)(z0 + z) * it.cy + (y0 + y)) * it.cx + (x0 + x);
+    it.seed[ci] = post_disco(lg[v], old[v], disco);
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -347,3 +347,60 @@ def test_full_size_properties_250(fib25_model):
   assert raw == int(np.sum(seed >= np.float32(thr)))
   assert actual == raw and len(ids) == 0
   canvas.close()
+
+
+def test_batched_device_canvases_through_threaded_executor(fib25_model):
+  """Config C3 shape: several DeviceCanvas client threads, one server thread
+  batching their FoV steps into single ffn_canvas_step(n, ...) calls.  Every
+  canvas must reproduce the reference trajectory independently of batching."""
+  import threading
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from ffn_amd.inference import seed as seed_lib
+  import bench
+  names = ['cells72', 'cells56', 'cells72', 'cells56', 'cells56']
+  gold = {n: np.load(os.path.join(GOLDEN, 'ref_canvas_%s.npz' % n))
+          for n in set(names)}
+  request = bench.make_request()
+  counters = inference_utils.Counters()
+  iface = executor.ExecutorInterface()
+  exe = executor.HipBatchExecutor(iface, fib25_model, fib25_model.info, None,
+                                  counters, batch_size=4,
+                                  expected_clients=len(names))
+  exe.start_server()
+  out = {}
+  errors = []
+
+  def work(k, name):
+    try:
+      g = gold[name]
+      sub = counters.get_sub_counters()
+      canvas = inference.DeviceCanvas(
+          fib25_model.info, exe.get_client(sub), synthetic.normalize(g['volume']),
+          request.inference_options, counters=sub,
+          movement_policy_fn=movement.get_policy_fn(request, fib25_model.info))
+      canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                       coords=g['seeds']))
+      out[k] = (np.asarray(canvas.segmentation),
+                sub['update_at-calls'].value)
+      canvas.close()
+    except Exception as e:  # pylint:disable=broad-except
+      errors.append(repr(e))
+
+  threads = [threading.Thread(target=work, args=(k, n), daemon=True)
+             for k, n in enumerate(names)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=600)
+  exe.stop_server()
+  assert not errors, errors
+  for k, n in enumerate(names):
+    assert np.array_equal(out[k][0], gold[n]['segmentation']), (k, n)
+    assert out[k][1] == len(gold[n]['steps'])
+  # steps were really batched (fewer engine calls than FoV steps)
+  total_steps = sum(len(gold[n]['steps']) for n in names)
+  assert counters['executor-inference-calls'].value < total_steps
