@@ -9,9 +9,12 @@ stays on the CPU (moving it to the GPU is a "next" row).
 `skimage.feature.peak_local_max`; neither is installable here.  It is restated
 with scipy (`distance_transform_edt`, `maximum_filter`): same pipeline (3-D
 Sobel magnitude -> gaussian adaptive threshold sigma=49/6 -> EDT -> local maxima
-with min_distance=3 and the fixed-seed 1e-4 noise -> ascending sort), but the
-peak lists are NOT guaranteed identical to skimage's: parity unpinned for seed
-lists.  Benchmarks and parity tests use `PolicyGrid3d` or an explicit list.
+with min_distance=3 and the fixed-seed 1e-4 noise -> ascending sort), and the
+result is pinned against the reference's own PolicyPeaks run with the real
+scikit-image 0.18.3 (tests/golden/ref_policy_peaks.npz, minted by
+tools/make_golden_peaks.py under the image's conda python; `edt` there is
+scipy's exact EDT).  Benchmarks use `PolicyGrid3d` so CPU and GPU runs consume
+identical seeds by construction.
 """
 
 from __future__ import annotations
@@ -90,12 +93,19 @@ class PolicyFixed(BaseSeedPolicy):
 
 
 def _peak_local_max(dist, min_distance=3):
-  """Local maxima of `dist` (> 0) at least `min_distance` apart (footprint
-  2*min_distance+1 cube, as skimage's peak_local_max does for a grid)."""
+  """Local maxima of `dist` (> 0) at least `min_distance` apart: what
+  skimage.feature.peak_local_max(min_distance, threshold_abs=0,
+  threshold_rel=0) returns for tie-free input -- maximum filter over the
+  (2*min_distance+1) cube, peaks within `min_distance` of the border excluded
+  (skimage's default exclude_border=True)."""
   size = 2 * min_distance + 1
-  mx = ndimage.maximum_filter(dist, size=size, mode='constant', cval=-np.inf)
+  mx = ndimage.maximum_filter(dist, size=size, mode='constant', cval=0.0)
   peaks = (dist == mx) & (dist > 0)
-  return np.argwhere(peaks)
+  border = np.zeros_like(peaks)
+  inner = tuple(slice(min_distance, max(n - min_distance, min_distance))
+                for n in dist.shape)
+  border[inner] = True
+  return np.argwhere(peaks & border)
 
 
 class PolicyPeaks(BaseSeedPolicy):
@@ -127,8 +137,9 @@ class PolicyPeaks(BaseSeedPolicy):
       dt[mask] = -1
       dt[~np.isfinite(dt)] = -1
       rng = np.random.RandomState(seed=42)
-      idxs = _peak_local_max(dt + rng.rand(*dt.shape).astype(np.float32) * 1e-4,
-                             min_distance=3)
+      # f32 dt + f64 noise -> f64, as in the reference (seed.py:136-138); in f32
+      # the 1e-4 noise would collapse into ties
+      idxs = _peak_local_max(dt + rng.rand(*dt.shape) * 1e-4, min_distance=3)
       idxs = np.array(sorted((z, y, x) for z, y, x in idxs)).reshape(-1, 3)
       logging.info('peaks: found %d local maxima', idxs.shape[0])
       self.coords = idxs

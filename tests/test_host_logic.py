@@ -332,3 +332,24 @@ def test_step_struct_layout_matches_header():
   assert ctypes.sizeof(_lib.StepRequest) == 4 * (3 + 3 + 1 + 3 * 16)
   assert ctypes.sizeof(_lib.StepResult) == 4 * (6 + 6 + 6 + 3 + 16 + 16)
   assert ctypes.sizeof(_lib.CommitCounts) == 24
+
+
+def test_policy_peaks_matches_reference_with_real_skimage():
+  """PolicyPeaks (scipy restatement) == the reference's PolicyPeaks run with
+  scikit-image 0.18.3 (fixture minted by tools/make_golden_peaks.py)."""
+  g = np.load(os.path.join(GOLDEN, 'ref_policy_peaks.npz'))
+
+  class C:
+    restrictor = None
+    voxel_size_zyx = (1, 1, 1)
+
+  for n in 'ab':
+    c = C()
+    c.image = synthetic.normalize(g[n + '_volume'])
+    c.shape = c.image.shape
+    c.margin = np.array([4, 4, 4])
+    c.segmentation = np.zeros(c.shape, np.int32)
+    c.segmentation[20:30, 20:30, 20:30] = 3
+    got = np.array([p for p in seed_lib.PolicyPeaks(c)]).reshape(-1, 3)
+    assert len(got) > 50
+    assert np.array_equal(got, g[n + '_seeds']), n
