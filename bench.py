@@ -156,7 +156,7 @@ def run_gpu(args, rank, local_rank, world):
   # HIP-event pairs around every conv32 launch of 1 FoV step in
   # `profile_every` (sampling keeps the event overhead out of `value`).
   eng.set_option('profile_every', args.profile_every)
-  eng.set_profiling(1)
+  eng.set_profiling(args.profile_mode)
   policy = functools.partial(seed_lib.PolicyGrid3d, step=16,
                              offsets=(0, 8, 4, 12, 2, 10, 14))
   try:
@@ -296,6 +296,8 @@ def main():
   ap.add_argument('--conv-variant', type=int, default=None)
   ap.add_argument('--profile-every', type=int, default=8)
   ap.add_argument('--sync-mode', type=int, default=None)
+  ap.add_argument('--profile-mode', type=int, default=2,
+                  help='1 = event pair per conv launch, 2 = per 23-conv chain')
   ap.add_argument('--cpu-seconds', type=float, default=15.0)
   ap.add_argument('--cpu-steps', type=int, default=60)
   ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -368,6 +370,11 @@ def main():
           'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
           'traffic': traffic,
           'avg_launch_us': round(avg_conv_ms * 1e3, 3),
+          'timing': ('HIP events around the 23-launch conv chain of every %dth '
+                     'step, / 23 (includes inter-kernel gaps)' %
+                     args.profile_every if args.profile_mode == 2 else
+                     'HIP event pair around each conv launch of every %dth step'
+                     % args.profile_every),
           'launches': int(res['conv_launches']),
           'flops_per_launch': CONV32_FLOPS,
       },

@@ -72,6 +72,7 @@ SIGNATURES = {
     'ffn_engine_get_profile': (_I, [_P, ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(ctypes.c_int64), _I]),
     'ffn_engine_synchronize': (_I, [_P]),
+    'ffn_engine_debug_clocks': (_I, [_P, _P]),
     'ffn_predict': (_I, [_P, _I, _P, _P, _P]),
     'ffn_forward_resident': (_I, [_P, _I, _I]),
     'ffn_canvas_create': (_I, [_P, _P, _I3, ctypes.POINTER(_P)]),

@@ -57,7 +57,12 @@ struct ffn_engine {
   float* bufT = nullptr;      // logical origins
   float* bufX = nullptr;
   uint32_t* validbits = nullptr;
-  int conv_variant = 1;       // 0 = conv32_kernel (simple), 1 = conv32p_kernel
+  int32_t* pidx = nullptr;    // dense FoV index -> padded position (variant 2)
+  int nchunks_c = 0, Rc = 0;
+  long long* d_dbg = nullptr;  // debug clocks of conv32c WG 0 (24 values)
+  int dbg_clock = 0;
+  size_t lds_bytes_c = 0;
+  int conv_variant = 2;       // 0 = conv32 (simple), 1 = conv32p, 2 = conv32c
   float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
   float* up_seed = nullptr;
   float* seed_raw = nullptr;  // raw (NaN-preserving) seed FoV of the current step
@@ -90,6 +95,7 @@ struct ffn_engine {
   long stack_calls = 0;
   bool prof_now = false;
   int ablate = 0;                     // debug: skip phases of the conv kernel
+  std::vector<int> chain_launches_pending;  // mode 2: launches per event pair
 };
 
 struct ffn_canvas {
@@ -133,6 +139,14 @@ int set_lds_attr_p(size_t bytes) {
   return FFN_OK;
 }
 
+template <bool RI, bool RO, bool SK, int DBG = 0>
+int set_lds_attr_c(size_t bytes) {
+  HIP_TRY(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&conv32c_kernel<RI, RO, SK, DBG>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return FFN_OK;
+}
+
 // Flush the per-launch event pairs recorded since the last flush.
 int flush_events(ffn_engine* e) {
   if (e->events_used == 0) return FFN_OK;
@@ -141,7 +155,12 @@ int flush_events(ffn_engine* e) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e->events[k], e->events[k + 1]));
     e->conv_ms += ms;
-    e->conv_launches += 1;
+    if (e->prof_mode == 2 && !e->chain_launches_pending.empty()) {
+      e->conv_launches += e->chain_launches_pending.front();
+      e->chain_launches_pending.erase(e->chain_launches_pending.begin());
+    } else {
+      e->conv_launches += 1;
+    }
   }
   e->events_used = 0;
   return FFN_OK;
@@ -228,12 +247,71 @@ int launch_conv32p(ffn_engine* e, int n, const float* in, float* out,
   return FFN_OK;
 }
 
+template <bool RI, bool RO, bool SK>
+int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
+                   const float* skip, int layer) {
+  ConvCArgs a;
+  a.in = in;
+  a.out = out;
+  a.skip = skip;
+  a.wpack = e->weights + e->wpack_off[layer];
+  a.bias = e->weights + e->bias_off[layer];
+  a.pidx = e->pidx;
+  a.act_stride = e->g.act_stride;
+  a.XS = e->g.XS;
+  a.plane = e->g.plane;
+  a.Rc = e->Rc;
+  a.nchunks = e->nchunks_c;
+  a.V = e->g.V;
+  a.fx = e->g.fx;
+  a.fyfx = e->g.fy * e->g.fx;
+  a.total_slots = n * e->nchunks_c;
+  a.slots_per_xcd = (a.total_slots + 7) / 8;
+  a.nbytes = (unsigned)((size_t)e->g.nchunks * kChunk * kFeatures * sizeof(float));
+  a.dbg = e->dbg_clock ? e->d_dbg : nullptr;
+  const bool prof = e->prof_now;
+  if (prof) {
+    if (e->events_used + 2 > (int)e->events.size()) {
+      int rc = flush_events(e);
+      if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  }
+  const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
+  if (RI == false && RO == false && SK == true && e->ablate != 0) {
+    switch (e->ablate) {  // issue-rate experiments (conv_b instantiation only)
+      case 8:
+        hipLaunchKernelGGL((conv32c_kernel<false, false, true, 8>), grid, block,
+                           e->lds_bytes_c, e->stream, a);
+        break;
+      case 16:
+        hipLaunchKernelGGL((conv32c_kernel<false, false, true, 16>), grid, block,
+                           e->lds_bytes_c, e->stream, a);
+        break;
+      case 24:
+        hipLaunchKernelGGL((conv32c_kernel<false, false, true, 24>), grid, block,
+                           e->lds_bytes_c, e->stream, a);
+        break;
+      default:
+        return fail(FFN_ERR_ARG, "unsupported ablate mask %d for variant 2",
+                    e->ablate);
+    }
+  } else {
+    hipLaunchKernelGGL((conv32c_kernel<RI, RO, SK>), grid, block,
+                       e->lds_bytes_c, e->stream, a);
+  }
+  if (prof) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  return FFN_OK;
+}
+
 // FoVs described by `si` -> logits (+ count of logits >= move_thr, + seed_raw)
 int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
               float move_thr) {
   const Geom& g = e->g;
-  e->prof_now = e->prof_mode == 1 && (e->stack_calls % e->prof_every) == 0;
+  const bool sampled = (e->stack_calls % e->prof_every) == 0;
   e->stack_calls++;
+  e->prof_now = e->prof_mode == 1 && sampled;
+  const bool prof_chain = e->prof_mode == 2 && sampled;
   const float* W = e->weights;
   const int tz = (g.fz + kC0Z - 1) / kC0Z, ty = (g.fy + kC0Y - 1) / kC0Y,
             tx = (g.fx + kC0X - 1) / kC0X;
@@ -242,6 +320,14 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
                      e->bufT, e->seed_raw, g, ty, tx);
   int rc;
   const float* head_in;
+  if (prof_chain) {
+    if (e->events_used + 2 > (int)e->events.size()) {
+      rc = flush_events(e);
+      if (rc) return rc;
+    }
+    e->chain_launches_pending.push_back(2 * e->depth - 1);
+    HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  }
   if (e->conv_variant == 0) {
     rc = launch_conv32<false, false, false>(e, n, e->bufT, e->bufX, nullptr, 0);
     if (rc) return rc;
@@ -251,6 +337,18 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
       if (rc) return rc;
       rc = launch_conv32<false, false, true>(e, n, e->bufT, e->bufX, e->bufX,
                                              2 * i);
+      if (rc) return rc;
+    }
+    head_in = e->bufX;
+  } else if (e->conv_variant == 2) {
+    rc = launch_conv32c<false, false, false>(e, n, e->bufT, e->bufX, nullptr, 0);
+    if (rc) return rc;
+    for (int i = 1; i < e->depth; ++i) {
+      rc = launch_conv32c<true, true, false>(e, n, e->bufX, e->bufT, nullptr,
+                                             2 * i - 1);
+      if (rc) return rc;
+      rc = launch_conv32c<false, false, true>(e, n, e->bufT, e->bufX, e->bufX,
+                                              2 * i);
       if (rc) return rc;
     }
     head_in = e->bufX;
@@ -268,6 +366,7 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     }
     head_in = e->bufX;
   }
+  if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   hipLaunchKernelGGL(head_kernel, dim3(kHeadBlocks, n), dim3(256), 0, e->stream, head_in,
                      e->seed_raw, pad_value, W + e->wl_off, move_thr, e->logits,
                      e->count, g);
@@ -386,7 +485,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   g.nchunks = (g.npos + kChunk - 1) / kChunk;
   g.V = g.fz * g.fy * g.fx;
   g.R = kChunk + 2 * (g.XS + 1);
-  const long positions = (long)g.guard + (long)g.nchunks * kChunk + g.guard;
+  const long positions = (long)g.guard + (long)g.nchunks * kChunk + g.guard + 320;
   g.act_stride = positions * kFeatures;
   e->lds_bytes = (size_t)3 * g.R * kFeatures * sizeof(float);
   if (e->lds_bytes > 160 * 1024) {
@@ -447,6 +546,32 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
                     hipMemcpyHostToDevice));
   }
 
+  // dense -> padded position table and LDS extent of the compact variant
+  {
+    e->nchunks_c = (g.V + kCChunk - 1) / kCChunk;
+    std::vector<int32_t> pidx((size_t)e->nchunks_c * kCChunk);
+    for (size_t v = 0; v < pidx.size(); ++v) {
+      const int vv = (int)std::min<size_t>(v, (size_t)g.V - 1);
+      const int x = vv % g.fx, y = (vv / g.fx) % g.fy, z = vv / (g.fx * g.fy);
+      pidx[v] = z * g.plane + y * g.XS + x;
+    }
+    int span = 0;
+    for (int c = 0; c < e->nchunks_c; ++c)
+      span = std::max(span, pidx[(size_t)c * kCChunk + kCChunk - 1] -
+                                pidx[(size_t)c * kCChunk] + 1);
+    e->Rc = ((span + 2 * (g.XS + 1)) + 31) / 32 * 32;
+    e->lds_bytes_c = (size_t)3 * e->Rc * kCLdsStride * sizeof(float);
+    E_TRY(hipMalloc(&e->d_dbg, 24 * sizeof(long long)));
+    E_TRY(hipMemset(e->d_dbg, 0, 24 * sizeof(long long)));
+    E_TRY(hipMalloc(&e->pidx, pidx.size() * sizeof(int32_t)));
+    E_TRY(hipMemcpy(e->pidx, pidx.data(), pidx.size() * sizeof(int32_t),
+                    hipMemcpyHostToDevice));
+    // variants 1 / 2 need 7*256 <= R*8 <= 8*256 resp. Rc in {256, 288}
+    const bool p_ok = g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256;
+    const bool c_ok = e->Rc >= 256 && e->Rc <= 288;
+    e->conv_variant = c_ok ? 2 : (p_ok ? 1 : 0);
+  }
+
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)
   // [wl 32 + 1]
   {
@@ -474,6 +599,12 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     int rc = set_lds_attr<false, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr<false, false, true>(e->lds_bytes);
+    if (!rc) rc = set_lds_attr_c<false, false, false>(e->lds_bytes_c);
+    if (!rc) rc = set_lds_attr_c<true, true, false>(e->lds_bytes_c);
+    if (!rc) rc = set_lds_attr_c<false, false, true>(e->lds_bytes_c);
+    if (!rc) rc = set_lds_attr_c<false, false, true, 8>(e->lds_bytes_c);
+    if (!rc) rc = set_lds_attr_c<false, false, true, 16>(e->lds_bytes_c);
+    if (!rc) rc = set_lds_attr_c<false, false, true, 24>(e->lds_bytes_c);
     if (!rc) rc = set_lds_attr_p<false, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
@@ -518,6 +649,8 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->count);
   (void)hipFree(e->valid);
   (void)hipFree(e->validbits);
+  (void)hipFree(e->pidx);
+  (void)hipFree(e->d_dbg);
   (void)hipFree(e->weights);
   (void)hipFree(e->d_items);
   (void)hipFree(e->d_scratch);
@@ -611,7 +744,12 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) {
-    if (value != 0 && value != 1) return fail(FFN_ERR_ARG, "conv_variant must be 0 or 1");
+    if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "conv_variant must be 0, 1 or 2");
+    const Geom& g = e->g;
+    if (value == 1 && !(g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256))
+      return fail(FFN_ERR_ARG, "conv_variant 1 unsupported for this fov");
+    if (value == 2 && !(e->Rc >= 256 && e->Rc <= 288))
+      return fail(FFN_ERR_ARG, "conv_variant 2 unsupported for this fov");
     e->conv_variant = value;
     return FFN_OK;
   }
@@ -625,11 +763,23 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->sync_mode = value;
     return FFN_OK;
   }
+  if (std::strcmp(name, "debug_clock") == 0) {
+    e->dbg_clock = value;
+    return FFN_OK;
+  }
   if (std::strcmp(name, "ablate") == 0) {
     e->ablate = value;
     return FFN_OK;
   }
   return fail(FFN_ERR_ARG, "unknown option '%s'", name);
+}
+
+int ffn_engine_debug_clocks(ffn_engine* e, long long* out24) {
+  if (!e || !out24) return fail(FFN_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(out24, e->d_dbg, 24 * sizeof(long long), hipMemcpyDeviceToHost));
+  return FFN_OK;
 }
 
 int ffn_engine_synchronize(ffn_engine* e) {
@@ -641,10 +791,11 @@ int ffn_engine_synchronize(ffn_engine* e) {
 
 int ffn_engine_set_profiling(ffn_engine* e, int mode) {
   if (!e) return fail(FFN_ERR_ARG, "null argument");
-  if (mode != 0 && mode != 1) return fail(FFN_ERR_ARG, "mode must be 0 or 1");
+  if (mode < 0 || mode > 2) return fail(FFN_ERR_ARG, "mode must be 0, 1 or 2");
   HIP_TRY(hipSetDevice(e->device));
   int rc = flush_events(e);
   if (rc) return rc;
+  e->chain_launches_pending.clear();
   e->prof_mode = mode;
   return FFN_OK;
 }

@@ -324,6 +324,18 @@ struct ConvPArgs {
   int total_slots, slots_per_xcd;
 };
 
+// Scheduling directive for one pipelined step: interleave the N MFMAs of the
+// step with the (independent) address VALU / SALU / ds_read / global_load
+// instructions that prefetch the NEXT step, one non-MFMA instruction in the
+// 32-cycle shadow of each MFMA, instead of issuing the whole prefetch block
+// in front of the MFMAs (measured with in-kernel clocks: 38 cycles per MFMA with
+// the block in front).
+#define FFN_INTERLEAVE(N)                                           \
+  _Pragma("unroll") for (int g_ = 0; g_ < (N); ++g_) {              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* MFMA */   \
+    __builtin_amdgcn_sched_group_barrier(0x1A6, 2, 0); /* other */  \
+  }
+
 #define FFN_MFMA20(AC, BC)                                                    \
   _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                          \
     _Pragma("unroll") for (int t_ = 0; t_ < kTilesPerWave; ++t_) acc[t_] =    \
@@ -452,8 +464,8 @@ __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
 #define FFN_STEP(K, ACUR, ANEXT, BCUR, BNEXT2)        \
   if ((K) + 1 < 54) loadA((K) + 1, ANEXT);            \
   if ((K) + 2 < 54) BNEXT2 = loadB((K) + 2);          \
-  __builtin_amdgcn_sched_barrier(0);                  \
   FFN_MFMA20(ACUR, BCUR)                              \
+  FFN_INTERLEAVE(20)                                  \
   __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
@@ -517,6 +529,346 @@ __global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
                                              rs_out, off, 0, 0);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// conv32c: "compact + K-split" variant of conv32p -- fewer MFMAs on the critical
+// path of a single field of view.
+//
+// conv32p walks the PADDED position space (6.2 % padding positions are computed
+// and dropped) in chunks of 160, which at batch 1 occupies 239 of 256 CUs with 5
+// tiles x 27 taps per wave = 1,080 MFMAs.  conv32c walks the DENSE FoV index v
+// (valid positions only; `pidx[v]` maps it to the padded position) in chunks of
+// 144 = 9 tiles -> 250 workgroups, and splits the middle tile's 27 taps between
+// the two tile groups: wave (nhalf, tgrp) owns 4 full tiles plus 14 (tgrp 0) or
+// 13 (tgrp 1) taps of tile 4 = 122 / 121 tile-taps = 976 MFMAs
+// (-9.6 %).  The two partial sums of tile 4 meet in the LDS transpose of the
+// epilogue.  The three dz segments of the input are staged progressively (all
+// loads in flight from the start; segment kz is written to LDS just before tap
+// 9*kz), so only the first third of the staging latency is exposed.
+// Lane -> LDS row is no longer affine in the lane id (row ends / plane ends
+// insert gaps), so each lane carries the LDS offset of its position per tile.
+// ---------------------------------------------------------------------------
+constexpr int kCChunk = 144;
+constexpr int kCTiles = 9;
+// LDS row stride in floats: 32 channels + 8 pad.  With 160-byte rows the
+// ds_read_b128 of 16 consecutive rows is bank-conflict free WITHOUT an XOR
+// swizzle (brute-forced over the b128 lane groups), so the address of every
+// tap is affine: lane base + wave-uniform offset.
+constexpr int kCLdsStride = 40;
+
+struct ConvCArgs {
+  const float* in;
+  float* out;
+  const float* skip;
+  const float* wpack;
+  const float* bias;
+  const int32_t* pidx;   // [nchunks_c * 144] dense index -> padded position
+  long act_stride;
+  int XS, plane, Rc;     // Rc = LDS rows per dz segment (multiple of 32)
+  int nchunks, V;
+  int fx, fyfx;          // FoV row length and plane size (dense index math)
+  int total_slots, slots_per_xcd;
+  unsigned nbytes;       // bytes of one activation buffer past its origin
+  long long* dbg;        // optional [4 waves][6]: shader / wall clocks of WG 0
+};
+
+template <int NT>
+__device__ __forceinline__ void mfma_tiles(const f32x4 (&A)[5], const f32x4& B,
+                                           f32x4 (&acc)[5]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][s], B[s], acc[t], 0, 0, 0);
+  }
+}
+
+// DBG (0 in production): 8 = no A-fragment reads after the first, 16 = no
+// weight loads after the first two (issue-rate experiments).
+template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int DBG = 0>
+__global__ __launch_bounds__(kConvThreads) void conv32c_kernel(ConvCArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const long long dbg_c0 = a.dbg ? clock64() : 0;
+  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
+  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
+  if (gc >= a.total_slots) return;
+  const int item = gc / a.nchunks;
+  const int chunk = gc - item * a.nchunks;
+  const int v0 = chunk * kCChunk;
+  const int32_t* pidx = a.pidx + v0;
+  // padded position of the chunk's first voxel, by arithmetic (a table lookup
+  // here would put one more memory round trip in front of the staging loads)
+  int p_first;
+  {
+    int z = (int)((float)v0 / (float)a.fyfx);
+    z -= (z * a.fyfx > v0);
+    z += ((z + 1) * a.fyfx <= v0);
+    const int rem = v0 - z * a.fyfx;
+    int y = (int)((float)rem / (float)a.fx);
+    y -= (y * a.fx > rem);
+    y += ((y + 1) * a.fx <= rem);
+    p_first = __builtin_amdgcn_readfirstlane(z * a.plane + y * a.XS +
+                                             (rem - y * a.fx));
+  }
+  const int p_lo = p_first - (a.XS + 1);  // first staged row of the dz=0 segment
+  const float* src = a.in + (size_t)item * a.act_stride;
+  const int Rc = a.Rc;
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nhalf = wave & 1;
+  const int tgrp = wave >> 1;
+  const int i = lane & 15;
+  const int grp = lane >> 4;
+
+  // LDS float offset of this lane's position in each of its 5 tiles: tiles 0..3
+  // (tgrp 0) / 5..8 (tgrp 1), then the shared tile 4.  (Oldest loads of the
+  // kernel: the first A-fragment read needs them.)
+  int prow[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int tile = t < 4 ? tgrp * 5 + t : 4;
+    prow[t] = (pidx[tile * kTile + i] - p_lo) * kCLdsStride + grp * 4;
+  }
+  // padded position of this thread's 5 epilogue pieces (also old loads: the
+  // residual prefetch below needs them without draining the staging loads)
+  // thread -> (position j = (tid >> 3) + 32 k, channel quad tid & 7), k = 0..4
+  const int q = tid & 7;
+  const int j0 = tid >> 3;
+  int pj[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = j0 + 32 * k;
+    pj[k] = pidx[(j < kCChunk && v0 + j < a.V) ? j : 0];
+  }
+  // weight fragments of taps 0 and 1: issued BEFORE the staging loads -- vmcnt
+  // retires in order, so a weight load queued behind the staging loads would
+  // make the first MFMA wait for all three dz segments.
+  struct AFrag { f32x4 h0[5], h1[5]; };
+  struct BFrag { f32x4 h0, h1; };
+  const f32x4* wp =
+      reinterpret_cast<const f32x4*>(a.wpack) + nhalf * 128 + lane;
+  auto loadB = [&](int s, BFrag& dst) {
+    dst.h0 = wp[s * 256];
+    dst.h1 = wp[s * 256 + 64];
+  };
+  BFrag B0, B1, B2;
+  loadB(0, B0);
+  loadB(1, B1);
+
+  // ---- staging: all 27 x 16-B loads of the three dz segments in flight at
+  // once; segment kz is written to LDS (and waited for) only right before the
+  // first tap that reads it, so dz = 0, +1 land behind the MFMAs of dz = -1.
+  const int nf4 = Rc * 8;  // 2048 (Rc = 256) or 2304 (Rc = 288)
+  f32x4 sv[3][9];
+#pragma unroll
+  for (int seg = 0; seg < 3; ++seg) {
+    const long p0 = (long)p_lo + (long)(seg - 1) * a.plane;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      sv[seg][k] = s4[tid + k * kConvThreads];
+    const int e8 = tid + 8 * kConvThreads;
+    sv[seg][8] = s4[e8 < nf4 ? e8 : tid];
+  }
+  auto write_segment = [&](int seg) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int e = tid + k * kConvThreads;
+      if (k < 8 || e < nf4) {
+        f32x4 v = sv[seg][k];
+        if (RELU_IN) {  // tf.nn.relu in front of conv_a (convstack_3d.py:44)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+        }
+        const int row = seg * Rc + (e >> 3);
+        *reinterpret_cast<f32x4*>(lds + row * kCLdsStride + (e & 7) * 4) = v;
+      }
+    }
+  };
+
+  // ---- per-thread epilogue operands (youngest loads: nothing waits on them
+  // until the epilogue) ----
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
+  unsigned ooff[5];
+  f32x4 skipv[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = j0 + 32 * k;
+    const bool ok = j < kCChunk && v0 + j < a.V;
+    const int p = pj[k];
+    ooff[k] = ok ? ((unsigned)p * kFeatures + q * 4) * 4u : 0x80000000u;
+    skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ADD_SKIP)
+      skipv[k] = *reinterpret_cast<const f32x4*>(
+          a.skip + (size_t)item * a.act_stride + (size_t)p * kFeatures + q * 4);
+  }
+
+  write_segment(0);
+  __syncthreads();
+
+  // ---- main loop: one step = one tap (two half-taps of 4 k-steps) ----
+  //   A fragments (LDS -> VGPR, 10 x ds_read_b128) one tap ahead, ring of 2;
+  //   B fragments (L2 -> VGPR, 2 x 16 B)           two taps ahead, ring of 3.
+  // Tiles 0..3 of the wave run every tap; the shared tile 4 runs in tile group
+  // 0 on the first 5 / 4 / 5 taps of the dz = -1 / 0 / +1 segment (14 taps) and
+  // in tile group 1 on the other 13 -- balanced PER SEGMENT, because the
+  // segment barriers would otherwise serialise the imbalance (two
+  // accumulators, so its 8 MFMAs per tap do not form one dependent chain).
+  auto a_off = [&](int s) {  // LDS float offset of tap s (compile-time kz/ky/kx)
+    const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
+    return (kz * Rc + (ky - 1) * a.XS + (kx - 1)) * kCLdsStride;
+  };
+  auto loadA_tile = [&](int t, int off, AFrag& dst) {
+    const float* p = lds + prow[t] + off;
+    dst.h0[t] = *reinterpret_cast<const f32x4*>(p);
+    dst.h1[t] = *reinterpret_cast<const f32x4*>(p + 16);
+  };
+  auto loadA = [&](int s, AFrag& dst) {
+    const int off = a_off(s);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) loadA_tile(t, off, dst);
+  };
+  f32x4 acc[4], acc4a, acc4b;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc4a = acc4b = f32x4{0.f, 0.f, 0.f, 0.f};
+  AFrag A0, A1;
+  const long long dbg_c1 = a.dbg ? clock64() : 0;
+  loadA(0, A0);
+  if (DBG & 8) loadA(1, A1);
+
+#define FFN_CGROUP(AH, BH, KS)                                               \
+  _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) acc[t_] =                 \
+      __builtin_amdgcn_mfma_f32_16x16x4f32(AH[t_][KS], BH[KS], acc[t_], 0,   \
+                                           0, 0);                            \
+  __builtin_amdgcn_sched_barrier(0);
+  // PF: prefetch the next tap's A fragments inside this step (false on the last
+  // tap of a dz segment: the next segment is not in LDS yet).
+#define FFN_CTAP(S, ACUR, ANEXT, BCUR, BNEXT2, PF)                           \
+  {                                                                          \
+    const bool pa_ = (PF) && (S) + 1 < 27 && !(DBG & 8);                     \
+    const int oa_ = a_off((S) + 1);                                          \
+    if (pa_) loadA_tile(0, oa_, ANEXT);                                      \
+    FFN_CGROUP(ACUR.h0, BCUR.h0, 0)                                          \
+    if (pa_) loadA_tile(1, oa_, ANEXT);                                      \
+    FFN_CGROUP(ACUR.h0, BCUR.h0, 1)                                          \
+    if (pa_) loadA_tile(2, oa_, ANEXT);                                      \
+    FFN_CGROUP(ACUR.h0, BCUR.h0, 2)                                          \
+    if (pa_) loadA_tile(3, oa_, ANEXT);                                      \
+    FFN_CGROUP(ACUR.h0, BCUR.h0, 3)                                          \
+    if (pa_) loadA_tile(4, oa_, ANEXT);                                      \
+    FFN_CGROUP(ACUR.h1, BCUR.h1, 0)                                          \
+    if ((S) + 2 < 27 && !(DBG & 16)) loadB((S) + 2, BNEXT2);                 \
+    FFN_CGROUP(ACUR.h1, BCUR.h1, 1)                                          \
+    FFN_CGROUP(ACUR.h1, BCUR.h1, 2)                                          \
+    FFN_CGROUP(ACUR.h1, BCUR.h1, 3)                                          \
+    if ((tgrp == 0) == (((S) % 9) < (((S) / 9) == 1 ? 4 : 5))) { /* ours */ \
+      _Pragma("unroll") for (int s_ = 0; s_ < 4; s_ += 2) {                  \
+        acc4a = __builtin_amdgcn_mfma_f32_16x16x4f32(                        \
+            ACUR.h0[4][s_], BCUR.h0[s_], acc4a, 0, 0, 0);                    \
+        acc4b = __builtin_amdgcn_mfma_f32_16x16x4f32(                        \
+            ACUR.h0[4][s_ + 1], BCUR.h0[s_ + 1], acc4b, 0, 0, 0);            \
+      }                                                                      \
+      _Pragma("unroll") for (int s_ = 0; s_ < 4; s_ += 2) {                  \
+        acc4a = __builtin_amdgcn_mfma_f32_16x16x4f32(                        \
+            ACUR.h1[4][s_], BCUR.h1[s_], acc4a, 0, 0, 0);                    \
+        acc4b = __builtin_amdgcn_mfma_f32_16x16x4f32(                        \
+            ACUR.h1[4][s_ + 1], BCUR.h1[s_ + 1], acc4b, 0, 0, 0);            \
+      }                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                     \
+    }                                                                        \
+  }
+  // A ring alternates every tap, B ring has period 3: the pattern repeats
+  // every 6 taps.  Taps 8 and 17 end a dz segment.
+  FFN_CTAP(0, A0, A1, B0, B2, true)
+  FFN_CTAP(1, A1, A0, B1, B0, true)
+  FFN_CTAP(2, A0, A1, B2, B1, true)
+  FFN_CTAP(3, A1, A0, B0, B2, true)
+  FFN_CTAP(4, A0, A1, B1, B0, true)
+  FFN_CTAP(5, A1, A0, B2, B1, true)
+  FFN_CTAP(6, A0, A1, B0, B2, true)
+  FFN_CTAP(7, A1, A0, B1, B0, true)
+  FFN_CTAP(8, A0, A1, B2, B1, false)
+  write_segment(1);
+  __syncthreads();
+  if (!(DBG & 8)) loadA(9, A1);
+  FFN_CTAP(9, A1, A0, B0, B2, true)
+  FFN_CTAP(10, A0, A1, B1, B0, true)
+  FFN_CTAP(11, A1, A0, B2, B1, true)
+  FFN_CTAP(12, A0, A1, B0, B2, true)
+  FFN_CTAP(13, A1, A0, B1, B0, true)
+  FFN_CTAP(14, A0, A1, B2, B1, true)
+  FFN_CTAP(15, A1, A0, B0, B2, true)
+  FFN_CTAP(16, A0, A1, B1, B0, true)
+  FFN_CTAP(17, A1, A0, B2, B1, false)
+  write_segment(2);
+  __syncthreads();
+  if (!(DBG & 8)) loadA(18, A0);
+  FFN_CTAP(18, A0, A1, B0, B2, true)
+  FFN_CTAP(19, A1, A0, B1, B0, true)
+  FFN_CTAP(20, A0, A1, B2, B1, true)
+  FFN_CTAP(21, A1, A0, B0, B2, true)
+  FFN_CTAP(22, A0, A1, B1, B0, true)
+  FFN_CTAP(23, A1, A0, B2, B1, true)
+  FFN_CTAP(24, A0, A1, B0, B2, true)
+  FFN_CTAP(25, A1, A0, B1, B0, true)
+  FFN_CTAP(26, A0, A1, B2, B1, true)
+#undef FFN_CTAP
+#undef FFN_CGROUP
+
+  const long long dbg_c2 = a.dbg ? clock64() : 0;
+  // ---- epilogue: accumulators -> LDS [position j][32 ch]; rows 144..159 hold
+  // tgrp 1's partial sums of the shared tile 4 ----
+  __syncthreads();
+  {
+    const int co = nhalf * 16 + i;
+    const f32x4 acc4 = acc4a + acc4b;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int tile = t < 4 ? tgrp * 5 + t : 4;
+      const int jrow = (t == 4 && tgrp == 1) ? kCChunk + grp * 4
+                                             : tile * kTile + grp * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        lds[(jrow + r) * 32 + co] = t < 4 ? acc[t][r] : acc4[r];
+    }
+  }
+  __syncthreads();
+  {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    float* obase = a.out + (size_t)item * a.act_stride;
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.nbytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int j = j0 + 32 * k;
+      const int jr = j < kCChunk ? j : 0;
+      f32x4 v = *reinterpret_cast<const f32x4*>(lds + jr * 32 + q * 4);
+      if (jr >= 4 * kTile && jr < 5 * kTile)  // shared tile: add the other half
+        v += *reinterpret_cast<const f32x4*>(
+            lds + (kCChunk + jr - 4 * kTile) * 32 + q * 4);
+      v += b4;
+      if (RELU_OUT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+      }
+      if (ADD_SKIP) v += skipv[k];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                             rs_out, ooff[k], 0, 0);
+    }
+  }
+  if (a.dbg && gc == 0 && (tid & 63) == 0) {
+    long long* d = a.dbg + (tid >> 6) * 6;
+    d[0] = dbg_c0;
+    d[1] = dbg_c1;
+    d[2] = dbg_c2;
+    d[3] = clock64();
+    d[4] = dbg_w0;
+    d[5] = wall_clock64();
   }
 }
 

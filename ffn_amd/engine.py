@@ -103,6 +103,11 @@ class HipEngine:
                                            ctypes.byref(n), int(reset)))
     return ms.value, n.value
 
+  def debug_clocks(self):
+    out = np.zeros(24, np.int64)
+    check(self._lib.ffn_engine_debug_clocks(self._h, out.ctypes.data))
+    return out.reshape(4, 6)
+
   def synchronize(self):
     check(self._lib.ffn_engine_synchronize(self._h))
 

@@ -156,14 +156,22 @@ int ffn_canvas_write_segmentation(ffn_canvas* canvas, const int32_t lo[3],
 
 /* ---- measurement ----------------------------------------------------------
  * HIP-event timing of the dominant kernel (the 32->32 3x3x3 MFMA conv) on the
- * engine's own stream.  mode 0 = off, 1 = one event pair per conv launch. */
+ * engine's own stream.  mode 0 = off, 1 = one event pair per conv launch,
+ * 2 = one event pair around the whole chain of 2*depth-1 conv launches of a
+ * step (duration / launches then includes the inter-kernel gaps but not the
+ * per-event barrier overhead of mode 1). */
 int ffn_engine_set_profiling(ffn_engine* engine, int mode);
 int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
                            int64_t* conv_launches, int reset);
 /* Tuning / A-B switches.  "conv_variant": 0 = simple MFMA conv, 1 = software-
- * pipelined MFMA conv (default).  Results are identical up to f32 summation
+ * pipelined MFMA conv over padded positions, 2 = pipelined + compact position
+ * space + K-split middle tile (default when the FoV allows).  Results are identical up to f32 summation
  * order. */
 int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
+/* Debug: with option "debug_clock" = 1 the compact conv kernel records, for its
+ * first workgroup, per wave {shader clock at entry, at main-loop start, at
+ * main-loop end, at exit, wall clock (100 MHz) at entry, at exit}. */
+int ffn_engine_debug_clocks(ffn_engine* engine, long long* out24);
 /* Blocks until all work queued on the engine's stream has finished. */
 int ffn_engine_synchronize(ffn_engine* engine);
 

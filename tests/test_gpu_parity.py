@@ -37,7 +37,7 @@ def _fov_inputs(rng, n=1):
   return img, seed
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2])
 def test_predict_matches_oracle(engine, fib25_blob, variant):
   from oracle import ffn_oracle
   engine.set_option('conv_variant', variant)
@@ -47,7 +47,7 @@ def test_predict_matches_oracle(engine, fib25_blob, variant):
   want = ffn_oracle.forward(img, seed, fib25_blob, 12)
   assert got.shape == want.shape
   assert np.abs(got - want).max() <= TOL
-  engine.set_option('conv_variant', 1)
+  engine.set_option('conv_variant', 2)
 
 
 def test_predict_batch_and_ragged(engine, fib25_blob):
@@ -70,10 +70,11 @@ def test_predict_is_deterministic_and_variants_agree(engine):
   a = engine.predict(seed, img)
   b = engine.predict(seed, img)
   assert np.array_equal(a, b)
-  engine.set_option('conv_variant', 0)
-  c = engine.predict(seed, img)
-  engine.set_option('conv_variant', 1)
-  assert np.abs(a - c).max() <= 2e-5
+  for variant in (0, 1):
+    engine.set_option('conv_variant', variant)
+    c = engine.predict(seed, img)
+    assert np.abs(a - c).max() <= 2e-5, variant
+  engine.set_option('conv_variant', 2)
 
 
 def test_predict_nan_seed_propagates_like_reference(engine):
@@ -118,7 +119,7 @@ def test_anisotropic_fov(fib25_model):
   img = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
   seed = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
   blob = ffn_oracle.weights_blob(variables, 2)
-  for variant in (0, 1):
+  for variant in (0, 1, 2):
     eng.set_option('conv_variant', variant)
     got = eng.predict(seed, img)
     want = ffn_oracle.forward(img, seed, blob, 2)

@@ -32,7 +32,7 @@ def main():
   seed = rng.normal(0, 1, (maxb, 33, 33, 33)).astype(np.float32)
   eng.predict(seed, img)  # fills the staging buffers
   flop = 2.0 * (2 * 27 * 32 + 23 * 27 * 32 * 32 + 32) * 33**3
-  for variant in (0, 1):
+  for variant in (1, 2):
     eng.set_option('conv_variant', variant)
     for b in args.batch:
       eng.forward_resident(b, 3)
@@ -50,6 +50,20 @@ def main():
             ' conv32 avg %.2f us (%d launches, %.1f TF/s in-kernel)' %
             (variant, b, dt * 1e6, b / dt, b * flop / dt / 1e12,
              ms / n * 1e3, n, b * 2.0 * 27 * 32 * 32 * 33**3 / (ms / n * 1e-3) / 1e12))
+  # in-kernel clocks of the compact kernel's first workgroup
+  eng.set_option('conv_variant', 2)
+  eng.set_option('debug_clock', 1)
+  for abl in (0, 8, 16, 24):
+   eng.set_option('ablate', abl)
+   eng.forward_resident(1, 3)
+   c = eng.debug_clocks()
+   print('variant 2 issue experiment %d (8 = no A reads, 16 = no B loads):' % abl)
+   for w in range(4):
+    tot, wall = c[w, 3] - c[w, 0], (c[w, 5] - c[w, 4]) * 10.0
+    print(' clock wave %d: stage %d  loop %d  epilogue %d  total %d shader cycles; wall %.0f ns -> %.2f GHz; %.2f cyc/MFMA' % (
+        w, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1], c[w, 3] - c[w, 2], tot, wall, tot / max(wall, 1), (c[w, 2] - c[w, 1]) / 976.0))
+  eng.set_option('ablate', 0)
+  eng.set_option('debug_clock', 0)
   # phase ablation of the pipelined conv_b kernel (11 of the 23 convs per stack)
   eng.set_option('conv_variant', 1)
   print('ablation (conv_b launches only; 1=no staging loads 2=no MFMA loop '
