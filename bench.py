@@ -173,8 +173,33 @@ def run_gpu(args, rank, local_rank, world):
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+  # Final segmentation merge (the ONLY collective of the path): the N per-rank
+  # volumes are treated as N sub-boxes stacked along z of one virtual volume;
+  # id offsets by all_gather, union by all_reduce(MAX) over RCCL.  Untimed
+  # extra, outside the FoV-step region; reported as merge_ms.
+  merge_ms = None
+  merged_ids = None
+  try:
+    from ffn_amd import distributed as ffn_dist
+    seg = np.array(canvas._handle.read_segmentation())
+    seg[seg < 0] = 0
+    full = (world * shape[0], shape[1], shape[2])
+    boxes = ffn_dist.tile_volume(full, shape, (0, 0, 0))
+    barrier()
+    tm = time.perf_counter()
+    merged, _ = ffn_dist.merge_segmentations(
+        [(boxes[rank], seg)], full, rank, world,
+        device=torch.device('cuda', local_rank))
+    barrier()
+    merge_ms = (time.perf_counter() - tm) * 1e3
+    merged_ids = int(merged.max())
+    del merged
+  except Exception as e:  # pylint:disable=broad-except
+    print('merge skipped: %r' % (e,), file=sys.stderr)
   cvals = {k: c.value for k, c in counters}
   result = {
+      'merge_ms': merge_ms,
+      'merged_ids': merged_ids,
       'counters': cvals,
       'elapsed': elapsed,
       'elapsed_local': elapsed_local,
@@ -358,6 +383,12 @@ def main():
           'movement_policy': round(1e3 * res['counters'].get(
               'movement_policy-time-ms', 0) / max(res['counters'].get(
                   'movement_policy-calls', 1), 1), 1),
+      },
+      'segmentation_merge': {
+          'ms': None if res['merge_ms'] is None else round(res['merge_ms'], 2),
+          'global_ids': res['merged_ids'],
+          'how': 'all_gather(id offsets) + all_reduce(MAX) of the int32 label '
+                 'volume over RCCL (no-op collective at n_gpus = 1); untimed',
       },
       'step_gflop': round(STEP_FLOPS / 1e9, 3),
       'end_to_end_tflops': round(steps_per_s * STEP_FLOPS / 1e12, 3),
