@@ -142,8 +142,12 @@ int set_lds_attr_p(size_t bytes) {
 template <bool RI, bool RO, bool SK, int DBG = 0>
 int set_lds_attr_c(size_t bytes) {
   HIP_TRY(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv32c_kernel<RI, RO, SK, DBG>),
+      reinterpret_cast<const void*>(&conv32c_kernel<RI, RO, SK, DBG, 8>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (DBG == 0)
+    HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv32c_kernel<RI, RO, SK, 0, 9>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return FFN_OK;
 }
 
@@ -278,7 +282,8 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
     HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   }
   const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
-  if (RI == false && RO == false && SK == true && e->ablate != 0) {
+  if (RI == false && RO == false && SK == true && e->ablate != 0 &&
+      e->Rc == 256) {
     switch (e->ablate) {  // issue-rate experiments (conv_b instantiation only)
       case 8:
         hipLaunchKernelGGL((conv32c_kernel<false, false, true, 8>), grid, block,
@@ -296,8 +301,11 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
         return fail(FFN_ERR_ARG, "unsupported ablate mask %d for variant 2",
                     e->ablate);
     }
+  } else if (e->Rc == 256) {
+    hipLaunchKernelGGL((conv32c_kernel<RI, RO, SK, 0, 8>), grid, block,
+                       e->lds_bytes_c, e->stream, a);
   } else {
-    hipLaunchKernelGGL((conv32c_kernel<RI, RO, SK>), grid, block,
+    hipLaunchKernelGGL((conv32c_kernel<RI, RO, SK, 0, 9>), grid, block,
                        e->lds_bytes_c, e->stream, a);
   }
   if (prof) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
@@ -560,7 +568,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
       span = std::max(span, pidx[(size_t)c * kCChunk + kCChunk - 1] -
                                 pidx[(size_t)c * kCChunk] + 1);
     e->Rc = ((span + 2 * (g.XS + 1)) + 31) / 32 * 32;
-    e->lds_bytes_c = (size_t)3 * e->Rc * kCLdsStride * sizeof(float);
+    if (e->Rc < 256) e->Rc = 256;  // the kernel stages 8 or 9 x 256 float4
+    e->lds_bytes_c = (size_t)2 * e->Rc * kCLdsStride * sizeof(float);
     E_TRY(hipMalloc(&e->d_dbg, 24 * sizeof(long long)));
     E_TRY(hipMemset(e->d_dbg, 0, 24 * sizeof(long long)));
     E_TRY(hipMalloc(&e->pidx, pidx.size() * sizeof(int32_t)));
@@ -568,7 +577,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
                     hipMemcpyHostToDevice));
     // variants 1 / 2 need 7*256 <= R*8 <= 8*256 resp. Rc in {256, 288}
     const bool p_ok = g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256;
-    const bool c_ok = e->Rc >= 256 && e->Rc <= 288;
+    const bool c_ok = e->Rc == 256 || e->Rc == 288;
     e->conv_variant = c_ok ? 2 : (p_ok ? 1 : 0);
   }
 
@@ -748,7 +757,7 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     const Geom& g = e->g;
     if (value == 1 && !(g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256))
       return fail(FFN_ERR_ARG, "conv_variant 1 unsupported for this fov");
-    if (value == 2 && !(e->Rc >= 256 && e->Rc <= 288))
+    if (value == 2 && !(e->Rc == 256 || e->Rc == 288))
       return fail(FFN_ERR_ARG, "conv_variant 2 unsupported for this fov");
     e->conv_variant = value;
     return FFN_OK;

@@ -587,8 +587,10 @@ __device__ __forceinline__ void mfma_tiles(const f32x4 (&A)[5], const f32x4& B,
 
 // DBG (0 in production): 8 = no A-fragment reads after the first, 16 = no
 // weight loads after the first two (issue-rate experiments).
-template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int DBG = 0>
-__global__ __launch_bounds__(kConvThreads) void conv32c_kernel(ConvCArgs a) {
+// KS = 16-B staging loads per lane and dz segment: 8 (Rc = 256 rows, e.g. the
+// 33^3 FoV) or 9 (Rc = 288).
+template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int DBG = 0, int KS = 8>
+__global__ __launch_bounds__(kConvThreads, 2) void conv32c_kernel(ConvCArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const long long dbg_c0 = a.dbg ? clock64() : 0;
@@ -662,50 +664,32 @@ __global__ __launch_bounds__(kConvThreads) void conv32c_kernel(ConvCArgs a) {
   // ---- staging: all 27 x 16-B loads of the three dz segments in flight at
   // once; segment kz is written to LDS (and waited for) only right before the
   // first tap that reads it, so dz = 0, +1 land behind the MFMAs of dz = -1.
-  const int nf4 = Rc * 8;  // 2048 (Rc = 256) or 2304 (Rc = 288)
-  f32x4 sv[3][9];
+  // Only TWO segment slots exist in LDS (dz = +1 overwrites dz = -1 once every
+  // wave is past tap 8): 2 x 256 rows x 160 B = 80 KiB, so two workgroups fit
+  // on a CU and fill each other's MFMA issue bubbles / staging / epilogue.
+  f32x4 sv[3][KS];  // Rc * 8 == KS * 256 float4 per segment
 #pragma unroll
   for (int seg = 0; seg < 3; ++seg) {
     const long p0 = (long)p_lo + (long)(seg - 1) * a.plane;
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      sv[seg][k] = s4[tid + k * kConvThreads];
-    const int e8 = tid + 8 * kConvThreads;
-    sv[seg][8] = s4[e8 < nf4 ? e8 : tid];
+    for (int k = 0; k < KS; ++k) sv[seg][k] = s4[tid + k * kConvThreads];
   }
   auto write_segment = [&](int seg) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < KS; ++k) {
       const int e = tid + k * kConvThreads;
-      if (k < 8 || e < nf4) {
+      {
         f32x4 v = sv[seg][k];
         if (RELU_IN) {  // tf.nn.relu in front of conv_a (convstack_3d.py:44)
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
         }
-        const int row = seg * Rc + (e >> 3);
+        const int row = (seg & 1) * Rc + (e >> 3);  // slot 0: dz -1, +1; slot 1: dz 0
         *reinterpret_cast<f32x4*>(lds + row * kCLdsStride + (e & 7) * 4) = v;
       }
     }
   };
-
-  // ---- per-thread epilogue operands (youngest loads: nothing waits on them
-  // until the epilogue) ----
-  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
-  unsigned ooff[5];
-  f32x4 skipv[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int j = j0 + 32 * k;
-    const bool ok = j < kCChunk && v0 + j < a.V;
-    const int p = pj[k];
-    ooff[k] = ok ? ((unsigned)p * kFeatures + q * 4) * 4u : 0x80000000u;
-    skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (ADD_SKIP)
-      skipv[k] = *reinterpret_cast<const f32x4*>(
-          a.skip + (size_t)item * a.act_stride + (size_t)p * kFeatures + q * 4);
-  }
 
   write_segment(0);
   __syncthreads();
@@ -720,7 +704,7 @@ __global__ __launch_bounds__(kConvThreads) void conv32c_kernel(ConvCArgs a) {
   // accumulators, so its 8 MFMAs per tap do not form one dependent chain).
   auto a_off = [&](int s) {  // LDS float offset of tap s (compile-time kz/ky/kx)
     const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
-    return (kz * Rc + (ky - 1) * a.XS + (kx - 1)) * kCLdsStride;
+    return ((kz & 1) * Rc + (ky - 1) * a.XS + (kx - 1)) * kCLdsStride;
   };
   auto loadA_tile = [&](int t, int off, AFrag& dst) {
     const float* p = lds + prow[t] + off;
@@ -807,6 +791,22 @@ __global__ __launch_bounds__(kConvThreads) void conv32c_kernel(ConvCArgs a) {
   FFN_CTAP(17, A1, A0, B2, B1, false)
   write_segment(2);
   __syncthreads();
+  // ---- per-thread epilogue operands: residual input and bias, fetched once the
+  // staging registers of the last segment are free (9 taps of MFMAs cover them)
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
+  unsigned ooff[5];
+  f32x4 skipv[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = j0 + 32 * k;
+    const bool ok = j < kCChunk && v0 + j < a.V;
+    const int p = pj[k];
+    ooff[k] = ok ? ((unsigned)p * kFeatures + q * 4) * 4u : 0x80000000u;
+    skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ADD_SKIP)
+      skipv[k] = *reinterpret_cast<const f32x4*>(
+          a.skip + (size_t)item * a.act_stride + (size_t)p * kFeatures + q * 4);
+  }
   if (!(DBG & 8)) loadA(18, A0);
   FFN_CTAP(18, A0, A1, B0, B2, true)
   FFN_CTAP(19, A1, A0, B1, B0, true)

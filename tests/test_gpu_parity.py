@@ -405,3 +405,124 @@ def test_batched_device_canvases_through_threaded_executor(fib25_model):
   # steps were really batched (fewer engine calls than FoV steps)
   total_steps = sum(len(gold[n]['steps']) for n in names)
   assert counters['executor-inference-calls'].value < total_steps
+
+
+def test_runner_end_to_end_writes_reference_format(fib25_model, tmp_path):
+  """run_inference.py flow: InferenceRequest (text format) -> Runner.start ->
+  Runner.run -> seg-*.npz with the reference's keys; the segmentation equals
+  the reference-minted fixture; a second run() skips the finished subvolume."""
+  import json as _json
+  from ffn_amd.inference import request as req_lib
+  from ffn_amd.inference import runner as runner_lib
+  from ffn_amd.inference import storage
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells56.npz'))
+  vol_path = str(tmp_path / 'vol.npy')
+  np.save(vol_path, g['volume'])
+  weights = os.path.join(GOLDEN, 'fib25_weights.npz')
+  out_dir = str(tmp_path / 'out')
+  seeds = _json.dumps({'coords': g['seeds'].tolist()}).replace('"', '\\"')
+  text = '''
+    image { npy: "%s" }
+    image_mean: 128
+    image_stddev: 33
+    checkpoint_interval: 1800
+    seed_policy: "PolicyFixed"
+    seed_policy_args: "%s"
+    model_checkpoint_path: "%s"
+    model_name: "convstack_3d.ConvStack3DFFNModel"
+    model_args: "{\\"depth\\": 12, \\"fov_size\\": [33, 33, 33], \\"deltas\\": [8, 8, 8]}"
+    segmentation_output_dir: "%s"
+    inference_options {
+      init_activation: 0.95
+      pad_value: 0.05
+      move_threshold: 0.9
+      min_boundary_dist { x: 1 y: 1 z: 1}
+      segment_threshold: 0.6
+      min_segment_size: 1000
+    }''' % (vol_path, seeds, weights, out_dir)
+  request = req_lib.request_from_text(text)
+  runner = runner_lib.Runner()
+  runner.start(request)
+  canvas = runner.run((0, 0, 0), tuple(g['volume'].shape))
+  assert canvas is not None
+  path = storage.segmentation_path(out_dir, (0, 0, 0))
+  assert path.endswith(os.path.join('0', '0', 'seg-0_0_0.npz'))
+  with np.load(path, allow_pickle=True) as d:
+    assert sorted(d.files) == ['counters', 'origins', 'overlaps', 'request',
+                               'segmentation']
+    want = g['segmentation'].copy()
+    want[want < 0] = 0
+    assert np.array_equal(d['segmentation'], want)
+    assert d['segmentation'].dtype == np.uint8
+    counters = _json.loads(str(d['counters']))
+    assert counters['update_at-calls'] == len(g['steps'])
+    origins = d['origins'].item()
+    ref_origins = _json.loads(str(g['origins']))
+    assert {int(k): [list(v.start_zyx), v.iters]
+            for k, v in origins.items()} == {int(k): v
+                                             for k, v in ref_origins.items()}
+  assert not os.path.exists(storage.checkpoint_path(out_dir, (0, 0, 0)))
+  assert runner.run((0, 0, 0), tuple(g['volume'].shape)) is None  # already done
+  seg, org = storage.load_segmentation(out_dir, (0, 0, 0))
+  assert np.array_equal(seg, want)
+  runner.stop_executor()
+
+
+def test_abi_rejects_bad_arguments(engine):
+  """Error behaviour of the C-ABI: negative return code + message, no crash."""
+  import ctypes
+  from ffn_amd import _lib
+  lib = _lib.load()
+  h = ctypes.c_void_p()
+  # even fov / wrong feature count / deltas larger than the fov
+  assert lib.ffn_engine_create(0, _lib.i3((32, 33, 33)), _lib.i3((8, 8, 8)), 12,
+                               32, 1, ctypes.byref(h)) == -1
+  assert lib.ffn_engine_create(0, _lib.i3((33, 33, 33)), _lib.i3((8, 8, 8)), 12,
+                               16, 1, ctypes.byref(h)) == -1
+  assert lib.ffn_engine_create(0, _lib.i3((33, 33, 33)), _lib.i3((20, 8, 8)),
+                               12, 32, 1, ctypes.byref(h)) == -1
+  assert b'deltas' in lib.ffn_last_error()
+  assert lib.ffn_engine_create(99, _lib.i3((33, 33, 33)), _lib.i3((8, 8, 8)),
+                               12, 32, 1, ctypes.byref(h)) == -1
+  with pytest.raises(_lib.FFNHipError):
+    engine.set_weights(np.zeros(10, np.float32))
+  with pytest.raises(_lib.FFNHipError):  # batch larger than max_batch
+    engine.predict(np.zeros((9, 33, 33, 33), np.float32),
+                   np.zeros((9, 33, 33, 33), np.float32))
+  # FoV leaving the canvas / canvas smaller than the FoV
+  small = engine.create_canvas(np.zeros((20, 40, 40), np.float32))
+  req = _lib.StepRequest()
+  req.pos[:] = (10, 20, 20)
+  req.start_pos[:] = (10, 20, 20)
+  with pytest.raises(_lib.FFNHipError):
+    engine.step1(small, req, _lib.StepParams(-2.9, 2.2, 0.0))
+  with pytest.raises(_lib.FFNHipError):
+    small.read_seed((0, 0, 0), (21, 40, 40))
+  small.close()
+
+
+def test_empty_and_exhausted_workloads(fib25_model):
+  """Edge cases the reference handles: no seeds at all, every seed too close to
+  the border, canvas smaller than the FoV -> empty segmentation, zero steps."""
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import seed as seed_lib
+  import bench
+  request = bench.make_request()
+  for shape, coords in [((40, 40, 40), []),
+                        ((40, 40, 40), [(2, 2, 2), (39, 20, 20)]),
+                        ((20, 34, 34), [(10, 17, 17)])]:
+    counters = inference_utils.Counters()
+    exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
+                                    fib25_model.info, None, counters, 1)
+    canvas = inference.DeviceCanvas(
+        fib25_model.info, exe.get_client(counters, direct=True),
+        np.zeros(shape, np.float32), request.inference_options,
+        counters=counters)
+    canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                     coords=coords))
+    assert counters['update_at-calls'].value == 0
+    assert not np.asarray(canvas.segmentation).any()
+    assert canvas.origins == {}
+    canvas.close()

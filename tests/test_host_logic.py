@@ -353,3 +353,62 @@ def test_policy_peaks_matches_reference_with_real_skimage():
     got = np.array([p for p in seed_lib.PolicyPeaks(c)]).reshape(-1, 3)
     assert len(got) > 50
     assert np.array_equal(got, g[n + '_seeds']), n
+
+
+def test_multi_canvas_driver_interleaves_without_changing_results(fib25_blob):
+  """Single-threaded batching scheduler: canvases advanced round-robin in
+  batches reproduce, each on its own, the reference runs."""
+  r = _request()
+  info = _info()
+  client = EmulatedDeviceClient(inference_utils.Counters(), fib25_blob, 12,
+                                (33, 33, 33), (8, 8, 8))
+
+  class EmulatedEngine:
+    max_batch = 2
+    calls = []
+
+    def step(self, handles, reqs, params):
+      self.calls.append(len(handles))
+      return [client.step(h, q, params) for h, q in zip(handles, reqs)]
+
+  names = ['cells56', 'cells72', 'cells56']
+  jobs, canvases = [], []
+  for n in names:
+    g = np.load(os.path.join(GOLDEN, 'ref_canvas_%s.npz' % n))
+    c = inference.make_canvas(info, client, synthetic.normalize(g['volume']),
+                              r.inference_options,
+                              movement_policy_fn=movement.get_policy_fn(r, info))
+    canvases.append((c, g))
+    jobs.append((c, functools.partial(seed_lib.PolicyFixed, coords=g['seeds'])))
+  eng = EmulatedEngine()
+  drv = inference.MultiCanvasDriver(eng, batch_size=2)
+  drv.run(jobs)
+  for c, g in canvases:
+    assert np.array_equal(np.asarray(c.segmentation), g['segmentation'])
+    assert c.counters['update_at-calls'].value == len(g['steps'])
+  assert max(eng.calls) == 2 and drv.steps == 4 + 94 + 4
+
+
+def test_update_at_override_is_honoured(fib25_blob):
+  """A subclass hooking update_at (as the reference's loop allows) still sees
+  every FoV step."""
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells56.npz'))
+  r = _request()
+  info = _info()
+  client = EmulatedDeviceClient(inference_utils.Counters(), fib25_blob, 12,
+                                (33, 33, 33), (8, 8, 8))
+  seen = []
+
+  class Hooked(inference.DeviceCanvas):
+
+    def update_at(self, pos):
+      seen.append(tuple(pos))
+      return super().update_at(pos)
+
+  c = Hooked(info, client, synthetic.normalize(g['volume']),
+             r.inference_options,
+             movement_policy_fn=movement.get_policy_fn(r, info))
+  c.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                              coords=g['seeds']))
+  assert np.array_equal(np.array(seen), g['steps'])
+  assert np.array_equal(np.asarray(c.segmentation), g['segmentation'])

@@ -1,8 +1,8 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-echo "== batched canvases (clients = 2 x batch)"
-timeout 300 python tools/gpu_batch_bench.py --canvases 8 --batch 4 --size 128 --steps 300 2>&1 | tail -1
-timeout 300 python tools/gpu_batch_bench.py --canvases 16 --batch 8 --size 128 --steps 300 2>&1 | tail -1
-timeout 400 python tools/gpu_batch_bench.py --canvases 32 --batch 16 --size 112 --steps 200 2>&1 | tail -1
-timeout 400 python tools/gpu_batch_bench.py --canvases 64 --batch 32 --size 112 --steps 150 2>&1 | tail -1
+echo "== new GPU tests"; timeout 600 python -m pytest tests -m gpu -x -q -k "runner or abi_rejects or empty" 2>&1 | tail -4
+echo "== driver mode"
+timeout 300 python tools/gpu_batch_bench.py --mode driver --canvases 8 --batch 8 --size 128 --steps 300 2>&1 | tail -1
+timeout 300 python tools/gpu_batch_bench.py --mode driver --canvases 32 --batch 32 --size 112 --steps 200 2>&1 | tail -1
+timeout 300 python tools/gpu_batch_bench.py --mode driver --canvases 32 --batch 16 --size 112 --steps 200 2>&1 | tail -1
