@@ -196,7 +196,9 @@ def run_gpu(args, rank, local_rank, world):
     del merged
   except Exception as e:  # pylint:disable=broad-except
     print('merge skipped: %r' % (e,), file=sys.stderr)
+  canvas._flush_hot()
   cvals = {k: c.value for k, c in counters}
+  cvals['gate_rejects'] = canvas.gate_rejects
   result = {
       'merge_ms': merge_ms,
       'merged_ids': merged_ids,
@@ -384,6 +386,9 @@ def main():
               'movement_policy-time-ms', 0) / max(res['counters'].get(
                   'movement_policy-calls', 1), 1), 1),
       },
+      'queue_stats': {k: res['counters'].get(k, 0) for k in (
+          'update_at-calls', 'skip_threshold', 'skip_invalid_pos',
+          'seed_got_too_weak', 'segment_at-loop-calls', 'gate_rejects')},
       'segmentation_merge': {
           'ms': None if res['merge_ms'] is None else round(res['merge_ms'], 2),
           'global_ids': res['merged_ids'],

@@ -619,6 +619,10 @@ class DeviceCanvas(Canvas):
     self._cache = {}
     self._cached_start = None
     self._hot = [0, 0.0, 0.0, 0.0, 0, 0.0]
+    #: in-bounds queue entries that failed the device-state part of
+    #: is_valid_pos (seed below threshold / already segmented): the cases a
+    #: speculative next step would have mispredicted
+    self.gate_rejects = 0
     self._pending = None
     self._step_req = _lib.StepRequest()
     self._step_params = _lib.StepParams()
@@ -671,12 +675,15 @@ class DeviceCanvas(Canvas):
     if not ignore_move_threshold:
       if self._read_point(pos)[0] < self.options.move_threshold:
         self.counters['skip_threshold'].Increment()
+        if self._in_bounds(pos):
+          self.gate_rejects += 1
         return False
     if not self._in_bounds(pos):
       self.counters['skip_invalid_pos'].Increment()
       return False
     if self._read_point(pos)[1] > 0:
       self.counters['skip_invalid_pos'].Increment()
+      self.gate_rejects += 1
       return False
     return True
 

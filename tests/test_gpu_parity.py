@@ -293,6 +293,11 @@ def test_reference_style_host_canvas_through_threaded_executor(fib25_model):
   assert counters['update_at-calls'].value == len(g['steps'])
 
 
+class _Halt(Exception):
+  """Stops a segment after a fixed number of steps (not StopIteration: the
+  canvas loops are generators, PEP 479)."""
+
+
 def test_full_size_properties_250(fib25_model):
   """BASELINE size (250^3): size-independent properties instead of the oracle:
   (1) re-running the same segment gives the identical trajectory/mask
@@ -322,13 +327,13 @@ def test_full_size_properties_250(fib25_model):
     def rec(pos, _o=orig, _s=steps):
       _s.append(tuple(pos))
       if len(_s) > 60:
-        raise StopIteration
+        raise _Halt()
       return _o(pos)
 
     canvas.update_at = rec
     try:
       canvas.segment_at(start)
-    except StopIteration:
+    except _Halt:
       pass
     canvas.update_at = orig
     runs.append((list(steps), canvas._handle.read_seed()))
