@@ -16,6 +16,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libffn_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'ffn_hip.h')
+HEADERS = [HEADER,
+           os.path.join(os.path.dirname(_HERE), 'include', 'ffn_labels.h')]
+SOURCES = ['ffn_hip.hip', 'ffn_labels.hip']
 
 MAX_CANDIDATES = 16
 
@@ -96,6 +99,21 @@ SIGNATURES = {
     'ffn_canvas_read_segmentation': (_I, [_P, _I3, _I3, _P]),
     'ffn_canvas_write_seed': (_I, [_P, _I3, _I3, _P]),
     'ffn_canvas_write_segmentation': (_I, [_P, _I3, _I3, _P]),
+    # include/ffn_labels.h
+    'ffn_labels_create': (_I, [_I, ctypes.POINTER(_P)]),
+    'ffn_labels_destroy': (None, [_P]),
+    'ffn_labels_pair_counts': (_I, [_P, _P, _P, _I, ctypes.c_size_t,
+                                    ctypes.c_size_t, _P, _P, _P, _P,
+                                    ctypes.POINTER(ctypes.c_size_t)]),
+    'ffn_labels_apply_pair_labels': (_I, [_P, ctypes.c_size_t, _P, _P, _P]),
+    'ffn_labels_remap': (_I, [_P, _P, _I, ctypes.c_size_t, ctypes.c_size_t,
+                              _P, _P, _I, _P]),
+    'ffn_labels_connected_components': (
+        _I, [_P, _P, _I, ctypes.POINTER(ctypes.c_int64), _I, _P,
+             ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, _P, _P,
+             ctypes.POINTER(ctypes.c_int64)]),
+    'ffn_labels_last_timing': (_I, [_P, ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None
@@ -103,9 +121,10 @@ _lock = threading.Lock()
 
 
 def build(force: bool = False) -> str:
-  """Compiles csrc/ffn_hip.hip for gfx950 into csrc/libffn_hip.so (in-tree)."""
-  src = os.path.join(CSRC, 'ffn_hip.hip')
-  deps = [src, os.path.join(CSRC, 'ffn_kernels.h'), HEADER]
+  """Compiles csrc/*.hip for gfx950 into csrc/libffn_hip.so (in-tree)."""
+  srcs = [os.path.join(CSRC, name) for name in SOURCES]
+  deps = srcs + HEADERS + [os.path.join(CSRC, 'ffn_kernels.h'),
+                           os.path.join(CSRC, 'ffn_internal.h')]
   if (not force and os.path.exists(LIB_PATH) and
       all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
     return LIB_PATH
@@ -113,7 +132,7 @@ def build(force: bool = False) -> str:
   if not os.path.exists(hipcc):
     hipcc = 'hipcc'
   cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared',
-         '-fPIC', '-o', LIB_PATH, src]
+         '-fPIC', '-o', LIB_PATH] + srcs
   subprocess.check_call(cmd, cwd=CSRC)
   return LIB_PATH
 

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "ffn_internal.h"
 #include "ffn_kernels.h"
 
 using namespace ffn;
@@ -34,6 +35,20 @@ int fail(int code, const char* fmt, ...) {
   g_error = buf;
   return code;
 }
+
+}  // namespace
+
+int ffn_set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+namespace {
 
 #define HIP_TRY(expr)                                                        \
   do {                                                                       \

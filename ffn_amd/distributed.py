@@ -18,9 +18,16 @@ the final assembly of one global label volume:
      segmentation.  An all_gather of owned slabs would be ~3.5 ms; see
      DESIGN.md.)
 
-Reconciliation of objects that cross a cut (overlap-zone consensus /
-union-find) is not implemented in the reference either
-(doc/manual.md:119-127) and is a "next" row.
+Reconciliation of objects that cross a cut is "currently *not implemented*" in
+the reference (doc/manual.md:119-127, which prescribes a union-find over the
+sub-box id spaces).  `reconcile_segmentations` implements it (SURVEY.md 8f rank
+1) without any extra exchange of voxel data: after the all-reduce every rank
+holds the assembled volume, so the labels its neighbours gave to its own
+margins are already local.  Each rank pairs its sub-boxes' own labelling with
+the assembled one over the margin (GPU joint histogram, include/ffn_labels.h),
+turns large overlaps into merge edges, the (tiny) edge lists are all-gathered,
+every rank runs the same deterministic union-find and relabels the volume with
+one table-driven GPU pass.
 
 The tiler mirrors the semantics of the reference's
 `OrderlyOverlappingCalculator` (ffn/utils/bounding_box.py:250-412): sub-boxes
@@ -142,3 +149,131 @@ def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     out = t.cpu().numpy()
   return out, offsets
+
+
+class _UnionFind:
+  """Union-find over global ids; the root of a set is its smallest id, so the
+  result does not depend on the order in which ranks contributed edges."""
+
+  def __init__(self):
+    self.parent = {}
+
+  def find(self, x):
+    parent = self.parent
+    root = parent.setdefault(x, x)
+    while root != parent[root]:
+      root = parent[root]
+    while parent[x] != root:
+      parent[x], x = root, parent[x]
+    return root
+
+  def union(self, x, y):
+    rx, ry = self.find(x), self.find(y)
+    if rx != ry:
+      if rx < ry:
+        self.parent[ry] = rx
+      else:
+        self.parent[rx] = ry
+
+
+def margin_edges(ops, seg_global_ids, assembled_box, core_lo, core_hi,
+                 min_overlap_voxels=1, min_overlap_fraction=0.0):
+  """Merge candidates between one sub-box's own labels and the assembled
+  volume over the sub-box's margin (everything outside its core).
+
+  Args:
+    ops: ffn_amd.labels.LabelOps (GPU joint histogram)
+    seg_global_ids: the sub-box labelling, ids already globally offset
+    assembled_box: the assembled volume restricted to the sub-box
+    core_lo, core_hi: the core in sub-box coordinates
+
+  Returns:
+    int64 [k, 3] array of (own id, assembled id, shared voxels), sorted, for
+    pairs of different non-zero ids with shared >= min_overlap_voxels and
+    shared >= min_overlap_fraction * min(voxels of either label in the margin).
+  """
+  a = np.array(seg_global_ids, np.uint32)
+  g = np.array(assembled_box, np.uint32)
+  core = tuple(slice(int(l), int(h)) for l, h in zip(core_lo, core_hi))
+  a[core] = 0
+  g[core] = 0
+  pa, pb, cnt, _ = ops.pair_counts(a, g)
+  if pa.size == 0:
+    return np.zeros((0, 3), np.int64)
+  cnt = cnt.astype(np.int64)
+  ua, ia = np.unique(pa, return_inverse=True)
+  ub, ib = np.unique(pb, return_inverse=True)
+  size_a = np.zeros(ua.size, np.int64)
+  size_b = np.zeros(ub.size, np.int64)
+  np.add.at(size_a, ia, cnt)
+  np.add.at(size_b, ib, cnt)
+  smaller = np.minimum(size_a[ia], size_b[ib])
+  keep = ((pa != 0) & (pb != 0) & (pa != pb) & (cnt >= min_overlap_voxels) &
+          (cnt >= min_overlap_fraction * smaller))
+  edges = np.stack([pa[keep].astype(np.int64), pb[keep].astype(np.int64),
+                    cnt[keep]], axis=1)
+  return edges[np.lexsort((edges[:, 2], edges[:, 1], edges[:, 0]))]
+
+
+def _all_gather_rows(rows: np.ndarray, world: int, device):
+  """all_gather of int64 [k, 3] arrays with per-rank k (pads to the max k)."""
+  import torch
+  import torch.distributed as dist
+  k = torch.tensor([rows.shape[0]], dtype=torch.int64, device=device)
+  ks = [torch.zeros_like(k) for _ in range(world)]
+  dist.all_gather(ks, k)
+  ks = [int(v.item()) for v in ks]
+  kmax = max(max(ks), 1)
+  mine = torch.zeros((kmax, 3), dtype=torch.int64, device=device)
+  if rows.shape[0]:
+    mine[:rows.shape[0]] = torch.from_numpy(np.ascontiguousarray(rows)).to(
+        mine.device)
+  parts = [torch.zeros_like(mine) for _ in range(world)]
+  dist.all_gather(parts, mine)
+  return np.concatenate([p[:n].cpu().numpy() for p, n in zip(parts, ks)])
+
+
+def reconcile_segmentations(local_results, shape_zyx, rank: int, world: int,
+                            device=None, min_overlap_voxels: int = 1,
+                            min_overlap_fraction: float = 0.0, ops=None):
+  """merge_segmentations + union-find reconciliation of objects that cross a
+  cut between sub-boxes (doc/manual.md:119-127).
+
+  Args:
+    local_results, shape_zyx, rank, world, device: as merge_segmentations
+    min_overlap_voxels, min_overlap_fraction: merge criterion (margin_edges)
+    ops: label-operations object (default: the GPU `LabelOps` of `device`)
+
+  Returns:
+    (global int32 ndarray with merged ids, id offsets of this rank's sub-boxes,
+     int64 [k, 3] array of all merge edges, {id: root id} for every id that
+     took part in an edge)
+  """
+  merged, offsets = merge_segmentations(local_results, shape_zyx, rank, world,
+                                        device)
+  if ops is None:
+    from . import labels  # pylint:disable=g-import-not-at-top
+    index = getattr(device, 'index', None)
+    ops = labels.default_ops(index if index is not None else 0)
+  mine = []
+  for (box, seg), off in zip(local_results, offsets):
+    own = np.where(seg > 0, seg.astype(np.int64) + off, 0)
+    sel = tuple(slice(c, c + n) for c, n in zip(box.corner, box.size))
+    lo = [c - b for c, b in zip(box.core_lo, box.corner)]
+    hi = [c - b for c, b in zip(box.core_hi, box.corner)]
+    mine.append(margin_edges(ops, own, merged[sel], lo, hi,
+                             min_overlap_voxels, min_overlap_fraction))
+  edges = (np.concatenate(mine) if mine else np.zeros((0, 3), np.int64))
+  if world > 1:
+    edges = _all_gather_rows(edges, world, device)
+  if edges.shape[0]:
+    edges = edges[np.lexsort((edges[:, 2], edges[:, 1], edges[:, 0]))]
+  uf = _UnionFind()
+  for x, y, _ in edges:
+    uf.union(int(x), int(y))
+  roots = {x: uf.find(x) for x in list(uf.parent)}
+  keys = np.array(sorted(k for k, v in roots.items() if k != v), np.uint64)
+  if keys.size:
+    vals = np.array([roots[int(k)] for k in keys], np.uint64)
+    merged = ops.remap(merged, keys, vals, keep_missing=True)
+  return merged, offsets, edges, roots

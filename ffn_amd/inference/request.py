@@ -186,8 +186,34 @@ class InferenceOptions(Message):
 
 
 class AlignmentOptions(Message):
-  NO_ALIGNMENT = 0
-  FIELDS = {'type': (int, 0, False), 'save_raw': (bool, False, False)}
+  # inference.proto:171-179 (default NO_ALIGNMENT)
+  UNKNOWN_ALIGNMENT = 0
+  NO_ALIGNMENT = 1
+  FIELDS = {'type': (int, 1, False), 'save_raw': (bool, False, False)}
+  ENUMS = {'type': {'UNKNOWN_ALIGNMENT': 0, 'NO_ALIGNMENT': 1}}
+
+
+class SegmentationSource(Message):
+  """inference.proto:111-127 (the `mask` field is out of scope)."""
+  FIELDS = {
+      'directory': (str, '', False),
+      'threshold': (float, 0.0, False),
+      'split_cc': (bool, False, False),
+      'min_size': (int, 0, False),
+  }
+
+
+class ConsensusRequest(Message):
+  """consensus.proto:22-37."""
+  CONSENSUS_SPLIT = 2
+  FIELDS = {
+      'segmentation1': (SegmentationSource, None, False),
+      'segmentation2': (SegmentationSource, None, False),
+      'segmentation_output_dir': (str, '', False),
+      'type': (int, 0, False),
+      'split_min_size': (int, 0, False),
+  }
+  ENUMS = {'type': {'CONSENSUS_SPLIT': 2}}
 
 
 class InferenceRequest(Message):
@@ -301,7 +327,7 @@ def _parse_fields(msg: Message, toks, i, closer):
       elif ftype is bool:
         value = str(val).lower() in ('true', '1', 't')
       elif ftype is int:
-        value = int(val) if kind == 'num' else _enum(ftype, name, val)
+        value = int(val) if kind == 'num' else _enum(type(msg), name, val)
       else:
         value = float(val.rstrip('f'))
       if repeated:
@@ -313,10 +339,12 @@ def _parse_fields(msg: Message, toks, i, closer):
   return i
 
 
-def _enum(ftype, name, val):
-  if name == 'type' and val == 'NO_ALIGNMENT':
-    return 0
-  raise ValueError('unsupported enum value %r for %s' % (val, name))
+def _enum(msg_cls, name, val):
+  enums = getattr(msg_cls, 'ENUMS', {}).get(name, {})
+  if val in enums:
+    return enums[val]
+  raise ValueError('unsupported enum value %r for %s.%s' %
+                   (val, msg_cls.__name__, name))
 
 
 def parse_text(text: str, msg: Message) -> Message:

@@ -199,27 +199,72 @@ def load_origins(segmentation_dir, corner):
     return data['origins'].item()
 
 
+def threshold_segmentation(segmentation_dir, corner, labels, threshold):
+  """Zeroes voxels whose saved object probability is below `threshold`, in
+  place (reference storage.py:380-411)."""
+  prob_path = object_prob_path(segmentation_dir, corner)
+  if not os.path.exists(prob_path):
+    prob_path = legacy_object_prob_path(segmentation_dir, corner)
+    if not os.path.exists(prob_path):
+      raise ValueError('Cannot find probability map %s' % prob_path)
+  with np.load(prob_path) as data:
+    if 'qprob' not in data:
+      raise ValueError('Invalid FFN probability map.')
+    prob = dequantize_probability(data['qprob'])
+    labels[prob < threshold] = 0
+
+
 def load_segmentation(segmentation_dir, corner, allow_cpoint=False,
-                      threshold=None, split_cc=True, min_size=0):
-  """Loads a saved segmentation subvolume (reference storage.py:414-488)."""
-  del split_cc  # CC splitting is a "next" row (SURVEY.md 8f)
+                      threshold=None, split_cc=True, min_size=0,
+                      mask_config=None):
+  """Loads a saved segmentation subvolume (reference storage.py:414-488).
+
+  Returns (uint64 zyx array, {segment id: origin info}).  Connected-component
+  splitting and dust removal run on the GPU (segmentation.clean_up).
+  """
+  if mask_config is not None:
+    raise NotImplementedError('masks are out of scope (SURVEY.md 8)')
   target_path = get_existing_subvolume_path(segmentation_dir, corner,
                                             allow_cpoint)
   if target_path is None:
-    raise ValueError('Segmentation not found, %s, %r' %
+    raise ValueError('Segmentation not found, %s, %r.' %
                      (segmentation_dir, corner))
   with np.load(target_path, allow_pickle=True) as data:
-    seg = data['segmentation'].astype(np.uint64)
+    if 'segmentation' not in data:
+      raise ValueError('FFN NPZ file %s does not contain valid segmentation.' %
+                       target_path)
+    seg = data['segmentation']
     origins = data['origins'].item()
-    output = seg
-    if threshold is not None and threshold > 0:
-      prob_path = object_prob_path(segmentation_dir, corner)
-      with np.load(prob_path) as pdata:
-        prob = dequantize_probability(pdata['qprob'])
-      output = np.where(prob >= threshold, seg, 0).astype(np.uint64)
-    if min_size:
-      segmentation.clear_dust(output, min_size=min_size)
+  if not np.any(seg):
+    return np.zeros(seg.shape, dtype=np.uint64), {}
+  output = seg.astype(np.uint64)
+  if threshold is not None:
+    threshold_segmentation(segmentation_dir, corner, output, threshold)
+  if split_cc or min_size:
+    # (the reference passes min_size in clean_up's `connectivity` slot,
+    # storage.py:476-478; 6-connectivity is what its callers get for the
+    # default min_size = 0 and is what is used here)
+    new_to_old = segmentation.clean_up(output, split_cc, min_size=min_size,
+                                       return_id_map=True)
+    new_origins = {}
+    for new_id, old_id in new_to_old.items():
+      if old_id in origins:
+        new_origins[new_id] = origins[old_id]
+    origins = new_origins
   return output, origins
+
+
+def load_segmentation_from_source(source, corner):
+  """load_segmentation configured by a SegmentationSource message
+  (reference storage.py:491-511)."""
+  kwargs = {}
+  if source.HasField('threshold'):
+    kwargs['threshold'] = source.threshold
+  if source.HasField('split_cc'):
+    kwargs['split_cc'] = source.split_cc
+  if source.HasField('min_size'):
+    kwargs['min_size'] = source.min_size
+  return load_segmentation(source.directory, corner, **kwargs)
 
 
 def dump_json(obj) -> str:

@@ -146,3 +146,48 @@ class EmulatedDeviceClient(executor.ExecutorClient):
       res.cand_seed[k] = h.seed[cpos]
       res.cand_seg[k] = h.seg[cpos]
     return res
+
+
+class EmulatedLabelOps:
+  """TEST DOUBLE for ffn_amd.labels.LabelOps (numpy via oracle/labels_oracle):
+  lets CPU-only tests run the host logic layered on the label kernels
+  (distributed reconciliation, segmentation tables).  Pair order is shuffled,
+  as the GPU hash table returns pairs in unspecified order."""
+
+  def __init__(self, seed=0):
+    self._rng = np.random.RandomState(seed)
+    self._resident = None
+
+  def pair_counts(self, a, b=None):
+    from oracle import labels_oracle
+    a = np.asarray(a)
+    pa, pb, cnt = labels_oracle.pair_counts(
+        a.astype(np.uint64) & np.uint64(0xffffffff) if a.dtype.itemsize == 4
+        else a, None if b is None else (
+            np.asarray(b).astype(np.uint64) & np.uint64(0xffffffff)
+            if np.asarray(b).dtype.itemsize == 4 else b))
+    perm = self._rng.permutation(pa.size)
+    self._resident = (a, None if b is None else np.asarray(b), pa, pb)
+    return pa[perm], pb[perm], cnt[perm], perm.astype(np.uint32)
+
+  def apply_pair_labels(self, slots, new_labels):
+    a, b, pa, pb = self._resident
+    table = np.zeros(pa.size, np.uint64)
+    table[np.asarray(slots, np.int64)] = new_labels
+    key = a.ravel().astype(np.uint64)
+    if b is not None:
+      key = key | (b.ravel().astype(np.uint64) << np.uint64(32))
+    ukeys = pa | (pb << np.uint64(32))
+    order = np.argsort(ukeys)
+    pos = order[np.searchsorted(ukeys[order], key)]
+    return table[pos].astype(a.dtype).reshape(a.shape)
+
+  def remap(self, arr, keys, values, keep_missing=True):
+    from oracle import labels_oracle
+    return labels_oracle.remap(arr, keys, values, keep_missing)
+
+  def connected_components(self, arr, connectivity=1, stats=False):
+    from oracle import labels_oracle
+    out, first, sizes, fz = labels_oracle.connected_components(arr,
+                                                               connectivity)
+    return (out, first, sizes, fz) if stats else out

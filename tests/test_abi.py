@@ -1,5 +1,5 @@
 """The C-ABI library loads (no GPU needed) and exports every symbol that
-include/ffn_hip.h declares; entry points fail loudly, never fall back."""
+include/*.h declare; entry points fail loudly, never fall back."""
 
 import ctypes
 import os
@@ -13,8 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-  with open(os.path.join(ROOT, 'include', 'ffn_hip.h')) as f:
-    text = f.read()
+  text = ''
+  for header in sorted(os.listdir(os.path.join(ROOT, 'include'))):
+    with open(os.path.join(ROOT, 'include', header)) as f:
+      text += f.read()
   text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
   return sorted(set(re.findall(r'\b(ffn_[a-z_0-9]+)\s*\(', text)))
 

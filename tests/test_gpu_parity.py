@@ -468,7 +468,7 @@ def test_runner_end_to_end_writes_reference_format(fib25_model, tmp_path):
                                              for k, v in ref_origins.items()}
   assert not os.path.exists(storage.checkpoint_path(out_dir, (0, 0, 0)))
   assert runner.run((0, 0, 0), tuple(g['volume'].shape)) is None  # already done
-  seg, org = storage.load_segmentation(out_dir, (0, 0, 0))
+  seg, org = storage.load_segmentation(out_dir, (0, 0, 0), split_cc=False)
   assert np.array_equal(seg, want)
   runner.stop_executor()
 

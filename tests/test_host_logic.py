@@ -281,7 +281,8 @@ def test_storage_formats_match_reference(tmp_path):
     assert sorted(d.files) == ['counters', 'origins', 'overlaps', 'request',
                                'segmentation']
     assert d['segmentation'].dtype == np.uint8
-  out, org = storage.load_segmentation(str(tmp_path), (0, 0, 0))
+  out, org = storage.load_segmentation(str(tmp_path), (0, 0, 0),
+                                           split_cc=False)
   assert np.array_equal(out, seg) and org[7].iters == 11
   arr = storage.NumpyArray(shape=(2, 2, 2), dtype=np.float32,
                            default_value=np.nan)
