@@ -74,6 +74,7 @@ struct ffn_engine {
   uint32_t* validbits = nullptr;
   int32_t* pidx = nullptr;    // dense FoV index -> padded position (variant 2)
   int nchunks_c = 0, Rc = 0;
+  int store_policy = 1;  // conv32c epilogue stores: sc1 write-through (-1.4 % per stack)
   long long* d_dbg = nullptr;  // debug clocks of conv32c WG 0 (24 values)
   int dbg_clock = 0;
   size_t lds_bytes_c = 0;
@@ -287,6 +288,7 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
   a.total_slots = n * e->nchunks_c;
   a.slots_per_xcd = (a.total_slots + 7) / 8;
   a.nbytes = (unsigned)((size_t)e->g.nchunks * kChunk * kFeatures * sizeof(float));
+  a.store_policy = e->store_policy;
   a.dbg = e->dbg_clock ? e->d_dbg : nullptr;
   const bool prof = e->prof_now;
   if (prof) {
@@ -793,6 +795,11 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   }
   if (std::strcmp(name, "ablate") == 0) {
     e->ablate = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "store_policy") == 0) {
+    if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "store_policy 0..2");
+    e->store_policy = value;
     return FFN_OK;
   }
   return fail(FFN_ERR_ARG, "unknown option '%s'", name);

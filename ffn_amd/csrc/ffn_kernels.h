@@ -571,6 +571,7 @@ struct ConvCArgs {
   int fx, fyfx;          // FoV row length and plane size (dense index math)
   int total_slots, slots_per_xcd;
   unsigned nbytes;       // bytes of one activation buffer past its origin
+  int store_policy;      // epilogue stores: 0 write-back, 1 sc1, 2 nt
   long long* dbg;        // optional [4 waves][6]: shader / wall clocks of WG 0
 };
 
@@ -857,8 +858,17 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv32c_kernel(ConvCArgs a) {
         for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
       }
       if (ADD_SKIP) v += skipv[k];
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                             rs_out, ooff[k], 0, 0);
+      // store_policy (A/B switch): 0 write-back, 1 write-through (sc1: no
+      // dirty L2 lines left for the kernel boundary to flush), 2 non-temporal
+      if (a.store_policy == 1)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 16);
+      else if (a.store_policy == 2)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 2);
+      else
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 0);
     }
   }
   if (a.dbg && gc == 0 && (tid & 63) == 0) {

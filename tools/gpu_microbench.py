@@ -50,6 +50,18 @@ def main():
             ' conv32 avg %.2f us (%d launches, %.1f TF/s in-kernel)' %
             (variant, b, dt * 1e6, b / dt, b * flop / dt / 1e12,
              ms / n * 1e3, n, b * 2.0 * 27 * 32 * 32 * 33**3 / (ms / n * 1e-3) / 1e12))
+  eng.set_option('conv_variant', 2)
+  for policy in (1, 2, 0):
+    eng.set_option('store_policy', policy)
+    for b in (1, 8):
+      eng.forward_resident(b, 3)
+      eng.synchronize()
+      t0 = time.perf_counter()
+      eng.forward_resident(b, args.repeats)
+      eng.synchronize()
+      dt = (time.perf_counter() - t0) / args.repeats
+      print('variant 2 store_policy %d batch %d: %8.1f us/stack' % (
+          policy, b, dt * 1e6))
   # in-kernel clocks of the compact kernel's first workgroup
   eng.set_option('conv_variant', 2)
   eng.set_option('debug_clock', 1)
