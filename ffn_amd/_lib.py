@@ -17,8 +17,9 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libffn_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'ffn_hip.h')
 HEADERS = [HEADER,
-           os.path.join(os.path.dirname(_HERE), 'include', 'ffn_labels.h')]
-SOURCES = ['ffn_hip.hip', 'ffn_labels.hip']
+           os.path.join(os.path.dirname(_HERE), 'include', 'ffn_labels.h'),
+           os.path.join(os.path.dirname(_HERE), 'include', 'ffn_seeds.h')]
+SOURCES = ['ffn_hip.hip', 'ffn_labels.hip', 'ffn_seeds.hip']
 
 MAX_CANDIDATES = 16
 
@@ -113,6 +114,22 @@ SIGNATURES = {
              ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, _P, _P,
              ctypes.POINTER(ctypes.c_int64)]),
     'ffn_labels_last_timing': (_I, [_P, ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_double)]),
+    # include/ffn_seeds.h
+    'ffn_seeder_create': (_I, [_I, ctypes.POINTER(_P)]),
+    'ffn_seeder_destroy': (None, [_P]),
+    'ffn_seeder_set_noise': (_I, [_P, _P, ctypes.c_size_t]),
+    'ffn_seeder_set_gaussian': (_I, [_P, _P, _I]),
+    'ffn_seeder_peaks': (_I, [_P, _P, _P, _P, ctypes.POINTER(ctypes.c_int64),
+                              ctypes.POINTER(ctypes.c_double), ctypes.c_size_t,
+                              _P, ctypes.POINTER(ctypes.c_size_t),
+                              ctypes.POINTER(ctypes.c_int32)]),
+    'ffn_seeder_peaks_canvas': (_I, [_P, _P, ctypes.POINTER(ctypes.c_double),
+                                     ctypes.c_size_t, _P,
+                                     ctypes.POINTER(ctypes.c_size_t),
+                                     ctypes.POINTER(ctypes.c_int32)]),
+    'ffn_seeder_read_stage': (_I, [_P, _I, _P]),
+    'ffn_seeder_last_timing': (_I, [_P, ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(ctypes.c_double)]),
 }
 

@@ -123,6 +123,20 @@ struct ffn_canvas {
   size_t nvox = 0;
 };
 
+int ffn_canvas_view(ffn_canvas* c, FfnCanvasView* out) {
+  if (!c || !out) return ffn_set_error(FFN_ERR_ARG, "NULL canvas");
+  if (!c->engine)
+    return ffn_set_error(FFN_ERR_STATE, "canvas outlived its engine");
+  out->device_id = c->engine->device;
+  out->engine_stream = c->engine->stream;
+  out->image = c->image;
+  out->segmentation = c->seg;
+  out->shape_zyx[0] = c->cz;
+  out->shape_zyx[1] = c->cy;
+  out->shape_zyx[2] = c->cx;
+  return FFN_OK;
+}
+
 namespace {
 
 int ensure_scratch(ffn_engine* e, size_t bytes) {

@@ -7,4 +7,15 @@
 int ffn_set_error(int code, const char* fmt, ...)
     __attribute__((format(printf, 2, 3)));
 
+// What other translation units may know about a device canvas.
+struct FfnCanvasView {
+  int device_id;
+  void* engine_stream;  // hipStream_t of the owning engine
+  const float* image;
+  const int* segmentation;
+  long long shape_zyx[3];
+};
+struct ffn_canvas;
+int ffn_canvas_view(ffn_canvas* canvas, FfnCanvasView* out);
+
 #endif  // FFN_INTERNAL_H_

@@ -2,18 +2,14 @@
 
 Mirror of reference ffn/inference/seed.py: `BaseSeedPolicy` (:37-130),
 `PolicyPeaks` (:142-199), `PolicyMax` (:330-362), `PolicyGrid3d` (:411-430),
-`PolicyGrid2d` (:433-450), `PolicyInvertOrigins` (:453-475).  Seed generation
-stays on the CPU (moving it to the GPU is a "next" row).
-
-`PolicyPeaks` in the reference depends on the un-vendored `edt` and
-`skimage.feature.peak_local_max`; neither is installable here.  It is restated
-with scipy (`distance_transform_edt`, `maximum_filter`): same pipeline (3-D
-Sobel magnitude -> gaussian adaptive threshold sigma=49/6 -> EDT -> local maxima
-with min_distance=3 and the fixed-seed 1e-4 noise -> ascending sort), and the
-result is pinned against the reference's own PolicyPeaks run with the real
-scikit-image 0.18.3 (tests/golden/ref_policy_peaks.npz, minted by
-tools/make_golden_peaks.py under the image's conda python; `edt` there is
-scipy's exact EDT).  Benchmarks use `PolicyGrid3d` so CPU and GPU runs consume
+`PolicyGrid2d` (:433-450), `PolicyInvertOrigins` (:453-475).  `PolicyPeaks`
+ runs on the GPU: 3-D Sobel magnitude ->
+gaussian adaptive threshold sigma=49/6 -> exact EDT -> local maxima with
+min_distance=3 and the fixed-seed 1e-4 noise -> ascending sort, bit-identical
+to the reference's scipy / edt / skimage pipeline (pinned through
+tests/golden/ref_policy_peaks.npz, minted by the reference's own PolicyPeaks
+with scikit-image 0.18.3, tools/make_golden_peaks.py).  The throughput
+benchmark uses `PolicyGrid3d` so the CPU baseline and the GPU run consume
 identical seeds by construction.
 """
 
@@ -24,7 +20,6 @@ import threading
 import weakref
 
 import numpy as np
-from scipy import ndimage
 
 
 class BaseSeedPolicy:
@@ -92,57 +87,56 @@ class PolicyFixed(BaseSeedPolicy):
     self.coords = self._fixed
 
 
-def _peak_local_max(dist, min_distance=3):
-  """Local maxima of `dist` (> 0) at least `min_distance` apart: what
-  skimage.feature.peak_local_max(min_distance, threshold_abs=0,
-  threshold_rel=0) returns for tie-free input -- maximum filter over the
-  (2*min_distance+1) cube, peaks within `min_distance` of the border excluded
-  (skimage's default exclude_border=True)."""
-  size = 2 * min_distance + 1
-  mx = ndimage.maximum_filter(dist, size=size, mode='constant', cval=0.0)
-  peaks = (dist == mx) & (dist > 0)
-  border = np.zeros_like(peaks)
-  inner = tuple(slice(min_distance, max(n - min_distance, min_distance))
-                for n in dist.shape)
-  border[inner] = True
-  return np.argwhere(peaks & border)
-
-
 class PolicyPeaks(BaseSeedPolicy):
-  """Points away from edges: Sobel -> adaptive threshold -> EDT -> peaks."""
+  """Points away from edges: 3-D Sobel -> adaptive threshold -> EDT -> peaks
+  (reference seed.py:142-199), computed on the GPU.
+
+  The whole pipeline runs as HIP kernels (`ffn_amd.seeding.Seeder`,
+  include/ffn_seeds.h) that reproduce the arithmetic of the scipy / edt /
+  skimage calls of the reference bit for bit; for a `DeviceCanvas` the image
+  and the segmentation are read where they already live, in HBM.  The
+  reference spends 7.9 s of CPU per 250^3 subvolume here.
+  """
 
   _sem = threading.Semaphore(4)
 
+  def __init__(self, canvas, seeder=None, **kwargs):
+    super().__init__(canvas, **kwargs)
+    self._seeder = seeder
+
+  def _get_seeder(self, device_id=0):
+    if self._seeder is None:
+      from .. import seeding  # pylint:disable=g-import-not-at-top
+      self._seeder = seeding.default_seeder(device_id)
+    return self._seeder
+
   def init_coords(self):
     logging.info('peaks: starting')
-    image = np.asarray(self.canvas.image).astype(np.float32)
-    edges = ndimage.generic_gradient_magnitude(image, ndimage.sobel)
-    sigma = 49.0 / 6.0
-    thresh_image = np.zeros(edges.shape, dtype=np.float32)
-    ndimage.gaussian_filter(edges, sigma, output=thresh_image, mode='reflect')
-    filt_edges = edges > thresh_image
-    del edges, thresh_image
-    mask = self.get_exclusion_mask()
-    if self.canvas.restrictor is not None:
-      if self.canvas.restrictor.mask is not None:
-        filt_edges[self.canvas.restrictor.mask] = 1
-      if self.canvas.restrictor.seed_mask is not None:
-        filt_edges[self.canvas.restrictor.seed_mask] = 1
-    if np.all(filt_edges == 1):
-      return
+    canvas = self.canvas
+    restrictor = getattr(canvas, 'restrictor', None)
+    rmask = getattr(restrictor, 'mask', None)
+    smask = getattr(restrictor, 'seed_mask', None)
+    voxel = getattr(canvas, 'voxel_size_zyx', (1, 1, 1))
+    handle = getattr(canvas, '_handle', None)
     with PolicyPeaks._sem:
-      dt = ndimage.distance_transform_edt(
-          1 - filt_edges,
-          sampling=self.canvas.voxel_size_zyx).astype(np.float32)
-      dt[mask] = -1
-      dt[~np.isfinite(dt)] = -1
-      rng = np.random.RandomState(seed=42)
-      # f32 dt + f64 noise -> f64, as in the reference (seed.py:136-138); in f32
-      # the 1e-4 noise would collapse into ties
-      idxs = _peak_local_max(dt + rng.rand(*dt.shape) * 1e-4, min_distance=3)
-      idxs = np.array(sorted((z, y, x) for z, y, x in idxs)).reshape(-1, 3)
-      logging.info('peaks: found %d local maxima', idxs.shape[0])
-      self.coords = idxs
+      if handle is not None and rmask is None and smask is None:
+        engine = getattr(handle, 'engine', None)
+        seeder = self._get_seeder(getattr(engine, 'device_id', 0))
+        idxs = seeder.peaks_canvas(handle, voxel)
+      else:
+        force = None  # masked areas count as edges (seed.py:172-176)
+        if rmask is not None or smask is not None:
+          force = np.zeros(canvas.shape, bool)
+          if rmask is not None:
+            force |= rmask
+          if smask is not None:
+            force |= smask
+        idxs = self._get_seeder().peaks(
+            np.asarray(canvas.image), self.get_exclusion_mask(), force, voxel)
+    if idxs is None:  # every voxel is an edge (seed.py:178-179)
+      return
+    logging.info('peaks: found %d local maxima', idxs.shape[0])
+    self.coords = idxs
 
 
 class PolicyMax(BaseSeedPolicy):

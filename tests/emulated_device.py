@@ -191,3 +191,18 @@ class EmulatedLabelOps:
     out, first, sizes, fz = labels_oracle.connected_components(arr,
                                                                connectivity)
     return (out, first, sizes, fz) if stats else out
+
+
+class EmulatedSeeder:
+  """TEST DOUBLE for ffn_amd.seeding.Seeder (scipy via oracle/seeds_oracle)."""
+
+  def peaks(self, image, exclusion_mask=None, force_edge=None,
+            voxel_size_zyx=(1, 1, 1)):
+    from oracle import seeds_oracle
+    return seeds_oracle.policy_peaks(image, exclusion_mask, force_edge,
+                                     voxel_size_zyx)
+
+  def peaks_canvas(self, handle, voxel_size_zyx=(1, 1, 1)):
+    from oracle import seeds_oracle
+    return seeds_oracle.policy_peaks(handle.image, handle.seg > 0, None,
+                                     voxel_size_zyx)

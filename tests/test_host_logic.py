@@ -336,8 +336,11 @@ def test_step_struct_layout_matches_header():
 
 
 def test_policy_peaks_matches_reference_with_real_skimage():
-  """PolicyPeaks (scipy restatement) == the reference's PolicyPeaks run with
-  scikit-image 0.18.3 (fixture minted by tools/make_golden_peaks.py)."""
+  """The PolicyPeaks oracle (scipy) and the product's PolicyPeaks host logic
+  (sorting, margin filter; device emulated) == the reference's PolicyPeaks run
+  with scikit-image 0.18.3 (fixture minted by tools/make_golden_peaks.py)."""
+  from oracle import seeds_oracle
+  from tests.emulated_device import EmulatedSeeder
   g = np.load(os.path.join(GOLDEN, 'ref_policy_peaks.npz'))
 
   class C:
@@ -351,9 +354,16 @@ def test_policy_peaks_matches_reference_with_real_skimage():
     c.margin = np.array([4, 4, 4])
     c.segmentation = np.zeros(c.shape, np.int32)
     c.segmentation[20:30, 20:30, 20:30] = 3
-    got = np.array([p for p in seed_lib.PolicyPeaks(c)]).reshape(-1, 3)
+    got = np.array([p for p in seed_lib.PolicyPeaks(
+        c, seeder=EmulatedSeeder())]).reshape(-1, 3)
     assert len(got) > 50
     assert np.array_equal(got, g[n + '_seeds']), n
+    # the explicit-arithmetic restatement the HIP kernels follow == scipy
+    stages = {}
+    seeds_oracle.policy_peaks(c.image, c.segmentation > 0, stages=stages)
+    edges = seeds_oracle.gradient_magnitude_exact(c.image)
+    assert np.array_equal(edges, stages['edges'])
+    assert np.array_equal(seeds_oracle.gaussian_exact(edges), stages['thresh'])
 
 
 def test_multi_canvas_driver_interleaves_without_changing_results(fib25_blob):
