@@ -86,6 +86,12 @@ SIGNATURES = {
                              ctypes.POINTER(StepRequest),
                              ctypes.POINTER(StepParams),
                              ctypes.POINTER(StepResult)]),
+    'ffn_canvas_step_submit': (_I, [_P, _I, ctypes.POINTER(_P),
+                                    ctypes.POINTER(StepRequest),
+                                    ctypes.POINTER(StepParams),
+                                    ctypes.POINTER(ctypes.c_uint32)]),
+    'ffn_canvas_step_wait': (_I, [_P, ctypes.c_uint32,
+                                  ctypes.POINTER(StepResult)]),
     'ffn_canvas_read_points': (_I, [_P, _I, _P, _P, _P]),
     'ffn_canvas_write_seg_points': (_I, [_P, _I, _P, _P]),
     'ffn_canvas_any_segmented': (_I, [_P, _I3, _I3,

@@ -94,6 +94,11 @@ struct ffn_engine {
   ffn_step_result* h_results = nullptr;  // pinned; written by the paste kernel
   unsigned* h_seq = nullptr;             // pinned per-item completion flags
   unsigned step_id = 0;
+  // two result / descriptor slots: one step may be queued behind the running one
+  int next_slot = 0;
+  int slot_n[2] = {0, 0};
+  unsigned slot_ticket[2] = {0, 0};
+  std::vector<ffn_canvas*> slot_canvas[2];
   int sync_mode = 1;  // 0 = hipStreamSynchronize, 1 = poll h_seq (then sync)
 
   void* d_scratch = nullptr;
@@ -558,14 +563,14 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   E_TRY(hipMemset(e->up_image, 0, vbytes));
   E_TRY(hipMemset(e->up_seed, 0, vbytes));
   E_TRY(hipMalloc(&e->count, sizeof(unsigned) * max_batch * kHeadBlocks));
-  E_TRY(hipMalloc(&e->d_items, sizeof(StepItem) * max_batch));
-  E_TRY(hipHostMalloc(&e->h_items, sizeof(StepItem) * max_batch,
+  E_TRY(hipMalloc(&e->d_items, sizeof(StepItem) * 2 * max_batch));
+  E_TRY(hipHostMalloc(&e->h_items, sizeof(StepItem) * 2 * max_batch,
                       hipHostMallocDefault));
-  E_TRY(hipHostMalloc(&e->h_results, sizeof(ffn_step_result) * max_batch,
+  E_TRY(hipHostMalloc(&e->h_results, sizeof(ffn_step_result) * 2 * max_batch,
                       hipHostMallocDefault));
-  E_TRY(hipHostMalloc(&e->h_seq, sizeof(unsigned) * max_batch,
+  E_TRY(hipHostMalloc(&e->h_seq, sizeof(unsigned) * 2 * max_batch,
                       hipHostMallocDefault));
-  std::memset(e->h_seq, 0, sizeof(unsigned) * max_batch);
+  std::memset(e->h_seq, 0, sizeof(unsigned) * 2 * max_batch);
 
   // validity table of the padded-flat layout
   {
@@ -929,15 +934,24 @@ int ffn_canvas_init_seed(ffn_canvas* c, const int32_t pos[3], float value) {
   return FFN_OK;
 }
 
-int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
-                    const ffn_step_request* requests,
-                    const ffn_step_params* params, ffn_step_result* results) {
-  if (!e || !canvases || !requests || !params || !results)
+int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
+                           const ffn_step_request* requests,
+                           const ffn_step_params* params, uint32_t* ticket) {
+  if (!e || !canvases || !requests || !params || !ticket)
     return fail(FFN_ERR_ARG, "null argument");
   if (n < 1 || n > e->max_batch)
     return fail(FFN_ERR_ARG, "batch %d outside [1, %d]", n, e->max_batch);
   if (!e->weights_set) return fail(FFN_ERR_STATE, "weights not set");
+  const int slot = e->next_slot;
+  if (e->slot_n[slot] != 0)
+    return fail(FFN_ERR_STATE,
+                "two steps already in flight: call ffn_canvas_step_wait first");
   const Geom& g = e->g;
+  StepItem* h_items = e->h_items + (size_t)slot * e->max_batch;
+  StepItem* d_items = e->d_items + (size_t)slot * e->max_batch;
+  ffn_step_result* h_results = e->h_results + (size_t)slot * e->max_batch;
+  unsigned* h_seq = e->h_seq + (size_t)slot * e->max_batch;
+  const int other = slot ^ 1;
   for (int k = 0; k < n; ++k) {
     const ffn_canvas* c = canvases[k];
     if (!c || c->engine != e) return fail(FFN_ERR_ARG, "canvas %d not of this engine", k);
@@ -953,7 +967,11 @@ int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
     for (int k2 = 0; k2 < k; ++k2)
       if (canvases[k2] == c)
         return fail(FFN_ERR_ARG, "canvas appears twice in one batch");
-    StepItem& it = e->h_items[k];
+    // a canvas steps sequentially: it cannot also be in the step in flight
+    for (int k2 = 0; k2 < e->slot_n[other]; ++k2)
+      if (e->slot_canvas[other][k2] == c)
+        return fail(FFN_ERR_STATE, "canvas %d already has a step in flight", k);
+    StepItem& it = h_items[k];
     it.image = c->image;
     it.seed = c->seed;
     it.seg = c->seg;
@@ -964,11 +982,11 @@ int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
   }
   HIP_TRY(hipSetDevice(e->device));
   StepItems si;
-  si.items = e->d_items;
+  si.items = d_items;
   si.use_inline = n == 1;
-  si.inline_item = e->h_items[0];
+  si.inline_item = h_items[0];
   if (n > 1)
-    HIP_TRY(hipMemcpyAsync(e->d_items, e->h_items, sizeof(StepItem) * n,
+    HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(StepItem) * n,
                            hipMemcpyHostToDevice, e->stream));
   int rc = run_stack(e, n, si, params->pad_value, params->move_threshold);
   if (rc) return rc;
@@ -976,16 +994,38 @@ int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
   hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, kHeadBlocks,
                      params->move_threshold, params->disco_seed_threshold,
-                     e->h_results, e->h_seq, step_id);
+                     h_results, h_seq, step_id);
   hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, kHeadBlocks,
                      params->disco_seed_threshold);
   HIP_TRY(hipGetLastError());
+  e->slot_n[slot] = n;
+  e->slot_ticket[slot] = step_id;
+  e->slot_canvas[slot].assign(canvases, canvases + n);
+  e->next_slot = other;
+  *ticket = step_id;
+  return FFN_OK;
+}
+
+int ffn_canvas_step_wait(ffn_engine* e, uint32_t ticket,
+                         ffn_step_result* results) {
+  if (!e || !results) return fail(FFN_ERR_ARG, "null argument");
+  int slot = -1;
+  for (int s = 0; s < 2; ++s)
+    if (e->slot_n[s] != 0 && e->slot_ticket[s] == ticket) slot = s;
+  if (slot < 0) return fail(FFN_ERR_STATE, "no step with ticket %u in flight", ticket);
+  const int n = e->slot_n[slot];
+  const unsigned step_id = ticket;
+  ffn_step_result* h_results = e->h_results + (size_t)slot * e->max_batch;
+  unsigned* h_seq = e->h_seq + (size_t)slot * e->max_batch;
+  e->slot_n[slot] = 0;  // the slot is free again whatever happens below
+  e->slot_canvas[slot].clear();
+  HIP_TRY(hipSetDevice(e->device));
   if (e->sync_mode == 1) {
-    // Poll the completion flags the paste kernel raises in pinned memory: lower
+    // Poll the completion flags the faces kernel raises in pinned memory: lower
     // wake-up latency than a blocking stream synchronise.  Bounded spin, then
     // fall back to the stream so that device faults still surface as errors.
-    volatile unsigned* seq = e->h_seq;
+    volatile unsigned* seq = h_seq;
     bool done = false;
     for (long spin = 0; spin < 200000000L && !done; ++spin) {
       done = true;
@@ -1006,8 +1046,18 @@ int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
   } else {
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
-  std::memcpy(results, e->h_results, sizeof(ffn_step_result) * n);
+  std::memcpy(results, h_results, sizeof(ffn_step_result) * n);
   return FFN_OK;
+}
+
+int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
+                    const ffn_step_request* requests,
+                    const ffn_step_params* params, ffn_step_result* results) {
+  if (!results) return fail(FFN_ERR_ARG, "null argument");
+  uint32_t ticket = 0;
+  int rc = ffn_canvas_step_submit(e, n, canvases, requests, params, &ticket);
+  if (rc) return rc;
+  return ffn_canvas_step_wait(e, ticket, results);
 }
 
 int ffn_canvas_read_points(ffn_canvas* c, int n, const int32_t* pos,

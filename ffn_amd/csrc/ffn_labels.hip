@@ -280,6 +280,11 @@ __global__ __launch_bounds__(kThreads) void cc_merge_kernel(
       continue;
     const u32 j = ((u32)zz * g.ny + (u32)yy) * g.nx + (u32)xx;
     if (in[j] == v) {
+      // Two x-runs that touch along a stretch need ONE union: skip the pair
+      // (i, j) when (i-1, j-1) joins the same two runs.
+      if (x > 0 && xx > 0 && in[i - 1] == v && in[j - 1] == v &&
+          (g.off[k][0] != 0 || g.off[k][1] != 0))
+        continue;
       // skip the atomics when i is pre-linked to j through its x-run
       if (uf_load(parent, i) == j || uf_load(parent, j) == uf_load(parent, i))
         continue;

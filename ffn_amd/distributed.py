@@ -54,38 +54,45 @@ class SubBox:
 
 
 def tile_volume(shape_zyx: Sequence[int], sub_size_zyx: Sequence[int],
-                overlap_zyx: Sequence[int]) -> List[SubBox]:
+                overlap_zyx: Sequence[int],
+                back_shift: bool = False) -> List[SubBox]:
   """Overlapping sub-boxes covering `shape`; cores partition the volume.
 
-  Consecutive sub-boxes along an axis start `sub_size - overlap` apart; the
-  last one is clipped to the volume.  The core of a sub-box extends to the
-  middle of each overlap zone, so cores tile the volume exactly once.
+  Consecutive sub-boxes along an axis start `sub_size - overlap` apart.  The
+  last one is clipped to the volume, or, with `back_shift`, moved back so that
+  it keeps the full size (`back_shift_small_sub_boxes` of the reference's
+  OrderlyOverlappingCalculator, bounding_box.py:276-280, :313-318).  A trailing
+  box that would be no larger than the overlap is dropped, as in the reference
+  (:296-299).  The core of a sub-box extends to the middle of each overlap
+  zone, so cores tile the volume exactly once.
   """
-  starts_per_axis = []
+  spans_per_axis = []
   for n, s, o in zip(shape_zyx, sub_size_zyx, overlap_zyx):
     if s <= o:
       raise ValueError('sub-box size must exceed the overlap')
     step = s - o
-    starts = [0]
-    while starts[-1] + s < n:
-      starts.append(starts[-1] + step)
-    starts_per_axis.append(starts)
+    count = max(1, -(-(n - o) // step))  # ceil((n - overlap) / stride)
+    spans = []
+    for k in range(count):
+      start = k * step
+      end = min(start + s, n)
+      if back_shift and start + s > n:
+        start, end = max(n - s, 0), n
+      spans.append((start, end))
+    spans_per_axis.append(spans)
   boxes = []
   idx = 0
-  for z0 in starts_per_axis[0]:
-    for y0 in starts_per_axis[1]:
-      for x0 in starts_per_axis[2]:
-        corner = (z0, y0, x0)
-        size, lo, hi = [], [], []
-        for a, (c, n, s, o) in enumerate(zip(corner, shape_zyx, sub_size_zyx,
-                                             overlap_zyx)):
-          e = min(c + s, n)
-          size.append(e - c)
-          starts = starts_per_axis[a]
-          k = starts.index(c)
-          lo.append(0 if k == 0 else c + o // 2)
-          hi.append(n if k == len(starts) - 1 else starts[k + 1] + o // 2)
-        boxes.append(SubBox(idx, corner, tuple(size), tuple(lo), tuple(hi)))
+  for kz, (z0, z1) in enumerate(spans_per_axis[0]):
+    for ky, (y0, y1) in enumerate(spans_per_axis[1]):
+      for kx, (x0, x1) in enumerate(spans_per_axis[2]):
+        lo, hi = [], []
+        for a, k in enumerate((kz, ky, kx)):
+          spans = spans_per_axis[a]
+          lo.append(0 if k == 0 else (spans[k][0] + spans[k - 1][1]) // 2)
+          hi.append(shape_zyx[a] if k == len(spans) - 1 else
+                    (spans[k + 1][0] + spans[k][1]) // 2)
+        boxes.append(SubBox(idx, (z0, y0, x0), (z1 - z0, y1 - y0, x1 - x0),
+                            tuple(lo), tuple(hi)))
         idx += 1
   return boxes
 
@@ -277,3 +284,63 @@ def reconcile_segmentations(local_results, shape_zyx, rank: int, world: int,
     vals = np.array([roots[int(k)] for k in keys], np.uint64)
     merged = ops.remap(merged, keys, vals, keep_missing=True)
   return merged, offsets, edges, roots
+
+
+def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
+                   rank: int = 0, world: int = 1, device=None,
+                   batch_size=None, reconcile: bool = True,
+                   min_overlap_voxels: int = 1,
+                   min_overlap_fraction: float = 0.0, save: bool = True):
+  """Segments a whole bounding box on `world` GPUs (BASELINE configs C4 / C5).
+
+  One process per GPU calls this with its rank.  The box is cut into
+  overlapping sub-boxes (`tile_volume`), dealt round-robin; each rank segments
+  its sub-boxes concurrently on its GPU (`Runner.run_many`: one batched engine
+  call per round) with no communication; then the ranks assemble one global
+  label volume (all-reduce over RCCL) and, if `reconcile`, merge objects cut by
+  sub-box borders (`reconcile_segmentations`).
+
+  Args:
+    runner: a started `ffn_amd.inference.runner.Runner` (direct=True)
+    corner_zyx, size_zyx: the bounding box inside the runner's image volume
+    sub_size_zyx, overlap_zyx: sub-box tiling (overlap >= the model FoV)
+    rank, world, device: torch.distributed coordinates (world == 1: no
+      collective is issued)
+    batch_size: sub-boxes advanced per engine call on one GPU
+
+  Returns:
+    (global int32 label volume of shape size_zyx -- identical on every rank --,
+     dict with 'boxes', 'mine', 'offsets', 'edges', 'roots')
+  """
+  corner_zyx = tuple(int(c) for c in corner_zyx)
+  size_zyx = tuple(int(s) for s in size_zyx)
+  # full-size sub-boxes at the back edge: a clipped sliver narrower than the
+  # FoV could not host a single seed
+  boxes = tile_volume(size_zyx, sub_size_zyx, overlap_zyx, back_shift=True)
+  mine = assign_round_robin(boxes, rank, world)
+  canvases = runner.run_many(
+      [(tuple(c + o for c, o in zip(corner_zyx, b.corner)), b.size)
+       for b in mine], batch_size=batch_size, save=save)
+  results = []
+  for b, canvas in zip(mine, canvases):
+    if canvas is None:
+      raise RuntimeError('sub-box %r was skipped (output exists / masked); '
+                         'assemble from the saved files instead' % (b,))
+    seg = np.array(np.asarray(canvas.segmentation), np.int32)
+    seg[seg < 0] = 0  # the -1 "excluded" markers (runner.py:452)
+    results.append((b, seg))
+    if hasattr(canvas, 'close'):
+      canvas.close()
+  info = {'boxes': boxes, 'mine': mine}
+  if reconcile:
+    merged, offsets, edges, roots = reconcile_segmentations(
+        results, size_zyx, rank, world, device, min_overlap_voxels,
+        min_overlap_fraction)
+    info.update(offsets=offsets, edges=edges, roots=roots)
+  else:
+    merged, offsets = merge_segmentations(results, size_zyx, rank, world,
+                                          device)
+    info.update(offsets=offsets, edges=np.zeros((0, 3), np.int64), roots={})
+  info['local_results'] = results
+  return merged, info
+

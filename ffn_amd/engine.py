@@ -55,6 +55,13 @@ class HipEngine:
     self._canvas_arr = (ctypes.c_void_p * self.max_batch)()
     self._req_arr = (StepRequest * self.max_batch)()
     self._res_arr = (StepResult * self.max_batch)()
+    # per-slot argument / result arrays of the split submit / wait calls
+    self._slot_canvas_arr = [(ctypes.c_void_p * self.max_batch)()
+                             for _ in range(2)]
+    self._slot_req_arr = [(StepRequest * self.max_batch)() for _ in range(2)]
+    self._slot_res_arr = [(StepResult * self.max_batch)() for _ in range(2)]
+    self._submit_slot = 0
+    self._ticket_slot = {}
     self._canvases = weakref.WeakSet()
     _LIVE_ENGINES.add(self)
 
@@ -143,6 +150,32 @@ class HipEngine:
                                     self._req_arr, ctypes.byref(params),
                                     self._res_arr))
     return self._res_arr
+
+  def step_submit(self, canvases: Sequence['DeviceCanvasHandle'],
+                  requests: Sequence[StepRequest], params: StepParams) -> int:
+    """Enqueues one FoV step for each canvas and returns its ticket at once
+    (at most two steps in flight; see ffn_canvas_step_submit)."""
+    n = len(canvases)
+    slot = self._submit_slot
+    self._submit_slot ^= 1
+    carr, rarr = self._slot_canvas_arr[slot], self._slot_req_arr[slot]
+    for k in range(n):
+      carr[k] = canvases[k]._h
+      ctypes.pointer(rarr[k])[0] = requests[k]
+    ticket = ctypes.c_uint32(0)
+    check(self._lib.ffn_canvas_step_submit(self._h, n, carr, rarr,
+                                           ctypes.byref(params),
+                                           ctypes.byref(ticket)))
+    self._ticket_slot[ticket.value] = slot
+    return ticket.value
+
+  def step_wait(self, ticket: int):
+    """Blocks until the step is done; returns its StepResult array (valid until
+    the second-next submit)."""
+    slot = self._ticket_slot.pop(ticket)
+    res = self._slot_res_arr[slot]
+    check(self._lib.ffn_canvas_step_wait(self._h, ticket, res))
+    return res
 
   def step1(self, canvas: 'DeviceCanvasHandle', request: StepRequest,
             params: StepParams) -> StepResult:

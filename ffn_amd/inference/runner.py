@@ -278,3 +278,53 @@ class Runner:
     except OSError:
       pass
     return canvas
+
+  def run_many(self, subvolumes, batch_size=None, reset_counters=True,
+               save=True):
+    """Segments several subvolumes CONCURRENTLY on this GPU (BASELINE config C3).
+
+    The reference gets this from one thread per subvolume calling `run()` on a
+    shared Runner (doc/manual.md:89-97); here ONE thread advances all canvases
+    in lock-free round-robin and every round is a single batched
+    `ffn_canvas_step(n, ...)` (`inference.MultiCanvasDriver`).  Needs a Runner
+    started with direct=True and batch_size >= the wanted concurrency.
+
+    Args:
+      subvolumes: iterable of (corner_zyx, size_zyx)
+      batch_size: FoV steps per engine call (default: the engine's max batch)
+      save: write each result like `run()` does (segmentation npz [+ prob])
+
+    Returns:
+      list of canvases (None where the output already existed / all masked),
+      in the order of `subvolumes`.
+    """
+    if not self._direct:
+      raise ValueError('run_many needs Runner.start(..., direct=True)')
+    if reset_counters:
+      self.counters.reset()
+    out_dir = self.request.segmentation_output_dir
+    canvases, jobs, meta = [], [], []
+    for corner, size in subvolumes:
+      corner = tuple(int(c) for c in corner)
+      size = tuple(int(s) for s in size)
+      seg_path = storage.segmentation_path(out_dir, corner)
+      if save and os.path.exists(seg_path):
+        canvases.append(None)
+        continue
+      canvas, alignment = self.make_canvas(corner, size)
+      canvases.append(canvas)
+      if canvas is None:
+        continue
+      self.canvases[corner] = canvas
+      jobs.append((canvas, self.get_seed_policy(corner, size)))
+      meta.append((canvas, alignment, corner))
+    driver = inference.MultiCanvasDriver(self.executor.engine, batch_size)
+    driver.run(jobs)
+    for canvas, alignment, corner in meta:
+      if save:
+        self.save_segmentation(canvas, alignment,
+                               storage.segmentation_path(out_dir, corner),
+                               storage.object_prob_path(out_dir, corner))
+      del self.canvases[corner]
+    return canvases
+

@@ -120,6 +120,20 @@ int ffn_canvas_step(ffn_engine* engine, int n, ffn_canvas* const* canvases,
                     const ffn_step_request* requests,
                     const ffn_step_params* params, ffn_step_result* results);
 
+/* The same step split in two, so that the host work of one group of canvases
+ * (queue bookkeeping in Python) overlaps the GPU work of another: submit
+ * enqueues the whole step and returns at once; wait blocks until its results
+ * are in host memory.  At most two steps may be in flight per engine and a
+ * canvas may be in only one of them; steps execute in submission order.
+ * ffn_canvas_step == submit + wait.  Other calls on the engine's canvases are
+ * ordered behind the steps in flight (same stream). */
+int ffn_canvas_step_submit(ffn_engine* engine, int n,
+                           ffn_canvas* const* canvases,
+                           const ffn_step_request* requests,
+                           const ffn_step_params* params, uint32_t* ticket);
+int ffn_canvas_step_wait(ffn_engine* engine, uint32_t ticket,
+                         ffn_step_result* results);
+
 /* Point reads used by Canvas.is_valid_pos (inference.py:312-346). */
 int ffn_canvas_read_points(ffn_canvas* canvas, int n, const int32_t* pos_zyx,
                            float* seed_out, int32_t* seg_out);

@@ -38,6 +38,14 @@ def main(argv=None):
                   'the whole bounding box on one rank).')
   ap.add_argument('--overlap', default='', help='x,y,z overlap of sub-boxes.')
   ap.add_argument('--batch_size', type=int, default=1)
+  ap.add_argument('--assemble', default='',
+                  help='With sharding: also assemble ONE global label volume '
+                  '(RCCL all-reduce + union-find reconciliation of objects cut '
+                  'by sub-box borders) and save it here (.npy, rank 0).  The '
+                  "sub-boxes of a rank then advance concurrently on its GPU "
+                  '(--batch_size of them per engine call).')
+  ap.add_argument('--min_overlap_voxels', type=int, default=64)
+  ap.add_argument('--min_overlap_fraction', type=float, default=0.25)
   args = ap.parse_args(argv)
   logging.basicConfig(level=logging.INFO)
 
@@ -52,7 +60,8 @@ def main(argv=None):
   world = int(os.environ.get('WORLD_SIZE', '1'))
 
   runner = runner_lib.Runner(device_id=local_rank)
-  runner.start(request, batch_size=args.batch_size)
+  runner.start(request, batch_size=args.batch_size,
+               direct=True if args.assemble else None)
 
   if args.subvolume_size or world > 1:
     sub = ([int(v) for v in args.subvolume_size.split(',')][::-1]
@@ -60,8 +69,28 @@ def main(argv=None):
     fov = runner._model_info.input_image_size[::-1]
     ov = ([int(v) for v in args.overlap.split(',')][::-1] if args.overlap else
           [int(v) for v in fov])
-    boxes = ffn_dist.tile_volume(size_zyx, sub, ov)
-    mine = ffn_dist.assign_round_robin(boxes, rank, world)
+    if args.assemble:
+      import numpy as np  # pylint:disable=g-import-not-at-top
+      device = None
+      if world > 1:
+        import torch  # pylint:disable=g-import-not-at-top
+        import torch.distributed as dist  # pylint:disable=g-import-not-at-top
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+        dist.init_process_group('nccl', device_id=device)
+      merged, info = ffn_dist.segment_volume(
+          runner, start_zyx, size_zyx, sub, ov, rank, world, device,
+          batch_size=args.batch_size,
+          min_overlap_voxels=args.min_overlap_voxels,
+          min_overlap_fraction=args.min_overlap_fraction)
+      if rank == 0:
+        np.save(args.assemble, merged)
+        logging.info('assembled %d sub-boxes, %d merge edges -> %s',
+                     len(info['boxes']), len(info['edges']), args.assemble)
+      mine = []
+    else:
+      boxes = ffn_dist.tile_volume(size_zyx, sub, ov)
+      mine = ffn_dist.assign_round_robin(boxes, rank, world)
   else:
     boxes = ffn_dist.tile_volume(size_zyx, size_zyx, (0, 0, 0))
     mine = boxes

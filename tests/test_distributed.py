@@ -12,23 +12,33 @@ from ffn_amd import distributed as ffn_dist
 
 
 def test_tiler_cores_partition_the_volume():
-  for shape, sub, ov in [((100, 90, 120), (64, 64, 64), (33, 33, 33)),
-                         ((250, 250, 250), (140, 140, 140), (40, 40, 40)),
-                         ((64, 64, 64), (64, 64, 64), (33, 33, 33)),
-                         ((256, 2048 // 8, 2048 // 8), (128, 160, 160),
-                          (21, 41, 41))]:
-    boxes = ffn_dist.tile_volume(shape, sub, ov)
-    cover = np.zeros(shape, np.int32)
-    for b in boxes:
-      for a in range(3):
-        assert 0 <= b.corner[a] and b.corner[a] + b.size[a] <= shape[a]
-        assert b.corner[a] <= b.core_lo[a] < b.core_hi[a] <= (
-            b.corner[a] + b.size[a])
-      cover[b.core_lo[0]:b.core_hi[0], b.core_lo[1]:b.core_hi[1],
-            b.core_lo[2]:b.core_hi[2]] += 1
-    assert cover.min() == 1 and cover.max() == 1
-    deal = [ffn_dist.assign_round_robin(boxes, r, 3) for r in range(3)]
-    assert sorted(b.index for d in deal for b in d) == list(range(len(boxes)))
+  cases = [((100, 90, 120), (64, 64, 64), (33, 33, 33)),
+           ((250, 250, 250), (140, 140, 140), (40, 40, 40)),
+           ((64, 64, 64), (64, 64, 64), (33, 33, 33)),
+           ((72, 80, 112), (72, 80, 72), (33, 33, 33)),
+           ((256, 2048 // 8, 2048 // 8), (128, 160, 160), (21, 41, 41))]
+  for shape, sub, ov in cases:
+    for back_shift in (False, True):
+      boxes = ffn_dist.tile_volume(shape, sub, ov, back_shift=back_shift)
+      if back_shift:  # every sub-box keeps the full size
+        assert all(tuple(b.size) == tuple(min(s, n) for s, n in zip(sub, shape))
+                   for b in boxes)
+      cover = np.zeros(shape, np.int32)
+      for b in boxes:
+        for a in range(3):
+          assert 0 <= b.corner[a] and b.corner[a] + b.size[a] <= shape[a]
+          assert b.corner[a] <= b.core_lo[a] < b.core_hi[a] <= (
+              b.corner[a] + b.size[a])
+        cover[b.core_lo[0]:b.core_hi[0], b.core_lo[1]:b.core_hi[1],
+              b.core_lo[2]:b.core_hi[2]] += 1
+      assert cover.min() == 1 and cover.max() == 1
+      deal = [ffn_dist.assign_round_robin(boxes, r, 3) for r in range(3)]
+      assert sorted(b.index for d in deal for b in d) == list(range(len(boxes)))
+  # box count per axis = ceil((n - overlap) / stride), as the reference's
+  # OrderlyOverlappingCalculator (bounding_box.py:296-305)
+  assert len(ffn_dist.tile_volume((111, 40, 40), (72, 40, 40), (33, 33, 33))) == 2
+  assert len(ffn_dist.tile_volume((112, 40, 40), (72, 40, 40), (33, 33, 33))) == 3
+  assert len(ffn_dist.tile_volume((105, 40, 40), (72, 40, 40), (33, 33, 33))) == 2
 
 
 def _worker(rank, world, port, tmpdir):

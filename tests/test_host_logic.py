@@ -378,26 +378,53 @@ def test_multi_canvas_driver_interleaves_without_changing_results(fib25_blob):
     max_batch = 2
     calls = []
 
-    def step(self, handles, reqs, params):
-      self.calls.append(len(handles))
-      return [client.step(h, q, params) for h, q in zip(handles, reqs)]
+    def __init__(self):
+      self.calls = []
+      self.pending = {}
+      self.max_in_flight = 0
 
-  names = ['cells56', 'cells72', 'cells56']
-  jobs, canvases = [], []
-  for n in names:
-    g = np.load(os.path.join(GOLDEN, 'ref_canvas_%s.npz' % n))
-    c = inference.make_canvas(info, client, synthetic.normalize(g['volume']),
-                              r.inference_options,
-                              movement_policy_fn=movement.get_policy_fn(r, info))
-    canvases.append((c, g))
-    jobs.append((c, functools.partial(seed_lib.PolicyFixed, coords=g['seeds'])))
-  eng = EmulatedEngine()
-  drv = inference.MultiCanvasDriver(eng, batch_size=2)
-  drv.run(jobs)
-  for c, g in canvases:
-    assert np.array_equal(np.asarray(c.segmentation), g['segmentation'])
-    assert c.counters['update_at-calls'].value == len(g['steps'])
-  assert max(eng.calls) == 2 and drv.steps == 4 + 94 + 4
+    def step_submit(self, handles, reqs, params):
+      # like the device, the emulation executes steps in submission order;
+      # results are handed out at wait time
+      self.calls.append(len(handles))
+      ticket = len(self.calls)
+      assert len(self.pending) < 2, 'more than two steps in flight'
+      busy = {id(h) for hs, _ in self.pending.values() for h in hs}
+      assert not busy & {id(h) for h in handles}, 'canvas in two steps'
+      self.pending[ticket] = (list(handles), [
+          client.step(h, q, params) for h, q in zip(handles, reqs)])
+      self.max_in_flight = max(self.max_in_flight, len(self.pending))
+      return ticket
+
+    def step_wait(self, ticket):
+      return self.pending.pop(ticket)[1]
+
+  for overlap, batch, names in (
+      (True, 2, ['cells56', 'cells72', 'cells56', 'cells56', 'cells56']),
+      (False, 2, ['cells56', 'cells56', 'cells56']),
+      (True, 8, ['cells56', 'cells72', 'cells56', 'cells56', 'cells56'])):
+    jobs, canvases = [], []
+    for n in names:
+      g = np.load(os.path.join(GOLDEN, 'ref_canvas_%s.npz' % n))
+      c = inference.make_canvas(info, client, synthetic.normalize(g['volume']),
+                                r.inference_options,
+                                movement_policy_fn=movement.get_policy_fn(r,
+                                                                         info))
+      canvases.append((c, g))
+      jobs.append((c, functools.partial(seed_lib.PolicyFixed,
+                                        coords=g['seeds'])))
+    eng = EmulatedEngine()
+    drv = inference.MultiCanvasDriver(eng, batch_size=batch, overlap=overlap)
+    drv.run(jobs)
+    for c, g in canvases:
+      assert np.array_equal(np.asarray(c.segmentation), g['segmentation'])
+      assert c.counters['update_at-calls'].value == len(g['steps'])
+    assert drv.steps == sum(len(g['steps']) for _, g in canvases)
+    assert not eng.pending
+    assert max(eng.calls) <= batch
+    assert eng.max_in_flight == (2 if overlap else 1)
+    if overlap and batch == 8:  # 5 live canvases -> groups of 3 and 2
+      assert eng.calls[:2] == [3, 2]
 
 
 def test_update_at_override_is_honoured(fib25_blob):

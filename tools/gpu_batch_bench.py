@@ -26,71 +26,33 @@ class _Done(Exception):
 
 def run_driver(args, model, request, counters):
   """Same workload through the single-threaded MultiCanvasDriver."""
-  exe = executor.HipBatchExecutor(executor.ExecutorInterface(), model,
-                                  model.info, None, counters, args.batch)
-  done = [0] * args.canvases
-  jobs = []
-  for k in range(args.canvases):
-    vol = synthetic.normalize(synthetic.cells_volume((args.size,) * 3,
-                                                     seed=100 + k))
-    sub = counters.get_sub_counters()
-
-    class C(inference.DeviceCanvas):
-      idx = k
-
-      def _finish_step(self, res):
-        pred = super()._finish_step(res)
-        done[self.idx] += 1
-        if done[self.idx] >= args.steps:
-          raise _Done()
-        return pred
-
-    canvas = C(model.info, exe.get_client(sub, direct=True), vol,
-               request.inference_options, counters=sub,
-               movement_policy_fn=movement.get_policy_fn(request, model.info))
-    jobs.append((canvas, functools.partial(seed_lib.PolicyGrid3d, step=16,
-                                           offsets=(0, 8, 4, 12))))
-  drv = inference.MultiCanvasDriver(exe.engine, args.batch)
-
-  class Quiet(inference.MultiCanvasDriver):
-    pass
-
-  # a canvas that reached its step budget raises _Done out of its generator:
-  # treat it as finished
-  orig_run = drv.run
-
-  t0 = time.perf_counter()
-  active = []
-  for canvas, sp in jobs:
-    gen = canvas._segment_all_gen(sp)
-    try:
-      active.append([canvas, gen, next(gen)])
-    except (StopIteration, _Done):
-      pass
-  rr = 0
-  calls = 0
-  while active:
-    n = min(args.batch, len(active))
-    rr %= len(active)
-    batch = [active[(rr + j) % len(active)] for j in range(n)]
-    rr += n
-    res = exe.engine.step([b[0]._handle for b in batch], [b[2] for b in batch],
-                          batch[0][0]._step_params)
-    calls += 1
-    fin = []
-    for j, entry in enumerate(batch):
-      try:
-        entry[2] = entry[1].send(res[j])
-      except (StopIteration, _Done):
-        fin.append(entry)
-    for entry in fin:
-      active.remove(entry)
-  dt = time.perf_counter() - t0
-  total = sum(done)
-  print('driver canvases %d batch %d: %d steps in %.2f s = %.1f FoV-steps/s; '
-        '%d engine calls (mean fill %.2f)' %
-        (args.canvases, args.batch, total, dt, total / dt, calls,
-         total / max(calls, 1)))
+  for overlap in (False, True):
+    exe = executor.HipBatchExecutor(executor.ExecutorInterface(), model,
+                                    model.info, None, counters, args.batch)
+    jobs = []
+    for k in range(args.canvases):
+      vol = synthetic.normalize(synthetic.cells_volume((args.size,) * 3,
+                                                       seed=100 + k))
+      sub = counters.get_sub_counters()
+      canvas = inference.DeviceCanvas(
+          model.info, exe.get_client(sub, direct=True), vol,
+          request.inference_options, counters=sub,
+          movement_policy_fn=movement.get_policy_fn(request, model.info))
+      jobs.append((canvas, functools.partial(seed_lib.PolicyGrid3d, step=16,
+                                             offsets=(0, 8, 4, 12))))
+    drv = inference.MultiCanvasDriver(exe.engine, args.batch, overlap=overlap,
+                                      max_steps_per_canvas=args.steps)
+    t0 = time.perf_counter()
+    drv.run(jobs)
+    exe.engine.synchronize()
+    dt = time.perf_counter() - t0
+    print('driver overlap=%d canvases %d batch %d: %d steps in %.2f s = %.1f '
+          'FoV-steps/s; %d engine calls (mean fill %.2f)' %
+          (overlap, args.canvases, args.batch, drv.steps, dt, drv.steps / dt,
+           drv.calls, drv.steps / max(drv.calls, 1)))
+    for canvas, _ in jobs:
+      canvas.close()
+    exe.engine.close()
 
 
 def main():
