@@ -74,6 +74,8 @@ struct ffn_engine {
   uint32_t* validbits = nullptr;
   int32_t* pidx = nullptr;    // dense FoV index -> padded position (variant 2)
   int nchunks_c = 0, Rc = 0;
+  int fuse_head = 1;      // 1x1x1 head fused into the last conv32c launch
+  int count_blocks = kHeadBlocks;  // entries per item in `count` for the last step
   int store_policy = 1;  // conv32c epilogue stores: sc1 write-through (-1.4 % per stack)
   long long* d_dbg = nullptr;  // debug clocks of conv32c WG 0 (24 values)
   int dbg_clock = 0;
@@ -183,6 +185,14 @@ int set_lds_attr_c(size_t bytes) {
     HIP_TRY(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv32c_kernel<RI, RO, SK, 0, 9>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (DBG == 0 && SK) {  // the fused-head form of the last conv
+    HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv32c_kernel<RI, RO, SK, 0, 8, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv32c_kernel<RI, RO, SK, 0, 9, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  }
   return FFN_OK;
 }
 
@@ -286,9 +296,15 @@ int launch_conv32p(ffn_engine* e, int n, const float* in, float* out,
   return FFN_OK;
 }
 
+struct HeadFusion {
+  bool on = false;
+  float pad_value = 0.f, move_thr = 0.f;
+};
+
 template <bool RI, bool RO, bool SK>
 int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
-                   const float* skip, int layer) {
+                   const float* skip, int layer,
+                   const HeadFusion& head = HeadFusion()) {
   ConvCArgs a;
   a.in = in;
   a.out = out;
@@ -309,6 +325,12 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
   a.nbytes = (unsigned)((size_t)e->g.nchunks * kChunk * kFeatures * sizeof(float));
   a.store_policy = e->store_policy;
   a.dbg = e->dbg_clock ? e->d_dbg : nullptr;
+  a.head_w = e->weights + e->wl_off;
+  a.seed_raw = e->seed_raw;
+  a.logits = e->logits;
+  a.head_count = e->count;
+  a.pad_value = head.pad_value;
+  a.move_thr = head.move_thr;
   const bool prof = e->prof_now;
   if (prof) {
     if (e->events_used + 2 > (int)e->events.size()) {
@@ -337,6 +359,13 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
         return fail(FFN_ERR_ARG, "unsupported ablate mask %d for variant 2",
                     e->ablate);
     }
+  } else if (head.on) {
+    if (e->Rc == 256)
+      hipLaunchKernelGGL((conv32c_kernel<RI, RO, SK, 0, 8, true>), grid, block,
+                         e->lds_bytes_c, e->stream, a);
+    else
+      hipLaunchKernelGGL((conv32c_kernel<RI, RO, SK, 0, 9, true>), grid, block,
+                         e->lds_bytes_c, e->stream, a);
   } else if (e->Rc == 256) {
     hipLaunchKernelGGL((conv32c_kernel<RI, RO, SK, 0, 8>), grid, block,
                        e->lds_bytes_c, e->stream, a);
@@ -359,11 +388,18 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   const float* W = e->weights;
   const int tz = (g.fz + kC0Z - 1) / kC0Z, ty = (g.fy + kC0Y - 1) / kC0Y,
             tx = (g.fx + kC0X - 1) / kC0X;
-  hipLaunchKernelGGL(conv0a_kernel, dim3(tz * ty * tx, n), dim3(kC0Threads), 0,
-                     e->stream, si, pad_value, W + e->w0a_off, W + e->b0a_off,
-                     e->bufT, e->seed_raw, g, ty, tx);
+  if (e->conv_variant == 0)  // plain VALU form, kept for A/B
+    hipLaunchKernelGGL(conv0a_kernel, dim3(tz * ty * tx, n), dim3(kC0Threads), 0,
+                       e->stream, si, pad_value, W + e->w0a_off, W + e->b0a_off,
+                       e->bufT, e->seed_raw, g, ty, tx);
+  else
+    hipLaunchKernelGGL(conv0a_mfma_kernel, dim3(tz * ty * tx, n),
+                       dim3(kC0Threads), 0, e->stream, si, pad_value,
+                       W + e->w0a_off, W + e->b0a_off, e->bufT, e->seed_raw, g,
+                       ty, tx);
   int rc;
   const float* head_in;
+  bool head_fused = false;
   if (prof_chain) {
     if (e->events_used + 2 > (int)e->events.size()) {
       rc = flush_events(e);
@@ -391,9 +427,14 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
       rc = launch_conv32c<true, true, false>(e, n, e->bufX, e->bufT, nullptr,
                                              2 * i - 1);
       if (rc) return rc;
+      HeadFusion hf;
+      hf.on = e->fuse_head && i == e->depth - 1 && e->ablate == 0;
+      hf.pad_value = pad_value;
+      hf.move_thr = move_thr;
       rc = launch_conv32c<false, false, true>(e, n, e->bufT, e->bufX, e->bufX,
-                                              2 * i);
+                                              2 * i, hf);
       if (rc) return rc;
+      head_fused = hf.on;
     }
     head_in = e->bufX;
   } else {
@@ -411,9 +452,14 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     head_in = e->bufX;
   }
   if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
-  hipLaunchKernelGGL(head_kernel, dim3(kHeadBlocks, n), dim3(256), 0, e->stream, head_in,
-                     e->seed_raw, pad_value, W + e->wl_off, move_thr, e->logits,
-                     e->count, g);
+  if (head_fused) {
+    e->count_blocks = e->nchunks_c;
+  } else {
+    e->count_blocks = kHeadBlocks;
+    hipLaunchKernelGGL(head_kernel, dim3(kHeadBlocks, n), dim3(256), 0, e->stream,
+                       head_in, e->seed_raw, pad_value, W + e->wl_off, move_thr,
+                       e->logits, e->count, g);
+  }
   HIP_TRY(hipGetLastError());
   return FFN_OK;
 }
@@ -562,7 +608,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   E_TRY(hipMalloc(&e->logits, vbytes));
   E_TRY(hipMemset(e->up_image, 0, vbytes));
   E_TRY(hipMemset(e->up_seed, 0, vbytes));
-  E_TRY(hipMalloc(&e->count, sizeof(unsigned) * max_batch * kHeadBlocks));
+  E_TRY(hipMalloc(&e->count, sizeof(unsigned) * max_batch *
+                                  std::max<size_t>(kHeadBlocks, (g.V + kCChunk - 1) / kCChunk)));
   E_TRY(hipMalloc(&e->d_items, sizeof(StepItem) * 2 * max_batch));
   E_TRY(hipHostMalloc(&e->h_items, sizeof(StepItem) * 2 * max_batch,
                       hipHostMallocDefault));
@@ -816,6 +863,10 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->ablate = value;
     return FFN_OK;
   }
+  if (std::strcmp(name, "fuse_head") == 0) {
+    e->fuse_head = value != 0;
+    return FFN_OK;
+  }
   if (std::strcmp(name, "store_policy") == 0) {
     if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "store_policy 0..2");
     e->store_policy = value;
@@ -992,11 +1043,11 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   if (rc) return rc;
   const unsigned step_id = ++e->step_id ? e->step_id : ++e->step_id;  // never 0
   hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
-                     e->logits, e->seed_raw, e->count, kHeadBlocks,
+                     e->logits, e->seed_raw, e->count, e->count_blocks,
                      params->move_threshold, params->disco_seed_threshold,
                      h_results, h_seq, step_id);
   hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
-                     e->logits, e->seed_raw, e->count, kHeadBlocks,
+                     e->logits, e->seed_raw, e->count, e->count_blocks,
                      params->disco_seed_threshold);
   HIP_TRY(hipGetLastError());
   e->slot_n[slot] = n;

@@ -156,6 +156,104 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_kernel(
   }
 }
 
+// conv0_a on the matrix cores: same tile / halo staging as conv0a_kernel, then
+// an implicit GEMM with K = 27 taps x 2 channels = 54 (padded to 56 = 14
+// k-steps of v_mfma_f32_16x16x4_f32).  A block = 256 positions = 16 M-tiles;
+// wave w owns M-tiles 2w, 2w+1 for both cout halves (56 MFMAs).  A operand: one
+// ds_read_b32 per k-step straight from the (image, seed) tile (lane group g
+// reads channel g & 1 of tap 2s + (g >> 1)); B operand: the [54][32] weights,
+// 28 registers per lane, loaded once.  5x fewer issue cycles than the VALU form.
+__global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
+    StepItems si, float pad_value, const float* __restrict__ w /*[27][2][32]*/,
+    const float* __restrict__ bias, float* __restrict__ out,
+    float* __restrict__ seed_raw, Geom g, int tiles_y, int tiles_x) {
+  constexpr int HZ = kC0Z + 2, HY = kC0Y + 2, HX = kC0X + 2;
+  __shared__ float tile[HZ * HY * HX * 2];  // (image, seed) interleaved
+  const int item = blockIdx.y;
+  const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
+  int b = blockIdx.x;
+  const int tx = b % tiles_x;
+  b /= tiles_x;
+  const int ty = b % tiles_y;
+  const int tz = b / tiles_y;
+  const int oz = tz * kC0Z, oy = ty * kC0Y, ox = tx * kC0X;  // FoV coords
+  const int z0 = it.req.pos[0] - g.fz / 2;
+  const int y0 = it.req.pos[1] - g.fy / 2;
+  const int x0 = it.req.pos[2] - g.fx / 2;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15;   // A row (position) / B column (cout) of this lane
+  const int grp = lane >> 4;  // k index inside a k-step
+  // B fragments: k = 4 s + grp -> w[k][16 nhalf + i]; k >= 54 is zero padding
+  float bw[2][14];
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int kk = 4 * s + grp;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      bw[h][s] = kk < 54 ? w[kk * kFeatures + 16 * h + i] : 0.0f;
+  }
+  const float bias0 = bias[i], bias1 = bias[16 + i];
+
+  for (int e = threadIdx.x; e < HZ * HY * HX; e += kC0Threads) {
+    const int hx = e % HX;
+    const int t = e / HX;
+    const int hy = t % HY;
+    const int hz = t / HY;
+    const int zz = oz + hz - 1, yy = oy + hy - 1, xx = ox + hx - 1;
+    float vi = 0.0f, vs = 0.0f;  // SAME zero padding outside the FoV
+    if (zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy && xx >= 0 && xx < g.fx) {
+      const size_t ci =
+          ((size_t)(z0 + zz) * it.cy + (y0 + yy)) * it.cx + (x0 + xx);
+      vi = it.image[ci];
+      vs = it.seed[ci];
+      if (hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y && hx >= 1 &&
+          hx <= kC0X)  // interior voxel: keep the raw seed (NaN preserved)
+        seed_raw[(size_t)item * g.V + ((size_t)zz * g.fy + yy) * g.fx + xx] = vs;
+      if (vs != vs) vs = pad_value;  // NaN -> pad (inference.py:406-407)
+    }
+    tile[2 * e] = vi;
+    tile[2 * e + 1] = vs;
+  }
+  __syncthreads();
+
+  const int ch = grp & 1;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int lp = (wave * 2 + m) * kTile + i;  // this lane's A row
+    const int lx = lp % kC0X;
+    const int ly = (lp / kC0X) % kC0Y;
+    const int lz = lp / (kC0X * kC0Y);
+    const int abase = ((lz * HY + ly) * HX + lx) * 2 + ch;
+    f32x4 acc0 = {bias0, bias0, bias0, bias0};
+    f32x4 acc1 = {bias1, bias1, bias1, bias1};
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+      int tap = 2 * s + (grp >> 1);
+      tap = tap > 26 ? 26 : tap;  // k = 54, 55: weight is zero, any finite A
+      const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+      const float av = tile[abase + ((kz * HY + ky) * HX + kx) * 2];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[0][s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[1][s], acc1, 0, 0, 0);
+    }
+    // D fragment: lane (i, grp) holds cout i of positions 4 grp + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int op = (wave * 2 + m) * kTile + grp * 4 + r;
+      const int ox_ = op % kC0X;
+      const int oy_ = (op / kC0X) % kC0Y;
+      const int oz_ = op / (kC0X * kC0Y);
+      const int z = oz + oz_, y = oy + oy_, x = ox + ox_;
+      if (z >= g.fz || y >= g.fy || x >= g.fx) continue;
+      const size_t p = (size_t)z * g.plane + (size_t)y * g.XS + x;
+      float* o = out + (size_t)item * g.act_stride + p * kFeatures;
+      o[i] = fmaxf(acc0[r], 0.0f);
+      o[16 + i] = fmaxf(acc1[r], 0.0f);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // conv32: 3x3x3 conv 32->32 as an implicit GEMM on the exact-f32 MFMA
 // (reference convstack_3d.py:39,45-47; 23 of the 24 convs of a depth-12 stack,
@@ -573,6 +671,12 @@ struct ConvCArgs {
   unsigned nbytes;       // bytes of one activation buffer past its origin
   int store_policy;      // epilogue stores: 0 write-back, 1 sc1, 2 nt
   long long* dbg;        // optional [4 waves][6]: shader / wall clocks of WG 0
+  // HEAD instantiation only (fused 1x1x1 head on the last conv of the stack)
+  const float* head_w;     // [32] weights + bias
+  const float* seed_raw;   // [n][V] raw seed FoV (NaN = never visited)
+  float* logits;           // [n][V]
+  unsigned* head_count;    // [n * nchunks] per-chunk count of logits >= move_thr
+  float pad_value, move_thr;
 };
 
 template <int NT>
@@ -590,7 +694,13 @@ __device__ __forceinline__ void mfma_tiles(const f32x4 (&A)[5], const f32x4& B,
 // weight loads after the first two (issue-rate experiments).
 // KS = 16-B staging loads per lane and dz segment: 8 (Rc = 256 rows, e.g. the
 // 33^3 FoV) or 9 (Rc = 288).
-template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int DBG = 0, int KS = 8>
+//
+// HEAD (last conv of the stack only): the epilogue does not store the residual
+// stream but finishes the network -- ReLU, 1x1x1 conv 32->1 + bias, logits =
+// seed + update (convstack_3d.py:51-54,91-94) and this chunk's count of logits
+// >= move_threshold -- saving the head launch and 4.6 MB of stores per FoV.
+template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int DBG = 0, int KS = 8,
+          bool HEAD = false>
 __global__ __launch_bounds__(kConvThreads, 2) void conv32c_kernel(ConvCArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -839,11 +949,18 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv32c_kernel(ConvCArgs a) {
     }
   }
   __syncthreads();
+  unsigned head_above = 0;
   {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     float* obase = a.out + (size_t)item * a.act_stride;
     const __amdgpu_buffer_rsrc_t rs_out =
         __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.nbytes, 0x00020000);
+    f32x4 hw4 = {0.f, 0.f, 0.f, 0.f};
+    float hbias = 0.f;
+    if (HEAD) {
+      hw4 = *reinterpret_cast<const f32x4*>(a.head_w + q * 4);
+      hbias = a.head_w[kFeatures];
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       const int j = j0 + 32 * k;
@@ -858,6 +975,28 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv32c_kernel(ConvCArgs a) {
         for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
       }
       if (ADD_SKIP) v += skipv[k];
+      if (HEAD) {
+        // 8 lanes hold the 32 channels of position j: dot with the 1x1x1
+        // weights (same association as head_kernel), xor-shuffle reduce
+        float partial = fmaxf(v[0], 0.f) * hw4[0];
+        partial = __builtin_fmaf(fmaxf(v[1], 0.f), hw4[1], partial);
+        partial = __builtin_fmaf(fmaxf(v[2], 0.f), hw4[2], partial);
+        partial = __builtin_fmaf(fmaxf(v[3], 0.f), hw4[3], partial);
+        partial += __shfl_xor(partial, 1);
+        partial += __shfl_xor(partial, 2);
+        partial += __shfl_xor(partial, 4);
+        bool above = false;
+        if (q == 0 && ooff[k] != 0x80000000u) {
+          const size_t dv = (size_t)item * a.V + (v0 + j);
+          float s = a.seed_raw[dv];
+          if (s != s) s = a.pad_value;
+          const float lg = s + (partial + hbias);
+          a.logits[dv] = lg;
+          above = lg >= a.move_thr;
+        }
+        head_above += (unsigned)__popcll(__ballot(above));  // wave-uniform
+        continue;
+      }
       // store_policy (A/B switch): 0 write-back, 1 write-through (sc1: no
       // dirty L2 lines left for the kernel boundary to flush), 2 non-temporal
       if (a.store_policy == 1)
@@ -870,6 +1009,14 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv32c_kernel(ConvCArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
                                                rs_out, ooff[k], 0, 0);
     }
+  }
+  if (HEAD) {  // this chunk's count of logits >= move_thr (summed by faces / paste)
+    float* cnt = lds + 160 * 32;  // past the transposed accumulators
+    if ((tid & 63) == 0) cnt[tid >> 6] = __uint_as_float(head_above);
+    __syncthreads();
+    if (tid == 0)
+      a.head_count[gc] = __float_as_uint(cnt[0]) + __float_as_uint(cnt[1]) +
+                         __float_as_uint(cnt[2]) + __float_as_uint(cnt[3]);
   }
   if (a.dbg && gc == 0 && (tid & 63) == 0) {
     long long* d = a.dbg + (tid >> 6) * 6;

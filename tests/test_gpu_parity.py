@@ -37,10 +37,13 @@ def _fov_inputs(rng, n=1):
   return img, seed
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 def test_predict_matches_oracle(engine, fib25_blob, variant):
+  """variant 3 = conv32c with the 1x1x1 head as its own launch (default: fused
+  into the last conv)."""
   from oracle import ffn_oracle
-  engine.set_option('conv_variant', variant)
+  engine.set_option('conv_variant', min(variant, 2))
+  engine.set_option('fuse_head', 0 if variant == 3 else 1)
   rng = np.random.RandomState(42)
   img, seed = _fov_inputs(rng, 1)
   got = engine.predict(seed, img)
@@ -48,6 +51,7 @@ def test_predict_matches_oracle(engine, fib25_blob, variant):
   assert got.shape == want.shape
   assert np.abs(got - want).max() <= TOL
   engine.set_option('conv_variant', 2)
+  engine.set_option('fuse_head', 1)
 
 
 def test_predict_batch_and_ragged(engine, fib25_blob):
