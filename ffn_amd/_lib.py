@@ -31,7 +31,14 @@ class FFNHipError(RuntimeError):
 class StepParams(ctypes.Structure):
   _fields_ = [('pad_value', ctypes.c_float),
               ('move_threshold', ctypes.c_float),
-              ('disco_seed_threshold', ctypes.c_float)]
+              ('disco_seed_threshold', ctypes.c_float),
+              ('deleted_threshold', ctypes.c_float)]
+
+  def __init__(self, pad_value=0.0, move_threshold=0.0,
+               disco_seed_threshold=0.0, deleted_threshold=float('nan')):
+    # deleted_threshold = NaN: the keep_history count is not requested
+    super().__init__(pad_value, move_threshold, disco_seed_threshold,
+                     deleted_threshold)
 
 
 class StepRequest(ctypes.Structure):
@@ -49,7 +56,8 @@ class StepResult(ctypes.Structure):
               ('num_above_move', ctypes.c_uint32),
               ('disco_applied', ctypes.c_int32),
               ('cand_seed', ctypes.c_float * MAX_CANDIDATES),
-              ('cand_seg', ctypes.c_int32 * MAX_CANDIDATES)]
+              ('cand_seg', ctypes.c_int32 * MAX_CANDIDATES),
+              ('num_deleted', ctypes.c_uint32)]
 
 
 class CommitCounts(ctypes.Structure):

@@ -527,7 +527,7 @@ int grid_for(long total, int block = 256) {
 
 extern "C" {
 
-int ffn_abi_version(void) { return 1; }
+int ffn_abi_version(void) { return 2; }
 
 const char* ffn_last_error(void) { return g_error.c_str(); }
 
@@ -1045,7 +1045,7 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, e->count_blocks,
                      params->move_threshold, params->disco_seed_threshold,
-                     h_results, h_seq, step_id);
+                     params->deleted_threshold, h_results, h_seq, step_id);
   hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, e->count_blocks,
                      params->disco_seed_threshold);

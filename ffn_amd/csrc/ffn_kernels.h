@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(512) void faces_kernel(
     StepItems si, Geom g, const float* __restrict__ logits,
     const float* __restrict__ in_seed,
     const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
-    float disco_thr, ffn_step_result* __restrict__ results,
+    float disco_thr, float deleted_thr, ffn_step_result* __restrict__ results,
     unsigned* __restrict__ seq, unsigned step_id) {
   __shared__ unsigned s_cnt[8];
   __shared__ ffn_step_result s_res;
@@ -1242,6 +1242,17 @@ __global__ __launch_bounds__(512) void faces_kernel(
         s_res.cand_seg[lane - 1] = gv;
       }
     }
+  } else {
+    // keep_history (inference.py:420-423): voxels that were confidently part
+    // of the object and that this prediction (before the disco bias) deletes
+    unsigned deleted = 0;
+    if (deleted_thr == deleted_thr) {  // NaN = not requested
+      for (int v = lane; v < g.V; v += 64)
+        deleted += (old[v] >= deleted_thr && lg[v] < 0.0f) ? 1u : 0u;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) deleted += __shfl_xor(deleted, off);
+    }
+    if (lane == 0) s_res.num_deleted = deleted;
   }
   __syncthreads();
   // Publish from ONE wave: copy the record into pinned host memory, make it

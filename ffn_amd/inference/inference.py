@@ -628,14 +628,15 @@ class DeviceCanvas(Canvas):
     self._pending = None
     self._step_req = _lib.StepRequest()
     self._step_params = _lib.StepParams()
-    if kwargs.get('keep_history'):
-      raise NotImplementedError('keep_history needs host-resident logits')
     super().__init__(model_info, exec_client, image, options, **kwargs)
     if np.any(self._pred_delta != 0):
       raise NotImplementedError('pred size must equal seed size')
     self._step_params.pad_value = self.options.pad_value
     self._step_params.move_threshold = self.options.move_threshold
     self._step_params.disco_seed_threshold = self.options.disco_seed_threshold
+    if self._keep_history and self.options.disco_seed_threshold >= 0:
+      # history_deleted (inference.py:420-423) is counted on the device
+      self._step_params.deleted_threshold = float(np.float32(logit(0.8)))
     self._pred_size_t = tuple(int(v) for v in self._pred_size)
     self._fast_policy = (
         type(self.movement_policy) is movement.FaceMaxMovementPolicy)
@@ -737,6 +738,9 @@ class DeviceCanvas(Canvas):
   def _finish_step(self, res):
     """Caches the post-step point values and wraps the face maxima."""
     pos, sp, cands = self._pending
+    if self._keep_history:
+      if self.options.disco_seed_threshold >= 0:
+        self.history_deleted.append(int(res.num_deleted))
     cs, cg = res.cand_seed, res.cand_seg
     self._cache = {c: (cs[k], cg[k]) for k, c in enumerate(cands)}
     self._cached_start = (sp, res.start_logit)
@@ -817,6 +821,8 @@ class DeviceCanvas(Canvas):
             if pos[a] > mx[a]:
               mx[a] = pos[a]
           num_iters += 1
+          if self._keep_history:
+            self.history.append(pos)
           t0 = time.time()
           self._policy_update(pred, pos)
           hot[4] += 1

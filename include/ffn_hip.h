@@ -40,6 +40,9 @@ typedef struct ffn_step_params {
   float pad_value;             /* NaN -> pad substitution  (inference.py:406-407) */
   float move_threshold;        /* disco mean test + counters (inference.py:429)   */
   float disco_seed_threshold;  /* < 0 disables the disco bias (inference.py:416)  */
+  float deleted_threshold;     /* keep_history (inference.py:420-423): count voxels
+                                  with old seed >= this and new logit < 0; NaN =
+                                  do not count                                    */
 } ffn_step_params;
 
 /* One FoV step request (one entry per canvas in a batched call). */
@@ -65,6 +68,8 @@ typedef struct ffn_step_result {
   int32_t disco_applied;  /* 1 if the disco mask was applied                   */
   float   cand_seed[FFN_MAX_CANDIDATES];  /* seed[candidate] after the paste   */
   int32_t cand_seg[FFN_MAX_CANDIDATES];   /* segmentation[candidate]           */
+  uint32_t num_deleted;   /* history_deleted entry of this step (see
+                             ffn_step_params.deleted_threshold), else 0        */
 } ffn_step_result;
 
 /* Result of the per-segment commit reduction (inference.py:614-646). */

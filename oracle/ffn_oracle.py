@@ -341,6 +341,10 @@ class OracleCanvas:
     if self.disco_seed_threshold >= 0:
       th_max = logit(0.5)
       old_seed = self.seed[sel]
+      # keep_history record (inference.py:420-423)
+      with np.errstate(invalid='ignore'):
+        self.last_deleted = int(np.sum(
+            (old_seed >= np.float32(logit(0.8))) & (logits < th_max)))
       if np.mean(logits >= self.move_threshold) > self.disco_seed_threshold:
         with np.errstate(invalid='ignore'):
           mask = (old_seed < th_max) & (logits > old_seed)

@@ -115,12 +115,16 @@ class EmulatedDeviceClient(executor.ExecutorClient):
     cnt = int(np.sum(logits >= np.float32(params.move_threshold)))
     disco = (params.disco_seed_threshold >= 0 and
              cnt / logits.size > params.disco_seed_threshold)
+    res = _lib.StepResult()
+    if params.deleted_threshold == params.deleted_threshold:
+      with np.errstate(invalid='ignore'):
+        res.num_deleted = int(np.sum(
+            (old >= np.float32(params.deleted_threshold)) & (logits < 0)))
     if disco:
       with np.errstate(invalid='ignore'):
         mask = (old < 0) & (logits > old)
       logits[mask] = old[mask]
     h.seed[sel] = logits
-    res = _lib.StepResult()
     scores, idx = ffn_oracle.face_maxima(self.deltas, logits)
     c = self.fov // 2
     k = 0

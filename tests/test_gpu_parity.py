@@ -144,7 +144,8 @@ def test_canvas_step_matches_oracle(engine, fib25_blob):
   canvas.init_seed(start, oc.init_activation)
   oc.seed[start] = oc.init_activation
   params = _lib.StepParams(oc.pad_value, oc.move_threshold,
-                           oc.disco_seed_threshold)
+                           oc.disco_seed_threshold,
+                           float(np.float32(ffn_oracle.logit(0.8))))
   positions = [start, (30, 30, 44), (38, 30, 36), (30, 22, 36), (30, 30, 44)]
   cands = [(30, 30, 44), (38, 30, 36), (20, 20, 20), (47, 43, 55)]
   for pos in positions:
@@ -160,6 +161,7 @@ def test_canvas_step_matches_oracle(engine, fib25_blob):
     assert np.allclose(list(res.face_score), scores, atol=TOL)
     assert list(res.face_index) == [int(i) for i in idx]
     assert abs(res.start_logit - oc.seed[start]) <= TOL
+    assert abs(int(res.num_deleted) - oc.last_deleted) <= 2  # |logit| ~ TOL ties
     for k, c in enumerate(cands):
       a, b = res.cand_seed[k], oc.seed[c]
       assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= TOL

@@ -190,6 +190,28 @@ def test_canvas_reproduces_reference_run(fib25_blob, device):
               int(k): v for k, v in origins.items()}
 
 
+def test_keep_history_host_and_device_canvas_agree(fib25_blob):
+  """keep_history (inference.py:420-423, 520-521): the device canvas gets the
+  per-step deleted-voxel count from the step result."""
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells56.npz'))
+  r = _request()
+  info = _info()
+  image = synthetic.normalize(g['volume'])
+  runs = []
+  for device in (False, True):
+    client = (EmulatedDeviceClient(inference_utils.Counters(), fib25_blob, 12,
+                                   (33, 33, 33), (8, 8, 8)) if device else
+              _OracleClient(fib25_blob))
+    canvas = inference.make_canvas(info, client, image, r.inference_options,
+                                   movement_policy_fn=movement.get_policy_fn(
+                                       r, info), keep_history=True)
+    n = canvas.segment_at(tuple(int(v) for v in g['seeds'][0]))
+    assert len(canvas.history) == n == len(canvas.history_deleted)
+    runs.append(([tuple(int(v) for v in p) for p in canvas.history],
+                 [int(v) for v in canvas.history_deleted]))
+  assert runs[0] == runs[1] and len(runs[0][0]) > 0
+
+
 def test_device_canvas_checkpoint_roundtrip(fib25_blob, tmp_path):
   g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells56.npz'))
   r = _request()
@@ -329,9 +351,9 @@ def test_model_geometry_and_weight_blob(fib25_variables):
 def test_step_struct_layout_matches_header():
   """ctypes mirrors of the C structs: sizes must match include/ffn_hip.h."""
   import ctypes
-  assert ctypes.sizeof(_lib.StepParams) == 12
+  assert ctypes.sizeof(_lib.StepParams) == 16
   assert ctypes.sizeof(_lib.StepRequest) == 4 * (3 + 3 + 1 + 3 * 16)
-  assert ctypes.sizeof(_lib.StepResult) == 4 * (6 + 6 + 6 + 3 + 16 + 16)
+  assert ctypes.sizeof(_lib.StepResult) == 4 * (6 + 6 + 6 + 3 + 16 + 16 + 1)
   assert ctypes.sizeof(_lib.CommitCounts) == 24
 
 
