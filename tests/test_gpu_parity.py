@@ -613,3 +613,47 @@ def test_sharded_volume_end_to_end(fib25_model, tmp_path):
   plain, _ = ffn_dist.merge_segmentations(info['local_results'], shape, 0, 1)
   assert len(info['edges']) > 0
   assert len(np.unique(merged)) < len(np.unique(plain))
+
+
+def test_anisotropic_canvas_step_matches_oracle():
+  """C5 geometry on the canvas path: FoV zyx (21, 41, 41), deltas (5, 10, 10),
+  depth 3: gather, paste, disco and the six NON-square face argmaxes
+  (21x21 / 11x21 / 11x21) against the oracle, step by step."""
+  from ffn_amd import _lib
+  from ffn_amd import engine as hip_engine
+  from ffn_amd import synthetic
+  from ffn_amd.training.models import convstack_3d
+  from oracle import ffn_oracle
+  fov, deltas, depth = (21, 41, 41), (5, 10, 10), 3
+  variables = ffn_oracle.random_weights(depth, seed=8, stddev=0.06)
+  m = convstack_3d.ConvStack3DFFNModel(fov_size=list(fov[::-1]),
+                                       deltas=list(deltas[::-1]), depth=depth)
+  m.set_variables(variables)
+  eng = hip_engine.HipEngine.from_model(m, max_batch=1)
+  blob = ffn_oracle.weights_blob(variables, depth)
+  vol = synthetic.normalize(synthetic.cells_volume((40, 90, 96), seed=3))
+  canvas = eng.create_canvas(vol)
+  oc = ffn_oracle.OracleCanvas(vol, blob, depth, fov, deltas,
+                               ffn_oracle.Options())
+  start = (20, 45, 48)
+  canvas.init_seed(start, oc.init_activation)
+  oc.seed[start] = oc.init_activation
+  params = _lib.StepParams(oc.pad_value, oc.move_threshold,
+                           oc.disco_seed_threshold)
+  positions = [start, (20, 45, 58), (25, 45, 48), (20, 35, 48), (15, 50, 53),
+               (20, 45, 58)]
+  for pos in positions:
+    req = _lib.StepRequest()
+    req.pos[:] = pos
+    req.start_pos[:] = start
+    req.num_candidates = 0
+    res = eng.step1(canvas, req, params)
+    logits = oc.update_at(pos)
+    scores, idx = ffn_oracle.face_maxima(deltas, logits)
+    assert np.allclose(list(res.face_score), scores, atol=TOL)
+    assert list(res.face_index) == [int(i) for i in idx]
+    got = canvas.read_seed()
+    assert np.array_equal(np.isnan(got), np.isnan(oc.seed))
+    assert np.nanmax(np.abs(got - oc.seed)) <= TOL
+  canvas.close()
+  eng.close()
