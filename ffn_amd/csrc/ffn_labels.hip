@@ -249,7 +249,11 @@ __global__ __launch_bounds__(kThreads) void cc_init_kernel(
   if (!valid) return;
   if (v == 0) {
     parent[i] = kBackground;
-    if (leader) atomicMin(first_zero, i);
+    // one hot address: look before the atomic (the minimum settles after the
+    // first few workgroups, later ones only read)
+    if (leader && i < __hip_atomic_load(first_zero, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT))
+      atomicMin(first_zero, i);
   } else {
     parent[i] = i - (u32)(lane - src);
   }

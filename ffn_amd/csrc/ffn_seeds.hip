@@ -7,6 +7,7 @@
 #pragma clang fp contract(off)
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -101,14 +102,28 @@ __global__ __launch_bounds__(kThreads) void gauss_kernel(
   const int len = axis == 0 ? s.nz : axis == 1 ? s.ny : s.nx;
   const int l = axis == 0 ? z : axis == 1 ? y : x;
   double t = (double)in[i] * w[radius];
-  for (int ii = -radius; ii < 0; ++ii) {
-    const double a = (double)in[neighbour(s, axis, z, y, x,
-                                          reflect_index(l + ii, len))];
-    const double b = (double)in[neighbour(s, axis, z, y, x,
-                                          reflect_index(l - ii, len))];
-    const double pair = a + b;
-    const double prod = pair * w[ii + radius];
-    t = t + prod;
+  if (l >= radius && l + radius < len) {
+    // interior: every tap is in range, constant stride (same sums, same order)
+    const size_t stride = axis == 2 ? 1 : axis == 1 ? (size_t)s.nx
+                                                    : (size_t)s.ny * s.nx;
+    const float* lo = in + i - (size_t)radius * stride;
+    const float* hi = in + i + (size_t)radius * stride;
+    for (int k = 0; k < radius; ++k) {
+      const double pair = (double)lo[(size_t)k * stride] +
+                          (double)hi[-(ptrdiff_t)((size_t)k * stride)];
+      const double prod = pair * w[k];
+      t = t + prod;
+    }
+  } else {
+    for (int ii = -radius; ii < 0; ++ii) {
+      const double a = (double)in[neighbour(s, axis, z, y, x,
+                                            reflect_index(l + ii, len))];
+      const double b = (double)in[neighbour(s, axis, z, y, x,
+                                            reflect_index(l - ii, len))];
+      const double pair = a + b;
+      const double prod = pair * w[ii + radius];
+      t = t + prod;
+    }
   }
   out[i] = (float)t;
 }
