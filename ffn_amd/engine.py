@@ -157,7 +157,6 @@ class HipEngine:
     (at most two steps in flight; see ffn_canvas_step_submit)."""
     n = len(canvases)
     slot = self._submit_slot
-    self._submit_slot ^= 1
     carr, rarr = self._slot_canvas_arr[slot], self._slot_req_arr[slot]
     for k in range(n):
       carr[k] = canvases[k]._h
@@ -166,6 +165,7 @@ class HipEngine:
     check(self._lib.ffn_canvas_step_submit(self._h, n, carr, rarr,
                                            ctypes.byref(params),
                                            ctypes.byref(ticket)))
+    self._submit_slot ^= 1  # only a successful submit occupies the slot
     self._ticket_slot[ticket.value] = slot
     return ticket.value
 

@@ -657,3 +657,73 @@ def test_anisotropic_canvas_step_matches_oracle():
     assert np.nanmax(np.abs(got - oc.seed)) <= TOL
   canvas.close()
   eng.close()
+
+
+def test_step_submit_wait_contract(engine, fib25_blob):
+  """Two steps in flight: results identical to blocking steps, and the error
+  behaviour of the split call (third submit, canvas in two steps, bad ticket)."""
+  import ctypes
+  from ffn_amd import _lib
+  from ffn_amd import synthetic
+  vols = [synthetic.normalize(synthetic.cells_volume((48, 48, 48), seed=40 + k))
+          for k in range(4)]
+  params = _lib.StepParams(-2.9444389343, 2.1972243786, 0.0)
+  start = (24, 24, 24)
+
+  def make():
+    cs = [engine.create_canvas(v) for v in vols]
+    for c in cs:
+      c.init_seed(start, 2.9444386959)
+    return cs
+
+  def req(pos):
+    r = _lib.StepRequest()
+    r.pos[:] = pos
+    r.start_pos[:] = start
+    r.num_candidates = 0
+    return r
+
+  def snapshot(res, n):
+    return [(tuple(res[k].face_score), tuple(res[k].face_index),
+             res[k].start_logit, res[k].num_above_move) for k in range(n)]
+
+  # blocking reference: canvases {0,1} then {2,3}, two rounds
+  a = make()
+  want = []
+  for pos in (start, (24, 24, 30)):
+    want.append(snapshot(engine.step(a[:2], [req(pos)] * 2, params), 2))
+    want.append(snapshot(engine.step(a[2:], [req(pos)] * 2, params), 2))
+  seeds_want = [c.read_seed() for c in a]
+  for c in a:
+    c.close()
+  # the same with both groups in flight
+  b = make()
+  got = []
+  for pos in (start, (24, 24, 30)):
+    t0 = engine.step_submit(b[:2], [req(pos)] * 2, params)
+    t1 = engine.step_submit(b[2:], [req(pos)] * 2, params)
+    lib = _lib.load()
+    # a third step cannot be queued; neither can a canvas already in flight
+    tk = ctypes.c_uint32(0)
+    arr = (ctypes.c_void_p * 1)()
+    arr[0] = b[0]._h
+    r1 = req(pos)
+    assert lib.ffn_canvas_step_submit(engine._h, 1, arr,
+                                      ctypes.byref(r1),
+                                      ctypes.byref(params),
+                                      ctypes.byref(tk)) < 0
+    assert b'in flight' in lib.ffn_last_error()
+    got.append(snapshot(engine.step_wait(t0), 2))
+    got.append(snapshot(engine.step_wait(t1), 2))
+  assert got == want
+  for c, s in zip(b, seeds_want):
+    assert np.array_equal(c.read_seed(), s, equal_nan=True)
+  # one slot busy: a canvas of that step cannot join the next one
+  t0 = engine.step_submit(b[:1], [req(start)], params)
+  with pytest.raises(_lib.FFNHipError, match='in flight'):
+    engine.step_submit(b[:1], [req(start)], params)
+  engine.step_wait(t0)
+  res = (_lib.StepResult * 1)()
+  assert _lib.load().ffn_canvas_step_wait(engine._h, 123456789, res) < 0
+  for c in b:
+    c.close()
