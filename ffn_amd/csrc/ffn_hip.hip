@@ -128,6 +128,21 @@ struct ffn_canvas {
   int32_t* seg = nullptr;
   int cz = 0, cy = 0, cx = 0;
   size_t nvox = 0;
+  // Bounding box of every seed voxel that may differ from NaN since the last
+  // clear: Canvas.init_seed (inference.py:443-450) clears the WHOLE volume per
+  // seed (62.5 MB at 250^3, 4.3 GB at 1024^3); here only this box is re-filled.
+  int dirty_lo[3] = {0, 0, 0};
+  int dirty_hi[3] = {0, 0, 0};  // exclusive; lo >= hi: nothing dirty
+
+  void mark_dirty(const int lo[3], const int hi[3]) {
+    const int dims[3] = {cz, cy, cx};
+    const bool empty = dirty_lo[0] >= dirty_hi[0];
+    for (int k = 0; k < 3; ++k) {
+      const int l = std::max(lo[k], 0), h = std::min(hi[k], dims[k]);
+      dirty_lo[k] = empty ? l : std::min(dirty_lo[k], l);
+      dirty_hi[k] = empty ? h : std::max(dirty_hi[k], h);
+    }
+  }
 };
 
 int ffn_canvas_view(ffn_canvas* c, FfnCanvasView* out) {
@@ -976,8 +991,26 @@ int ffn_canvas_init_seed(ffn_canvas* c, const int32_t pos[3], float value) {
   ffn_engine* e = c->engine;
   if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
-  hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, e->stream,
-                     reinterpret_cast<uint32_t*>(c->seed), 0x7fc00000u, c->nvox);
+  if (c->dirty_lo[0] < c->dirty_hi[0]) {
+    long total = 0;
+    Box b = make_box(c, c->dirty_lo, c->dirty_hi, &total);
+    if ((size_t)total * 2 >= c->nvox) {  // most of the volume: linear fill
+      hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, e->stream,
+                         reinterpret_cast<uint32_t*>(c->seed), 0x7fc00000u,
+                         c->nvox);
+    } else if (total > 0) {
+      hipLaunchKernelGGL((box_fill_kernel<uint32_t>), dim3(grid_for(total)),
+                         dim3(256), 0, e->stream,
+                         reinterpret_cast<uint32_t*>(c->seed), b, total,
+                         0x7fc00000u);
+    }
+  }
+  {
+    const int lo[3] = {pos[0], pos[1], pos[2]};
+    const int hi[3] = {pos[0] + 1, pos[1] + 1, pos[2] + 1};
+    c->dirty_lo[0] = c->dirty_hi[0] = 0;  // clean, then the seed point itself
+    c->mark_dirty(lo, hi);
+  }
   const size_t ci = ((size_t)pos[0] * c->cy + pos[1]) * c->cx + pos[2];
   hipLaunchKernelGGL(set_seed_point_kernel, dim3(1), dim3(1), 0, e->stream,
                      c->seed, ci, value);
@@ -1022,6 +1055,12 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     for (int k2 = 0; k2 < e->slot_n[other]; ++k2)
       if (e->slot_canvas[other][k2] == c)
         return fail(FFN_ERR_STATE, "canvas %d already has a step in flight", k);
+    {
+      const int lo[3] = {r.pos[0] - half[0], r.pos[1] - half[1], r.pos[2] - half[2]};
+      const int hi[3] = {r.pos[0] + half[0] + 1, r.pos[1] + half[1] + 1,
+                         r.pos[2] + half[2] + 1};
+      const_cast<ffn_canvas*>(c)->mark_dirty(lo, hi);
+    }
     StepItem& it = h_items[k];
     it.image = c->image;
     it.seed = c->seed;
@@ -1343,6 +1382,7 @@ int ffn_canvas_read_segmentation(ffn_canvas* c, const int32_t lo[3],
 
 int ffn_canvas_write_seed(ffn_canvas* c, const int32_t lo[3], const int32_t hi[3],
                           const float* src) {
+  if (c && lo && hi) c->mark_dirty(lo, hi);
   return box_write<float>(c, c ? c->seed : nullptr, lo, hi, src);
 }
 

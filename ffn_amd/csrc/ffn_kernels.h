@@ -1329,6 +1329,13 @@ __global__ void box_write_kernel(T* __restrict__ vol, Box b, long total,
     vol[box_index(b, e)] = src[e];
 }
 
+template <typename T>
+__global__ void box_fill_kernel(T* __restrict__ vol, Box b, long total, T value) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x)
+    vol[box_index(b, e)] = value;
+}
+
 __global__ void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, size_t n) {
   // 16-byte stores, grid-stride: the per-seed "seed.clear()" (storage.py:69-71).
   const size_t n4 = n / 4;
