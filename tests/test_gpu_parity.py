@@ -727,3 +727,46 @@ def test_step_submit_wait_contract(engine, fib25_blob):
   assert _lib.load().ffn_canvas_step_wait(engine._h, 123456789, res) < 0
   for c in b:
     c.close()
+
+
+def test_large_canvas_offsets_beyond_2gib(engine, fib25_blob):
+  """A canvas whose arrays exceed 2 GiB (539 M voxels): a step in the far
+  corner must address the right voxels (size_t index math in every kernel)."""
+  from ffn_amd import _lib
+  from oracle import ffn_oracle
+  shape = (1100, 700, 700)
+  rng = np.random.RandomState(5)
+  image = np.zeros(shape, np.float32)
+  pos = (1100 - 20, 700 - 22, 700 - 19)
+  lo = [p - 16 for p in pos]
+  sel = tuple(slice(l, l + 33) for l in lo)
+  image[sel] = rng.normal(0, 1, (33, 33, 33)).astype(np.float32)
+  canvas = engine.create_canvas(image)
+  del image
+  canvas.init_seed(pos, 2.9444386959)
+  params = _lib.StepParams(-2.9444389343, 2.1972243786, 0.0)
+  req = _lib.StepRequest()
+  req.pos[:] = pos
+  req.start_pos[:] = pos
+  req.num_candidates = 1
+  req.candidates[0][:] = (pos[0] - 8, pos[1], pos[2])
+  res = engine.step1(canvas, req, params)
+  rng = np.random.RandomState(5)
+  fov = rng.normal(0, 1, (33, 33, 33)).astype(np.float32)
+  seed = np.full((33, 33, 33), np.float32(-2.9444389343), np.float32)
+  seed[16, 16, 16] = np.float32(2.9444386959)
+  want = ffn_oracle.forward(fov[None], seed[None], fib25_blob, 12)[0]
+  got = canvas.read_seed(lo, [l + 33 for l in lo])
+  # disco bias: positions whose old seed was NaN keep the new logits
+  assert np.abs(got - want).max() <= TOL
+  assert abs(res.start_logit - want[16, 16, 16]) <= TOL
+  assert abs(res.cand_seed[0] - want[8, 16, 16]) <= TOL
+  # nothing else was touched; a far-away voxel is still NaN, the point API agrees
+  assert np.isnan(canvas.read_seed((0, 0, 0), (4, 4, 4))).all()
+  sv, gv = canvas.read_point((lo[0] - 1, lo[1], lo[2]))
+  assert np.isnan(sv) and gv == 0
+  # second seed elsewhere: the dirty-box clear wipes the first FoV
+  canvas.init_seed((40, 40, 40), 1.0)
+  assert np.isnan(canvas.read_seed(lo, [l + 33 for l in lo])).all()
+  assert canvas.read_point((40, 40, 40))[0] == 1.0
+  canvas.close()

@@ -1,5 +1,5 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -6
-timeout 300 python bench.py --steps 1500 --warmup 100 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-260
+free -g | head -2
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "large_canvas" 2>&1 | tail -12
