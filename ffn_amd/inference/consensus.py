@@ -1,6 +1,10 @@
-"""Consensus between FFN segmentations (reference ffn/inference/consensus.py)."""
+"""Consensus between FFN segmentations.
 
-import logging
+Entry points and semantics of reference ffn/inference/consensus.py
+(`compute_consensus_for_segmentations` :30-57, `compute_consensus` :60-96); the
+voxel work (joint histogram of the two label volumes, relabelling) runs on the
+GPU through `segmentation.split_segmentation_by_intersection`.
+"""
 
 import numpy as np
 
@@ -8,34 +12,32 @@ from . import request as request_lib
 from . import segmentation
 from . import storage
 
+_SPLIT = request_lib.ConsensusRequest.CONSENSUS_SPLIT
+
 
 def compute_consensus_for_segmentations(v1, v2, request):
-  """Split consensus of two segmentations (consensus.py:30-57): the
-  intersection is computed on the GPU, ids are then narrowed."""
-  if request.type == request_lib.ConsensusRequest.CONSENSUS_SPLIT:
-    segmentation.split_segmentation_by_intersection(v1, v2,
-                                                    request.split_min_size)
-    v1 = segmentation.reduce_id_bits(v1)
-  else:
+  """Split consensus: every (id in v1, id in v2) overlap of at least
+  `request.split_min_size` voxels becomes its own segment; the largest overlap
+  of an id keeps that id.  Returns v1 narrowed to the smallest uint type."""
+  if request.type != _SPLIT:
     raise ValueError('Unsupported mode: %s' % request.type)
-  return v1
+  segmentation.split_segmentation_by_intersection(v1, v2,
+                                                  request.split_min_size)
+  # narrowed only now: the split mints ids above v1.max()
+  return segmentation.reduce_id_bits(v1)
 
 
 def compute_consensus(corner, request):
-  """Consensus segmentation between two FFN subvolumes (consensus.py:60-96).
+  """Consensus of the two subvolumes at `corner` (z, y, x) named by the
+  request's SegmentationSources.
 
-  Returns (uint array zyx, {segment id: origin info of segmentation1}).
+  Returns (uint zyx array, {segment id: origin info}) -- origins are those of
+  segmentation1 for the ids that survive.
   """
-  v1, v1_origins = storage.load_segmentation_from_source(
-      request.segmentation1, corner)
-  logging.info('consensus: v1 data loaded')
-  v2, _ = storage.load_segmentation_from_source(request.segmentation2, corner)
-  logging.info('consensus: v2 data loaded')
-  v1 = compute_consensus_for_segmentations(v1, v2, request)
-  relabeled_origins = {}
-  for seg_id in np.unique(v1):
-    if seg_id == 0:
-      continue
-    if seg_id in v1_origins:
-      relabeled_origins[seg_id] = v1_origins[seg_id]
-  return v1, relabeled_origins
+  first, origins = storage.load_segmentation_from_source(request.segmentation1,
+                                                         corner)
+  second, _ = storage.load_segmentation_from_source(request.segmentation2,
+                                                    corner)
+  merged = compute_consensus_for_segmentations(first, second, request)
+  alive = set(int(i) for i in np.unique(merged)) - {0}
+  return merged, {k: v for k, v in origins.items() if int(k) in alive}

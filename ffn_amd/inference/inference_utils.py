@@ -1,8 +1,11 @@
 """Counters and timers -- the source of the benchmark metric.
 
-Mirror of reference ffn/inference/inference_utils.py:32-198: `StatCounter`,
-`Counters` (per-subvolume counters propagate to the parent), `timer_counter`
-(`<name>-calls`, `<name>-time-ms`), `TimedIter`.
+API-compatible with reference ffn/inference/inference_utils.py:32-198
+(`StatCounter.Increment/IncrementBy/Set/value`, `Counters[...]`,
+`get_sub_counters`, `dump/dumps/loads`, `timer_counter`, `TimedIter`) because
+canvases, executors and result files use it; the implementation is this
+repository's own and tuned for the per-FoV-step path (a slotted counter, a
+class-based timer context instead of a generator, one lock per container).
 
 FoV-steps/sec = `update_at-calls` / `segment_all-time-ms`; voxels/sec =
 `voxels-segmented` / the same wall time (reference inference.py:398,555,648).
@@ -10,12 +13,11 @@ FoV-steps/sec = `update_at-calls` / `segment_all-time-ms`; voxels/sec =
 One deliberate deviation: the reference truncates every increment with
 `int(x)` (inference_utils.py:61), so sub-millisecond timer intervals
 accumulate as 0.  Here increments are accumulated exactly and truncated only
-when dumped (`dump` / `dumps` still emit integers, as the reference does).
+when written out (`dump` / `dumps` still emit integers, as the reference does).
 """
 
 from __future__ import annotations
 
-import contextlib
 import json
 import os
 import tempfile
@@ -25,114 +27,123 @@ import time
 MSEC_IN_SEC = 1000
 
 
-# pylint: disable=invalid-name
 class StatCounter:
-  """Counter with the MR counter interface (Increment / IncrementBy / Set)."""
+  """One named tally; increments also flow into the parent container's tally
+  of the same name (a subvolume's counters roll up into the runner's)."""
 
-  def __init__(self, update, name, parent=None):
-    self._counter = 0
-    self._update = update
-    self._lock = threading.Lock()
-    self._parent = parent
+  __slots__ = ('name', '_total', '_parent', '_lock')
+
+  def __init__(self, update=None, name='', parent=None):
+    del update  # status export hook of the reference: nothing to export here
     self.name = name
+    self._total = 0
+    self._parent = parent
+    self._lock = threading.Lock()
+
+  # pylint: disable=invalid-name
+  def IncrementBy(self, x, export=True):
+    del export
+    node = self
+    while node is not None:  # this tally, then every ancestor's
+      with node._lock:
+        node._total += x
+      node = node._parent
 
   def Increment(self):
     self.IncrementBy(1)
 
-  def IncrementBy(self, x, export=True):
-    with self._lock:
-      self._counter += x
-      self._update()
-    if self._parent is not None:
-      self._parent.IncrementBy(x)
-
   def Set(self, x, export=True):
-    self.IncrementBy(x - self._counter, export=export)
-
-  def __repr__(self):
-    return 'StatCounter(total=%g)' % (self.value)
+    self.IncrementBy(x - self._total, export)
+  # pylint: enable=invalid-name
 
   @property
   def value(self):
-    return self._counter
+    return self._total
 
-
-# pylint: enable=invalid-name
+  def __repr__(self):
+    return 'StatCounter(total=%g)' % self._total
 
 
 class Counters:
-  """Container for counters; sub-containers forward to their parent."""
+  """Name -> StatCounter, created on first use.  `get_sub_counters()` makes a
+  child container whose tallies roll up into this one."""
 
   def __init__(self, parent=None):
-    self._lock = threading.Lock()
-    self.reset()
     self.parent = parent
+    self._guard = threading.Lock()
+    self._tallies = {}
 
   def reset(self):
-    with self._lock:
-      self._counters = {}
-    self._last_update = 0
-
-  def __getitem__(self, name: str) -> StatCounter:
-    return self.get(name)
+    with self._guard:
+      self._tallies = {}
 
   def get(self, name: str, **kwargs) -> StatCounter:
-    with self._lock:
-      c = self._counters.get(name)
-      if c is None:
-        c = self._make_counter(name, **kwargs)
-        self._counters[name] = c
-      return c
+    del kwargs
+    tally = self._tallies.get(name)
+    if tally is None:
+      with self._guard:
+        tally = self._tallies.get(name)
+        if tally is None:
+          up = self.parent.get(name) if self.parent is not None else None
+          tally = self._tallies[name] = StatCounter(None, name, up)
+    return tally
+
+  __getitem__ = get
 
   def __iter__(self):
-    return iter(list(self._counters.items()))
-
-  def _make_counter(self, name: str, **kwargs) -> StatCounter:
-    del kwargs
-    parent = self.parent.get(name) if self.parent is not None else None
-    return StatCounter(self.update_status, name, parent)
+    return iter(list(self._tallies.items()))
 
   def update_status(self):
-    pass
+    """Hook of the reference (periodic status export); intentionally empty."""
 
   def get_sub_counters(self):
     return Counters(self)
 
+  def _snapshot(self):
+    return {name: int(t.value) for name, t in sorted(self._tallies.items())}
+
   def dump(self, filename: str):
-    d = os.path.dirname(os.path.abspath(filename))
-    with tempfile.NamedTemporaryFile('w', dir=d, delete=False) as fd:
-      for name, counter in sorted(self._counters.items()):
-        fd.write('%s: %d\n' % (name, counter.value))
-      tmp = fd.name
-    os.replace(tmp, filename)
+    """`name: value` lines, written atomically (reference :139-143)."""
+    folder = os.path.dirname(os.path.abspath(filename))
+    with tempfile.NamedTemporaryFile('w', dir=folder, delete=False) as fd:
+      fd.writelines('%s: %d\n' % kv for kv in self._snapshot().items())
+    os.replace(fd.name, filename)
 
   def dumps(self) -> str:
-    state = {name: int(counter.value) for name, counter in self._counters.items()}
-    return json.dumps(state)
+    return json.dumps(self._snapshot())
 
   def loads(self, encoded_state: str):
-    state = json.loads(encoded_state)
-    for name, value in state.items():
-      self[name].Set(value, export=False)
+    for name, value in json.loads(encoded_state).items():
+      self.get(name).Set(value, export=False)
 
 
-@contextlib.contextmanager
-def timer_counter(counters: Counters, name: str, export=True,
-                  increment: int = 1):
-  """Counts calls and milliseconds spent inside the context."""
-  assert isinstance(counters, Counters)
-  counter = counters.get(name + '-calls', export=export)
-  timer = counters.get(name + '-time-ms', export=export)
-  start_time = time.time()
-  try:
-    yield timer, counter
-  finally:
-    counter.IncrementBy(increment)
-    timer.IncrementBy((time.time() - start_time) * MSEC_IN_SEC)
+class timer_counter:  # pylint: disable=invalid-name
+  """`with timer_counter(counters, 'x'):` adds `increment` to `x-calls` and the
+  elapsed milliseconds to `x-time-ms` (reference :147-175)."""
+
+  __slots__ = ('_calls', '_timer', '_increment', '_t0')
+
+  def __init__(self, counters: Counters, name: str, export=True,
+               increment: int = 1):
+    del export
+    assert isinstance(counters, Counters)
+    self._calls = counters.get(name + '-calls')
+    self._timer = counters.get(name + '-time-ms')
+    self._increment = increment
+
+  def __enter__(self):
+    self._t0 = time.time()
+    return self._timer, self._calls
+
+  def __exit__(self, exc_type, exc, tb):
+    self._calls.IncrementBy(self._increment)
+    self._timer.IncrementBy((time.time() - self._t0) * MSEC_IN_SEC)
+    return False
 
 
 class TimedIter:
-  """Wraps an iterator with a timing counter."""
+  """Iterator proxy that charges the time spent producing each item to
+  `<counter_name>-calls` / `-time-ms` (reference :178-198)."""
 
   def __init__(self, it, counters, counter_name):
     self.it = it
@@ -144,8 +155,6 @@ class TimedIter:
 
   def __next__(self):
     with timer_counter(self.counters, self.counter_name):
-      ret = next(self.it)
-    return ret
+      return next(self.it)
 
-  def next(self):
-    return self.__next__()
+  next = __next__
