@@ -50,7 +50,16 @@ def main():
             ' conv32 avg %.2f us (%d launches, %.1f TF/s in-kernel)' %
             (variant, b, dt * 1e6, b / dt, b * flop / dt / 1e12,
              ms / n * 1e3, n, b * 2.0 * 27 * 32 * 32 * 33**3 / (ms / n * 1e-3) / 1e12))
+  # stateless boundary (ffn_predict): host seed + image in, host logits out
   eng.set_option('conv_variant', 2)
+  for b in (1, maxb):
+    eng.predict(seed[:b], img[:b])
+    t0 = time.perf_counter()
+    for _ in range(args.repeats):
+      eng.predict(seed[:b], img[:b])
+    dt = (time.perf_counter() - t0) / args.repeats
+    print('variant 2 ffn_predict (PCIe-inclusive, %d x 3 x 144 KB) batch %2d: '
+          '%8.1f us/call  %8.1f FoV/s' % (b, b, dt * 1e6, b / dt))
   for policy in (1, 2, 0):
     eng.set_option('store_policy', policy)
     for b in (1, 8):
