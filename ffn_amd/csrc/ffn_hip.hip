@@ -81,6 +81,7 @@ struct ffn_engine {
   int dbg_clock = 0;
   size_t lds_bytes_c = 0;
   int conv_variant = 2;       // 0 = conv32 (simple), 1 = conv32p, 2 = conv32c
+  float* h_io = nullptr;      // pinned staging of ffn_predict: seed, image, logits
   float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
   float* up_seed = nullptr;
   float* seed_raw = nullptr;  // raw (NaN-preserving) seed FoV of the current step
@@ -621,6 +622,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   E_TRY(hipMalloc(&e->up_seed, vbytes));
   E_TRY(hipMalloc(&e->seed_raw, vbytes));
   E_TRY(hipMalloc(&e->logits, vbytes));
+  E_TRY(hipHostMalloc(&e->h_io, 3 * vbytes, hipHostMallocDefault));
   E_TRY(hipMemset(e->up_image, 0, vbytes));
   E_TRY(hipMemset(e->up_seed, 0, vbytes));
   E_TRY(hipMalloc(&e->count, sizeof(unsigned) * max_batch *
@@ -761,6 +763,7 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->weights);
   (void)hipFree(e->d_items);
   (void)hipFree(e->d_scratch);
+  if (e->h_io) (void)hipHostFree(e->h_io);
   if (e->h_items) (void)hipHostFree(e->h_items);
   if (e->h_results) (void)hipHostFree(e->h_results);
   if (e->h_seq) (void)hipHostFree(e->h_seq);
@@ -818,17 +821,24 @@ int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
   if (!e->weights_set) return fail(FFN_ERR_STATE, "weights not set");
   HIP_TRY(hipSetDevice(e->device));
   const size_t bytes = (size_t)n * e->g.V * sizeof(float);
-  HIP_TRY(hipMemcpyAsync(e->up_seed, seed, bytes, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->up_image, image, bytes, hipMemcpyHostToDevice, e->stream));
+  // through engine-owned pinned buffers: a pageable hipMemcpy costs ~80 us each
+  float* h_seed = e->h_io;
+  float* h_image = e->h_io + (size_t)e->max_batch * e->g.V;
+  float* h_logits = e->h_io + 2 * (size_t)e->max_batch * e->g.V;
+  std::memcpy(h_seed, seed, bytes);
+  std::memcpy(h_image, image, bytes);
+  HIP_TRY(hipMemcpyAsync(e->up_seed, h_seed, bytes, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->up_image, h_image, bytes, hipMemcpyHostToDevice, e->stream));
   StepItems si;
   int rc = dense_items(e, n, &si);
   if (rc) return rc;
   // NaNs in a caller-provided seed stay NaN (the reference would feed them to TF).
   rc = run_stack(e, n, si, std::nanf(""), INFINITY);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(logits_out, e->logits, bytes, hipMemcpyDeviceToHost,
+  HIP_TRY(hipMemcpyAsync(h_logits, e->logits, bytes, hipMemcpyDeviceToHost,
                          e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  std::memcpy(logits_out, h_logits, bytes);
   return FFN_OK;
 }
 

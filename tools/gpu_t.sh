@@ -1,5 +1,5 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-free -g | head -2
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "large_canvas" 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "predict or threaded" 2>&1 | tail -4
+timeout 400 python tools/gpu_microbench.py --batch 1 8 2>&1 | grep -E "ffn_predict"
