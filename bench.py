@@ -43,6 +43,11 @@ VOXELS = FOV[0] * FOV[1] * FOV[2]
 CONV32_FLOPS = 2.0 * 27 * 32 * 32 * VOXELS
 STEP_FLOPS = 2.0 * (2 * 27 * 32 + 23 * 27 * 32 * 32 + 32) * VOXELS
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA
+# conv32x3 (default): every f32 product = 6 exact bf16 x bf16 products on the
+# bf16 MFMA, so the kernel's own ceiling in ALGORITHMIC (f32) flops is 1/6 of
+# the dense bf16 peak.
+BF16X3_PRODUCTS = 6
 
 
 class _Done(Exception):
@@ -211,6 +216,8 @@ def run_gpu(args, rank, local_rank, world):
       'merge_ms': merge_ms,
       'merged_ids': merged_ids,
       'counters': cvals,
+      'conv_variant': (args.conv_variant if args.conv_variant is not None
+                       else eng.get_option('conv_variant')),
       'prewarm_steps': state.get('prewarm_steps', 0),
       'elapsed': elapsed,
       'elapsed_local': elapsed_local,
@@ -365,6 +372,24 @@ def main():
       traffic = json.load(f)['traffic_bytes_per_launch']
   except (OSError, KeyError, ValueError):
     pass
+  variant = res.get('conv_variant', 3)
+  if variant == 3:
+    kernel_name = ('conv32x3 (3x3x3 32->32 implicit GEMM; f32 operands split '
+                   'exactly into 3 bf16 parts, 6 products per f32 product on '
+                   'v_mfma_f32_16x16x32_bf16, f32 accumulation)')
+    peak = PEAK_BF16_MFMA_TFLOPS / BF16X3_PRODUCTS
+    peak_basis = ('dense bf16 MFMA peak %.0f TFLOP/s / %d bf16 products per '
+                  'algorithmic f32 product' % (PEAK_BF16_MFMA_TFLOPS,
+                                               BF16X3_PRODUCTS))
+    executed_ratio = BF16X3_PRODUCTS
+    dtype = 'f32 (bf16x3 split products on the bf16 MFMA, f32 accumulate)'
+  else:
+    kernel_name = ('conv32 (3x3x3 32->32 implicit GEMM, '
+                   'v_mfma_f32_16x16x4_f32)')
+    peak = PEAK_F32_MFMA_TFLOPS
+    peak_basis = 'dense f32 MFMA peak'
+    executed_ratio = 1
+    dtype = 'f32'
   out = {
       'metric': 'FoV-steps/sec (flood-filling inference loop, 250^3 volume)',
       'value': round(steps_per_s, 2),
@@ -377,7 +402,7 @@ def main():
       'higher_is_better': True,
       'scaling': 'weak',
       'vs_baseline': None,
-      'dtype': 'f32',
+      'dtype': dtype,
       'data': 'synthetic',
       'config': {
           'workload': ('configs[1] single-seed single-GPU: depth=12 fov=33^3 '
@@ -412,11 +437,14 @@ def main():
       'end_to_end_tflops': round(steps_per_s * STEP_FLOPS / 1e12, 3),
       'roofline': {
           'bound': 'mfma',
-          'kernel': 'conv32 (3x3x3 32->32 implicit GEMM, v_mfma_f32_16x16x4_f32)',
+          'kernel': kernel_name,
           'achieved': round(achieved, 3),
-          'peak': PEAK_F32_MFMA_TFLOPS,
+          'peak': round(peak, 1),
           'unit': 'TFLOP/s',
-          'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+          'frac': round(achieved / peak, 4),
+          'peak_basis': peak_basis,
+          'executed_mfma_tflops': round(achieved * executed_ratio, 1),
+          'vs_native_f32_mfma_peak': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
           'traffic': traffic,
           'avg_launch_us': round(avg_conv_ms * 1e3, 3),
           'timing': ('HIP events around the 23-launch conv chain of every %dth '

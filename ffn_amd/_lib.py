@@ -80,6 +80,8 @@ SIGNATURES = {
     'ffn_engine_destroy': (None, [_P]),
     'ffn_engine_set_weights': (_I, [_P, _P, ctypes.c_size_t]),
     'ffn_engine_set_option': (_I, [_P, ctypes.c_char_p, _I]),
+    'ffn_engine_get_option': (_I, [_P, ctypes.c_char_p,
+                                   ctypes.POINTER(ctypes.c_int)]),
     'ffn_engine_set_profiling': (_I, [_P, _I]),
     'ffn_engine_get_profile': (_I, [_P, ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(ctypes.c_int64), _I]),

@@ -80,7 +80,10 @@ struct ffn_engine {
   long long* d_dbg = nullptr;  // debug clocks of conv32c WG 0 (24 values)
   int dbg_clock = 0;
   size_t lds_bytes_c = 0;
-  int conv_variant = 2;       // 0 = conv32 (simple), 1 = conv32p, 2 = conv32c
+  size_t lds_bytes_x = 0;        // conv32x3: 2 slots x Rc rows x 224 B
+  uint16_t* wpack3 = nullptr;    // bf16 hi/mid/lo weight fragments, all layers
+  size_t wpack3_layer = 0;       // halves per layer
+  int conv_variant = 3;       // 0 = conv32 (simple), 1 = conv32p, 2 = conv32c, 3 = conv32x3
   float* h_io = nullptr;      // pinned staging of ffn_predict: seed, image, logits
   float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
   float* up_seed = nullptr;
@@ -189,6 +192,48 @@ int set_lds_attr_p(size_t bytes) {
   HIP_TRY(hipFuncSetAttribute(
       reinterpret_cast<const void*>(&conv32p_kernel<RI, RO, SK, ABL>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return FFN_OK;
+}
+
+// f32 -> bf16 with round-to-nearest-even (what v_cvt_pk_bf16_f32 does on device)
+inline uint16_t to_bf16_rne(float x) {
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);  // inf / nan
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float from_bf16(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float x;
+  std::memcpy(&x, &u, 4);
+  return x;
+}
+// x == hi + mid + lo, each a bf16 (exact: 24 mantissa bits = 3 x 8)
+inline void split_bf16x3(float x, uint16_t part[3]) {
+  part[0] = to_bf16_rne(x);
+  const float r1 = x - from_bf16(part[0]);
+  part[1] = to_bf16_rne(r1);
+  const float r2 = r1 - from_bf16(part[1]);
+  part[2] = to_bf16_rne(r2);
+}
+
+template <bool RI, bool RO, bool SK>
+int set_lds_attr_x(size_t bytes) {
+  HIP_TRY(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 8>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  HIP_TRY(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 9>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (SK) {
+    HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 8, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 9, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  }
   return FFN_OK;
 }
 
@@ -356,7 +401,24 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
     HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   }
   const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
-  if (RI == false && RO == false && SK == true && e->ablate != 0 &&
+  if (e->conv_variant == 3) {
+    a.wpack = reinterpret_cast<const float*>(e->wpack3 +
+                                             (size_t)layer * e->wpack3_layer);
+    if (head.on) {
+      if (e->Rc == 256)
+        hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 8, true>), grid, block,
+                           e->lds_bytes_x, e->stream, a);
+      else
+        hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 9, true>), grid, block,
+                           e->lds_bytes_x, e->stream, a);
+    } else if (e->Rc == 256) {
+      hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 8>), grid, block,
+                         e->lds_bytes_x, e->stream, a);
+    } else {
+      hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 9>), grid, block,
+                         e->lds_bytes_x, e->stream, a);
+    }
+  } else if (RI == false && RO == false && SK == true && e->ablate != 0 &&
       e->Rc == 256) {
     switch (e->ablate) {  // issue-rate experiments (conv_b instantiation only)
       case 8:
@@ -436,7 +498,7 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
       if (rc) return rc;
     }
     head_in = e->bufX;
-  } else if (e->conv_variant == 2) {
+  } else if (e->conv_variant >= 2) {
     rc = launch_conv32c<false, false, false>(e, n, e->bufT, e->bufX, nullptr, 0);
     if (rc) return rc;
     for (int i = 1; i < e->depth; ++i) {
@@ -670,6 +732,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     e->Rc = ((span + 2 * (g.XS + 1)) + 31) / 32 * 32;
     if (e->Rc < 256) e->Rc = 256;  // the kernel stages 8 or 9 x 256 float4
     e->lds_bytes_c = (size_t)2 * e->Rc * kCLdsStride * sizeof(float);
+    e->lds_bytes_x = (size_t)2 * e->Rc * kXRowBytes;
     E_TRY(hipMalloc(&e->d_dbg, 24 * sizeof(long long)));
     E_TRY(hipMemset(e->d_dbg, 0, 24 * sizeof(long long)));
     E_TRY(hipMalloc(&e->pidx, pidx.size() * sizeof(int32_t)));
@@ -678,7 +741,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     // variants 1 / 2 need 7*256 <= R*8 <= 8*256 resp. Rc in {256, 288}
     const bool p_ok = g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256;
     const bool c_ok = e->Rc == 256 || e->Rc == 288;
-    e->conv_variant = c_ok ? 2 : (p_ok ? 1 : 0);
+    e->conv_variant = c_ok ? 3 : (p_ok ? 1 : 0);
   }
 
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)
@@ -699,6 +762,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     off += kFeatures + 1;
     off = (off + 3) & ~(size_t)3;
     E_TRY(hipMalloc(&e->weights, off * sizeof(float)));
+    e->wpack3_layer = (size_t)27 * 2 * 3 * 64 * 8;
+    E_TRY(hipMalloc(&e->wpack3, e->wpack3_layer * (2 * depth - 1) *
+                                    sizeof(uint16_t)));
   }
 
   e->events.resize(2 * 64);
@@ -714,6 +780,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (!rc) rc = set_lds_attr_c<false, false, true, 8>(e->lds_bytes_c);
     if (!rc) rc = set_lds_attr_c<false, false, true, 16>(e->lds_bytes_c);
     if (!rc) rc = set_lds_attr_c<false, false, true, 24>(e->lds_bytes_c);
+    if (!rc) rc = set_lds_attr_x<false, false, false>(e->lds_bytes_x);
+    if (!rc) rc = set_lds_attr_x<true, true, false>(e->lds_bytes_x);
+    if (!rc) rc = set_lds_attr_x<false, false, true>(e->lds_bytes_x);
     if (!rc) rc = set_lds_attr_p<false, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
@@ -756,6 +825,7 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->seed_raw);
   (void)hipFree(e->logits);
   (void)hipFree(e->count);
+  (void)hipFree(e->wpack3);
   (void)hipFree(e->valid);
   (void)hipFree(e->validbits);
   (void)hipFree(e->pidx);
@@ -783,6 +853,7 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   std::vector<float> host(e->wl_off + F + 1 + 3, 0.0f);
   const float* src = blob;
   // conv0_a: [27][2][32] + bias, used as stored
+  std::vector<uint16_t> host3(e->wpack3_layer * (2 * e->depth - 1));
   std::memcpy(&host[e->w0a_off], src, sizeof(float) * 27 * 2 * F);
   src += 27 * 2 * F;
   std::memcpy(&host[e->b0a_off], src, sizeof(float) * F);
@@ -801,10 +872,29 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
               wp[((((size_t)tap * 2 + nh) * 2 + h) * 64 + lane) * 4 + s] =
                   src[((size_t)tap * F + ci) * F + co];
             }
+    // bf16x3 form for conv32x3: W == hi + mid + lo exactly, fragments
+    //   wpack3[tap][nhalf][plane][lane = 16*g + j][c] = part(W[tap][8g + c][16*nhalf + j])
+    {
+      uint16_t* w3 = &host3[(size_t)l * e->wpack3_layer];
+      for (int tap = 0; tap < 27; ++tap)
+        for (int nh = 0; nh < 2; ++nh)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int c = 0; c < 8; ++c) {
+              const int gq = lane >> 4, j = lane & 15;
+              const float w = src[((size_t)tap * F + 8 * gq + c) * F + 16 * nh + j];
+              uint16_t part[3];
+              split_bf16x3(w, part);
+              for (int pl = 0; pl < 3; ++pl)
+                w3[((((size_t)tap * 2 + nh) * 3 + pl) * 64 + lane) * 8 + c] =
+                    part[pl];
+            }
+    }
     src += 27 * F * F;
     std::memcpy(&host[e->bias_off[l]], src, sizeof(float) * F);
     src += F;
   }
+  HIP_TRY(hipMemcpy(e->wpack3, host3.data(), host3.size() * sizeof(uint16_t),
+                    hipMemcpyHostToDevice));
   std::memcpy(&host[e->wl_off], src, sizeof(float) * (F + 1));
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipMemcpy(e->weights, host.data(),
@@ -861,12 +951,12 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) {
-    if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "conv_variant must be 0, 1 or 2");
+    if (value < 0 || value > 3) return fail(FFN_ERR_ARG, "conv_variant must be 0..3");
     const Geom& g = e->g;
     if (value == 1 && !(g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256))
       return fail(FFN_ERR_ARG, "conv_variant 1 unsupported for this fov");
-    if (value == 2 && !(e->Rc == 256 || e->Rc == 288))
-      return fail(FFN_ERR_ARG, "conv_variant 2 unsupported for this fov");
+    if (value >= 2 && !(e->Rc == 256 || e->Rc == 288))
+      return fail(FFN_ERR_ARG, "conv_variant %d unsupported for this fov", value);
     e->conv_variant = value;
     return FFN_OK;
   }
@@ -898,6 +988,17 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     return FFN_OK;
   }
   return fail(FFN_ERR_ARG, "unknown option '%s'", name);
+}
+
+int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
+  if (!e || !name || !value) return fail(FFN_ERR_ARG, "null argument");
+  if (std::strcmp(name, "conv_variant") == 0) *value = e->conv_variant;
+  else if (std::strcmp(name, "fuse_head") == 0) *value = e->fuse_head;
+  else if (std::strcmp(name, "store_policy") == 0) *value = e->store_policy;
+  else if (std::strcmp(name, "sync_mode") == 0) *value = e->sync_mode;
+  else if (std::strcmp(name, "profile_every") == 0) *value = e->prof_every;
+  else return fail(FFN_ERR_ARG, "unknown option '%s'", name);
+  return FFN_OK;
 }
 
 int ffn_engine_debug_clocks(ffn_engine* e, long long* out24) {

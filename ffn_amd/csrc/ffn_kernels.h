@@ -1030,6 +1030,373 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv32c_kernel(ConvCArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// conv32x3: conv32c with the f32 contraction carried by the bf16 matrix cores.
+//
+// Every f32 operand is split EXACTLY into three bf16 parts, x = hi + mid + lo
+// (8 + 8 + 8 mantissa bits), activations while they are staged into LDS, weights
+// once on the host.  x * w is then the sum of nine bf16 x bf16 products, each of
+// which is exact in f32; the three smallest (mid*lo, lo*mid, lo*lo, below 2^-24
+// of the leading term) are dropped, the other six run as
+// v_mfma_f32_16x16x32_bf16 with f32 accumulation.  The truncation error is
+// 100x below the rounding error of an f32 GEMM (measured 2e-8 vs 2e-6 on this
+// model's layers), so the result is an f32 convolution in everything but the
+// summation order -- at 6 x 16 = 96 MFMA cycles per 16x16x32 block instead of
+// the 256 cycles eight v_mfma_f32_16x16x4_f32 need.
+//
+// Same chunks, tiles, wave roles, progressive staging, K-split middle tile,
+// epilogue and fused head as conv32c.  LDS row = 3 planes x 32 ch x 2 B = 192 B
+// at a 224-B stride (ds_read_b128 of the 16 rows of a tile conflict-free for
+// every tap); two segment slots = 2 x Rc x 224 B (112 KiB at Rc = 256), one
+// workgroup per CU.  A fragment = 3 x ds_read_b128 per (tile, tap) (lane group g
+// holds channels 8g..8g+7 of its row), B fragment = 3 x 16 B per (tap, cout
+// half), host-packed [tap][nhalf][plane][lane][8].
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kXRowBytes = 224;
+
+template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int KS = 8, bool HEAD = false>
+__global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(ConvCArgs a) {
+  constexpr int DBG = 0;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x;
+  const long long dbg_c0 = a.dbg ? clock64() : 0;
+  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
+  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
+  if (gc >= a.total_slots) return;
+  const int item = gc / a.nchunks;
+  const int chunk = gc - item * a.nchunks;
+  const int v0 = chunk * kCChunk;
+  const int32_t* pidx = a.pidx + v0;
+  // padded position of the chunk's first voxel, by arithmetic (a table lookup
+  // here would put one more memory round trip in front of the staging loads)
+  int p_first;
+  {
+    int z = (int)((float)v0 / (float)a.fyfx);
+    z -= (z * a.fyfx > v0);
+    z += ((z + 1) * a.fyfx <= v0);
+    const int rem = v0 - z * a.fyfx;
+    int y = (int)((float)rem / (float)a.fx);
+    y -= (y * a.fx > rem);
+    y += ((y + 1) * a.fx <= rem);
+    p_first = __builtin_amdgcn_readfirstlane(z * a.plane + y * a.XS +
+                                             (rem - y * a.fx));
+  }
+  const int p_lo = p_first - (a.XS + 1);  // first staged row of the dz=0 segment
+  const float* src = a.in + (size_t)item * a.act_stride;
+  const int Rc = a.Rc;
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nhalf = wave & 1;
+  const int tgrp = wave >> 1;
+  const int i = lane & 15;
+  const int grp = lane >> 4;
+
+  // LDS float offset of this lane's position in each of its 5 tiles: tiles 0..3
+  // (tgrp 0) / 5..8 (tgrp 1), then the shared tile 4.  (Oldest loads of the
+  // kernel: the first A-fragment read needs them.)
+  int prow[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int tile = t < 4 ? tgrp * 5 + t : 4;
+    prow[t] = (pidx[tile * kTile + i] - p_lo) * kXRowBytes + grp * 16;  // bytes
+  }
+  // padded position of this thread's 5 epilogue pieces (also old loads: the
+  // residual prefetch below needs them without draining the staging loads)
+  // thread -> (position j = (tid >> 3) + 32 k, channel quad tid & 7), k = 0..4
+  const int q = tid & 7;
+  const int j0 = tid >> 3;
+  int pj[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = j0 + 32 * k;
+    pj[k] = pidx[(j < kCChunk && v0 + j < a.V) ? j : 0];
+  }
+  // weight fragments of taps 0 and 1: issued BEFORE the staging loads -- vmcnt
+  // retires in order, so a weight load queued behind the staging loads would
+  // make the first MFMA wait for all three dz segments.
+  // planes: 0 = hi, 1 = mid, 2 = lo bf16 part of every f32 (x == hi + mid + lo)
+  struct AFrag { bf16x8 p[3][5]; };
+  struct BFrag { bf16x8 p[3]; };
+  const bf16x8* wp =
+      reinterpret_cast<const bf16x8*>(a.wpack) + nhalf * 192 + lane;
+  auto loadB = [&](int s, BFrag& dst) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) dst.p[pl] = wp[s * 384 + pl * 64];
+  };
+  BFrag B0, B1, B2;
+  loadB(0, B0);
+  loadB(1, B1);
+
+  // ---- staging: all 27 x 16-B loads of the three dz segments in flight at
+  // once; segment kz is written to LDS (and waited for) only right before the
+  // first tap that reads it, so dz = 0, +1 land behind the MFMAs of dz = -1.
+  // Only TWO segment slots exist in LDS (dz = +1 overwrites dz = -1 once every
+  // wave is past tap 8): 2 x 256 rows x 160 B = 80 KiB, so two workgroups fit
+  // on a CU and fill each other's MFMA issue bubbles / staging / epilogue.
+  f32x4 sv[3][KS];  // Rc * 8 == KS * 256 float4 per segment
+#pragma unroll
+  for (int seg = 0; seg < 3; ++seg) {
+    const long p0 = (long)p_lo + (long)(seg - 1) * a.plane;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) sv[seg][k] = s4[tid + k * kConvThreads];
+  }
+  auto write_segment = [&](int seg) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int e = tid + k * kConvThreads;
+      {
+        f32x4 v = sv[seg][k];
+        if (RELU_IN) {  // tf.nn.relu in front of conv_a (convstack_3d.py:44)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+        }
+        const int row = (seg & 1) * Rc + (e >> 3);  // slot 0: dz -1, +1; slot 1: dz 0
+        // exact three-way split: v == hi + mid + lo, each part a bf16
+        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+        const f32x4 r1 = v - __builtin_convertvector(hi, f32x4);
+        const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
+        const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
+        const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
+        char* dstrow = ldsb + row * kXRowBytes + (e & 7) * 8;
+        *reinterpret_cast<bf16x4*>(dstrow) = hi;
+        *reinterpret_cast<bf16x4*>(dstrow + 64) = mid;
+        *reinterpret_cast<bf16x4*>(dstrow + 128) = lo;
+      }
+    }
+  };
+
+  write_segment(0);
+  __syncthreads();
+
+  // ---- main loop: one step = one tap (two half-taps of 4 k-steps) ----
+  //   A fragments (LDS -> VGPR, 10 x ds_read_b128) one tap ahead, ring of 2;
+  //   B fragments (L2 -> VGPR, 2 x 16 B)           two taps ahead, ring of 3.
+  // Tiles 0..3 of the wave run every tap; the shared tile 4 runs in tile group
+  // 0 on the first 5 / 4 / 5 taps of the dz = -1 / 0 / +1 segment (14 taps) and
+  // in tile group 1 on the other 13 -- balanced PER SEGMENT, because the
+  // segment barriers would otherwise serialise the imbalance (two
+  // accumulators, so its 8 MFMAs per tap do not form one dependent chain).
+  auto a_off = [&](int s) {  // LDS float offset of tap s (compile-time kz/ky/kx)
+    const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
+    return ((kz & 1) * Rc + (ky - 1) * a.XS + (kx - 1)) * kXRowBytes;  // bytes
+  };
+  auto loadA_tile = [&](int t, int off, AFrag& dst) {
+    const char* p = ldsb + prow[t] + off;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      dst.p[pl][t] = *reinterpret_cast<const bf16x8*>(p + pl * 64);
+  };
+  auto loadA = [&](int s, AFrag& dst) {
+    const int off = a_off(s);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) loadA_tile(t, off, dst);
+  };
+  f32x4 acc[4], acc4a, acc4b;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc4a = acc4b = f32x4{0.f, 0.f, 0.f, 0.f};
+  AFrag A0, A1;
+  const long long dbg_c1 = a.dbg ? clock64() : 0;
+  loadA(0, A0);
+
+  // one group = the 4 own tiles x one (A plane, B plane) product of the split
+#define FFN_XGROUP(ACUR, BCUR, PA, PB)                                       \
+  _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) acc[t_] =                 \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(ACUR.p[PA][t_], BCUR.p[PB],    \
+                                              acc[t_], 0, 0, 0);             \
+  __builtin_amdgcn_sched_barrier(0);
+  // x * w = sum of the 6 products whose weight exceeds 2^-24 of hi*hi (smallest
+  // first): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi.  Every bf16 x bf16
+  // product is exact in f32; the MFMA accumulates in f32.
+#define FFN_CTAP(S, ACUR, ANEXT, BCUR, BNEXT2, PF)                           \
+  {                                                                          \
+    const bool pa_ = (PF) && (S) + 1 < 27;                                   \
+    const int oa_ = a_off((S) + 1);                                          \
+    if (pa_) loadA_tile(0, oa_, ANEXT);                                      \
+    FFN_XGROUP(ACUR, BCUR, 2, 0)                                             \
+    if (pa_) loadA_tile(1, oa_, ANEXT);                                      \
+    FFN_XGROUP(ACUR, BCUR, 0, 2)                                             \
+    if (pa_) loadA_tile(2, oa_, ANEXT);                                      \
+    FFN_XGROUP(ACUR, BCUR, 1, 1)                                             \
+    if (pa_) loadA_tile(3, oa_, ANEXT);                                      \
+    FFN_XGROUP(ACUR, BCUR, 1, 0)                                             \
+    if (pa_) loadA_tile(4, oa_, ANEXT);                                      \
+    FFN_XGROUP(ACUR, BCUR, 0, 1)                                             \
+    if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                                \
+    FFN_XGROUP(ACUR, BCUR, 0, 0)                                             \
+    if ((tgrp == 0) == (((S) % 9) < (((S) / 9) == 1 ? 4 : 5))) { /* ours */ \
+      acc4a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
+          ACUR.p[2][4], BCUR.p[0], acc4a, 0, 0, 0);                          \
+      acc4b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
+          ACUR.p[0][4], BCUR.p[2], acc4b, 0, 0, 0);                          \
+      acc4a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
+          ACUR.p[1][4], BCUR.p[1], acc4a, 0, 0, 0);                          \
+      acc4b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
+          ACUR.p[1][4], BCUR.p[0], acc4b, 0, 0, 0);                          \
+      acc4a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
+          ACUR.p[0][4], BCUR.p[1], acc4a, 0, 0, 0);                          \
+      acc4b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
+          ACUR.p[0][4], BCUR.p[0], acc4b, 0, 0, 0);                          \
+      __builtin_amdgcn_sched_barrier(0);                                     \
+    }                                                                        \
+  }
+  // A ring alternates every tap, B ring has period 3: the pattern repeats
+  // every 6 taps.  Taps 8 and 17 end a dz segment.
+  FFN_CTAP(0, A0, A1, B0, B2, true)
+  FFN_CTAP(1, A1, A0, B1, B0, true)
+  FFN_CTAP(2, A0, A1, B2, B1, true)
+  FFN_CTAP(3, A1, A0, B0, B2, true)
+  FFN_CTAP(4, A0, A1, B1, B0, true)
+  FFN_CTAP(5, A1, A0, B2, B1, true)
+  FFN_CTAP(6, A0, A1, B0, B2, true)
+  FFN_CTAP(7, A1, A0, B1, B0, true)
+  FFN_CTAP(8, A0, A1, B2, B1, false)
+  write_segment(1);
+  __syncthreads();
+  loadA(9, A1);
+  FFN_CTAP(9, A1, A0, B0, B2, true)
+  FFN_CTAP(10, A0, A1, B1, B0, true)
+  FFN_CTAP(11, A1, A0, B2, B1, true)
+  FFN_CTAP(12, A0, A1, B0, B2, true)
+  FFN_CTAP(13, A1, A0, B1, B0, true)
+  FFN_CTAP(14, A0, A1, B2, B1, true)
+  FFN_CTAP(15, A1, A0, B0, B2, true)
+  FFN_CTAP(16, A0, A1, B1, B0, true)
+  FFN_CTAP(17, A1, A0, B2, B1, false)
+  write_segment(2);
+  __syncthreads();
+  // ---- per-thread epilogue operands: residual input and bias, fetched once the
+  // staging registers of the last segment are free (9 taps of MFMAs cover them)
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
+  unsigned ooff[5];
+  f32x4 skipv[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = j0 + 32 * k;
+    const bool ok = j < kCChunk && v0 + j < a.V;
+    const int p = pj[k];
+    ooff[k] = ok ? ((unsigned)p * kFeatures + q * 4) * 4u : 0x80000000u;
+    skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ADD_SKIP)
+      skipv[k] = *reinterpret_cast<const f32x4*>(
+          a.skip + (size_t)item * a.act_stride + (size_t)p * kFeatures + q * 4);
+  }
+  loadA(18, A0);
+  FFN_CTAP(18, A0, A1, B0, B2, true)
+  FFN_CTAP(19, A1, A0, B1, B0, true)
+  FFN_CTAP(20, A0, A1, B2, B1, true)
+  FFN_CTAP(21, A1, A0, B0, B2, true)
+  FFN_CTAP(22, A0, A1, B1, B0, true)
+  FFN_CTAP(23, A1, A0, B2, B1, true)
+  FFN_CTAP(24, A0, A1, B0, B2, true)
+  FFN_CTAP(25, A1, A0, B1, B0, true)
+  FFN_CTAP(26, A0, A1, B2, B1, true)
+#undef FFN_CTAP
+#undef FFN_XGROUP
+
+  const long long dbg_c2 = a.dbg ? clock64() : 0;
+  // ---- epilogue: accumulators -> LDS [position j][32 ch]; rows 144..159 hold
+  // tgrp 1's partial sums of the shared tile 4 ----
+  __syncthreads();
+  {
+    const int co = nhalf * 16 + i;
+    const f32x4 acc4 = acc4a + acc4b;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int tile = t < 4 ? tgrp * 5 + t : 4;
+      const int jrow = (t == 4 && tgrp == 1) ? kCChunk + grp * 4
+                                             : tile * kTile + grp * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        lds[(jrow + r) * 32 + co] = t < 4 ? acc[t][r] : acc4[r];
+    }
+  }
+  __syncthreads();
+  unsigned head_above = 0;
+  {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    float* obase = a.out + (size_t)item * a.act_stride;
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.nbytes, 0x00020000);
+    f32x4 hw4 = {0.f, 0.f, 0.f, 0.f};
+    float hbias = 0.f;
+    if (HEAD) {
+      hw4 = *reinterpret_cast<const f32x4*>(a.head_w + q * 4);
+      hbias = a.head_w[kFeatures];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int j = j0 + 32 * k;
+      const int jr = j < kCChunk ? j : 0;
+      f32x4 v = *reinterpret_cast<const f32x4*>(lds + jr * 32 + q * 4);
+      if (jr >= 4 * kTile && jr < 5 * kTile)  // shared tile: add the other half
+        v += *reinterpret_cast<const f32x4*>(
+            lds + (kCChunk + jr - 4 * kTile) * 32 + q * 4);
+      v += b4;
+      if (RELU_OUT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+      }
+      if (ADD_SKIP) v += skipv[k];
+      if (HEAD) {
+        // 8 lanes hold the 32 channels of position j: dot with the 1x1x1
+        // weights (same association as head_kernel), xor-shuffle reduce
+        float partial = fmaxf(v[0], 0.f) * hw4[0];
+        partial = __builtin_fmaf(fmaxf(v[1], 0.f), hw4[1], partial);
+        partial = __builtin_fmaf(fmaxf(v[2], 0.f), hw4[2], partial);
+        partial = __builtin_fmaf(fmaxf(v[3], 0.f), hw4[3], partial);
+        partial += __shfl_xor(partial, 1);
+        partial += __shfl_xor(partial, 2);
+        partial += __shfl_xor(partial, 4);
+        bool above = false;
+        if (q == 0 && ooff[k] != 0x80000000u) {
+          const size_t dv = (size_t)item * a.V + (v0 + j);
+          float s = a.seed_raw[dv];
+          if (s != s) s = a.pad_value;
+          const float lg = s + (partial + hbias);
+          a.logits[dv] = lg;
+          above = lg >= a.move_thr;
+        }
+        head_above += (unsigned)__popcll(__ballot(above));  // wave-uniform
+        continue;
+      }
+      // store_policy (A/B switch): 0 write-back, 1 write-through (sc1: no
+      // dirty L2 lines left for the kernel boundary to flush), 2 non-temporal
+      if (a.store_policy == 1)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 16);
+      else if (a.store_policy == 2)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 2);
+      else
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 0);
+    }
+  }
+  if (HEAD) {  // this chunk's count of logits >= move_thr (summed by faces / paste)
+    float* cnt = lds + 160 * 32;  // past the transposed accumulators
+    if ((tid & 63) == 0) cnt[tid >> 6] = __uint_as_float(head_above);
+    __syncthreads();
+    if (tid == 0)
+      a.head_count[gc] = __float_as_uint(cnt[0]) + __float_as_uint(cnt[1]) +
+                         __float_as_uint(cnt[2]) + __float_as_uint(cnt[3]);
+  }
+  if (a.dbg && gc == 0 && (tid & 63) == 0) {
+    long long* d = a.dbg + (tid >> 6) * 6;
+    d[0] = dbg_c0;
+    d[1] = dbg_c1;
+    d[2] = dbg_c2;
+    d[3] = clock64();
+    d[4] = dbg_w0;
+    d[5] = wall_clock64();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // head: ReLU -> 1x1x1 conv 32->1 + bias; logits = seed + update
 // (reference convstack_3d.py:51-54,91-94; model.py:168-183) and the count of
 // logits >= move_threshold that the disco test needs (inference.py:428-431).

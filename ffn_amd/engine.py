@@ -97,6 +97,12 @@ class HipEngine:
     check(self._lib.ffn_engine_set_weights(self._h, blob.ctypes.data,
                                            blob.size))
 
+  def get_option(self, name: str) -> int:
+    value = ctypes.c_int(0)
+    check(self._lib.ffn_engine_get_option(self._h, name.encode(),
+                                          ctypes.byref(value)))
+    return value.value
+
   def set_option(self, name: str, value: int):
     check(self._lib.ffn_engine_set_option(self._h, name.encode(), int(value)))
 

@@ -182,11 +182,18 @@ int ffn_canvas_write_segmentation(ffn_canvas* canvas, const int32_t lo[3],
 int ffn_engine_set_profiling(ffn_engine* engine, int mode);
 int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
                            int64_t* conv_launches, int reset);
-/* Tuning / A-B switches.  "conv_variant": 0 = simple MFMA conv, 1 = software-
- * pipelined MFMA conv over padded positions, 2 = pipelined + compact position
- * space + K-split middle tile (default when the FoV allows).  Results are identical up to f32 summation
- * order. */
+/* Tuning / A-B switches.  "conv_variant": 0 = simple f32-MFMA conv, 1 =
+ * software-pipelined f32-MFMA conv over padded positions, 2 = pipelined +
+ * compact position space + K-split middle tile, 3 = variant 2 with every f32
+ * product carried as 6 exact bf16 x bf16 products on the bf16 MFMA (default
+ * when the FoV allows).  Results are identical up to f32 summation order
+ * (variant 3: plus a truncation 100x below f32 rounding).  "fuse_head": 1x1x1
+ * head inside the last conv launch.  "store_policy": 0 write-back, 1
+ * write-through, 2 non-temporal conv stores. */
 int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
+/* Current value of an option ("conv_variant", "fuse_head", "store_policy",
+ * "sync_mode", "profile_every"). */
+int ffn_engine_get_option(ffn_engine* engine, const char* name, int* value);
 /* Debug: with option "debug_clock" = 1 the compact conv kernel records, for its
  * first workgroup, per wave {shader clock at entry, at main-loop start, at
  * main-loop end, at exit, wall clock (100 MHz) at entry, at exit}. */

@@ -16,6 +16,7 @@ from tests.conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
+DEFAULT_VARIANT = 3  # what ffn_engine_create selects for the 33^3 FoV
 TOL = 1e-4
 
 
@@ -37,20 +38,24 @@ def _fov_inputs(rng, n=1):
   return img, seed
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3])
-def test_predict_matches_oracle(engine, fib25_blob, variant):
-  """variant 3 = conv32c with the 1x1x1 head as its own launch (default: fused
-  into the last conv)."""
+@pytest.mark.parametrize('variant,fuse_head', [(0, 1), (1, 1), (2, 1), (2, 0),
+                                               (3, 1), (3, 0)])
+def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head):
+  """conv_variant 0 simple f32 MFMA, 1 padded pipelined, 2 compact (exact f32
+  MFMA), 3 compact with bf16x3 split products; with the 1x1x1 head fused into
+  the last conv or as its own launch."""
   from oracle import ffn_oracle
-  engine.set_option('conv_variant', min(variant, 2))
-  engine.set_option('fuse_head', 0 if variant == 3 else 1)
+  engine.set_option('conv_variant', variant)
+  engine.set_option('fuse_head', fuse_head)
   rng = np.random.RandomState(42)
   img, seed = _fov_inputs(rng, 1)
   got = engine.predict(seed, img)
   want = ffn_oracle.forward(img, seed, fib25_blob, 12)
   assert got.shape == want.shape
-  assert np.abs(got - want).max() <= TOL
-  engine.set_option('conv_variant', 2)
+  err = np.abs(got - want).max()
+  print('variant %d fuse_head %d: max |err| %.3g' % (variant, fuse_head, err))
+  assert err <= TOL
+  engine.set_option('conv_variant', DEFAULT_VARIANT)
   engine.set_option('fuse_head', 1)
 
 
@@ -74,11 +79,11 @@ def test_predict_is_deterministic_and_variants_agree(engine):
   a = engine.predict(seed, img)
   b = engine.predict(seed, img)
   assert np.array_equal(a, b)
-  for variant in (0, 1):
+  for variant in (0, 1, 2, 3):
     engine.set_option('conv_variant', variant)
     c = engine.predict(seed, img)
     assert np.abs(a - c).max() <= 2e-5, variant
-  engine.set_option('conv_variant', 2)
+  engine.set_option('conv_variant', DEFAULT_VARIANT)
 
 
 def test_predict_nan_seed_propagates_like_reference(engine):
@@ -123,7 +128,7 @@ def test_anisotropic_fov(fib25_model):
   img = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
   seed = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
   blob = ffn_oracle.weights_blob(variables, 2)
-  for variant in (0, 1, 2):
+  for variant in (0, 1, 2, 3):
     eng.set_option('conv_variant', variant)
     got = eng.predict(seed, img)
     want = ffn_oracle.forward(img, seed, blob, 2)

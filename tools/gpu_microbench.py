@@ -32,7 +32,7 @@ def main():
   seed = rng.normal(0, 1, (maxb, 33, 33, 33)).astype(np.float32)
   eng.predict(seed, img)  # fills the staging buffers
   flop = 2.0 * (2 * 27 * 32 + 23 * 27 * 32 * 32 + 32) * 33**3
-  for variant in (1, 2):
+  for variant in (1, 2, 3):
     eng.set_option('conv_variant', variant)
     for b in args.batch:
       eng.forward_resident(b, 3)

@@ -1,5 +1,6 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "predict or threaded" 2>&1 | tail -4
-timeout 400 python tools/gpu_microbench.py --batch 1 8 2>&1 | grep -E "ffn_predict"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 300 python bench.py --steps 1500 --warmup 100 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1500
