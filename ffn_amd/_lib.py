@@ -28,6 +28,14 @@ class FFNHipError(RuntimeError):
   """Raised for any non-zero return code of the C-ABI."""
 
 
+class FFNRangeError(FFNHipError):
+  """FFN_ERR_RANGE: conv_variant 4 met an operand outside the fp16 range; the
+  step changed nothing and can be repeated with conv_variant 3."""
+
+
+ERR_RANGE = -4
+
+
 class StepParams(ctypes.Structure):
   _fields_ = [('pad_value', ctypes.c_float),
               ('move_threshold', ctypes.c_float),
@@ -57,7 +65,8 @@ class StepResult(ctypes.Structure):
               ('disco_applied', ctypes.c_int32),
               ('cand_seed', ctypes.c_float * MAX_CANDIDATES),
               ('cand_seg', ctypes.c_int32 * MAX_CANDIDATES),
-              ('num_deleted', ctypes.c_uint32)]
+              ('num_deleted', ctypes.c_uint32),
+              ('range_error', ctypes.c_int32)]
 
 
 class CommitCounts(ctypes.Structure):
@@ -193,7 +202,8 @@ def load() -> ctypes.CDLL:
 def check(rc: int):
   if rc != 0:
     msg = load().ffn_last_error()
-    raise FFNHipError('libffn_hip error %d: %s' %
+    cls = FFNRangeError if rc == ERR_RANGE else FFNHipError
+    raise cls('libffn_hip error %d: %s' %
                       (rc, msg.decode('utf-8', 'replace') if msg else '?'))
 
 

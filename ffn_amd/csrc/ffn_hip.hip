@@ -83,7 +83,13 @@ struct ffn_engine {
   size_t lds_bytes_x = 0;        // conv32x3: 2 slots x Rc rows x 224 B
   uint16_t* wpack3 = nullptr;    // bf16 hi/mid/lo weight fragments, all layers
   size_t wpack3_layer = 0;       // halves per layer
-  int conv_variant = 3;       // 0 = conv32 (simple), 1 = conv32p, 2 = conv32c, 3 = conv32x3
+  uint16_t* wpack2h = nullptr;   // fp16 hi / scaled-residual fragments (variant 4)
+  size_t wpack2h_layer = 0;
+  size_t lds_bytes_h = 0;        // conv32x3<SCHEME 2>: 2 slots x Rc rows x 160 B
+  unsigned* range_flag = nullptr;  // device word: tag of the last void run
+  unsigned range_tag = 0;        // tag of the run being queued
+  bool fp16_ok = true;           // every weight inside the fp16 range
+  int conv_variant = 4;       // 0 conv32, 1 conv32p, 2 conv32c, 3 conv32x3 bf16x3, 4 fp16x2
   float* h_io = nullptr;      // pinned staging of ffn_predict: seed, image, logits
   float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
   float* up_seed = nullptr;
@@ -216,6 +222,34 @@ inline void split_bf16x3(float x, uint16_t part[3]) {
   part[1] = to_bf16_rne(r1);
   const float r2 = r1 - from_bf16(part[1]);
   part[2] = to_bf16_rne(r2);
+}
+
+// x ~= hi + 2^-11 * res with hi, res fp16 (what the device does when staging)
+inline void split_fp16x2(float x, uint16_t part[2]) {
+  const float xh = std::fabs(x) < 6.103515625e-05f ? 0.0f : x;
+  const _Float16 hi = (_Float16)xh;
+  const _Float16 res = (_Float16)((x - (float)hi) * 2048.0f);
+  std::memcpy(&part[0], &hi, 2);
+  std::memcpy(&part[1], &res, 2);
+}
+
+template <bool RI, bool RO, bool SK>
+int set_lds_attr_h(size_t bytes) {
+  HIP_TRY(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 8, false, 2>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  HIP_TRY(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 9, false, 2>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (SK) {
+    HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 8, true, 2>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 9, true, 2>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  }
+  return FFN_OK;
 }
 
 template <bool RI, bool RO, bool SK>
@@ -385,7 +419,8 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
   a.slots_per_xcd = (a.total_slots + 7) / 8;
   a.nbytes = (unsigned)((size_t)e->g.nchunks * kChunk * kFeatures * sizeof(float));
   a.store_policy = e->store_policy;
-  a.dbg = e->dbg_clock ? e->d_dbg : nullptr;
+  // clocks of ONE mid-stack launch (a conv_a: ReLU in and out, no residual)
+  a.dbg = (e->dbg_clock && layer == 3) ? e->d_dbg : nullptr;
   a.head_w = e->weights + e->wl_off;
   a.seed_raw = e->seed_raw;
   a.logits = e->logits;
@@ -401,7 +436,26 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
     HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   }
   const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
-  if (e->conv_variant == 3) {
+  a.range_flag = e->range_flag;
+  a.range_tag = e->range_tag;
+  if (e->conv_variant == 4) {
+    a.wpack = reinterpret_cast<const float*>(e->wpack2h +
+                                             (size_t)layer * e->wpack2h_layer);
+    if (head.on) {
+      if (e->Rc == 256)
+        hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 8, true, 2>), grid,
+                           block, e->lds_bytes_h, e->stream, a);
+      else
+        hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 9, true, 2>), grid,
+                           block, e->lds_bytes_h, e->stream, a);
+    } else if (e->Rc == 256) {
+      hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 8, false, 2>), grid, block,
+                         e->lds_bytes_h, e->stream, a);
+    } else {
+      hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 9, false, 2>), grid, block,
+                         e->lds_bytes_h, e->stream, a);
+    }
+  } else if (e->conv_variant == 3) {
     a.wpack = reinterpret_cast<const float*>(e->wpack3 +
                                              (size_t)layer * e->wpack3_layer);
     if (head.on) {
@@ -459,6 +513,7 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
 int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
               float move_thr) {
   const Geom& g = e->g;
+  e->range_tag = e->range_tag + 1 ? e->range_tag + 1 : 1;  // never 0
   const bool sampled = (e->stack_calls % e->prof_every) == 0;
   e->stack_calls++;
   e->prof_now = e->prof_mode == 1 && sampled;
@@ -733,6 +788,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (e->Rc < 256) e->Rc = 256;  // the kernel stages 8 or 9 x 256 float4
     e->lds_bytes_c = (size_t)2 * e->Rc * kCLdsStride * sizeof(float);
     e->lds_bytes_x = (size_t)2 * e->Rc * kXRowBytes;
+    e->lds_bytes_h = (size_t)2 * e->Rc * kHRowBytes;
     E_TRY(hipMalloc(&e->d_dbg, 24 * sizeof(long long)));
     E_TRY(hipMemset(e->d_dbg, 0, 24 * sizeof(long long)));
     E_TRY(hipMalloc(&e->pidx, pidx.size() * sizeof(int32_t)));
@@ -741,7 +797,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     // variants 1 / 2 need 7*256 <= R*8 <= 8*256 resp. Rc in {256, 288}
     const bool p_ok = g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256;
     const bool c_ok = e->Rc == 256 || e->Rc == 288;
-    e->conv_variant = c_ok ? 3 : (p_ok ? 1 : 0);
+    e->conv_variant = c_ok ? 4 : (p_ok ? 1 : 0);
   }
 
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)
@@ -765,6 +821,11 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     e->wpack3_layer = (size_t)27 * 2 * 3 * 64 * 8;
     E_TRY(hipMalloc(&e->wpack3, e->wpack3_layer * (2 * depth - 1) *
                                     sizeof(uint16_t)));
+    e->wpack2h_layer = (size_t)27 * 2 * 2 * 64 * 8;
+    E_TRY(hipMalloc(&e->wpack2h, e->wpack2h_layer * (2 * depth - 1) *
+                                     sizeof(uint16_t)));
+    E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
+    E_TRY(hipMemset(e->range_flag, 0, sizeof(unsigned)));
   }
 
   e->events.resize(2 * 64);
@@ -783,6 +844,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (!rc) rc = set_lds_attr_x<false, false, false>(e->lds_bytes_x);
     if (!rc) rc = set_lds_attr_x<true, true, false>(e->lds_bytes_x);
     if (!rc) rc = set_lds_attr_x<false, false, true>(e->lds_bytes_x);
+    if (!rc) rc = set_lds_attr_h<false, false, false>(e->lds_bytes_h);
+    if (!rc) rc = set_lds_attr_h<true, true, false>(e->lds_bytes_h);
+    if (!rc) rc = set_lds_attr_h<false, false, true>(e->lds_bytes_h);
     if (!rc) rc = set_lds_attr_p<false, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
@@ -826,6 +890,8 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->logits);
   (void)hipFree(e->count);
   (void)hipFree(e->wpack3);
+  (void)hipFree(e->wpack2h);
+  (void)hipFree(e->range_flag);
   (void)hipFree(e->valid);
   (void)hipFree(e->validbits);
   (void)hipFree(e->pidx);
@@ -854,6 +920,8 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   const float* src = blob;
   // conv0_a: [27][2][32] + bias, used as stored
   std::vector<uint16_t> host3(e->wpack3_layer * (2 * e->depth - 1));
+  std::vector<uint16_t> host2(e->wpack2h_layer * (2 * e->depth - 1));
+  bool weights_in_fp16_range = true;
   std::memcpy(&host[e->w0a_off], src, sizeof(float) * 27 * 2 * F);
   src += 27 * 2 * F;
   std::memcpy(&host[e->b0a_off], src, sizeof(float) * F);
@@ -889,12 +957,33 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
                     part[pl];
             }
     }
+    // fp16 form for conv32x3<SCHEME 2>: W ~= hi + 2^-11 * res, planes hi, res
+    {
+      uint16_t* w2 = &host2[(size_t)l * e->wpack2h_layer];
+      for (int tap = 0; tap < 27; ++tap)
+        for (int nh = 0; nh < 2; ++nh)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int c = 0; c < 8; ++c) {
+              const int gq = lane >> 4, j = lane & 15;
+              const float w = src[((size_t)tap * F + 8 * gq + c) * F + 16 * nh + j];
+              if (!(std::fabs(w) <= 65504.0f)) weights_in_fp16_range = false;
+              uint16_t part[2];
+              split_fp16x2(w, part);
+              for (int pl = 0; pl < 2; ++pl)
+                w2[((((size_t)tap * 2 + nh) * 2 + pl) * 64 + lane) * 8 + c] =
+                    part[pl];
+            }
+    }
     src += 27 * F * F;
     std::memcpy(&host[e->bias_off[l]], src, sizeof(float) * F);
     src += F;
   }
   HIP_TRY(hipMemcpy(e->wpack3, host3.data(), host3.size() * sizeof(uint16_t),
                     hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->wpack2h, host2.data(), host2.size() * sizeof(uint16_t),
+                    hipMemcpyHostToDevice));
+  e->fp16_ok = weights_in_fp16_range;
+  if (!e->fp16_ok && e->conv_variant == 4) e->conv_variant = 3;
   std::memcpy(&host[e->wl_off], src, sizeof(float) * (F + 1));
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipMemcpy(e->weights, host.data(),
@@ -927,7 +1016,20 @@ int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(h_logits, e->logits, bytes, hipMemcpyDeviceToHost,
                          e->stream));
+  unsigned flag = 0;
+  if (e->conv_variant == 4)
+    HIP_TRY(hipMemcpyAsync(&flag, e->range_flag, sizeof(flag),
+                           hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->conv_variant == 4 && flag == e->range_tag) {
+    // an operand left the fp16 range: this engine stays on the bf16x3 scheme
+    e->conv_variant = 3;
+    rc = run_stack(e, n, si, std::nanf(""), INFINITY);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h_logits, e->logits, bytes, hipMemcpyDeviceToHost,
+                           e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   std::memcpy(logits_out, h_logits, bytes);
   return FFN_OK;
 }
@@ -951,7 +1053,9 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) {
-    if (value < 0 || value > 3) return fail(FFN_ERR_ARG, "conv_variant must be 0..3");
+    if (value < 0 || value > 4) return fail(FFN_ERR_ARG, "conv_variant must be 0..4");
+    if (value == 4 && e->weights_set && !e->fp16_ok)
+      return fail(FFN_ERR_ARG, "conv_variant 4: a weight is outside the fp16 range");
     const Geom& g = e->g;
     if (value == 1 && !(g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256))
       return fail(FFN_ERR_ARG, "conv_variant 1 unsupported for this fov");
@@ -1195,10 +1299,11 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, e->count_blocks,
                      params->move_threshold, params->disco_seed_threshold,
-                     params->deleted_threshold, h_results, h_seq, step_id);
+                     params->deleted_threshold, e->range_flag, e->range_tag,
+                     h_results, h_seq, step_id);
   hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, e->count_blocks,
-                     params->disco_seed_threshold);
+                     params->disco_seed_threshold, e->range_flag, e->range_tag);
   HIP_TRY(hipGetLastError());
   e->slot_n[slot] = n;
   e->slot_ticket[slot] = step_id;
@@ -1248,6 +1353,11 @@ int ffn_canvas_step_wait(ffn_engine* e, uint32_t ticket,
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
   std::memcpy(results, h_results, sizeof(ffn_step_result) * n);
+  for (int k = 0; k < n; ++k)
+    if (results[k].range_error)
+      return fail(FFN_ERR_RANGE,
+                  "an activation left the fp16 range (conv_variant 4): the step "
+                  "changed nothing; set conv_variant 3 and repeat it");
   return FFN_OK;
 }
 

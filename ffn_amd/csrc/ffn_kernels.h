@@ -677,6 +677,10 @@ struct ConvCArgs {
   float* logits;           // [n][V]
   unsigned* head_count;    // [n * nchunks] per-chunk count of logits >= move_thr
   float pad_value, move_thr;
+  // fp16x2 scheme only: *range_flag = range_tag when an operand is outside the
+  // fp16 range (the step is then void and re-run with the bf16x3 scheme)
+  unsigned* range_flag;
+  unsigned range_tag;
 };
 
 template <int NT>
@@ -1053,11 +1057,24 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv32c_kernel(ConvCArgs a) {
 // ---------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int kXRowBytes = 224;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int kXRowBytes = 224;  // SCHEME 3: 3 planes x 64 B + 32 B pad
+constexpr int kHRowBytes = 160;  // SCHEME 2: 2 planes x 64 B + 32 B pad
+template <int SCHEME> struct XFrag { typedef bf16x8 type; };
+template <> struct XFrag<2> { typedef f16x8 type; };
 
-template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int KS = 8, bool HEAD = false>
-__global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(ConvCArgs a) {
-  constexpr int DBG = 0;
+template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int KS = 8, bool HEAD = false,
+          int SCHEME = 3>
+__global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(
+    ConvCArgs a) {
+  // SCHEME 3: bf16 hi/mid/lo planes, 6 products.  SCHEME 2: fp16 hi plane + the
+  // residual scaled by 2^11 (so that it stays a normal fp16), 3 products, the
+  // two cross products accumulate separately and join scaled by 2^-11.
+  constexpr int NP = SCHEME == 3 ? 3 : 2;
+  constexpr int kRowB = SCHEME == 3 ? kXRowBytes : kHRowBytes;
+  typedef typename XFrag<SCHEME>::type frag_t;
+  unsigned range_max = 0;  // SCHEME 2: max |operand| bit pattern seen by this thread
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x;
@@ -1101,7 +1118,7 @@ __global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(ConvCArgs a) 
 #pragma unroll
   for (int t = 0; t < 5; ++t) {
     const int tile = t < 4 ? tgrp * 5 + t : 4;
-    prow[t] = (pidx[tile * kTile + i] - p_lo) * kXRowBytes + grp * 16;  // bytes
+    prow[t] = (pidx[tile * kTile + i] - p_lo) * kRowB + grp * 16;  // bytes
   }
   // padded position of this thread's 5 epilogue pieces (also old loads: the
   // residual prefetch below needs them without draining the staging loads)
@@ -1118,13 +1135,13 @@ __global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(ConvCArgs a) 
   // retires in order, so a weight load queued behind the staging loads would
   // make the first MFMA wait for all three dz segments.
   // planes: 0 = hi, 1 = mid, 2 = lo bf16 part of every f32 (x == hi + mid + lo)
-  struct AFrag { bf16x8 p[3][5]; };
-  struct BFrag { bf16x8 p[3]; };
-  const bf16x8* wp =
-      reinterpret_cast<const bf16x8*>(a.wpack) + nhalf * 192 + lane;
+  struct AFrag { frag_t p[3][5]; };
+  struct BFrag { frag_t p[3]; };
+  const frag_t* wp =
+      reinterpret_cast<const frag_t*>(a.wpack) + nhalf * NP * 64 + lane;
   auto loadB = [&](int s, BFrag& dst) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) dst.p[pl] = wp[s * 384 + pl * 64];
+    for (int pl = 0; pl < NP; ++pl) dst.p[pl] = wp[s * 2 * NP * 64 + pl * 64];
   };
   BFrag B0, B1, B2;
   loadB(0, B0);
@@ -1155,16 +1172,36 @@ __global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(ConvCArgs a) 
           for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
         }
         const int row = (seg & 1) * Rc + (e >> 3);  // slot 0: dz -1, +1; slot 1: dz 0
-        // exact three-way split: v == hi + mid + lo, each part a bf16
-        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-        const f32x4 r1 = v - __builtin_convertvector(hi, f32x4);
-        const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
-        const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
-        const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
-        char* dstrow = ldsb + row * kXRowBytes + (e & 7) * 8;
-        *reinterpret_cast<bf16x4*>(dstrow) = hi;
-        *reinterpret_cast<bf16x4*>(dstrow + 64) = mid;
-        *reinterpret_cast<bf16x4*>(dstrow + 128) = lo;
+        char* dstrow = ldsb + row * kRowB + (e & 7) * 8;
+        if constexpr (SCHEME == 3) {
+          // exact three-way split: v == hi + mid + lo, each part a bf16
+          const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+          const f32x4 r1 = v - __builtin_convertvector(hi, f32x4);
+          const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
+          const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
+          const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
+          *reinterpret_cast<bf16x4*>(dstrow) = hi;
+          *reinterpret_cast<bf16x4*>(dstrow + 64) = mid;
+          *reinterpret_cast<bf16x4*>(dstrow + 128) = lo;
+        } else {
+          // v ~= hi + 2^-11 * res, both fp16, 22 mantissa bits together.  A hi
+          // that would be subnormal is dropped (the residual carries it), and
+          // anything outside the fp16 range raises the range flag.
+          f32x4 vh = v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            // |x| as an integer is monotonic (NaN sorts above inf): one running
+            // maximum per thread, compared with 65504 once in the epilogue
+            const unsigned mbits = __float_as_uint(v[c]) & 0x7fffffffu;
+            range_max = mbits > range_max ? mbits : range_max;
+            vh[c] = mbits < 0x38800000u ? 0.0f : v[c];  // |x| < 2^-14
+          }
+          const f16x4 hi = __builtin_convertvector(vh, f16x4);
+          const f32x4 r1 = (v - __builtin_convertvector(hi, f32x4)) * 2048.0f;
+          const f16x4 res = __builtin_convertvector(r1, f16x4);
+          *reinterpret_cast<f16x4*>(dstrow) = hi;
+          *reinterpret_cast<f16x4*>(dstrow + 64) = res;
+        }
       }
     }
   };
@@ -1182,66 +1219,84 @@ __global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(ConvCArgs a) 
   // accumulators, so its 8 MFMAs per tap do not form one dependent chain).
   auto a_off = [&](int s) {  // LDS float offset of tap s (compile-time kz/ky/kx)
     const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
-    return ((kz & 1) * Rc + (ky - 1) * a.XS + (kx - 1)) * kXRowBytes;  // bytes
+    return ((kz & 1) * Rc + (ky - 1) * a.XS + (kx - 1)) * kRowB;  // bytes
   };
   auto loadA_tile = [&](int t, int off, AFrag& dst) {
     const char* p = ldsb + prow[t] + off;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      dst.p[pl][t] = *reinterpret_cast<const bf16x8*>(p + pl * 64);
+    for (int pl = 0; pl < NP; ++pl)
+      dst.p[pl][t] = *reinterpret_cast<const frag_t*>(p + pl * 64);
   };
   auto loadA = [&](int s, AFrag& dst) {
     const int off = a_off(s);
 #pragma unroll
     for (int t = 0; t < 5; ++t) loadA_tile(t, off, dst);
   };
-  f32x4 acc[4], acc4a, acc4b;
+  // SCHEME 2: accC / acc4b collect the cross products (weight 2^-11)
+  f32x4 acc[4], accC[4], acc4a, acc4b;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < 4; ++t) acc[t] = accC[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   acc4a = acc4b = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [](const frag_t& fa, const frag_t& fb, f32x4 c) {
+    if constexpr (SCHEME == 3)
+      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, c, 0, 0, 0);
+    else
+      return __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, c, 0, 0, 0);
+  };
   AFrag A0, A1;
   const long long dbg_c1 = a.dbg ? clock64() : 0;
   loadA(0, A0);
 
   // one group = the 4 own tiles x one (A plane, B plane) product of the split
-#define FFN_XGROUP(ACUR, BCUR, PA, PB)                                       \
-  _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) acc[t_] =                 \
-      __builtin_amdgcn_mfma_f32_16x16x32_bf16(ACUR.p[PA][t_], BCUR.p[PB],    \
-                                              acc[t_], 0, 0, 0);             \
+#define FFN_XGROUP(ACC, ACUR, BCUR, PA, PB)                                  \
+  _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) ACC[t_] =                 \
+      mma(ACUR.p[PA][t_], BCUR.p[PB], ACC[t_]);                              \
   __builtin_amdgcn_sched_barrier(0);
-  // x * w = sum of the 6 products whose weight exceeds 2^-24 of hi*hi (smallest
-  // first): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi.  Every bf16 x bf16
-  // product is exact in f32; the MFMA accumulates in f32.
+  // SCHEME 3: x * w = sum of the 6 products whose weight exceeds 2^-24 of hi*hi
+  // (smallest first): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi.  Every
+  // bf16 x bf16 product is exact in f32; the MFMA accumulates in f32.
+  // SCHEME 2: hi*hi into acc, res*hi + hi*res into accC.
 #define FFN_CTAP(S, ACUR, ANEXT, BCUR, BNEXT2, PF)                           \
   {                                                                          \
     const bool pa_ = (PF) && (S) + 1 < 27;                                   \
     const int oa_ = a_off((S) + 1);                                          \
-    if (pa_) loadA_tile(0, oa_, ANEXT);                                      \
-    FFN_XGROUP(ACUR, BCUR, 2, 0)                                             \
-    if (pa_) loadA_tile(1, oa_, ANEXT);                                      \
-    FFN_XGROUP(ACUR, BCUR, 0, 2)                                             \
-    if (pa_) loadA_tile(2, oa_, ANEXT);                                      \
-    FFN_XGROUP(ACUR, BCUR, 1, 1)                                             \
-    if (pa_) loadA_tile(3, oa_, ANEXT);                                      \
-    FFN_XGROUP(ACUR, BCUR, 1, 0)                                             \
-    if (pa_) loadA_tile(4, oa_, ANEXT);                                      \
-    FFN_XGROUP(ACUR, BCUR, 0, 1)                                             \
-    if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                                \
-    FFN_XGROUP(ACUR, BCUR, 0, 0)                                             \
-    if ((tgrp == 0) == (((S) % 9) < (((S) / 9) == 1 ? 4 : 5))) { /* ours */ \
-      acc4a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
-          ACUR.p[2][4], BCUR.p[0], acc4a, 0, 0, 0);                          \
-      acc4b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
-          ACUR.p[0][4], BCUR.p[2], acc4b, 0, 0, 0);                          \
-      acc4a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
-          ACUR.p[1][4], BCUR.p[1], acc4a, 0, 0, 0);                          \
-      acc4b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
-          ACUR.p[1][4], BCUR.p[0], acc4b, 0, 0, 0);                          \
-      acc4a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
-          ACUR.p[0][4], BCUR.p[1], acc4a, 0, 0, 0);                          \
-      acc4b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
-          ACUR.p[0][4], BCUR.p[0], acc4b, 0, 0, 0);                          \
-      __builtin_amdgcn_sched_barrier(0);                                     \
+    const bool t4_ = (tgrp == 0) == (((S) % 9) < (((S) / 9) == 1 ? 4 : 5)); \
+    if constexpr (SCHEME == 3) {                                             \
+      if (pa_) loadA_tile(0, oa_, ANEXT);                                    \
+      FFN_XGROUP(acc, ACUR, BCUR, 2, 0)                                      \
+      if (pa_) loadA_tile(1, oa_, ANEXT);                                    \
+      FFN_XGROUP(acc, ACUR, BCUR, 0, 2)                                      \
+      if (pa_) loadA_tile(2, oa_, ANEXT);                                    \
+      FFN_XGROUP(acc, ACUR, BCUR, 1, 1)                                      \
+      if (pa_) loadA_tile(3, oa_, ANEXT);                                    \
+      FFN_XGROUP(acc, ACUR, BCUR, 1, 0)                                      \
+      if (pa_) loadA_tile(4, oa_, ANEXT);                                    \
+      FFN_XGROUP(acc, ACUR, BCUR, 0, 1)                                      \
+      if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                              \
+      FFN_XGROUP(acc, ACUR, BCUR, 0, 0)                                      \
+      if (t4_) { /* the shared tile's taps of this tile group */            \
+        acc4a = mma(ACUR.p[2][4], BCUR.p[0], acc4a);                         \
+        acc4b = mma(ACUR.p[0][4], BCUR.p[2], acc4b);                         \
+        acc4a = mma(ACUR.p[1][4], BCUR.p[1], acc4a);                         \
+        acc4b = mma(ACUR.p[1][4], BCUR.p[0], acc4b);                         \
+        acc4a = mma(ACUR.p[0][4], BCUR.p[1], acc4a);                         \
+        acc4b = mma(ACUR.p[0][4], BCUR.p[0], acc4b);                         \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+      }                                                                      \
+    } else {                                                                 \
+      if (pa_) { loadA_tile(0, oa_, ANEXT); loadA_tile(1, oa_, ANEXT); }     \
+      FFN_XGROUP(accC, ACUR, BCUR, 1, 0)                                     \
+      if (pa_) { loadA_tile(2, oa_, ANEXT); loadA_tile(3, oa_, ANEXT); }     \
+      FFN_XGROUP(accC, ACUR, BCUR, 0, 1)                                     \
+      if (pa_) loadA_tile(4, oa_, ANEXT);                                    \
+      if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                              \
+      FFN_XGROUP(acc, ACUR, BCUR, 0, 0)                                      \
+      if (t4_) {                                                             \
+        acc4b = mma(ACUR.p[1][4], BCUR.p[0], acc4b);                         \
+        acc4a = mma(ACUR.p[0][4], BCUR.p[0], acc4a);                         \
+        acc4b = mma(ACUR.p[0][4], BCUR.p[1], acc4b);                         \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+      }                                                                      \
     }                                                                        \
   }
   // A ring alternates every tap, B ring has period 3: the pattern repeats
@@ -1304,7 +1359,16 @@ __global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(ConvCArgs a) 
   __syncthreads();
   {
     const int co = nhalf * 16 + i;
-    const f32x4 acc4 = acc4a + acc4b;
+    f32x4 acc4 = acc4a + acc4b;
+    if constexpr (SCHEME == 2) {
+      acc4 = acc4a + acc4b * 4.8828125e-4f;  // 2^-11
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] += accC[t] * 4.8828125e-4f;
+      // an operand left the fp16 range: the step is void, the host re-runs it
+      // with the bf16x3 scheme (ffn_step_result.range_error)
+      if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
+        *a.range_flag = a.range_tag;
+    }
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const int tile = t < 4 ? tgrp * 5 + t : 4;
@@ -1495,7 +1559,8 @@ __global__ __launch_bounds__(512) void faces_kernel(
     StepItems si, Geom g, const float* __restrict__ logits,
     const float* __restrict__ in_seed,
     const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
-    float disco_thr, float deleted_thr, ffn_step_result* __restrict__ results,
+    float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
+    unsigned range_tag, ffn_step_result* __restrict__ results,
     unsigned* __restrict__ seq, unsigned step_id) {
   __shared__ unsigned s_cnt[8];
   __shared__ ffn_step_result s_res;
@@ -1619,7 +1684,10 @@ __global__ __launch_bounds__(512) void faces_kernel(
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) deleted += __shfl_xor(deleted, off);
     }
-    if (lane == 0) s_res.num_deleted = deleted;
+    if (lane == 0) {
+      s_res.num_deleted = deleted;
+      s_res.range_error = (*range_flag == range_tag) ? 1 : 0;
+    }
   }
   __syncthreads();
   // Publish from ONE wave: copy the record into pinned host memory, make it
@@ -1641,8 +1709,10 @@ __global__ __launch_bounds__(512) void paste_kernel(
     StepItems si, Geom g, const float* __restrict__ logits,
     const float* __restrict__ in_seed,
     const unsigned* __restrict__ block_count, int head_blocks,
-    float disco_thr) {
+    float disco_thr, const unsigned* __restrict__ range_flag,
+    unsigned range_tag) {
   __shared__ unsigned s_cnt[8];
+  if (*range_flag == range_tag) return;  // void step (fp16 range): no paste
   const int item = blockIdx.y;
   const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
   const unsigned cnt = sum_block_counts(block_count, head_blocks, item, s_cnt);

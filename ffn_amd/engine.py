@@ -62,6 +62,8 @@ class HipEngine:
     self._slot_res_arr = [(StepResult * self.max_batch)() for _ in range(2)]
     self._submit_slot = 0
     self._ticket_slot = {}
+    #: steps repeated because conv_variant 4 met a value outside the fp16 range
+    self.range_fallbacks = 0
     self._canvases = weakref.WeakSet()
     _LIVE_ENGINES.add(self)
 
@@ -152,10 +154,21 @@ class HipEngine:
     for k in range(n):
       self._canvas_arr[k] = canvases[k]._h
       ctypes.pointer(self._req_arr[k])[0] = requests[k]
-    check(self._lib.ffn_canvas_step(self._h, n, self._canvas_arr,
-                                    self._req_arr, ctypes.byref(params),
-                                    self._res_arr))
+    self._blocking_step(n, self._req_arr, params)
     return self._res_arr
+
+  def _blocking_step(self, n, req, params):
+    """ffn_canvas_step; a step voided by the fp16 range check (conv_variant 4)
+    changed nothing on the device: it is repeated with the bf16x3 scheme, which
+    has the full f32 exponent range, and the engine stays on that scheme."""
+    rc = self._lib.ffn_canvas_step(self._h, n, self._canvas_arr, req,
+                                   ctypes.byref(params), self._res_arr)
+    if rc == _lib.ERR_RANGE:
+      self.range_fallbacks += 1
+      self.set_option('conv_variant', 3)
+      rc = self._lib.ffn_canvas_step(self._h, n, self._canvas_arr, req,
+                                     ctypes.byref(params), self._res_arr)
+    check(rc)
 
   def step_submit(self, canvases: Sequence['DeviceCanvasHandle'],
                   requests: Sequence[StepRequest], params: StepParams) -> int:
@@ -172,24 +185,34 @@ class HipEngine:
                                            ctypes.byref(params),
                                            ctypes.byref(ticket)))
     self._submit_slot ^= 1  # only a successful submit occupies the slot
-    self._ticket_slot[ticket.value] = slot
+    self._ticket_slot[ticket.value] = (slot, n, params)
     return ticket.value
 
   def step_wait(self, ticket: int):
     """Blocks until the step is done; returns its StepResult array (valid until
     the second-next submit)."""
-    slot = self._ticket_slot.pop(ticket)
+    slot, n, params = self._ticket_slot.pop(ticket)
     res = self._slot_res_arr[slot]
-    check(self._lib.ffn_canvas_step_wait(self._h, ticket, res))
+    rc = self._lib.ffn_canvas_step_wait(self._h, ticket, res)
+    if rc == _lib.ERR_RANGE:
+      # voided by the fp16 range check: nothing was pasted.  Repeat this batch
+      # with the bf16x3 scheme (its descriptor arrays are still intact); a step
+      # of the other group that is already queued finishes first.
+      self.range_fallbacks += 1
+      self.set_option('conv_variant', 3)
+      again = ctypes.c_uint32(0)
+      check(self._lib.ffn_canvas_step_submit(
+          self._h, n, self._slot_canvas_arr[slot], self._slot_req_arr[slot],
+          ctypes.byref(params), ctypes.byref(again)))
+      rc = self._lib.ffn_canvas_step_wait(self._h, again.value, res)
+    check(rc)
     return res
 
   def step1(self, canvas: 'DeviceCanvasHandle', request: StepRequest,
             params: StepParams) -> StepResult:
     """Single-canvas fast path: no per-call copies of the request."""
     self._canvas_arr[0] = canvas._h
-    check(self._lib.ffn_canvas_step(self._h, 1, self._canvas_arr,
-                                    ctypes.byref(request), ctypes.byref(params),
-                                    self._res_arr))
+    self._blocking_step(1, ctypes.byref(request), params)
     return self._res_arr[0]
 
 

@@ -28,6 +28,9 @@ extern "C" {
 #define FFN_ERR_ARG (-1)     /* invalid argument / unsupported geometry      */
 #define FFN_ERR_HIP (-2)     /* HIP runtime failure (see ffn_last_error)     */
 #define FFN_ERR_STATE (-3)   /* call order violated (e.g. weights not set)   */
+#define FFN_ERR_RANGE (-4)   /* conv_variant 4 only: an operand left the fp16
+                                range; the step changed nothing -- switch to
+                                conv_variant 3 and repeat it                    */
 
 #define FFN_MAX_CANDIDATES 16
 
@@ -70,6 +73,8 @@ typedef struct ffn_step_result {
   int32_t cand_seg[FFN_MAX_CANDIDATES];   /* segmentation[candidate]           */
   uint32_t num_deleted;   /* history_deleted entry of this step (see
                              ffn_step_params.deleted_threshold), else 0        */
+  int32_t range_error;    /* conv_variant 4: 1 = an operand left the fp16 range,
+                             the step was NOT pasted (FFN_ERR_RANGE)           */
 } ffn_step_result;
 
 /* Result of the per-segment commit reduction (inference.py:614-646). */
@@ -186,7 +191,9 @@ int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
  * software-pipelined f32-MFMA conv over padded positions, 2 = pipelined +
  * compact position space + K-split middle tile, 3 = variant 2 with every f32
  * product carried as 6 exact bf16 x bf16 products on the bf16 MFMA (default
- * when the FoV allows).  Results are identical up to f32 summation order
+ * when the FoV allows), 4 = the same with fp16 (hi + 2^-11 * residual, 3
+ * products, 22 mantissa bits: about the rounding noise of an f32 GEMM; operands
+ * must stay inside the fp16 range, else FFN_ERR_RANGE).  Results are identical up to f32 summation order
  * (variant 3: plus a truncation 100x below f32 rounding).  "fuse_head": 1x1x1
  * head inside the last conv launch.  "store_policy": 0 write-back, 1
  * write-through, 2 non-temporal conv stores. */

@@ -7,6 +7,7 @@ segment ids, queue trajectory, commit counts) must be bit-exact.
 
 import functools
 import json
+import ctypes
 import os
 
 import numpy as np
@@ -16,7 +17,7 @@ from tests.conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-DEFAULT_VARIANT = 3  # what ffn_engine_create selects for the 33^3 FoV
+DEFAULT_VARIANT = 4  # what ffn_engine_create selects for the 33^3 FoV
 TOL = 1e-4
 
 
@@ -39,10 +40,11 @@ def _fov_inputs(rng, n=1):
 
 
 @pytest.mark.parametrize('variant,fuse_head', [(0, 1), (1, 1), (2, 1), (2, 0),
-                                               (3, 1), (3, 0)])
+                                               (3, 1), (3, 0), (4, 1), (4, 0)])
 def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head):
   """conv_variant 0 simple f32 MFMA, 1 padded pipelined, 2 compact (exact f32
-  MFMA), 3 compact with bf16x3 split products; with the 1x1x1 head fused into
+  MFMA), 3 compact with bf16x3 split products, 4 with fp16 hi + scaled
+  residual; with the 1x1x1 head fused into
   the last conv or as its own launch."""
   from oracle import ffn_oracle
   engine.set_option('conv_variant', variant)
@@ -79,7 +81,7 @@ def test_predict_is_deterministic_and_variants_agree(engine):
   a = engine.predict(seed, img)
   b = engine.predict(seed, img)
   assert np.array_equal(a, b)
-  for variant in (0, 1, 2, 3):
+  for variant in (0, 1, 2, 3, 4):
     engine.set_option('conv_variant', variant)
     c = engine.predict(seed, img)
     assert np.abs(a - c).max() <= 2e-5, variant
@@ -128,7 +130,7 @@ def test_anisotropic_fov(fib25_model):
   img = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
   seed = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
   blob = ffn_oracle.weights_blob(variables, 2)
-  for variant in (0, 1, 2, 3):
+  for variant in (0, 1, 2, 3, 4):
     eng.set_option('conv_variant', variant)
     got = eng.predict(seed, img)
     want = ffn_oracle.forward(img, seed, blob, 2)
@@ -775,3 +777,54 @@ def test_large_canvas_offsets_beyond_2gib(engine, fib25_blob):
   assert np.isnan(canvas.read_seed(lo, [l + 33 for l in lo])).all()
   assert canvas.read_point((40, 40, 40))[0] == 1.0
   canvas.close()
+
+
+def test_fp16_range_fallback(fib25_model, fib25_blob):
+  """conv_variant 4 keeps operands in fp16: a value beyond 65504 must void the
+  run (nothing pasted) and repeat it with the bf16x3 scheme -- silently for
+  ffn_predict, through FFN_ERR_RANGE + retry for canvas steps."""
+  from ffn_amd import _lib
+  from ffn_amd import engine as hip_engine
+  from oracle import ffn_oracle
+  eng = hip_engine.HipEngine.from_model(fib25_model, max_batch=1)
+  assert eng.get_option('conv_variant') == 4
+  rng = np.random.RandomState(12)
+  img, seed = _fov_inputs(rng, 1)
+  ok = eng.predict(seed, img)
+  assert eng.get_option('conv_variant') == 4  # ordinary data stays on fp16x2
+  big = (img * 3e5).astype(np.float32)  # conv0_a outputs far beyond 65504
+  got = eng.predict(seed, big)
+  assert eng.get_option('conv_variant') == 3
+  want = ffn_oracle.forward(big, seed, fib25_blob, 12)
+  assert np.isfinite(got).all()
+  assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+  assert np.array_equal(eng.predict(seed, img), eng.predict(seed, img))
+  assert np.abs(eng.predict(seed, img) - ok).max() <= 2e-5
+  # canvas step: the voided step must leave the canvas untouched, then repeat
+  eng.set_option('conv_variant', 4)
+  vol = np.zeros((40, 40, 40), np.float32)
+  vol[4:37, 4:37, 4:37] = big[0]
+  canvas = eng.create_canvas(vol)
+  start = (20, 20, 20)
+  canvas.init_seed(start, 2.9444386959)
+  params = _lib.StepParams(-2.9444389343, 2.1972243786, 0.0)
+  req = _lib.StepRequest()
+  req.pos[:] = start
+  req.start_pos[:] = start
+  req.num_candidates = 0
+  lib = _lib.load()
+  arr = (ctypes.c_void_p * 1)()
+  arr[0] = canvas._h
+  res = (_lib.StepResult * 1)()
+  rc = lib.ffn_canvas_step(eng._h, 1, arr, ctypes.byref(req),
+                           ctypes.byref(params), res)
+  assert rc == _lib.ERR_RANGE and res[0].range_error == 1
+  seed_now = canvas.read_seed()
+  assert np.isnan(seed_now).sum() == seed_now.size - 1  # nothing was pasted
+  eng.set_option('conv_variant', 4)
+  r = eng.step1(canvas, req, params)  # Python handle: retries with bf16x3
+  assert eng.range_fallbacks == 1 and eng.get_option('conv_variant') == 3
+  assert r.range_error == 0 and np.isfinite(r.start_logit)
+  assert np.isfinite(canvas.read_seed((4, 4, 4), (37, 37, 37))).all()
+  canvas.close()
+  eng.close()

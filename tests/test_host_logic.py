@@ -353,7 +353,7 @@ def test_step_struct_layout_matches_header():
   import ctypes
   assert ctypes.sizeof(_lib.StepParams) == 16
   assert ctypes.sizeof(_lib.StepRequest) == 4 * (3 + 3 + 1 + 3 * 16)
-  assert ctypes.sizeof(_lib.StepResult) == 4 * (6 + 6 + 6 + 3 + 16 + 16 + 1)
+  assert ctypes.sizeof(_lib.StepResult) == 4 * (6 + 6 + 6 + 3 + 16 + 16 + 2)
   assert ctypes.sizeof(_lib.CommitCounts) == 24
 
 

@@ -32,7 +32,7 @@ def main():
   seed = rng.normal(0, 1, (maxb, 33, 33, 33)).astype(np.float32)
   eng.predict(seed, img)  # fills the staging buffers
   flop = 2.0 * (2 * 27 * 32 + 23 * 27 * 32 * 32 + 32) * 33**3
-  for variant in (1, 2, 3):
+  for variant in (1, 2, 3, 4):
     eng.set_option('conv_variant', variant)
     for b in args.batch:
       eng.forward_resident(b, 3)
@@ -51,14 +51,14 @@ def main():
             (variant, b, dt * 1e6, b / dt, b * flop / dt / 1e12,
              ms / n * 1e3, n, b * 2.0 * 27 * 32 * 32 * 33**3 / (ms / n * 1e-3) / 1e12))
   # stateless boundary (ffn_predict): host seed + image in, host logits out
-  eng.set_option('conv_variant', 2)
+  eng.set_option('conv_variant', 3)
   for b in (1, maxb):
     eng.predict(seed[:b], img[:b])
     t0 = time.perf_counter()
     for _ in range(args.repeats):
       eng.predict(seed[:b], img[:b])
     dt = (time.perf_counter() - t0) / args.repeats
-    print('variant 2 ffn_predict (PCIe-inclusive, %d x 3 x 144 KB) batch %2d: '
+    print('variant 3 ffn_predict (PCIe-inclusive, %d x 3 x 144 KB) batch %2d: '
           '%8.1f us/call  %8.1f FoV/s' % (b, b, dt * 1e6, b / dt))
   for policy in (1, 2, 0):
     eng.set_option('store_policy', policy)
@@ -69,20 +69,25 @@ def main():
       eng.forward_resident(b, args.repeats)
       eng.synchronize()
       dt = (time.perf_counter() - t0) / args.repeats
-      print('variant 2 store_policy %d batch %d: %8.1f us/stack' % (
+      print('variant 3 store_policy %d batch %d: %8.1f us/stack' % (
           policy, b, dt * 1e6))
-  # in-kernel clocks of the compact kernel's first workgroup
-  eng.set_option('conv_variant', 2)
+  # in-kernel clocks of the compact kernels' first workgroup
   eng.set_option('debug_clock', 1)
-  for abl in (0, 8, 16, 24):
-   eng.set_option('ablate', abl)
-   eng.forward_resident(1, 3)
-   c = eng.debug_clocks()
-   print('variant 2 issue experiment %d (8 = no A reads, 16 = no B loads):' % abl)
-   for w in range(4):
-    tot, wall = c[w, 3] - c[w, 0], (c[w, 5] - c[w, 4]) * 10.0
-    print(' clock wave %d: stage %d  loop %d  epilogue %d  total %d shader cycles; wall %.0f ns -> %.2f GHz; %.2f cyc/MFMA' % (
-        w, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1], c[w, 3] - c[w, 2], tot, wall, tot / max(wall, 1), (c[w, 2] - c[w, 1]) / 976.0))
+  for variant, abls, nmfma in ((4, (0,), 13.5 * 27.0), (3, (0,), 27 * 27.0),
+                               (2, (0, 8, 16, 24), 972.0)):
+    eng.set_option('conv_variant', variant)
+    for abl in abls:
+      eng.set_option('ablate', abl)
+      eng.forward_resident(1, 3)
+      c = eng.debug_clocks()
+      print('variant %d issue experiment %d (8 = no A reads, 16 = no B loads):'
+            % (variant, abl))
+      for w in range(4):
+        tot, wall = c[w, 3] - c[w, 0], (c[w, 5] - c[w, 4]) * 10.0
+        print(' clock wave %d: stage %d  loop %d  epilogue %d  total %d shader '
+              'cycles; wall %.0f ns -> %.2f GHz; %.2f cyc/MFMA' % (
+                  w, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1], c[w, 3] - c[w, 2],
+                  tot, wall, tot / max(wall, 1), (c[w, 2] - c[w, 1]) / nmfma))
   eng.set_option('ablate', 0)
   eng.set_option('debug_clock', 0)
   # phase ablation of the pipelined conv_b kernel (11 of the 23 convs per stack)
