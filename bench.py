@@ -372,17 +372,26 @@ def main():
       traffic = json.load(f)['traffic_bytes_per_launch']
   except (OSError, KeyError, ValueError):
     pass
-  variant = res.get('conv_variant', 3)
-  if variant == 3:
-    kernel_name = ('conv32x3 (3x3x3 32->32 implicit GEMM; f32 operands split '
-                   'exactly into 3 bf16 parts, 6 products per f32 product on '
-                   'v_mfma_f32_16x16x32_bf16, f32 accumulation)')
-    peak = PEAK_BF16_MFMA_TFLOPS / BF16X3_PRODUCTS
-    peak_basis = ('dense bf16 MFMA peak %.0f TFLOP/s / %d bf16 products per '
-                  'algorithmic f32 product' % (PEAK_BF16_MFMA_TFLOPS,
-                                               BF16X3_PRODUCTS))
-    executed_ratio = BF16X3_PRODUCTS
-    dtype = 'f32 (bf16x3 split products on the bf16 MFMA, f32 accumulate)'
+  variant = res.get('conv_variant', 4)
+  PEAK_F16_MFMA_TFLOPS = PEAK_BF16_MFMA_TFLOPS  # same dense rate on gfx950
+  if variant in (3, 4):
+    products = BF16X3_PRODUCTS if variant == 3 else 3
+    mfma = ('v_mfma_f32_16x16x32_bf16' if variant == 3 else
+            'v_mfma_f32_16x16x32_f16')
+    kernel_name = (
+        'conv32w8 (3x3x3 32->32 implicit GEMM, 8-wave workgroups; f32 operands split %s, %d '
+        'products per f32 product on %s, f32 accumulation)' %
+        ('exactly into 3 bf16 parts' if variant == 3 else
+         'into fp16 hi + 2^-11-scaled fp16 residual (22 mantissa bits)',
+         products, mfma))
+    peak = PEAK_F16_MFMA_TFLOPS / products
+    peak_basis = ('dense 16-bit MFMA peak %.0f TFLOP/s / %d products per '
+                  'algorithmic f32 product' % (PEAK_F16_MFMA_TFLOPS, products))
+    executed_ratio = products
+    dtype = ('f32 (bf16x3 split products on the bf16 MFMA, f32 accumulate)'
+             if variant == 3 else
+             'f32 (fp16 hi + scaled-residual split products on the fp16 MFMA, '
+             'f32 accumulate)')
   else:
     kernel_name = ('conv32 (3x3x3 32->32 implicit GEMM, '
                    'v_mfma_f32_16x16x4_f32)')

@@ -75,6 +75,7 @@ struct ffn_engine {
   int32_t* pidx = nullptr;    // dense FoV index -> padded position (variant 2)
   int nchunks_c = 0, Rc = 0;
   int fuse_head = 1;      // 1x1x1 head fused into the last conv32c launch
+  int waves8 = 1;         // variants 3 / 4: 8-wave workgroups (conv32w8)
   int count_blocks = kHeadBlocks;  // entries per item in `count` for the last step
   int store_policy = 1;  // conv32c epilogue stores: sc1 write-through (-1.4 % per stack)
   long long* d_dbg = nullptr;  // debug clocks of conv32c WG 0 (24 values)
@@ -231,6 +232,25 @@ inline void split_fp16x2(float x, uint16_t part[2]) {
   const _Float16 res = (_Float16)((x - (float)hi) * 2048.0f);
   std::memcpy(&part[0], &hi, 2);
   std::memcpy(&part[1], &res, 2);
+}
+
+template <bool RI, bool RO, bool SK, int SCHEME>
+int set_lds_attr_w8(size_t bytes) {
+  HIP_TRY(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&conv32w8_kernel<RI, RO, SK, 8, false, SCHEME>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  HIP_TRY(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&conv32w8_kernel<RI, RO, SK, 9, false, SCHEME>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (SK) {
+    HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv32w8_kernel<RI, RO, SK, 8, true, SCHEME>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv32w8_kernel<RI, RO, SK, 9, true, SCHEME>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  }
+  return FFN_OK;
 }
 
 template <bool RI, bool RO, bool SK>
@@ -438,7 +458,28 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
   const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
   a.range_flag = e->range_flag;
   a.range_tag = e->range_tag;
-  if (e->conv_variant == 4) {
+  if (e->conv_variant >= 3 && e->waves8) {
+    // 8-wave workgroups: two waves per SIMD hide each other's operand loads
+    const dim3 block8(kW8Threads);
+    const bool h = e->conv_variant == 4;
+    a.wpack = h ? reinterpret_cast<const float*>(e->wpack2h +
+                                                 (size_t)layer * e->wpack2h_layer)
+                : reinterpret_cast<const float*>(e->wpack3 +
+                                                 (size_t)layer * e->wpack3_layer);
+    const size_t lb = h ? e->lds_bytes_h : e->lds_bytes_x;
+#define FFN_W8_LAUNCH(KSV, HEADV, SCH)                                        \
+  hipLaunchKernelGGL((conv32w8_kernel<RI, RO, SK, KSV, HEADV, SCH>), grid,    \
+                     block8, lb, e->stream, a)
+    const bool k8 = e->Rc == 256;
+    if (h) {
+      if (head.on) { if (k8) FFN_W8_LAUNCH(8, true, 2); else FFN_W8_LAUNCH(9, true, 2); }
+      else { if (k8) FFN_W8_LAUNCH(8, false, 2); else FFN_W8_LAUNCH(9, false, 2); }
+    } else {
+      if (head.on) { if (k8) FFN_W8_LAUNCH(8, true, 3); else FFN_W8_LAUNCH(9, true, 3); }
+      else { if (k8) FFN_W8_LAUNCH(8, false, 3); else FFN_W8_LAUNCH(9, false, 3); }
+    }
+#undef FFN_W8_LAUNCH
+  } else   if (e->conv_variant == 4) {
     a.wpack = reinterpret_cast<const float*>(e->wpack2h +
                                              (size_t)layer * e->wpack2h_layer);
     if (head.on) {
@@ -847,6 +888,12 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (!rc) rc = set_lds_attr_h<false, false, false>(e->lds_bytes_h);
     if (!rc) rc = set_lds_attr_h<true, true, false>(e->lds_bytes_h);
     if (!rc) rc = set_lds_attr_h<false, false, true>(e->lds_bytes_h);
+    if (!rc) rc = set_lds_attr_w8<false, false, false, 2>(e->lds_bytes_h);
+    if (!rc) rc = set_lds_attr_w8<true, true, false, 2>(e->lds_bytes_h);
+    if (!rc) rc = set_lds_attr_w8<false, false, true, 2>(e->lds_bytes_h);
+    if (!rc) rc = set_lds_attr_w8<false, false, false, 3>(e->lds_bytes_x);
+    if (!rc) rc = set_lds_attr_w8<true, true, false, 3>(e->lds_bytes_x);
+    if (!rc) rc = set_lds_attr_w8<false, false, true, 3>(e->lds_bytes_x);
     if (!rc) rc = set_lds_attr_p<false, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
@@ -1086,6 +1133,10 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->fuse_head = value != 0;
     return FFN_OK;
   }
+  if (std::strcmp(name, "waves8") == 0) {
+    e->waves8 = value != 0;
+    return FFN_OK;
+  }
   if (std::strcmp(name, "store_policy") == 0) {
     if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "store_policy 0..2");
     e->store_policy = value;
@@ -1098,6 +1149,7 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   if (!e || !name || !value) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) *value = e->conv_variant;
   else if (std::strcmp(name, "fuse_head") == 0) *value = e->fuse_head;
+  else if (std::strcmp(name, "waves8") == 0) *value = e->waves8;
   else if (std::strcmp(name, "store_policy") == 0) *value = e->store_policy;
   else if (std::strcmp(name, "sync_mode") == 0) *value = e->sync_mode;
   else if (std::strcmp(name, "profile_every") == 0) *value = e->prof_every;

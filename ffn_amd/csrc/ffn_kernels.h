@@ -1461,6 +1461,379 @@ __global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// conv32w8: conv32x3 with 8 waves per workgroup (two per SIMD).
+//
+// With the contraction on the 16-bit matrix cores the main loop of conv32x3 is
+// no longer MFMA-bound: a wave spends about as long issuing its operand loads
+// (10 ds_read_b128 + 2 global 16-B loads per tap) as the MFMA pipe spends on its
+// 13.5 MFMAs.  Two waves per SIMD hide each other's issue: wave = (cout half,
+// tile quarter tq), tiles 2tq and 2tq+1 on every tap, the ninth tile on the taps
+// whose owner is tq (3/2/2/2 of each dz segment, rotating, so the quarters carry
+// 7/7/7/6 of its 27 taps).  No K split: only the ninth tile's four partial sums
+// meet in the LDS transpose of the epilogue.  Staging, splitting, tap order,
+// epilogue and fused head are those of conv32x3; each thread stages half as many
+// rows, so the kernel fits the 256 registers two waves per SIMD leave.
+// ---------------------------------------------------------------------------
+constexpr int kW8Threads = 512;
+
+template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int KS = 8, bool HEAD = false,
+          int SCHEME = 2>
+__global__ __launch_bounds__(kW8Threads, 2) void conv32w8_kernel(ConvCArgs a) {
+  constexpr int NP = SCHEME == 3 ? 3 : 2;
+  constexpr int kRowB = SCHEME == 3 ? kXRowBytes : kHRowBytes;
+  constexpr int KT = (KS * 256 + kW8Threads - 1) / kW8Threads;  // quads / thread / segment
+  constexpr bool kExact = KT * kW8Threads == KS * 256;
+  typedef typename XFrag<SCHEME>::type frag_t;
+  unsigned range_max = 0;  // SCHEME 2: max |operand| bit pattern seen by this thread
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x;
+  const long long dbg_c0 = a.dbg ? clock64() : 0;
+  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
+  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
+  if (gc >= a.total_slots) return;
+  const int item = gc / a.nchunks;
+  const int chunk = gc - item * a.nchunks;
+  const int v0 = chunk * kCChunk;
+  const int32_t* pidx = a.pidx + v0;
+  int p_first;
+  {
+    int z = (int)((float)v0 / (float)a.fyfx);
+    z -= (z * a.fyfx > v0);
+    z += ((z + 1) * a.fyfx <= v0);
+    const int rem = v0 - z * a.fyfx;
+    int y = (int)((float)rem / (float)a.fx);
+    y -= (y * a.fx > rem);
+    y += ((y + 1) * a.fx <= rem);
+    p_first = __builtin_amdgcn_readfirstlane(z * a.plane + y * a.XS +
+                                             (rem - y * a.fx));
+  }
+  const int p_lo = p_first - (a.XS + 1);  // first staged row of the dz=0 segment
+  const float* src = a.in + (size_t)item * a.act_stride;
+  const int Rc = a.Rc;
+  const int nquads = Rc * 8;
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nhalf = wave & 1;
+  const int tq = wave >> 1;
+  const int i = lane & 15;
+  const int grp = lane >> 4;
+
+  // LDS byte offset of this lane's row in its tiles: 2tq, 2tq+1 and the ninth
+  int prow[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tile = t < 2 ? tq * 2 + t : 8;
+    prow[t] = (pidx[tile * kTile + i] - p_lo) * kRowB + grp * 16;
+  }
+  // epilogue pieces: thread -> (position j = (tid >> 3) + 64 k, quad tid & 7)
+  const int q = tid & 7;
+  const int j0 = tid >> 3;
+  int pj[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int j = j0 + 64 * k;
+    pj[k] = pidx[(j < kCChunk && v0 + j < a.V) ? j : 0];
+  }
+  struct AFrag { frag_t p[3][3]; };  // [plane][tile]
+  struct BFrag { frag_t p[3]; };
+  const frag_t* wp =
+      reinterpret_cast<const frag_t*>(a.wpack) + nhalf * NP * 64 + lane;
+  auto loadB = [&](int s, BFrag& dst) {
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) dst.p[pl] = wp[s * 2 * NP * 64 + pl * 64];
+  };
+  BFrag B0, B1, B2;
+  loadB(0, B0);
+  loadB(1, B1);
+
+  // ---- staging (all loads of the three dz segments in flight, written to LDS
+  // segment by segment; two segment slots) ----
+  f32x4 sv[3][KT];
+#pragma unroll
+  for (int seg = 0; seg < 3; ++seg) {
+    const long p0 = (long)p_lo + (long)(seg - 1) * a.plane;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int e = tid + k * kW8Threads;
+      sv[seg][k] = s4[(kExact || e < nquads) ? e : tid];
+    }
+  }
+  auto write_segment = [&](int seg) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const int e = tid + k * kW8Threads;
+      if (kExact || e < nquads) {
+        f32x4 v = sv[seg][k];
+        if (RELU_IN) {  // tf.nn.relu in front of conv_a (convstack_3d.py:44)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+        }
+        const int row = (seg & 1) * Rc + (e >> 3);  // slot 0: dz -1, +1; slot 1: dz 0
+        char* dstrow = ldsb + row * kRowB + (e & 7) * 8;
+        if constexpr (SCHEME == 3) {
+          const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+          const f32x4 r1 = v - __builtin_convertvector(hi, f32x4);
+          const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
+          const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
+          const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
+          *reinterpret_cast<bf16x4*>(dstrow) = hi;
+          *reinterpret_cast<bf16x4*>(dstrow + 64) = mid;
+          *reinterpret_cast<bf16x4*>(dstrow + 128) = lo;
+        } else {
+          f32x4 vh = v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const unsigned mbits = __float_as_uint(v[c]) & 0x7fffffffu;
+            range_max = mbits > range_max ? mbits : range_max;
+            vh[c] = mbits < 0x38800000u ? 0.0f : v[c];  // |x| < 2^-14
+          }
+          const f16x4 hi = __builtin_convertvector(vh, f16x4);
+          const f32x4 r1 = (v - __builtin_convertvector(hi, f32x4)) * 2048.0f;
+          const f16x4 res = __builtin_convertvector(r1, f16x4);
+          *reinterpret_cast<f16x4*>(dstrow) = hi;
+          *reinterpret_cast<f16x4*>(dstrow + 64) = res;
+        }
+      }
+    }
+  };
+  write_segment(0);
+  __syncthreads();
+
+  auto a_off = [&](int s) {  // LDS byte offset of tap s (compile-time kz/ky/kx)
+    const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
+    return ((kz & 1) * Rc + (ky - 1) * a.XS + (kx - 1)) * kRowB;
+  };
+  // owner (tile quarter) of the ninth tile on tap s
+  auto owner = [](int s) {
+    const int r = s % 9;
+    return ((r < 3 ? 0 : r < 5 ? 1 : r < 7 ? 2 : 3) + s / 9) & 3;
+  };
+  auto loadA_tile = [&](int t, int off, AFrag& dst) {
+    const char* p = ldsb + prow[t] + off;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+      dst.p[pl][t] = *reinterpret_cast<const frag_t*>(p + pl * 64);
+  };
+  // acc[t]: products of weight 1; accC[t] (SCHEME 2): cross products, weight 2^-11
+  f32x4 acc[3], accC[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = accC[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma = [](const frag_t& fa, const frag_t& fb, f32x4 c) {
+    if constexpr (SCHEME == 3)
+      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, c, 0, 0, 0);
+    else
+      return __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, c, 0, 0, 0);
+  };
+  AFrag A0, A1;
+  const long long dbg_c1 = a.dbg ? clock64() : 0;
+  {
+    const int off = a_off(0);
+    loadA_tile(0, off, A0);
+    loadA_tile(1, off, A0);
+    if (owner(0) == tq) loadA_tile(2, off, A0);
+  }
+
+  // one product of the split on the wave's tiles (NT = 2, or 3 on its own taps)
+#define FFN_W8PROD(ACC, ACUR, BCUR, PA, PB, OWN)                             \
+  ACC[0] = mma(ACUR.p[PA][0], BCUR.p[PB], ACC[0]);                           \
+  ACC[1] = mma(ACUR.p[PA][1], BCUR.p[PB], ACC[1]);                           \
+  if (OWN) ACC[2] = mma(ACUR.p[PA][2], BCUR.p[PB], ACC[2]);                  \
+  __builtin_amdgcn_sched_barrier(0);
+#define FFN_W8TAP(S, ACUR, ANEXT, BCUR, BNEXT2, PF)                          \
+  {                                                                          \
+    const bool pa_ = (PF) && (S) + 1 < 27;                                   \
+    const int oa_ = a_off((S) + 1);                                          \
+    const bool own_ = owner(S) == tq;                                        \
+    const bool ownn_ = pa_ && owner((S) + 1) == tq;                          \
+    if constexpr (SCHEME == 3) {                                             \
+      if (pa_) loadA_tile(0, oa_, ANEXT);                                    \
+      FFN_W8PROD(acc, ACUR, BCUR, 2, 0, own_)                                \
+      FFN_W8PROD(acc, ACUR, BCUR, 0, 2, own_)                                \
+      if (pa_) loadA_tile(1, oa_, ANEXT);                                    \
+      FFN_W8PROD(acc, ACUR, BCUR, 1, 1, own_)                                \
+      FFN_W8PROD(acc, ACUR, BCUR, 1, 0, own_)                                \
+      if (ownn_) loadA_tile(2, oa_, ANEXT);                                  \
+      FFN_W8PROD(acc, ACUR, BCUR, 0, 1, own_)                                \
+      if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                              \
+      FFN_W8PROD(acc, ACUR, BCUR, 0, 0, own_)                                \
+    } else {                                                                 \
+      if (pa_) loadA_tile(0, oa_, ANEXT);                                    \
+      FFN_W8PROD(accC, ACUR, BCUR, 1, 0, own_)                               \
+      if (pa_) loadA_tile(1, oa_, ANEXT);                                    \
+      FFN_W8PROD(acc, ACUR, BCUR, 0, 0, own_)                                \
+      if (ownn_) loadA_tile(2, oa_, ANEXT);                                  \
+      if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                              \
+      FFN_W8PROD(accC, ACUR, BCUR, 0, 1, own_)                               \
+    }                                                                        \
+  }
+  FFN_W8TAP(0, A0, A1, B0, B2, true)
+  FFN_W8TAP(1, A1, A0, B1, B0, true)
+  FFN_W8TAP(2, A0, A1, B2, B1, true)
+  FFN_W8TAP(3, A1, A0, B0, B2, true)
+  FFN_W8TAP(4, A0, A1, B1, B0, true)
+  FFN_W8TAP(5, A1, A0, B2, B1, true)
+  FFN_W8TAP(6, A0, A1, B0, B2, true)
+  FFN_W8TAP(7, A1, A0, B1, B0, true)
+  FFN_W8TAP(8, A0, A1, B2, B1, false)
+  write_segment(1);
+  __syncthreads();
+  {
+    const int off = a_off(9);
+    loadA_tile(0, off, A1);
+    loadA_tile(1, off, A1);
+    if (owner(9) == tq) loadA_tile(2, off, A1);
+  }
+  FFN_W8TAP(9, A1, A0, B0, B2, true)
+  FFN_W8TAP(10, A0, A1, B1, B0, true)
+  FFN_W8TAP(11, A1, A0, B2, B1, true)
+  FFN_W8TAP(12, A0, A1, B0, B2, true)
+  FFN_W8TAP(13, A1, A0, B1, B0, true)
+  FFN_W8TAP(14, A0, A1, B2, B1, true)
+  FFN_W8TAP(15, A1, A0, B0, B2, true)
+  FFN_W8TAP(16, A0, A1, B1, B0, true)
+  FFN_W8TAP(17, A1, A0, B2, B1, false)
+  write_segment(2);
+  __syncthreads();
+  // residual input and bias of this thread's epilogue pieces
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
+  unsigned ooff[3];
+  f32x4 skipv[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int j = j0 + 64 * k;
+    const bool ok = j < kCChunk && v0 + j < a.V;
+    const int p = pj[k];
+    ooff[k] = ok ? ((unsigned)p * kFeatures + q * 4) * 4u : 0x80000000u;
+    skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ADD_SKIP)
+      skipv[k] = *reinterpret_cast<const f32x4*>(
+          a.skip + (size_t)item * a.act_stride + (size_t)p * kFeatures + q * 4);
+  }
+  {
+    const int off = a_off(18);
+    loadA_tile(0, off, A0);
+    loadA_tile(1, off, A0);
+    if (owner(18) == tq) loadA_tile(2, off, A0);
+  }
+  FFN_W8TAP(18, A0, A1, B0, B2, true)
+  FFN_W8TAP(19, A1, A0, B1, B0, true)
+  FFN_W8TAP(20, A0, A1, B2, B1, true)
+  FFN_W8TAP(21, A1, A0, B0, B2, true)
+  FFN_W8TAP(22, A0, A1, B1, B0, true)
+  FFN_W8TAP(23, A1, A0, B2, B1, true)
+  FFN_W8TAP(24, A0, A1, B0, B2, true)
+  FFN_W8TAP(25, A1, A0, B1, B0, true)
+  FFN_W8TAP(26, A0, A1, B2, B1, true)
+#undef FFN_W8TAP
+#undef FFN_W8PROD
+
+  const long long dbg_c2 = a.dbg ? clock64() : 0;
+  // ---- epilogue: accumulators -> LDS [row][32 ch]; rows 0..127 tiles 0..7,
+  // rows 128 + 16 tq .. the four partial sums of the ninth tile ----
+  __syncthreads();
+  {
+    if constexpr (SCHEME == 2) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] += accC[t] * 4.8828125e-4f;  // 2^-11
+      // an operand left the fp16 range: the step is void, the host re-runs it
+      // with the bf16x3 scheme (ffn_step_result.range_error)
+      if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
+        *a.range_flag = a.range_tag;
+    }
+    const int co = nhalf * 16 + i;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int jrow = (t < 2 ? (tq * 2 + t) * kTile : 128 + tq * kTile) + grp * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[(jrow + r) * 32 + co] = acc[t][r];
+    }
+  }
+  __syncthreads();
+  unsigned head_above = 0;
+  {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    float* obase = a.out + (size_t)item * a.act_stride;
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.nbytes, 0x00020000);
+    f32x4 hw4 = {0.f, 0.f, 0.f, 0.f};
+    float hbias = 0.f;
+    if (HEAD) {
+      hw4 = *reinterpret_cast<const f32x4*>(a.head_w + q * 4);
+      hbias = a.head_w[kFeatures];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = j0 + 64 * k;
+      const int jr = j < kCChunk ? j : 0;
+      f32x4 v = *reinterpret_cast<const f32x4*>(lds + jr * 32 + q * 4);
+      if (jr >= 8 * kTile) {  // ninth tile: add the other three quarters' sums
+#pragma unroll
+        for (int o = 1; o < 4; ++o)
+          v += *reinterpret_cast<const f32x4*>(lds + (jr + o * kTile) * 32 + q * 4);
+      }
+      v += b4;
+      if (RELU_OUT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+      }
+      if (ADD_SKIP) v += skipv[k];
+      if (HEAD) {
+        float partial = fmaxf(v[0], 0.f) * hw4[0];
+        partial = __builtin_fmaf(fmaxf(v[1], 0.f), hw4[1], partial);
+        partial = __builtin_fmaf(fmaxf(v[2], 0.f), hw4[2], partial);
+        partial = __builtin_fmaf(fmaxf(v[3], 0.f), hw4[3], partial);
+        partial += __shfl_xor(partial, 1);
+        partial += __shfl_xor(partial, 2);
+        partial += __shfl_xor(partial, 4);
+        bool above = false;
+        if (q == 0 && ooff[k] != 0x80000000u) {
+          const size_t dv = (size_t)item * a.V + (v0 + j);
+          float s = a.seed_raw[dv];
+          if (s != s) s = a.pad_value;
+          const float lg = s + (partial + hbias);
+          a.logits[dv] = lg;
+          above = lg >= a.move_thr;
+        }
+        head_above += (unsigned)__popcll(__ballot(above));  // wave-uniform
+        continue;
+      }
+      if (a.store_policy == 1)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 16);
+      else if (a.store_policy == 2)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 2);
+      else
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 0);
+    }
+  }
+  if (HEAD) {  // this chunk's count of logits >= move_thr (summed by faces / paste)
+    float* cnt = lds + 192 * 32;  // past the transposed accumulators
+    if ((tid & 63) == 0) cnt[tid >> 6] = __uint_as_float(head_above);
+    __syncthreads();
+    if (tid == 0) {
+      unsigned total = 0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) total += __float_as_uint(cnt[w]);
+      a.head_count[gc] = total;
+    }
+  }
+  if (a.dbg && gc == 0 && (tid & 63) == 0 && wave < 4) {
+    long long* d = a.dbg + wave * 6;
+    d[0] = dbg_c0;
+    d[1] = dbg_c1;
+    d[2] = dbg_c2;
+    d[3] = clock64();
+    d[4] = dbg_w0;
+    d[5] = wall_clock64();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // head: ReLU -> 1x1x1 conv 32->1 + bias; logits = seed + update
 // (reference convstack_3d.py:51-54,91-94; model.py:168-183) and the count of
 // logits >= move_threshold that the disco test needs (inference.py:428-431).

@@ -39,9 +39,10 @@ def _fov_inputs(rng, n=1):
   return img, seed
 
 
-@pytest.mark.parametrize('variant,fuse_head', [(0, 1), (1, 1), (2, 1), (2, 0),
-                                               (3, 1), (3, 0), (4, 1), (4, 0)])
-def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head):
+@pytest.mark.parametrize('variant,fuse_head,waves8', [
+    (0, 1, 1), (1, 1, 1), (2, 1, 1), (2, 0, 1), (3, 1, 1), (3, 0, 1), (4, 1, 1),
+    (4, 0, 1), (3, 1, 0), (4, 1, 0), (4, 0, 0)])
+def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head, waves8):
   """conv_variant 0 simple f32 MFMA, 1 padded pipelined, 2 compact (exact f32
   MFMA), 3 compact with bf16x3 split products, 4 with fp16 hi + scaled
   residual; with the 1x1x1 head fused into
@@ -49,16 +50,19 @@ def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head):
   from oracle import ffn_oracle
   engine.set_option('conv_variant', variant)
   engine.set_option('fuse_head', fuse_head)
+  engine.set_option('waves8', waves8)  # variants 3 / 4: 8- or 4-wave workgroups
   rng = np.random.RandomState(42)
   img, seed = _fov_inputs(rng, 1)
   got = engine.predict(seed, img)
   want = ffn_oracle.forward(img, seed, fib25_blob, 12)
   assert got.shape == want.shape
   err = np.abs(got - want).max()
-  print('variant %d fuse_head %d: max |err| %.3g' % (variant, fuse_head, err))
+  print('variant %d fuse_head %d waves8 %d: max |err| %.3g' % (
+      variant, fuse_head, waves8, err))
   assert err <= TOL
   engine.set_option('conv_variant', DEFAULT_VARIANT)
   engine.set_option('fuse_head', 1)
+  engine.set_option('waves8', 1)
 
 
 def test_predict_batch_and_ragged(engine, fib25_blob):

@@ -32,8 +32,9 @@ def main():
   seed = rng.normal(0, 1, (maxb, 33, 33, 33)).astype(np.float32)
   eng.predict(seed, img)  # fills the staging buffers
   flop = 2.0 * (2 * 27 * 32 + 23 * 27 * 32 * 32 + 32) * 33**3
-  for variant in (1, 2, 3, 4):
+  for variant, w8 in ((1, 0), (2, 0), (3, 0), (3, 1), (4, 0), (4, 1)):
     eng.set_option('conv_variant', variant)
+    eng.set_option('waves8', w8)
     for b in args.batch:
       eng.forward_resident(b, 3)
       eng.synchronize()
@@ -46,19 +47,20 @@ def main():
       eng.forward_resident(b, 10)
       ms, n = eng.get_profile(reset=True)
       eng.set_profiling(0)
-      print('variant %d batch %2d: %8.1f us/stack  %8.1f FoV/s  %6.2f TFLOP/s '
+      print('variant %d%s batch %2d: %8.1f us/stack  %8.1f FoV/s  %6.2f TFLOP/s '
             ' conv32 avg %.2f us (%d launches, %.1f TF/s in-kernel)' %
-            (variant, b, dt * 1e6, b / dt, b * flop / dt / 1e12,
+            (variant, '+w8' if w8 else '', b, dt * 1e6, b / dt, b * flop / dt / 1e12,
              ms / n * 1e3, n, b * 2.0 * 27 * 32 * 32 * 33**3 / (ms / n * 1e-3) / 1e12))
   # stateless boundary (ffn_predict): host seed + image in, host logits out
-  eng.set_option('conv_variant', 3)
+  eng.set_option('conv_variant', 4)
+  eng.set_option('waves8', 1)
   for b in (1, maxb):
     eng.predict(seed[:b], img[:b])
     t0 = time.perf_counter()
     for _ in range(args.repeats):
       eng.predict(seed[:b], img[:b])
     dt = (time.perf_counter() - t0) / args.repeats
-    print('variant 3 ffn_predict (PCIe-inclusive, %d x 3 x 144 KB) batch %2d: '
+    print('variant 4+w8 ffn_predict (PCIe-inclusive, %d x 3 x 144 KB) batch %2d: '
           '%8.1f us/call  %8.1f FoV/s' % (b, b, dt * 1e6, b / dt))
   for policy in (1, 2, 0):
     eng.set_option('store_policy', policy)
@@ -69,7 +71,7 @@ def main():
       eng.forward_resident(b, args.repeats)
       eng.synchronize()
       dt = (time.perf_counter() - t0) / args.repeats
-      print('variant 3 store_policy %d batch %d: %8.1f us/stack' % (
+      print('variant 4+w8 store_policy %d batch %d: %8.1f us/stack' % (
           policy, b, dt * 1e6))
   # in-kernel clocks of the compact kernels' first workgroup
   eng.set_option('debug_clock', 1)
