@@ -1,6 +1,5 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-timeout 300 python bench.py --steps 1500 --warmup 100 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-2400
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -s -k "predict_matches or variants_agree or anisotropic or predict_batch or cells56 or range" 2>&1 | grep -E "variant 4|passed|failed|Error|assert" | head -12
+timeout 400 python tools/gpu_microbench.py --batch 1 8 32 2>&1 | grep -E "^variant 4\+w8 batch|clock wave 0|issue exp" | head -12
