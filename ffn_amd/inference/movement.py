@@ -252,19 +252,28 @@ class FaceMaxMovementPolicy(BaseMovementPolicy):
           rel = (fi - d_row, fj - d_col, off)
         moves.append((score, rel, fg[k]))
       if len(moves) > 1:
-        # duplicates of the same (score, offset) are dropped (movement.py:98-100)
-        uniq = {}
-        for mv in moves:
-          uniq.setdefault((mv[0], mv[1]), mv)
-        moves = sorted(uniq.values(), key=lambda mv: (mv[0], mv[1]),
-                       reverse=True)
+        # descending (score, offset), as sorted(..., reverse=True) of the
+        # reference (movement.py:220); duplicates of the same (score, offset)
+        # -- one voxel shared by two faces -- are dropped (movement.py:98-100)
+        moves.sort(reverse=True)
+        k = 1
+        while k < len(moves):
+          if moves[k][0] == moves[k - 1][0] and moves[k][1] == moves[k - 1][1]:
+            del moves[k]
+          else:
+            k += 1
       new = []
       pz, py, px = position
-      qp = self.quantize_pos
+      sz, sy, sx = self._start_pos
+      hz, hy, hx = self._dh
+      mz, my, mx = self._dm
       sc = self.scored_coords
       for score, rel, seg in moves:
-        coord = (rel[0] + pz, rel[1] + py, rel[2] + px)
-        sc.append((score, coord, qp(coord)))
+        cz, cy, cx = rel[0] + pz, rel[1] + py, rel[2] + px
+        coord = (cz, cy, cx)
+        # quantize_pos, inlined (this loop runs 6 x per FoV step)
+        sc.append((score, coord, ((cz - sz + hz) // mz, (cy - sy + hy) // my,
+                                  (cx - sx + hx) // mx)))
         new.append((coord, score, seg))
       return new
     scored = sorted(
