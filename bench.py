@@ -142,7 +142,8 @@ def run_gpu(args, rank, local_rank, world):
       if state['n'] == 0 and args.prewarm_seconds > 0:
         if state.get('pre_until') is None:
           state['pre_until'] = time.perf_counter() + args.prewarm_seconds
-        if time.perf_counter() < state['pre_until']:
+        if (time.perf_counter() < state['pre_until'] and
+            state.get('prewarm_steps', 0) < args.prewarm_max_steps):
           state['prewarm_steps'] = state.get('prewarm_steps', 0) + 1
           return super().update_at(pos)
       if state['n'] == args.warmup:
@@ -334,6 +335,7 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=1500)
   ap.add_argument('--warmup', type=int, default=100)
+  ap.add_argument('--prewarm-max-steps', type=int, default=2500)
   ap.add_argument('--prewarm-seconds', type=float, default=1.0,
                   help='untimed spin-up (extra FoV steps) before the warmup '
                   'steps are counted')
