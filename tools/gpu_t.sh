@@ -1,5 +1,7 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -s -k "predict_matches" 2>&1 | grep -E "variant [34].*waves8 1|passed|failed|Error|assert" | head -8
-timeout 400 python tools/gpu_microbench.py --batch 1 8 32 2>&1 | grep -E "^variant [34]\+w8 batch|clock wave 0|issue exp" | head -12
+mkdir -p gpurun_out
+timeout 300 python tools/gpu_batch_bench.py --mode driver --canvases 16 --batch 8 --size 128 --steps 300 2>&1 | grep "^driver"
+timeout 300 python tools/gpu_batch_bench.py --mode driver --canvases 64 --batch 32 --size 112 --steps 150 2>&1 | grep "^driver"
+bash tools/gpu_pmc_sq.sh 2>&1 | tail -24
