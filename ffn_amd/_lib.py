@@ -153,6 +153,8 @@ SIGNATURES = {
                                      ctypes.c_size_t, _P,
                                      ctypes.POINTER(ctypes.c_size_t),
                                      ctypes.POINTER(ctypes.c_int32)]),
+    'ffn_seeder_edt': (_I, [_P, _P, ctypes.POINTER(ctypes.c_int64),
+                            ctypes.POINTER(ctypes.c_double), _P]),
     'ffn_seeder_read_stage': (_I, [_P, _I, _P]),
     'ffn_seeder_last_timing': (_I, [_P, ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(ctypes.c_double)]),

@@ -276,6 +276,19 @@ __global__ __launch_bounds__(kThreads) void max7_kernel(
   out[i] = m;
 }
 
+// features of the EDT = voxels where the mask is 0
+__global__ __launch_bounds__(kThreads) void mask_to_features_kernel(
+    const uint8_t* __restrict__ mask, uint8_t* __restrict__ feat, size_t n) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) feat[i] = mask[i] ? 0 : 1;
+}
+
+__global__ __launch_bounds__(kThreads) void sqrt_kernel(double* __restrict__ d,
+                                                        size_t n) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) d[i] = __dsqrt_rn(d[i]);
+}
+
 __global__ __launch_bounds__(kThreads) void peaks_kernel(
     const double* __restrict__ val, const double* __restrict__ mx, Shape s,
     size_t n, int border, int32_t* coords, unsigned cap, unsigned* count) {
@@ -589,6 +602,56 @@ int ffn_seeder_peaks_canvas(ffn_seeder* s, ffn_canvas* canvas,
   S_OK(check_shape(shape, &n));
   return run_peaks(s, v.image, nullptr, v.segmentation, nullptr, shape,
                    voxel_size_zyx, cap, coords_zyx, n_peaks, all_edges);
+}
+
+int ffn_seeder_edt(ffn_seeder* s, const uint8_t* mask,
+                   const int64_t shape_zyx[3], const double voxel_size_zyx[3],
+                   double* dist) {
+  if (!s || !mask || !voxel_size_zyx || !dist)
+    return ffn_set_error(FFN_ERR_ARG, "NULL argument");
+  size_t n = 0;
+  S_OK(check_shape(shape_zyx, &n));
+  S_TRY(hipSetDevice(s->device_id));
+  const Shape sh{(int)shape_zyx[0], (int)shape_zyx[1], (int)shape_zyx[2]};
+  S_OK(ensure(s->mask, n));
+  S_OK(ensure(s->filt, n));
+  S_OK(ensure(s->d2a, n * sizeof(double)));
+  S_OK(ensure(s->d2b, n * sizeof(double)));
+  S_OK(ensure(s->zstack, n * sizeof(double)));
+  S_OK(ensure(s->vstack, n * sizeof(int)));
+  hipStream_t st = s->stream;
+  const dim3 b(kThreads);
+  S_TRY(hipMemcpyAsync(s->mask.p, mask, n, hipMemcpyHostToDevice, st));
+  S_TRY(hipEventRecord(s->ev0, st));
+  hipLaunchKernelGGL(mask_to_features_kernel, grid_for(n), b, 0, st,
+                     static_cast<const uint8_t*>(s->mask.p),
+                     static_cast<uint8_t*>(s->filt.p), n);
+  double* d2a = static_cast<double*>(s->d2a.p);
+  double* d2b = static_cast<double*>(s->d2b.p);
+  const size_t rows = (size_t)sh.nz * sh.ny;
+  hipLaunchKernelGGL(edt_x_kernel, grid_for(rows), b, 0, st,
+                     static_cast<const uint8_t*>(s->filt.p), d2a, sh, rows,
+                     voxel_size_zyx[2]);
+  const size_t ylines = (size_t)sh.nz * sh.nx;
+  hipLaunchKernelGGL(edt_line_kernel, grid_for(ylines), b, 0, st,
+                     (const double*)d2a, d2b, sh, 1, voxel_size_zyx[1],
+                     static_cast<int*>(s->vstack.p),
+                     static_cast<double*>(s->zstack.p), ylines);
+  const size_t zlines = (size_t)sh.ny * sh.nx;
+  hipLaunchKernelGGL(edt_line_kernel, grid_for(zlines), b, 0, st,
+                     (const double*)d2b, d2a, sh, 0, voxel_size_zyx[0],
+                     static_cast<int*>(s->vstack.p),
+                     static_cast<double*>(s->zstack.p), zlines);
+  hipLaunchKernelGGL(sqrt_kernel, grid_for(n), b, 0, st, d2a, n);
+  S_TRY(hipGetLastError());
+  S_TRY(hipEventRecord(s->ev1, st));
+  S_TRY(hipMemcpyAsync(dist, d2a, n * sizeof(double), hipMemcpyDeviceToHost, st));
+  S_TRY(hipStreamSynchronize(st));
+  float ms = 0.f;
+  S_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  s->last_ms = ms;
+  s->last_n = 0;  // no peaks stages to read back
+  return FFN_OK;
 }
 
 int ffn_seeder_read_stage(ffn_seeder* s, int which, float* dst) {

@@ -21,6 +21,27 @@ from typing import Any, Dict, Tuple
 _SCALARS = (float, int, str, bool)
 
 
+class _Repeated(list):
+  """Repeated field: a list with protobuf's `add()` for message elements."""
+
+  __slots__ = ('_ftype',)
+
+  def __init__(self, ftype, items=()):
+    super().__init__(items)
+    self._ftype = ftype
+
+  def add(self, **kwargs):
+    item = self._ftype(**kwargs)
+    self.append(item)
+    return item
+
+  def __deepcopy__(self, memo):
+    return _Repeated(self._ftype, (copy.deepcopy(v, memo) for v in self))
+
+  def __reduce__(self):
+    return (_Repeated, (self._ftype, list(self)))
+
+
 class Message:
   """Minimal proto2-like message: typed fields, presence tracking."""
 
@@ -43,7 +64,7 @@ class Message:
       return values[name]
     ftype, default, repeated = fields[name]
     if repeated:
-      values[name] = []
+      values[name] = _Repeated(ftype)
       return values[name]
     if isinstance(ftype, type) and issubclass(ftype, Message):
       # Reading an unset sub-message yields a default instance that becomes
@@ -68,6 +89,8 @@ class Message:
         value = bool(value)
       else:
         value = str(value)
+    elif repeated and not isinstance(value, _Repeated):
+      value = _Repeated(ftype, value)
     self._values[name] = value
     for members in type(self).ONEOFS.values():
       if name in members:
@@ -130,6 +153,15 @@ class Message:
 
   def SerializeToString(self) -> bytes:  # pylint:disable=invalid-name
     return self.to_text().encode('utf-8')
+
+  def ParseFromString(self, data) -> int:  # pylint:disable=invalid-name
+    """Inverse of SerializeToString (which writes protobuf TEXT format: there
+    is no protobuf wire codec in this package)."""
+    object.__setattr__(self, '_values', {})
+    if isinstance(data, (bytes, bytearray)):
+      data = bytes(data).decode('utf-8')
+    parse_text(data, self)
+    return len(data)
 
   def __repr__(self):
     return '%s(\n%s)' % (type(self).__name__, self.to_text(1))
@@ -247,6 +279,33 @@ class InferenceRequest(Message):
       import numpy as np  # pylint:disable=g-import-not-at-top
       value = float(np.float32(value))
     super().__setattr__(name, value)
+
+
+class ResegmentationPoint(Message):
+  """inference.proto:284-293; `id_b` unset = endpoint extension request."""
+  FIELDS = {
+      'id_a': (int, 0, False),
+      'id_b': (int, 0, False),
+      'point': (Vector3j, None, False),
+  }
+
+
+class ResegmentationRequest(Message):
+  """inference.proto:295-341."""
+  FIELDS = {
+      'inference': (InferenceRequest, None, False),
+      'points': (ResegmentationPoint, None, True),
+      'radius': (Vector3j, None, False),
+      'output_directory': (str, '', False),
+      'subdir_digits': (int, 0, False),
+      'max_retry_iters': (int, 1, False),
+      'exclusion_radius': (Vector3j, None, False),
+      'init_exclusion_radius': (Vector3j, None, False),
+      'segment_recovery_fraction': (float, 0.0, False),
+      'terminate_early': (bool, False, False),
+      'analysis_radius': (Vector3j, None, False),
+  }
+
 
 
 # ---------------------------------------------------------------------------

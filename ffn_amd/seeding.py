@@ -119,6 +119,20 @@ class Seeder:
               self._h, canvas_handle._h, voxel, cap, coords, found, all_edges),
           n)
 
+  def edt(self, mask, voxel_size_zyx=(1, 1, 1)):
+    """scipy.ndimage.distance_transform_edt(mask, sampling=voxel_size_zyx) on
+    the GPU (exact): f64 distances to the nearest voxel where `mask` is 0."""
+    m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+    if m.ndim != 3:
+      raise ValueError('edt expects a 3d mask')
+    out = np.empty(m.shape, np.float64)
+    shape = (ctypes.c_int64 * 3)(*m.shape)
+    voxel = (ctypes.c_double * 3)(*[float(v) for v in voxel_size_zyx])
+    with self._lock:
+      check(self._lib.ffn_seeder_edt(self._h, m.ctypes.data, shape, voxel,
+                                     out.ctypes.data))
+    return out
+
   def read_stage(self, which: int, shape):
     out = np.empty(shape, np.float32)
     check(self._lib.ffn_seeder_read_stage(self._h, which, out.ctypes.data))

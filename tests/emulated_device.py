@@ -210,3 +210,8 @@ class EmulatedSeeder:
     from oracle import seeds_oracle
     return seeds_oracle.policy_peaks(handle.image, handle.seg > 0, None,
                                      voxel_size_zyx)
+
+  def edt(self, mask, voxel_size_zyx=(1, 1, 1)):
+    from scipy import ndimage
+    return ndimage.distance_transform_edt(np.asarray(mask) != 0,
+                                          sampling=voxel_size_zyx)
