@@ -23,6 +23,7 @@ canvases (`create_canvas` + `step`), else `Canvas`.
 from __future__ import annotations
 
 import collections
+import inspect
 import ctypes
 
 import logging
@@ -941,10 +942,15 @@ class MultiCanvasDriver:
     self.steps = 0
 
   def run(self, jobs):
-    """jobs: iterable of (DeviceCanvas, seed_policy_factory)."""
+    """jobs: iterable of (DeviceCanvas, seed_policy_factory) -- a whole
+    `segment_all` per canvas -- or (DeviceCanvas, generator) for any other
+    step-yielding task on that canvas (e.g. a resegmentation point)."""
     ready = collections.deque()  # [canvas, generator, pending request, steps]
     for canvas, seed_policy in jobs:
-      gen = canvas._segment_all_gen(seed_policy)
+      if inspect.isgenerator(seed_policy):
+        gen = seed_policy
+      else:
+        gen = canvas._segment_all_gen(seed_policy)
       try:
         ready.append([canvas, gen, next(gen), 0])
       except StopIteration:

@@ -136,6 +136,53 @@ def test_resegmentation_reproduces_reference(golden, fib25_blob, tmp_path):
   assert runner.counters['resegmentation-calls'].value == 2
 
 
+def test_process_many_batches_points_without_changing_results(golden, fib25_blob,
+                                                              tmp_path):
+  """process_many: the points advance concurrently in batched engine steps and
+  every point's file equals what the one-at-a-time reference run wrote."""
+  from tests.emulated_device import EmulatedDeviceClient, EmulatedSeeder
+  request = build_request(golden, tmp_path)
+  client = EmulatedDeviceClient(inference_utils.Counters(), fib25_blob, 12,
+                                (33, 33, 33), (8, 8, 8))
+
+  class EmulatedEngine:
+    max_batch = 2
+
+    def __init__(self):
+      self.calls, self.pending = [], {}
+
+    def step_submit(self, handles, reqs, params):
+      self.calls.append(len(handles))
+      ticket = len(self.calls)
+      self.pending[ticket] = [client.step(h, q, params)
+                              for h, q in zip(handles, reqs)]
+      return ticket
+
+    def step_wait(self, ticket):
+      return self.pending.pop(ticket)
+
+  runner = StandInRunner(
+      golden, lambda counters: EmulatedDeviceClient(
+          counters, fib25_blob, 12, (33, 33, 33), (8, 8, 8)), request.inference)
+  engine = EmulatedEngine()
+  for k in range(2):  # two more points next to the golden ones
+    p = request.points.add()
+    p.id_a = request.points[1].id_a
+    p.point.z, p.point.y = request.points[1].point.z, request.points[1].point.y
+    p.point.x = request.points[1].point.x + 1 + k
+  resegmentation.process_many(request, runner, (1, 1, 1), engine=engine,
+                              seeder=EmulatedSeeder())
+  for n in range(2):
+    check_against_golden(golden, request, n, exact_probs=True)
+  assert len(os.listdir(str(tmp_path))) == 4
+  # two steps in flight, four live points -> groups of two
+  assert max(engine.calls) == 2 and not engine.pending
+  assert runner.counters['resegmentation-calls'].value == 4
+  # a second pass finds both outputs and does nothing
+  resegmentation.process_many(request, runner, (1, 1, 1), engine=engine,
+                              seeder=EmulatedSeeder())
+
+
 def test_get_target_path_subdirs(tmp_path):
   import hashlib
   request = request_lib.ResegmentationRequest()
@@ -205,3 +252,35 @@ def test_gpu_resegmentation_reproduces_reference(golden, fib25_model, tmp_path):
   for n in range(2):
     resegmentation.process_point(request, runner, n, (1, 1, 1))
     check_against_golden(golden, request, n, exact_probs=False)
+
+
+@pytest.mark.gpu
+def test_gpu_process_many_reproduces_reference(golden, fib25_model, tmp_path):
+  import time
+  from ffn_amd.inference import executor
+  request = build_request(golden, tmp_path)
+  # 16 more points: the golden pair / endpoint requests again, shifted by one
+  # voxel each (their own files; only the two golden ones are compared)
+  for k in range(16):
+    src = request.points[k % 2]
+    p = request.points.add()
+    p.id_a = src.id_a
+    if src.HasField('id_b'):
+      p.id_b = src.id_b
+    p.point.z, p.point.y = src.point.z, src.point.y
+    p.point.x = src.point.x + 1 + k // 2
+  exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
+                                  fib25_model.info, None,
+                                  inference_utils.Counters(), 8)
+  runner = StandInRunner(
+      golden, lambda counters: exe.get_client(counters, direct=True),
+      request.inference)
+  t0 = time.time()
+  resegmentation.process_many(request, runner, (1, 1, 1), engine=exe.engine)
+  dt = time.time() - t0
+  for n in range(2):
+    check_against_golden(golden, request, n, exact_probs=False)
+  assert len(os.listdir(str(tmp_path))) == 18
+  steps = runner.counters['update_at-calls'].value
+  print('\nprocess_many: 18 points, %d FoV steps in %.3f s (%.0f steps/s)' %
+        (steps, dt, steps / dt))
