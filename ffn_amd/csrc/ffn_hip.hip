@@ -75,7 +75,8 @@ struct ffn_engine {
   int32_t* pidx = nullptr;    // dense FoV index -> padded position (variant 2)
   int nchunks_c = 0, Rc = 0;
   int fuse_head = 1;      // 1x1x1 head fused into the last conv32c launch
-  int waves8 = 1;         // variants 3 / 4: 8-wave workgroups (conv32w8)
+  int waves8 = 2;         // variants 3 / 4: 8-wave workgroups (conv32w8); 2 = with
+                          // the staging conversion interleaved into the taps
   int count_blocks = kHeadBlocks;  // entries per item in `count` for the last step
   int store_policy = 1;  // conv32c epilogue stores: sc1 write-through (-1.4 % per stack)
   long long* d_dbg = nullptr;  // debug clocks of conv32c WG 0 (24 values)
@@ -471,7 +472,14 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
   hipLaunchKernelGGL((conv32w8_kernel<RI, RO, SK, KSV, HEADV, SCH>), grid,    \
                      block8, lb, e->stream, a)
     const bool k8 = e->Rc == 256;
-    if (h) {
+    if (h && e->waves8 == 2) {  // staging conversion interleaved with the taps
+#define FFN_W8I_LAUNCH(KSV, HEADV)                                            \
+  hipLaunchKernelGGL((conv32w8_kernel<RI, RO, SK, KSV, HEADV, 2, true>), grid, \
+                     block8, lb, e->stream, a)
+      if (head.on) { if (k8) FFN_W8I_LAUNCH(8, true); else FFN_W8I_LAUNCH(9, true); }
+      else { if (k8) FFN_W8I_LAUNCH(8, false); else FFN_W8I_LAUNCH(9, false); }
+#undef FFN_W8I_LAUNCH
+    } else if (h) {
       if (head.on) { if (k8) FFN_W8_LAUNCH(8, true, 2); else FFN_W8_LAUNCH(9, true, 2); }
       else { if (k8) FFN_W8_LAUNCH(8, false, 2); else FFN_W8_LAUNCH(9, false, 2); }
     } else {
@@ -1134,7 +1142,8 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     return FFN_OK;
   }
   if (std::strcmp(name, "waves8") == 0) {
-    e->waves8 = value != 0;
+    if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "waves8 must be 0, 1 or 2");
+    e->waves8 = value;
     return FFN_OK;
   }
   if (std::strcmp(name, "store_policy") == 0) {

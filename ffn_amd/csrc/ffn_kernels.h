@@ -1477,7 +1477,7 @@ __global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(
 constexpr int kW8Threads = 512;
 
 template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int KS = 8, bool HEAD = false,
-          int SCHEME = 2>
+          int SCHEME = 2, bool ILV = false>
 __global__ __launch_bounds__(kW8Threads, 2) void conv32w8_kernel(ConvCArgs a) {
   constexpr int NP = SCHEME == 3 ? 3 : 2;
   constexpr int kRowB = SCHEME == 3 ? kXRowBytes : kHRowBytes;
@@ -1561,9 +1561,8 @@ __global__ __launch_bounds__(kW8Threads, 2) void conv32w8_kernel(ConvCArgs a) {
       sv[seg][k] = s4[(kExact || e < nquads) ? e : tid];
     }
   }
-  auto write_segment = [&](int seg) {
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
+  auto write_piece = [&](int seg, int k) {
+    {
       const int e = tid + k * kW8Threads;
       if (kExact || e < nquads) {
         f32x4 v = sv[seg][k];
@@ -1597,6 +1596,21 @@ __global__ __launch_bounds__(kW8Threads, 2) void conv32w8_kernel(ConvCArgs a) {
           *reinterpret_cast<f16x4*>(dstrow + 64) = res;
         }
       }
+    }
+  };
+  auto write_segment = [&](int seg) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) write_piece(seg, k);
+  };
+  // ILV: the conversion + LDS writes of the NEXT dz segment are spread over the
+  // taps of the current one (one piece after the first product group of a tap),
+  // so their VALU work runs in the shadow of the MFMAs instead of between two
+  // barriers.  The slot they fill is not read by any wave during those taps.
+  auto ilv_piece = [&](int s) {
+    if constexpr (ILV) {
+      const int r = s % 9, seg = s / 9 + 1;
+      // pieces 0..KT-1 after taps 3, 4, 5, 6 (, 7) of the segment
+      if (seg < 3 && r >= 3 && r - 3 < KT) write_piece(seg, r - 3);
     }
   };
   write_segment(0);
@@ -1663,6 +1677,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void conv32w8_kernel(ConvCArgs a) {
       if (pa_) loadA_tile(0, oa_, ANEXT);                                    \
       FFN_W8PROD(accC, ACUR, BCUR, 1, 0, own_)                               \
       if (pa_) loadA_tile(1, oa_, ANEXT);                                    \
+      ilv_piece(S);                                                          \
       FFN_W8PROD(acc, ACUR, BCUR, 0, 0, own_)                                \
       if (ownn_) loadA_tile(2, oa_, ANEXT);                                  \
       if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                              \
@@ -1678,7 +1693,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void conv32w8_kernel(ConvCArgs a) {
   FFN_W8TAP(6, A0, A1, B0, B2, true)
   FFN_W8TAP(7, A1, A0, B1, B0, true)
   FFN_W8TAP(8, A0, A1, B2, B1, false)
-  write_segment(1);
+  if constexpr (!ILV) write_segment(1);
   __syncthreads();
   {
     const int off = a_off(9);
@@ -1695,7 +1710,7 @@ __global__ __launch_bounds__(kW8Threads, 2) void conv32w8_kernel(ConvCArgs a) {
   FFN_W8TAP(15, A1, A0, B0, B2, true)
   FFN_W8TAP(16, A0, A1, B1, B0, true)
   FFN_W8TAP(17, A1, A0, B2, B1, false)
-  write_segment(2);
+  if constexpr (!ILV) write_segment(2);
   __syncthreads();
   // residual input and bias of this thread's epilogue pieces
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);

@@ -196,10 +196,12 @@ int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
  * must stay inside the fp16 range, else FFN_ERR_RANGE).  Results are identical up to f32 summation order
  * (variant 3: plus a truncation 100x below f32 rounding).  "fuse_head": 1x1x1
  * head inside the last conv launch.  "store_policy": 0 write-back, 1
- * write-through, 2 non-temporal conv stores. */
+ * write-through, 2 non-temporal conv stores.  "waves8" (variants 3 / 4): 0 =
+ * 4-wave workgroups, 1 = 8-wave, 2 (default) = 8-wave with the staging of the
+ * next depth segment interleaved into the taps (variant 4; bit-identical). */
 int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
 /* Current value of an option ("conv_variant", "fuse_head", "store_policy",
- * "sync_mode", "profile_every"). */
+ * "sync_mode", "profile_every", "waves8"). */
 int ffn_engine_get_option(ffn_engine* engine, const char* name, int* value);
 /* Debug: with option "debug_clock" = 1 the compact conv kernel records, for its
  * first workgroup, per wave {shader clock at entry, at main-loop start, at

@@ -17,7 +17,8 @@ from tests.conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-DEFAULT_VARIANT = 4  # what ffn_engine_create selects for the 33^3 FoV
+DEFAULT_VARIANT = 4
+DEFAULT_WAVES8 = 2  # what ffn_engine_create selects for the 33^3 FoV
 TOL = 1e-4
 
 
@@ -41,7 +42,7 @@ def _fov_inputs(rng, n=1):
 
 @pytest.mark.parametrize('variant,fuse_head,waves8', [
     (0, 1, 1), (1, 1, 1), (2, 1, 1), (2, 0, 1), (3, 1, 1), (3, 0, 1), (4, 1, 1),
-    (4, 0, 1), (3, 1, 0), (4, 1, 0), (4, 0, 0)])
+    (4, 0, 1), (3, 1, 0), (4, 1, 0), (4, 0, 0), (4, 1, 2), (4, 0, 2)])
 def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head, waves8):
   """conv_variant 0 simple f32 MFMA, 1 padded pipelined, 2 compact (exact f32
   MFMA), 3 compact with bf16x3 split products, 4 with fp16 hi + scaled
@@ -50,7 +51,9 @@ def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head, waves8):
   from oracle import ffn_oracle
   engine.set_option('conv_variant', variant)
   engine.set_option('fuse_head', fuse_head)
-  engine.set_option('waves8', waves8)  # variants 3 / 4: 8- or 4-wave workgroups
+  # variants 3 / 4: 0 = 4-wave workgroups, 1 = 8-wave, 2 = 8-wave with the
+  # staging conversion interleaved into the taps (variant 4; the default)
+  engine.set_option('waves8', waves8)
   rng = np.random.RandomState(42)
   img, seed = _fov_inputs(rng, 1)
   got = engine.predict(seed, img)
@@ -62,7 +65,7 @@ def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head, waves8):
   assert err <= TOL
   engine.set_option('conv_variant', DEFAULT_VARIANT)
   engine.set_option('fuse_head', 1)
-  engine.set_option('waves8', 1)
+  engine.set_option('waves8', DEFAULT_WAVES8)
 
 
 def test_predict_batch_and_ragged(engine, fib25_blob):
