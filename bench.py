@@ -163,22 +163,35 @@ def run_gpu(args, rank, local_rank, world):
         raise _Done()
       return pred
 
-  canvas = BenchCanvas(model.info, exe.get_client(counters, direct=True), image,
+  def new_canvas():
+    return BenchCanvas(model.info, exe.get_client(counters, direct=True), image,
                        request.inference_options, counters=counters,
                        movement_policy_fn=movement.get_policy_fn(
                            request, model.info))
+
+  canvas = new_canvas()
   # HIP-event pairs around every conv32 launch of 1 FoV step in
   # `profile_every` (sampling keeps the event overhead out of `value`).
   eng.set_option('profile_every', args.profile_every)
   eng.set_profiling(args.profile_mode)
   policy = functools.partial(seed_lib.PolicyGrid3d, step=16,
                              offsets=(0, 8, 4, 12, 2, 10, 14))
+  # The 250^3 phantom holds ~80 k FoV steps; should K ask for more (or a small
+  # --volume be used) the same volume is segmented again on a fresh canvas --
+  # its set-up then sits inside the timed region and is reported.
+  passes = 0
   try:
-    canvas.segment_all(seed_policy=policy)
-    raise RuntimeError('workload exhausted after %d steps (< warmup+steps = %d)'
-                       % (state['n'] + state.get('prewarm_steps', 0), total))
+    while True:
+      done_before = state['n'] + state.get('prewarm_steps', 0)
+      canvas.segment_all(seed_policy=policy)
+      passes += 1
+      if state['n'] + state.get('prewarm_steps', 0) == done_before:
+        raise RuntimeError('workload yields no FoV steps')
+      canvas.close()
+      canvas = new_canvas()
   except _Done:
     pass
+  state['volume_passes_completed'] = passes
 
   conv_ms, conv_launches = eng.get_profile()
   elapsed = state['t1'] - state['t0']
@@ -220,6 +233,7 @@ def run_gpu(args, rank, local_rank, world):
       'conv_variant': (args.conv_variant if args.conv_variant is not None
                        else eng.get_option('conv_variant')),
       'prewarm_steps': state.get('prewarm_steps', 0),
+      'volume_passes_completed': state['volume_passes_completed'],
       'elapsed': elapsed,
       'elapsed_local': elapsed_local,
       'conv_ms': conv_ms,
@@ -409,6 +423,7 @@ def main():
       'steps': args.steps,
       'warmup': args.warmup,
       'prewarm_steps_untimed': res.get('prewarm_steps', 0),
+      'volume_passes_completed': res.get('volume_passes_completed', 0),
       'ms_per_step': round(1e3 * res['elapsed'] / args.steps, 4),
       'higher_is_better': True,
       'scaling': 'weak',

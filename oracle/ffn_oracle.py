@@ -29,7 +29,7 @@ import subprocess
 import time
 
 import numpy as np
-from scipy.special import expit, logit
+from scipy.special import logit
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None

@@ -3,10 +3,8 @@ the final segmentation merge (the only collective of the path)."""
 
 import os
 import socket
-import sys
 
 import numpy as np
-import pytest
 
 from ffn_amd import distributed as ffn_dist
 

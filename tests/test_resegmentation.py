@@ -6,7 +6,6 @@ import os
 import numpy as np
 import pytest
 
-from ffn_amd import synthetic
 from ffn_amd.inference import align
 from ffn_amd.inference import inference
 from ffn_amd.inference import inference_utils
