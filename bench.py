@@ -244,6 +244,7 @@ def run_gpu(args, rank, local_rank, world):
   }
   if world > 1:
     dist.barrier()
+    dist.destroy_process_group()
   return result
 
 
