@@ -163,8 +163,55 @@ def run_gpu(args, rank, local_rank, world):
         raise _Done()
       return pred
 
+  class NativeBenchCanvas(inference.DeviceCanvas):
+    """The default: every segment's FoV loop runs inside the library
+    (ffn_canvas_segment_at); the loop is called with step budgets that end
+    exactly on the prewarm / warmup / timed boundaries and resumed."""
+
+    def _segment_at_native(self, start_pos, max_steps=0, resume=False):
+      del max_steps, resume
+      done, first = 0, True
+      while True:
+        if state['n'] == 0 and args.prewarm_seconds > 0 and not state.get(
+            'prewarm_over'):
+          if state.get('pre_until') is None:
+            state['pre_until'] = time.perf_counter() + args.prewarm_seconds
+          left = args.prewarm_max_steps - state.get('prewarm_steps', 0)
+          if time.perf_counter() < state['pre_until'] and left > 0:
+            n = super()._segment_at_native(start_pos, max_steps=min(left, 64),
+                                           resume=not first)
+            state['prewarm_steps'] = state.get('prewarm_steps', 0) + n
+            done, first = done + n, False
+            if not self._native_active:
+              return done
+            continue
+          state['prewarm_over'] = True
+        if state['n'] == args.warmup and state['t0'] is None:
+          eng.synchronize()
+          barrier()
+          eng.get_profile(reset=True)
+          state['vox0'] = self.counters['voxels-segmented'].value
+          state['t0'] = time.perf_counter()
+        boundary = args.warmup if state['n'] < args.warmup else total
+        n = super()._segment_at_native(start_pos,
+                                       max_steps=boundary - state['n'],
+                                       resume=not first)
+        state['n'] += n
+        done, first = done + n, False
+        if state['n'] == total:
+          eng.synchronize()
+          state['t1_local'] = time.perf_counter()
+          barrier()
+          state['t1'] = time.perf_counter()
+          state['vox1'] = self.counters['voxels-segmented'].value
+          raise _Done()
+        if not self._native_active:
+          return done
+
+  canvas_cls = BenchCanvas if args.host_loop == 'python' else NativeBenchCanvas
+
   def new_canvas():
-    return BenchCanvas(model.info, exe.get_client(counters, direct=True), image,
+    return canvas_cls(model.info, exe.get_client(counters, direct=True), image,
                        request.inference_options, counters=counters,
                        movement_policy_fn=movement.get_policy_fn(
                            request, model.info))
@@ -364,6 +411,10 @@ def main():
   ap.add_argument('--cpu-seconds', type=float, default=15.0)
   ap.add_argument('--cpu-steps', type=int, default=60)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--host-loop', choices=['native', 'python'], default='native',
+                  help='native: ffn_canvas_segment_at runs each segment\'s FoV '
+                  'loop inside the library; python: one ffn_canvas_step call '
+                  'per step from the interpreter')
   args = ap.parse_args()
 
   rank, local_rank, world = _dist_env()
@@ -438,6 +489,9 @@ def main():
                        % (args.workload, args.volume)),
           'volume': [args.volume] * 3,
           'parallelism': 'independent volume per rank (no data-path collective)',
+          'host_loop': ('ffn_canvas_segment_at (segment loop inside the library)'
+                        if args.host_loop == 'native' else
+                        'Python, one ffn_canvas_step per FoV step'),
       },
       'voxels_segmented_per_s': round(world * res['voxels'] / res['elapsed'], 1),
       'host_breakdown_us_per_step': {

@@ -69,6 +69,37 @@ class StepResult(ctypes.Structure):
               ('range_error', ctypes.c_int32)]
 
 
+class SegmentParams(ctypes.Structure):
+  """ffn_segment_params (include/ffn_hip.h)."""
+  _fields_ = [('step', StepParams),
+              ('score_threshold', ctypes.c_double),
+              ('deltas_zyx', ctypes.c_int32 * 3),
+              ('margin_zyx', ctypes.c_int32 * 3),
+              ('shape_zyx', ctypes.c_int32 * 3),
+              ('init_min_pos', ctypes.c_int32 * 3),
+              ('init_max_pos', ctypes.c_int32 * 3),
+              ('initial_start_logit', ctypes.c_float),
+              ('prefetch', ctypes.c_int32),
+              ('keep_history', ctypes.c_int32),
+              ('max_steps', ctypes.c_int64)]
+
+
+class SegmentResult(ctypes.Structure):
+  """ffn_segment_result (include/ffn_hip.h)."""
+  _fields_ = [('num_steps', ctypes.c_int64),
+              ('skip_threshold', ctypes.c_int64),
+              ('skip_invalid_pos', ctypes.c_int64),
+              ('gate_rejects', ctypes.c_int64),
+              ('queue_len', ctypes.c_int64),
+              ('seed_got_too_weak', ctypes.c_int32),
+              ('budget_exhausted', ctypes.c_int32),
+              ('active', ctypes.c_int32),
+              ('start_logit_known', ctypes.c_int32),
+              ('start_logit', ctypes.c_float),
+              ('min_pos', ctypes.c_int32 * 3),
+              ('max_pos', ctypes.c_int32 * 3)]
+
+
 class CommitCounts(ctypes.Structure):
   _fields_ = [('raw_segmented_voxels', ctypes.c_int64),
               ('actual_segmented_voxels', ctypes.c_int64),
@@ -111,6 +142,11 @@ SIGNATURES = {
                                     ctypes.POINTER(ctypes.c_uint32)]),
     'ffn_canvas_step_wait': (_I, [_P, ctypes.c_uint32,
                                   ctypes.POINTER(StepResult)]),
+    'ffn_canvas_segment_at': (_I, [_P, _I3, ctypes.POINTER(SegmentParams), _I,
+                                   ctypes.POINTER(SegmentResult)]),
+    'ffn_canvas_segment_history': (_I, [_P, ctypes.c_size_t, ctypes.c_size_t,
+                                        _P, _P,
+                                        ctypes.POINTER(ctypes.c_size_t)]),
     'ffn_canvas_read_points': (_I, [_P, _I, _P, _P, _P]),
     'ffn_canvas_write_seg_points': (_I, [_P, _I, _P, _P]),
     'ffn_canvas_any_segmented': (_I, [_P, _I3, _I3,

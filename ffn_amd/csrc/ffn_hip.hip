@@ -17,6 +17,7 @@
 
 #include "ffn_internal.h"
 #include "ffn_kernels.h"
+#include "ffn_host_loop.h"
 
 using namespace ffn;
 
@@ -145,6 +146,7 @@ struct ffn_canvas {
   // seed (62.5 MB at 250^3, 4.3 GB at 1024^3); here only this box is re-filled.
   int dirty_lo[3] = {0, 0, 0};
   int dirty_hi[3] = {0, 0, 0};  // exclusive; lo >= hi: nothing dirty
+  ffn_host::SegmentState loop;  // ffn_canvas_segment_at's queue / visited set
 
   void mark_dirty(const int lo[3], const int hi[3]) {
     const int dims[3] = {cz, cy, cx};
@@ -709,7 +711,7 @@ int grid_for(long total, int block = 256) {
 
 extern "C" {
 
-int ffn_abi_version(void) { return 2; }
+int ffn_abi_version(void) { return 3; }
 
 const char* ffn_last_error(void) { return g_error.c_str(); }
 
@@ -1430,6 +1432,54 @@ int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
   int rc = ffn_canvas_step_submit(e, n, canvases, requests, params, &ticket);
   if (rc) return rc;
   return ffn_canvas_step_wait(e, ticket, results);
+}
+
+namespace {
+// the HIP canvas as the device of the host loop
+struct HipLoopDevice {
+  ffn_canvas* c;
+  int step(const ffn_step_request& req, const ffn_step_params& params,
+           ffn_step_result* res) {
+    ffn_canvas* one = c;
+    return ffn_canvas_step(c->engine, 1, &one, &req, &params, res);
+  }
+  int read_point(const int32_t pos[3], float* seed, int32_t* seg) {
+    return ffn_canvas_read_points(c, 1, pos, seed, seg);
+  }
+};
+}  // namespace
+
+int ffn_canvas_segment_at(ffn_canvas* c, const int32_t start[3],
+                          const ffn_segment_params* p, int resume,
+                          ffn_segment_result* out) {
+  if (!c || !start || !p || !out) return fail(FFN_ERR_ARG, "null argument");
+  if (!c->engine) return fail(FFN_ERR_STATE, "canvas outlived its engine");
+  if (p->prefetch < 0 || p->prefetch > FFN_MAX_CANDIDATES)
+    return fail(FFN_ERR_ARG, "prefetch must be 0..%d", FFN_MAX_CANDIDATES);
+  if (p->shape_zyx[0] != c->cz || p->shape_zyx[1] != c->cy ||
+      p->shape_zyx[2] != c->cx)
+    return fail(FFN_ERR_ARG, "shape_zyx does not match the canvas");
+  for (int a = 0; a < 3; ++a)
+    if (p->deltas_zyx[a] < 0 || p->margin_zyx[a] < 0)
+      return fail(FFN_ERR_ARG, "negative deltas / margin");
+  if (resume && !c->loop.active)
+    return fail(FFN_ERR_STATE, "no segment to resume");
+  HipLoopDevice dev{c};
+  ffn_host::SegmentLoop<HipLoopDevice> loop(dev, c->loop, *p);
+  return loop.run(start, resume, out);
+}
+
+int ffn_canvas_segment_history(ffn_canvas* c, size_t first, size_t n,
+                               int32_t* pos, uint32_t* deleted, size_t* total) {
+  if (!c) return fail(FFN_ERR_ARG, "null canvas");
+  const size_t have = c->loop.history_deleted.size();
+  if (total) *total = have;
+  if (n == 0) return FFN_OK;
+  if (first > have || n > have - first)
+    return fail(FFN_ERR_ARG, "history range [%zu, +%zu) of %zu", first, n, have);
+  if (pos) std::memcpy(pos, c->loop.history.data() + 3 * first, 12 * n);
+  if (deleted) std::memcpy(deleted, c->loop.history_deleted.data() + first, 4 * n);
+  return FFN_OK;
 }
 
 int ffn_canvas_read_points(ffn_canvas* c, int n, const int32_t* pos,

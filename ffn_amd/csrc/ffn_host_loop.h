@@ -1,0 +1,356 @@
+// Canvas.segment_at on the host side of the library: the FoV loop of one
+// segment without an interpreter between the steps.
+//
+// What runs here is the reference's inner loop (ffn/inference/inference.py:
+// 460-533) with its default movement policy (FaceMaxMovementPolicy,
+// ffn/inference/movement.py:166-222) and position test (Canvas.is_valid_pos,
+// inference.py:312-346): a FIFO of (score, position) candidates, a visited set
+// of positions quantised to the delta grid, six face maxima per step sorted by
+// descending (score, offset) with duplicates dropped.  Every decision is the
+// same integer / f32 comparison the Python mirror (ffn_amd/inference) makes, in
+// the same order, so the visited positions are identical step for step.
+//
+// Pure C++17, no HIP: the device is a template parameter with
+//   int step(const ffn_step_request&, const ffn_step_params&, ffn_step_result*)
+//   int read_point(const int32_t pos[3], float* seed, int32_t* seg)
+// (FFN_OK or an error code that is passed through).  libffn_hip.so instantiates
+// it with the HIP canvas; tests/host_loop_shim.cpp with callbacks into the
+// emulated device, so the loop itself is covered without a GPU.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/ffn_hip.h"
+
+namespace ffn_host {
+
+struct Coord {
+  int32_t z, y, x;
+  bool operator==(const Coord& o) const { return z == o.z && y == o.y && x == o.x; }
+};
+
+struct CoordHash {
+  size_t operator()(const Coord& c) const {
+    uint64_t h = (uint64_t)(uint32_t)c.z * 0x9E3779B97F4A7C15ull;
+    h ^= (uint64_t)(uint32_t)c.y * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+    h ^= (uint64_t)(uint32_t)c.x * 0x165667B19E3779F9ull + (h << 6) + (h >> 2);
+    return (size_t)h;
+  }
+};
+
+inline int32_t floordiv(int32_t a, int32_t b) {  // Python's //, b > 0
+  int32_t q = a / b;
+  if ((a % b != 0) && (a < 0)) --q;
+  return q;
+}
+
+// State of one segment's loop; lives in the canvas between calls so that a call
+// bounded by max_steps can be resumed.
+struct SegmentState {
+  struct Entry {
+    float score;
+    Coord pos;
+    Coord q;  // pos quantised to the delta grid (movement.py:200-208)
+  };
+  std::deque<Entry> queue;
+  std::unordered_set<Coord, CoordHash> done;
+  // post-step values at positions the next validity tests may ask for
+  // (DeviceCanvas._cache): seed logit and segmentation id
+  std::unordered_map<Coord, std::pair<float, int32_t>, CoordHash> cache;
+  Coord start{0, 0, 0};
+  float start_logit = 0.f;
+  bool start_logit_known = false;
+  bool active = false;     // a segment is in progress (resumable)
+  bool has_pending = false;  // a popped position whose step did not complete
+  Coord pending{0, 0, 0};
+  int32_t min_pos[3] = {0, 0, 0}, max_pos[3] = {0, 0, 0};
+  // history of the segment (keep_history): positions and deleted-voxel counts
+  std::vector<int32_t> history;          // 3 per step
+  std::vector<uint32_t> history_deleted;  // 1 per step
+};
+
+template <class Dev>
+class SegmentLoop {
+ public:
+  SegmentLoop(Dev& dev, SegmentState& st, const ffn_segment_params& p)
+      : dev_(dev), st_(st), p_(p) {
+    for (int a = 0; a < 3; ++a) {
+      d_[a] = p.deltas_zyx[a];
+      dh_[a] = d_[a] / 2;
+      dm_[a] = d_[a] > 1 ? d_[a] : 1;
+    }
+  }
+
+  // Starts (resume = 0) or continues (resume = 1) the segment at `start`.
+  int run(const int32_t start[3], int resume, ffn_segment_result* out) {
+    std::memset(out, 0, sizeof(*out));
+    if (!resume) {
+      st_.queue.clear();
+      st_.done.clear();
+      st_.cache.clear();
+      st_.history.clear();
+      st_.history_deleted.clear();
+      st_.start = Coord{start[0], start[1], start[2]};
+      st_.has_pending = false;
+      st_.active = true;
+      for (int a = 0; a < 3; ++a) {
+        st_.min_pos[a] = p_.init_min_pos[a];
+        st_.max_pos[a] = p_.init_max_pos[a];
+      }
+      st_.start_logit_known = p_.initial_start_logit == p_.initial_start_logit;
+      st_.start_logit = p_.initial_start_logit;
+      // the first move: the start position itself, at twice the threshold
+      // (inference.py:481-483)
+      push((float)(p_.score_threshold * 2.0), st_.start);
+    } else if (!st_.active) {
+      return FFN_ERR_STATE;
+    }
+    int rc = FFN_OK;
+    int64_t steps = 0;
+    for (;;) {
+      if (p_.max_steps > 0 && steps >= p_.max_steps) {
+        out->budget_exhausted = 1;
+        break;
+      }
+      Coord pos;
+      if (st_.has_pending) {
+        pos = st_.pending;
+      } else {
+        bool found = false;
+        rc = next(&pos, &found, out);
+        if (rc) break;
+        if (!found) {
+          st_.active = false;
+          break;
+        }
+      }
+      // "seed got too weak" (inference.py:503-505)
+      if (!st_.start_logit_known) {
+        int32_t seg;
+        const int32_t sp[3] = {st_.start.z, st_.start.y, st_.start.x};
+        rc = dev_.read_point(sp, &st_.start_logit, &seg);
+        if (rc) {
+          st_.pending = pos;
+          st_.has_pending = true;
+          break;
+        }
+        st_.start_logit_known = true;
+      }
+      if (st_.start_logit < p_.step.move_threshold) {
+        out->seed_got_too_weak = 1;
+        st_.has_pending = false;
+        st_.active = false;
+        break;
+      }
+      // ---- one FoV step --------------------------------------------------------
+      ffn_step_request req;
+      req.pos[0] = pos.z, req.pos[1] = pos.y, req.pos[2] = pos.x;
+      req.start_pos[0] = st_.start.z, req.start_pos[1] = st_.start.y,
+      req.start_pos[2] = st_.start.x;
+      Coord cands[FFN_MAX_CANDIDATES];
+      const int nc = peek(cands, p_.prefetch < FFN_MAX_CANDIDATES
+                                     ? p_.prefetch : FFN_MAX_CANDIDATES);
+      req.num_candidates = nc;
+      for (int k = 0; k < nc; ++k) {
+        req.candidates[k][0] = cands[k].z;
+        req.candidates[k][1] = cands[k].y;
+        req.candidates[k][2] = cands[k].x;
+      }
+      ffn_step_result res;
+      rc = dev_.step(req, p_.step, &res);
+      if (rc) {  // nothing was pasted: the position stays pending
+        st_.pending = pos;
+        st_.has_pending = true;
+        break;
+      }
+      st_.has_pending = false;
+      ++steps;
+      st_.cache.clear();
+      for (int k = 0; k < nc; ++k)
+        st_.cache.emplace(cands[k], std::make_pair(res.cand_seed[k], res.cand_seg[k]));
+      st_.start_logit = res.start_logit;
+      st_.start_logit_known = true;
+      const int32_t pv[3] = {pos.z, pos.y, pos.x};
+      for (int a = 0; a < 3; ++a) {
+        if (pv[a] < st_.min_pos[a]) st_.min_pos[a] = pv[a];
+        if (pv[a] > st_.max_pos[a]) st_.max_pos[a] = pv[a];
+      }
+      if (p_.keep_history) {
+        st_.history.insert(st_.history.end(), pv, pv + 3);
+        st_.history_deleted.push_back(res.num_deleted);
+      }
+      update(res, pos);
+    }
+    out->num_steps = steps;
+    out->start_logit = st_.start_logit;
+    out->start_logit_known = st_.start_logit_known ? 1 : 0;
+    out->active = st_.active ? 1 : 0;
+    for (int a = 0; a < 3; ++a) {
+      out->min_pos[a] = st_.min_pos[a];
+      out->max_pos[a] = st_.max_pos[a];
+    }
+    out->queue_len = (int64_t)st_.queue.size();
+    return rc;
+  }
+
+ private:
+  Coord quantize(const Coord& c) const {
+    return Coord{floordiv(c.z - st_.start.z + dh_[0], dm_[0]),
+                 floordiv(c.y - st_.start.y + dh_[1], dm_[1]),
+                 floordiv(c.x - st_.start.x + dh_[2], dm_[2])};
+  }
+  void push(float score, const Coord& c) {
+    st_.queue.push_back(SegmentState::Entry{score, c, quantize(c)});
+  }
+
+  int read_cached(const Coord& c, float* seed, int32_t* seg) {
+    auto it = st_.cache.find(c);
+    if (it != st_.cache.end()) {
+      *seed = it->second.first;
+      *seg = it->second.second;
+      return FFN_OK;
+    }
+    const int32_t pv[3] = {c.z, c.y, c.x};
+    const int rc = dev_.read_point(pv, seed, seg);
+    if (rc) return rc;
+    st_.cache.emplace(c, std::make_pair(*seed, *seg));
+    return FFN_OK;
+  }
+
+  bool in_bounds(const Coord& c) const {
+    const int32_t pv[3] = {c.z, c.y, c.x};
+    for (int a = 0; a < 3; ++a)
+      if (pv[a] - p_.margin_zyx[a] < 0 || pv[a] + p_.margin_zyx[a] >= p_.shape_zyx[a])
+        return false;
+    return true;
+  }
+
+  // Canvas.is_valid_pos (inference.py:312-346), device-state part included
+  int is_valid(const Coord& c, bool* ok, ffn_segment_result* out) {
+    *ok = false;
+    float seed;
+    int32_t seg;
+    int rc = read_cached(c, &seed, &seg);
+    if (rc) return rc;
+    if (seed < p_.step.move_threshold) {
+      ++out->skip_threshold;
+      if (in_bounds(c)) ++out->gate_rejects;
+      return FFN_OK;
+    }
+    if (!in_bounds(c)) {
+      ++out->skip_invalid_pos;
+      return FFN_OK;
+    }
+    if (seg > 0) {
+      ++out->skip_invalid_pos;
+      ++out->gate_rejects;
+      return FFN_OK;
+    }
+    *ok = true;
+    return FFN_OK;
+  }
+
+  // FaceMaxMovementPolicy.__next__ (movement.py:182-198)
+  int next(Coord* pos, bool* found, ffn_segment_result* out) {
+    *found = false;
+    while (!st_.queue.empty()) {
+      const SegmentState::Entry e = st_.queue.front();
+      if (st_.done.count(e.q)) {
+        st_.queue.pop_front();
+        continue;
+      }
+      bool ok = false;
+      // the entry leaves the queue only once its test could be made
+      const int rc = is_valid(e.pos, &ok, out);
+      if (rc) return rc;
+      st_.queue.pop_front();
+      if (ok) {
+        *pos = e.pos;
+        *found = true;
+        return FFN_OK;
+      }
+    }
+    return FFN_OK;
+  }
+
+  // first `limit` queued positions not yet visited (their post-step seed /
+  // segmentation values come back with the step result)
+  int peek(Coord* out, int limit) {
+    while (!st_.queue.empty() && st_.done.count(st_.queue.front().q))
+      st_.queue.pop_front();
+    int n = 0;
+    for (const auto& e : st_.queue) {
+      if (n >= limit) break;
+      if (st_.done.count(e.q)) continue;
+      out[n++] = e.pos;
+    }
+    return n;
+  }
+
+  // FaceMaxMovementPolicy.update (movement.py:210-222) on the six face maxima
+  // of get_scored_move_offsets (movement.py:42-100)
+  void update(const ffn_step_result& res, const Coord& pos) {
+    st_.done.insert(quantize(pos));
+    struct Move {
+      float score;
+      int32_t rel[3];
+      int32_t seg;
+    };
+    Move moves[6];
+    int nm = 0;
+    int k = 0;
+    for (int axis = 0; axis < 3; ++axis) {
+      const int o0 = axis == 0 ? 1 : 0;
+      const int o1 = axis == 2 ? 1 : 2;
+      for (int sign = -1; sign <= 1; sign += 2, ++k) {
+        const int32_t off = sign * d_[axis];
+        if (off == 0) continue;
+        const float score = res.face_score[k];
+        if ((double)score < p_.score_threshold) continue;
+        const int32_t ncols = 2 * d_[o1] + 1;
+        const int32_t fi = res.face_index[k] / ncols;
+        const int32_t fj = res.face_index[k] - fi * ncols;
+        Move m;
+        m.score = score;
+        m.rel[axis] = off;
+        m.rel[o0] = fi - d_[o0];
+        m.rel[o1] = fj - d_[o1];
+        m.seg = res.face_seg[k];
+        moves[nm++] = m;
+      }
+    }
+    // descending (score, offset, seg), as sorted(..., reverse=True) of tuples
+    std::sort(moves, moves + nm, [](const Move& a, const Move& b) {
+      if (a.score != b.score) return a.score > b.score;
+      for (int i = 0; i < 3; ++i)
+        if (a.rel[i] != b.rel[i]) return a.rel[i] > b.rel[i];
+      return a.seg > b.seg;
+    });
+    for (int i = 0; i < nm; ++i) {
+      // one voxel shared by two faces: keep the first (movement.py:98-100)
+      if (i > 0 && moves[i].score == moves[i - 1].score &&
+          moves[i].rel[0] == moves[i - 1].rel[0] &&
+          moves[i].rel[1] == moves[i - 1].rel[1] &&
+          moves[i].rel[2] == moves[i - 1].rel[2])
+        continue;
+      const Coord c{moves[i].rel[0] + pos.z, moves[i].rel[1] + pos.y,
+                    moves[i].rel[2] + pos.x};
+      push(moves[i].score, c);
+      // freshly queued: its seed logit is the face maximum just pasted
+      st_.cache.emplace(c, std::make_pair(moves[i].score, moves[i].seg));
+    }
+  }
+
+  Dev& dev_;
+  SegmentState& st_;
+  const ffn_segment_params& p_;
+  int32_t d_[3], dh_[3], dm_[3];
+};
+
+}  // namespace ffn_host

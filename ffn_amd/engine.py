@@ -256,6 +256,48 @@ class DeviceCanvasHandle:
         ctypes.addressof(self._pt_seg)))
     return self._pt_seed.value, self._pt_seg.value
 
+  def segment_at(self, start_pos, params: '_lib.SegmentParams',
+                 resume: bool = False) -> '_lib.SegmentResult':
+    """ffn_canvas_segment_at: the whole FoV loop of a segment inside the
+    library.  A step voided by the fp16 range check is repeated with the bf16x3
+    scheme (as `HipEngine._blocking_step` does) and the loop resumed."""
+    res = _lib.SegmentResult()
+    rc = self._lib.ffn_canvas_segment_at(self._h, i3(start_pos),
+                                         ctypes.byref(params), int(resume),
+                                         ctypes.byref(res))
+    if rc == _lib.ERR_RANGE:
+      # the voided step changed nothing on the device; the loop keeps the
+      # position pending, so resuming repeats exactly that step
+      self.engine.range_fallbacks += 1
+      self.engine.set_option('conv_variant', 3)
+      first = _lib.SegmentResult.from_buffer_copy(res)
+      budget = params.max_steps
+      if budget > 0:
+        params.max_steps = max(budget - first.num_steps, 1)
+      rc = self._lib.ffn_canvas_segment_at(self._h, i3(start_pos),
+                                           ctypes.byref(params), 1,
+                                           ctypes.byref(res))
+      params.max_steps = budget
+      for name in ('num_steps', 'skip_threshold', 'skip_invalid_pos',
+                   'gate_rejects'):
+        setattr(res, name, getattr(res, name) + getattr(first, name))
+    check(rc)
+    return res
+
+  def segment_history(self):
+    """(positions [n, 3] int32, deleted counts [n] uint32) of the segment the
+    last `segment_at` calls ran with keep_history."""
+    total = ctypes.c_size_t(0)
+    check(self._lib.ffn_canvas_segment_history(self._h, 0, 0, None, None,
+                                               ctypes.byref(total)))
+    n = total.value
+    pos = np.empty((n, 3), np.int32)
+    deleted = np.empty(n, np.uint32)
+    if n:
+      check(self._lib.ffn_canvas_segment_history(
+          self._h, 0, n, pos.ctypes.data, deleted.ctypes.data, None))
+    return pos, deleted
+
   def read_points(self, pos: np.ndarray):
     pos = np.ascontiguousarray(pos, dtype=np.int32).reshape(-1, 3)
     seed = np.empty(len(pos), np.float32)

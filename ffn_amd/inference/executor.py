@@ -320,6 +320,10 @@ class DirectHipClient(ExecutorClient):
   `predict` contract and adds `step` for device canvases.
   """
 
+  #: device calls run in the caller's thread: a canvas may keep the engine for a
+  #: whole segment (DeviceCanvas._segment_at_native)
+  in_thread = True
+
   def __init__(self, counters, executor: 'HipBatchExecutor'):
     super().__init__(counters, None)
     self._executor = executor

@@ -340,12 +340,16 @@ class Canvas:
   # host-array Canvas never yields: its steps happen inside `segment_at`.
   def _drive(self, gen):
     """Runs a step generator to completion with blocking executor calls."""
+    outer = self.__dict__.get('_blocking_drive', False)
+    self._blocking_drive = True  # nobody interleaves this canvas' steps
     try:
       req = next(gen)
       while True:
         req = gen.send(self._blocking_step(req))
     except StopIteration as stop:
       return stop.value
+    finally:
+      self._blocking_drive = outer
 
   def _blocking_step(self, req):
     raise RuntimeError('host-array Canvas does not yield step requests')
@@ -787,14 +791,122 @@ class DeviceCanvas(Canvas):
     del dynamic_image, vis_update_every, vis_fixed_z
     return self._drive(self._segment_at_gen(start_pos, partial_segment_iters))
 
+  # -- the whole segment loop inside the library ---------------------------------
+  #: class-wide switch (FFN_AMD_NATIVE_LOOP=0 in the environment turns it off)
+  NATIVE_LOOP = os.environ.get('FFN_AMD_NATIVE_LOOP', '1') != '0'
+
+  def _native_loop_ok(self) -> bool:
+    """True if `ffn_canvas_segment_at` may run this canvas' segment loop: the
+    default movement policy and validity test, nothing hooked in between the
+    steps, and an in-thread client (a loop on the executor's server thread
+    would starve the other clients)."""
+    ok = self.__dict__.get('_native_ok')
+    if ok is None:
+      cls = type(self)
+      ok = (cls.NATIVE_LOOP and
+            hasattr(self._handle, 'segment_at') and
+            getattr(self._exec_client, 'in_thread', False) and
+            type(self.movement_policy) is movement.FaceMaxMovementPolicy and
+            getattr(self.restrictor, 'is_trivial', self.restrictor is None) and
+            cls._segment_at_gen is DeviceCanvas._segment_at_gen and
+            not (self.checkpoint_path is not None and
+                 self.checkpoint_interval_sec > 0))
+      self._native_ok = ok
+    # hooks may also be set on the instance (canvas.update_at = ...)
+    return (ok and
+            getattr(self.update_at, '__func__', None) is DeviceCanvas.update_at
+            and getattr(self.is_valid_pos, '__func__', None)
+            is DeviceCanvas.is_valid_pos)
+
+  def _segment_params(self):
+    sp = self.__dict__.get('_seg_params')
+    if sp is None:
+      sp = _lib.SegmentParams()
+      policy = self.movement_policy
+      sp.score_threshold = float(policy.score_threshold)
+      for a in range(3):
+        sp.deltas_zyx[a] = int(policy.deltas[a])
+        sp.margin_zyx[a] = int(self._margin_t[a])
+        sp.shape_zyx[a] = int(self.shape[a])
+      sp.prefetch = self.PREFETCH
+      sp.keep_history = 1 if self._keep_history else 0
+      self._seg_params = sp
+    sp.step = self._step_params
+    return sp
+
+  def _segment_at_native(self, start_pos, max_steps=0, resume=False):
+    """Canvas.segment_at through `ffn_canvas_segment_at`; same state and
+    counters afterwards as the Python loop leaves."""
+    start_pos = tuple(int(v) for v in start_pos)
+    sp = self._segment_params()
+    if not resume:
+      if self.reset_seed_per_segment:
+        self.init_seed(start_pos)
+      self.reset_state(start_pos, reset_extents=self.reset_seed_per_segment)
+      if self.movement_policy or self._min_pos is None:
+        # a pre-filled queue is the caller's business: Python loop
+        return self._drive(self._segment_at_gen_body(start_pos))
+      for a in range(3):
+        sp.init_min_pos[a] = int(self._min_pos[a])
+        sp.init_max_pos[a] = int(self._max_pos[a])
+      cs = self._cached_start
+      sp.initial_start_logit = (cs[1] if cs is not None and cs[0] == start_pos
+                                else float('nan'))
+    sp.max_steps = int(max_steps)
+    t0 = time.time()
+    with timer_counter(self.counters, 'segment_at-loop'):
+      self._invalidate_cache()
+      res = self._call(self._handle.segment_at, start_pos, sp, resume)
+    dt = time.time() - t0
+    n = int(res.num_steps)
+    c = self.counters
+    if n:
+      c['update_at-calls'].IncrementBy(n)
+      c['inference-calls'].IncrementBy(n)
+      c['predict-calls'].IncrementBy(n)
+      c['movement_policy-calls'].IncrementBy(n)
+      c['update_at-time-ms'].IncrementBy(dt * MSEC_IN_SEC)
+      c['inference-time-ms'].IncrementBy(dt * MSEC_IN_SEC)
+    if res.skip_threshold:
+      c['skip_threshold'].IncrementBy(int(res.skip_threshold))
+    if res.skip_invalid_pos:
+      c['skip_invalid_pos'].IncrementBy(int(res.skip_invalid_pos))
+    if res.seed_got_too_weak:
+      c['seed_got_too_weak'].Increment()
+    self.gate_rejects += int(res.gate_rejects)
+    self._min_pos = np.array([int(v) for v in res.min_pos])
+    self._max_pos = np.array([int(v) for v in res.max_pos])
+    if res.start_logit_known:
+      self._cached_start = (start_pos, float(res.start_logit))
+    self.t_last_predict = time.time()
+    if self._keep_history and not res.budget_exhausted:
+      pos, deleted = self._call(self._handle.segment_history)
+      self.history = [tuple(int(v) for v in p) for p in pos]
+      if self.options.disco_seed_threshold >= 0:
+        self.history_deleted = [int(v) for v in deleted]
+    self._native_active = bool(res.active)
+    return n
+
   def _segment_at_gen(self, start_pos, partial_segment_iters=0):
     """Same loop as Canvas.segment_at (reference inference.py:460-533), with
     the per-step tallies kept in plain Python numbers."""
     start_pos = tuple(int(v) for v in start_pos)
+    if (not partial_segment_iters and
+        self.__dict__.get('_blocking_drive', False) and
+        self._native_loop_ok()):
+      # driven by blocking calls (segment_at / segment_all, not interleaved by
+      # a MultiCanvasDriver): the whole loop runs inside the library
+      return self._segment_at_native(start_pos)
     if not partial_segment_iters:
       if self.reset_seed_per_segment:
         self.init_seed(start_pos)
       self.reset_state(start_pos, reset_extents=self.reset_seed_per_segment)
+    return (yield from self._segment_at_gen_body(start_pos,
+                                                 partial_segment_iters))
+
+  def _segment_at_gen_body(self, start_pos, partial_segment_iters=0):
+    """The loop proper, after init_seed / reset_state."""
+    if not partial_segment_iters:
       if not self.movement_policy:
         self.movement_policy.append(
             (self.movement_policy.score_threshold * 2, start_pos))

@@ -84,6 +84,38 @@ typedef struct ffn_commit_counts {
   int32_t num_overlapped_ids;       /* distinct ids > 0 under the raw mask      */
 } ffn_commit_counts;
 
+/* Canvas.segment_at as ONE call: the FoV loop of a segment with the default
+ * movement policy, run by the library's host code (ffn_canvas_segment_at). */
+typedef struct ffn_segment_params {
+  ffn_step_params step;       /* thresholds of every FoV step                   */
+  double  score_threshold;    /* FaceMaxMovementPolicy.score_threshold
+                                 (movement.py:176,214): logit(move_threshold)  */
+  int32_t deltas_zyx[3];      /* policy deltas (model_info.deltas[::-1])        */
+  int32_t margin_zyx[3];      /* input_image_size // 2 (inference.py:216)       */
+  int32_t shape_zyx[3];       /* canvas shape, for the bounds test              */
+  int32_t init_min_pos[3];    /* Canvas._min_pos / _max_pos after reset_state   */
+  int32_t init_max_pos[3];    /*   (inference.py:288-310)                       */
+  float   initial_start_logit;/* seed[start] if known (init_seed), else NaN     */
+  int32_t prefetch;           /* queue-head candidates sent with a step (<= 16) */
+  int32_t keep_history;       /* record positions (+ deleted counts)            */
+  int64_t max_steps;          /* > 0: return after this many steps (resumable)  */
+} ffn_segment_params;
+
+typedef struct ffn_segment_result {
+  int64_t num_steps;          /* FoV steps made by this call                    */
+  int64_t skip_threshold;     /* counters of Canvas.is_valid_pos                */
+  int64_t skip_invalid_pos;
+  int64_t gate_rejects;       /* in-bounds entries refused on device state      */
+  int64_t queue_len;          /* entries left in the policy queue               */
+  int32_t seed_got_too_weak;  /* loop left through inference.py:503-505         */
+  int32_t budget_exhausted;   /* max_steps reached; call again with resume = 1  */
+  int32_t active;             /* the segment can be resumed                     */
+  int32_t start_logit_known;
+  float   start_logit;        /* seed[start] after the last step                */
+  int32_t min_pos[3];         /* extents of the visited positions               */
+  int32_t max_pos[3];
+} ffn_segment_result;
+
 /* ---- lifecycle -----------------------------------------------------------
  * Replaces model construction in Runner._init_tf_model
  * (ffn/inference/runner.py:116-163) and ConvStack3DFFNModel.__init__ /
@@ -143,6 +175,24 @@ int ffn_canvas_step_submit(ffn_engine* engine, int n,
                            const ffn_step_params* params, uint32_t* ticket);
 int ffn_canvas_step_wait(ffn_engine* engine, uint32_t ticket,
                          ffn_step_result* results);
+
+/* Canvas.segment_at (inference.py:460-533) with FaceMaxMovementPolicy
+ * (movement.py:166-222) and Canvas.is_valid_pos (inference.py:312-346), looped
+ * inside the library: pop a position, test it, one ffn_canvas_step, queue the
+ * face maxima -- until the queue is empty, the start logit falls below
+ * move_threshold, or max_steps.  The seed must have been initialised
+ * (ffn_canvas_init_seed) by the caller.  resume = 1 continues a segment that
+ * returned with budget_exhausted or with an error (e.g. FFN_ERR_RANGE: switch
+ * conv_variant and resume; the voided step is repeated).  The visited positions
+ * are those of the Python loop, step for step. */
+int ffn_canvas_segment_at(ffn_canvas* canvas, const int32_t start_zyx[3],
+                          const ffn_segment_params* params, int resume,
+                          ffn_segment_result* result);
+/* keep_history: entries [first, first + n) of the current segment's history
+ * (positions zyx, deleted-voxel counts); *total = entries recorded. */
+int ffn_canvas_segment_history(ffn_canvas* canvas, size_t first, size_t n,
+                               int32_t* pos_zyx, uint32_t* deleted,
+                               size_t* total);
 
 /* Point reads used by Canvas.is_valid_pos (inference.py:312-346). */
 int ffn_canvas_read_points(ffn_canvas* canvas, int n, const int32_t* pos_zyx,

@@ -1,0 +1,51 @@
+// TEST INFRASTRUCTURE: ffn_amd/csrc/ffn_host_loop.h instantiated over callbacks,
+// so that the library's segment_at loop -- the same template libffn_hip.so
+// instantiates over the HIP canvas -- runs against the emulated device of
+// tests/emulated_device.py without a GPU.  Built by tests/test_host_loop.py
+// with g++; never part of the product.
+#include "../ffn_amd/csrc/ffn_host_loop.h"
+
+extern "C" {
+
+typedef int (*shim_step_fn)(const ffn_step_request*, const ffn_step_params*,
+                            ffn_step_result*);
+typedef int (*shim_read_fn)(const int32_t*, float*, int32_t*);
+
+struct ShimDevice {
+  shim_step_fn step_cb;
+  shim_read_fn read_cb;
+  int step(const ffn_step_request& req, const ffn_step_params& params,
+           ffn_step_result* res) {
+    return step_cb(&req, &params, res);
+  }
+  int read_point(const int32_t pos[3], float* seed, int32_t* seg) {
+    return read_cb(pos, seed, seg);
+  }
+};
+
+void* shim_state_create() { return new ffn_host::SegmentState(); }
+void shim_state_destroy(void* s) { delete static_cast<ffn_host::SegmentState*>(s); }
+
+int shim_segment_at(void* state, shim_step_fn step_cb, shim_read_fn read_cb,
+                    const int32_t start[3], const ffn_segment_params* p,
+                    int resume, ffn_segment_result* out) {
+  ShimDevice dev{step_cb, read_cb};
+  auto& st = *static_cast<ffn_host::SegmentState*>(state);
+  ffn_host::SegmentLoop<ShimDevice> loop(dev, st, *p);
+  return loop.run(start, resume, out);
+}
+
+size_t shim_history(void* state, int32_t* pos, uint32_t* deleted, size_t cap) {
+  auto& st = *static_cast<ffn_host::SegmentState*>(state);
+  const size_t n = st.history_deleted.size() < cap ? st.history_deleted.size() : cap;
+  if (n) {
+    std::memcpy(pos, st.history.data(), 12 * n);
+    std::memcpy(deleted, st.history_deleted.data(), 4 * n);
+  }
+  return st.history_deleted.size();
+}
+
+}  // extern "C"
+
+extern "C" size_t shim_sizeof_params() { return sizeof(ffn_segment_params); }
+extern "C" size_t shim_sizeof_result() { return sizeof(ffn_segment_result); }

@@ -835,3 +835,94 @@ def test_fp16_range_fallback(fib25_model, fib25_blob):
   assert np.isfinite(canvas.read_seed((4, 4, 4), (37, 37, 37))).all()
   canvas.close()
   eng.close()
+
+
+def test_native_segment_loop_matches_python_loop(fib25_model):
+  """ffn_canvas_segment_at (the FoV loop of a segment inside the library) ==
+  the Python loop over ffn_canvas_step: same segmentation, seed logits,
+  histories, counters -- and both equal the reference-minted run."""
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from ffn_amd.inference import seed as seed_lib
+  import bench
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  request = bench.make_request()
+  image = synthetic.normalize(g['volume'])
+
+  class PythonLoop(inference.DeviceCanvas):
+    NATIVE_LOOP = False
+
+  runs = {}
+  for cls in (inference.DeviceCanvas, PythonLoop):
+    counters = inference_utils.Counters()
+    exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
+                                    fib25_model.info, None, counters, 1)
+    canvas = cls(fib25_model.info, exe.get_client(counters, direct=True), image,
+                 request.inference_options, counters=counters,
+                 keep_history=True,
+                 movement_policy_fn=movement.get_policy_fn(request,
+                                                           fib25_model.info))
+    assert canvas._native_loop_ok() == (cls is inference.DeviceCanvas)
+    n = canvas.segment_at((16, 16, 32))
+    first = dict(n=n, history=list(canvas.history),
+                 deleted=list(canvas.history_deleted),
+                 mn=canvas._min_pos.tolist(), mx=canvas._max_pos.tolist(),
+                 seed=np.array(canvas._handle.read_seed()))
+    canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                     coords=g['seeds']))
+    runs[cls.__name__] = dict(
+        first=first, seg=np.array(np.asarray(canvas.segmentation)),
+        seed=np.array(canvas._handle.read_seed()),
+        rejects=canvas.gate_rejects,
+        counters={k: counters[k].value for k in (
+            'update_at-calls', 'skip_threshold', 'skip_invalid_pos',
+            'seed_got_too_weak', 'segment_at-loop-calls', 'voxels-segmented',
+            'movement_policy-calls')})
+    canvas.close()
+  a, b = runs['DeviceCanvas'], runs['PythonLoop']
+  assert a['first']['n'] == b['first']['n'] > 7
+  for key in ('history', 'deleted', 'mn', 'mx'):
+    assert a['first'][key] == b['first'][key], key
+  assert np.array_equal(a['first']['seed'], b['first']['seed'], equal_nan=True)
+  assert a['counters'] == b['counters'] and a['rejects'] == b['rejects']
+  assert np.array_equal(a['seg'], b['seg'])
+  assert np.array_equal(a['seed'], b['seed'], equal_nan=True)
+  # the extra segment_at in front changes nothing the golden run pins but ids
+  assert np.array_equal(a['seg'] > 0, g['segmentation'] > 0)
+
+
+def test_native_segment_loop_budget_and_resume(fib25_model):
+  """max_steps + resume over the real device: the same trajectory as one call."""
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  import bench
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  request = bench.make_request()
+  image = synthetic.normalize(g['volume'])
+  out = []
+  for budget in (0, 4):
+    counters = inference_utils.Counters()
+    exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
+                                    fib25_model.info, None, counters, 1)
+    canvas = inference.DeviceCanvas(
+        fib25_model.info, exe.get_client(counters, direct=True), image,
+        request.inference_options, counters=counters, keep_history=True,
+        movement_policy_fn=movement.get_policy_fn(request, fib25_model.info))
+    n = canvas._segment_at_native((32, 16, 16), max_steps=budget)
+    calls = 1
+    while canvas._native_active:
+      assert budget and n % budget == 0
+      n += canvas._segment_at_native((32, 16, 16), max_steps=budget, resume=True)
+      calls += 1
+    out.append((n, list(canvas.history), list(canvas.history_deleted),
+                np.array(canvas._handle.read_seed()), calls))
+    canvas.close()
+  assert out[0][0] == out[1][0] > 20 and out[1][4] > 5
+  assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+  assert np.array_equal(out[0][3], out[1][3], equal_nan=True)

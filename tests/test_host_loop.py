@@ -1,0 +1,249 @@
+"""The library's host-side segment loop (ffn_amd/csrc/ffn_host_loop.h ->
+ffn_canvas_segment_at) against the Python loop and the reference-minted runs.
+
+The loop is a C++ template over the device; tests/host_loop_shim.cpp (built
+here with g++) instantiates it over callbacks into the emulated device, so the
+very code libffn_hip.so runs over the HIP canvas is exercised on the CPU."""
+import ctypes
+import functools
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ffn_amd import _lib
+from ffn_amd import synthetic
+from ffn_amd.inference import inference
+from ffn_amd.inference import inference_utils
+from ffn_amd.inference import movement
+from ffn_amd.inference import request as request_lib
+from ffn_amd.inference import seed as seed_lib
+from ffn_amd.training.model import ModelInfo
+from tests.emulated_device import EmulatedDeviceClient, EmulatedHandle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, 'golden')
+
+_STEP_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(_lib.StepRequest),
+                            ctypes.POINTER(_lib.StepParams),
+                            ctypes.POINTER(_lib.StepResult))
+_READ_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
+                            ctypes.POINTER(ctypes.c_float),
+                            ctypes.POINTER(ctypes.c_int32))
+
+
+@pytest.fixture(scope='module')
+def shim(tmp_path_factory):
+  out = str(tmp_path_factory.mktemp('shim') / 'host_loop_shim.so')
+  subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-o',
+                         out, os.path.join(HERE, 'host_loop_shim.cpp')])
+  lib = ctypes.CDLL(out)
+  lib.shim_state_create.restype = ctypes.c_void_p
+  lib.shim_state_destroy.argtypes = [ctypes.c_void_p]
+  lib.shim_segment_at.restype = ctypes.c_int
+  lib.shim_segment_at.argtypes = [
+      ctypes.c_void_p, _STEP_CB, _READ_CB, ctypes.POINTER(ctypes.c_int32),
+      ctypes.POINTER(_lib.SegmentParams), ctypes.c_int,
+      ctypes.POINTER(_lib.SegmentResult)]
+  lib.shim_history.restype = ctypes.c_size_t
+  lib.shim_history.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
+                               ctypes.c_void_p, ctypes.c_size_t]
+  lib.shim_sizeof_params.restype = ctypes.c_size_t
+  lib.shim_sizeof_result.restype = ctypes.c_size_t
+  return lib
+
+
+class ShimHandle(EmulatedHandle):
+  """Emulated canvas + `segment_at` through the C++ loop (what
+  DeviceCanvasHandle.segment_at is on the GPU)."""
+
+  shim = None
+  client = None
+  fail_step = None  # step number at which the device reports FFN_ERR_RANGE once
+
+  def __init__(self, image):
+    super().__init__(image)
+    self._state = self.shim.shim_state_create()
+    self.native_calls = 0
+    self.steps_seen = []
+
+  def segment_at(self, start_pos, params, resume=False):
+    self.native_calls += 1
+
+    def step_cb(req, par, res):
+      if self.fail_step is not None and len(self.steps_seen) == self.fail_step:
+        self.fail_step = None
+        return _lib.ERR_RANGE
+      self.steps_seen.append(tuple(req.contents.pos))
+      out = self.client.step(self, req.contents, par.contents)
+      ctypes.memmove(res, ctypes.addressof(out), ctypes.sizeof(out))
+      return 0
+
+    def read_cb(pos, seed, seg):
+      s, g = self.read_point((pos[0], pos[1], pos[2]))
+      seed[0], seg[0] = s, g
+      return 0
+
+    res = _lib.SegmentResult()
+    start = (ctypes.c_int32 * 3)(*start_pos)
+    rc = self.shim.shim_segment_at(self._state, _STEP_CB(step_cb),
+                                   _READ_CB(read_cb), start,
+                                   ctypes.byref(params), int(resume),
+                                   ctypes.byref(res))
+    if rc == _lib.ERR_RANGE:  # what DeviceCanvasHandle.segment_at does
+      first = _lib.SegmentResult.from_buffer_copy(res)
+      rc = self.shim.shim_segment_at(self._state, _STEP_CB(step_cb),
+                                     _READ_CB(read_cb), start,
+                                     ctypes.byref(params), 1, ctypes.byref(res))
+      for name in ('num_steps', 'skip_threshold', 'skip_invalid_pos',
+                   'gate_rejects'):
+        setattr(res, name, getattr(res, name) + getattr(first, name))
+    assert rc == 0, rc
+    return res
+
+  def segment_history(self):
+    n = self.shim.shim_history(self._state, None, None, 0)
+    pos = np.empty((n, 3), np.int32)
+    deleted = np.empty(n, np.uint32)
+    self.shim.shim_history(self._state, pos.ctypes.data, deleted.ctypes.data, n)
+    return pos, deleted
+
+
+class ShimClient(EmulatedDeviceClient):
+  in_thread = True
+
+  def create_canvas(self, image):
+    ShimHandle.client = self
+    return ShimHandle(image)
+
+
+def _request():
+  r = request_lib.InferenceRequest()
+  o = r.inference_options
+  o.init_activation, o.pad_value, o.move_threshold = 0.95, 0.05, 0.9
+  o.segment_threshold, o.min_segment_size = 0.6, 1000
+  o.min_boundary_dist.x = o.min_boundary_dist.y = o.min_boundary_dist.z = 1
+  return r
+
+
+def _info():
+  return ModelInfo(deltas=(8, 8, 8), pred_mask_size=(33, 33, 33),
+                   input_seed_size=(33, 33, 33), input_image_size=(33, 33, 33))
+
+
+def _canvas(shim, blob, image, native, **kwargs):
+  ShimHandle.shim = shim
+  r = _request()
+  info = _info()
+  cls = ShimClient if native else EmulatedDeviceClient
+  client = cls(inference_utils.Counters(), blob, 12, (33, 33, 33), (8, 8, 8))
+  counters = inference_utils.Counters()
+  c = inference.make_canvas(info, client, image, r.inference_options,
+                            counters=counters,
+                            movement_policy_fn=movement.get_policy_fn(r, info),
+                            **kwargs)
+  return c
+
+
+def test_struct_layout_matches_the_header(shim):
+  assert ctypes.sizeof(_lib.SegmentParams) == shim.shim_sizeof_params() == 104
+  assert ctypes.sizeof(_lib.SegmentResult) == shim.shim_sizeof_result() == 88
+
+
+@pytest.mark.parametrize('name', ['cells56', 'cells72'])
+def test_native_loop_reproduces_reference_run(shim, fib25_blob, name):
+  """segment_all with every segment_at inside the C++ loop == the reference's
+  own Canvas.segment_all (steps, segmentation, counters)."""
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_%s.npz' % name))
+  c = _canvas(shim, fib25_blob, synthetic.normalize(g['volume']), True)
+  assert c._native_loop_ok()
+  c.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                              coords=g['seeds']))
+  h = c._handle
+  assert h.native_calls > 0
+  assert np.array_equal(np.array(h.steps_seen).reshape(-1, 3), g['steps'])
+  assert np.array_equal(np.asarray(c.segmentation), g['segmentation'])
+  import json
+  ref = json.loads(str(g['counters']))
+  for key in ('update_at-calls', 'voxels-segmented', 'skip_invalid_pos',
+              'skip_threshold', 'seed_got_too_weak', 'segment_at-loop-calls'):
+    if key in ref:
+      assert c.counters[key].value == ref[key], key
+
+
+def test_native_and_python_loops_leave_the_same_canvas_state(shim, fib25_blob):
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  image = synthetic.normalize(g['volume'])
+  seed0 = (16, 16, 32)  # 13 FoV steps in the reference run
+  runs = []
+  for native in (False, True):
+    c = _canvas(shim, fib25_blob, image, native, keep_history=True)
+    assert c._native_loop_ok() == native
+    n = c.segment_at(seed0)
+    runs.append(dict(
+        n=n, history=[tuple(int(v) for v in p) for p in c.history],
+        deleted=[int(v) for v in c.history_deleted],
+        mn=[int(v) for v in c._min_pos], mx=[int(v) for v in c._max_pos],
+        seed=np.array(np.asarray(c.seed)), rejects=c.gate_rejects,
+        counters={k: c.counters[k].value for k in (
+            'update_at-calls', 'skip_threshold', 'skip_invalid_pos',
+            'seed_got_too_weak', 'segment_at-loop-calls',
+            'movement_policy-calls')},
+        start=c._start_logit(seed0)))
+  a, b = runs
+  assert a['n'] == b['n'] > 7
+  for key in ('history', 'deleted', 'mn', 'mx', 'rejects', 'counters', 'start'):
+    assert a[key] == b[key], key
+  assert np.array_equal(a['seed'], b['seed'], equal_nan=True)
+
+
+def test_budgeted_calls_resume_to_the_same_result(shim, fib25_blob):
+  """max_steps + resume (what bench.py uses to time exactly K steps), and a
+  voided step (FFN_ERR_RANGE) repeated on resume."""
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  image = synthetic.normalize(g['volume'])
+  seed0 = (16, 16, 32)  # 13 FoV steps in the reference run
+  full = _canvas(shim, fib25_blob, image, True, keep_history=True)
+  n_full = full.segment_at(seed0)
+  assert n_full > 7
+
+  part = _canvas(shim, fib25_blob, image, True, keep_history=True)
+  ShimHandle.fail_step = 4
+  try:
+    got = part._segment_at_native(seed0, max_steps=3)
+    assert got == 3 and part._native_active
+    while part._native_active:
+      got += part._segment_at_native(seed0, max_steps=3, resume=True)
+  finally:
+    ShimHandle.fail_step = None
+  assert got == n_full
+  assert part._handle.steps_seen == full._handle.steps_seen
+  assert part.history == full.history
+  assert part.history_deleted == full.history_deleted
+  assert np.array_equal(np.asarray(part.seed), np.asarray(full.seed),
+                        equal_nan=True)
+  for key in ('update_at-calls', 'skip_threshold', 'skip_invalid_pos'):
+    assert part.counters[key].value == full.counters[key].value, key
+
+
+def test_python_loop_kept_for_hooked_canvases(shim, fib25_blob):
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells56.npz'))
+  image = synthetic.normalize(g['volume'])
+
+  class Hooked(inference.DeviceCanvas):
+    seen = 0
+
+    def update_at(self, pos):
+      Hooked.seen += 1
+      return super().update_at(pos)
+
+  ShimHandle.shim = shim
+  r, info = _request(), _info()
+  client = ShimClient(inference_utils.Counters(), fib25_blob, 12, (33, 33, 33),
+                      (8, 8, 8))
+  c = Hooked(info, client, image, r.inference_options,
+             movement_policy_fn=movement.get_policy_fn(r, info))
+  assert not c._native_loop_ok()
+  n = c.segment_at(tuple(int(v) for v in g['seeds'][0]))
+  assert n == Hooked.seen > 0 and c._handle.native_calls == 0
