@@ -854,7 +854,9 @@ class DeviceCanvas(Canvas):
                                 else float('nan'))
     sp.max_steps = int(max_steps)
     t0 = time.time()
-    with timer_counter(self.counters, 'segment_at-loop'):
+    # a resumed leg belongs to the loop call that started the segment
+    with timer_counter(self.counters, 'segment_at-loop',
+                       increment=0 if resume else 1):
       self._invalidate_cache()
       res = self._call(self._handle.segment_at, start_pos, sp, resume)
     dt = time.time() - t0

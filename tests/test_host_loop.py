@@ -223,7 +223,8 @@ def test_budgeted_calls_resume_to_the_same_result(shim, fib25_blob):
   assert part.history_deleted == full.history_deleted
   assert np.array_equal(np.asarray(part.seed), np.asarray(full.seed),
                         equal_nan=True)
-  for key in ('update_at-calls', 'skip_threshold', 'skip_invalid_pos'):
+  for key in ('update_at-calls', 'skip_threshold', 'skip_invalid_pos',
+              'segment_at-loop-calls'):
     assert part.counters[key].value == full.counters[key].value, key
 
 
