@@ -248,3 +248,120 @@ def test_python_loop_kept_for_hooked_canvases(shim, fib25_blob):
   assert not c._native_loop_ok()
   n = c.segment_at(tuple(int(v) for v in g['seeds'][0]))
   assert n == Hooked.seen > 0 and c._handle.native_calls == 0
+
+
+# -- randomized differential test: C++ loop vs Python loop on a scripted device ----------
+class ScriptedClient(EmulatedDeviceClient):
+  """Device whose step results are a hash of (position, visit count): face
+  scores drawn from a few levels (many exact ties and sub-threshold faces),
+  duplicate corner voxels, occasional positive segment ids, a start logit that
+  decays.  No conv stack -- thousands of steps per second -- but every value the
+  loops look at is deterministic device state."""
+
+  in_thread = False
+
+  def __init__(self, deltas, fov, seed):
+    super().__init__(inference_utils.Counters(), None, 0, fov, deltas)
+    self.rs_seed = seed
+    self.trace = []
+
+  def step(self, h, req, params):
+    pos = tuple(req.pos)
+    self.trace.append(pos)
+    rng = np.random.RandomState(
+        (hash((pos, self.rs_seed, len(self.trace) // 7)) & 0x7fffffff))
+    d = [int(v) for v in self.deltas]
+    res = _lib.StepResult()
+    levels = np.float32([1.5, 2.2, 2.5, 2.5, 3.0, 3.0, 4.25])
+    k = 0
+    for axis in range(3):
+      others = [a for a in range(3) if a != axis]
+      for sign in (-1, 1):
+        nrows, ncols = 2 * d[others[0]] + 1, 2 * d[others[1]] + 1
+        mode = rng.randint(4)
+        if mode == 0:  # a corner shared with other faces
+          fi, fj = rng.choice([0, nrows - 1]), rng.choice([0, ncols - 1])
+        else:
+          fi, fj = rng.randint(nrows), rng.randint(ncols)
+        score = levels[rng.randint(len(levels))]
+        res.face_score[k] = score
+        res.face_index[k] = int(fi * ncols + fj)
+        rel = [0, 0, 0]
+        rel[axis] = sign * d[axis]
+        rel[others[0]] = int(fi) - d[others[0]]
+        rel[others[1]] = int(fj) - d[others[1]]
+        coord = tuple(int(p + r) for p, r in zip(pos, rel))
+        if all(0 <= c < s for c, s in zip(coord, h.shape)):
+          h.seed[coord] = score  # what the paste would have written
+          res.face_seg[k] = int(h.seg[coord])
+        k += 1
+    start = tuple(req.start_pos)
+    h.seed[start] = np.float32(h.seed[start] - rng.choice([0.0, 0.0, 0.02]))
+    res.start_logit = h.seed[start]
+    res.num_deleted = int(rng.randint(50))
+    for j in range(req.num_candidates):
+      cpos = tuple(req.candidates[j])
+      res.cand_seed[j] = h.seed[cpos]
+      res.cand_seg[j] = h.seg[cpos]
+    return res
+
+
+class ScriptedShimClient(ScriptedClient):
+  in_thread = True
+
+  def create_canvas(self, image):
+    ShimHandle.client = self
+    return ShimHandle(image)
+
+
+@pytest.mark.parametrize('deltas,fov', [((8, 8, 8), (33, 33, 33)),
+                                        ((2, 5, 3), (9, 21, 13)),
+                                        ((0, 4, 4), (1, 17, 17))])
+def test_randomized_loops_agree_on_scripted_device(shim, deltas, fov):
+  ShimHandle.shim = shim
+  shape = (48, 72, 64) if deltas[0] else (1, 72, 64)
+  rng = np.random.RandomState(5)
+  info = ModelInfo(deltas=deltas[::-1], pred_mask_size=fov[::-1],
+                   input_seed_size=fov[::-1], input_image_size=fov[::-1])
+  r = _request()
+  r.inference_options.disco_seed_threshold = 0.002
+  total_steps = 0
+  stats = {}
+  for trial in range(6):
+    runs = []
+    seg0 = (rng.random_sample(shape) < 0.03).astype(np.int32) * 7
+    starts = [tuple(int(rng.randint(m, s - m)) if s - 2 * m > 0 else 0
+                    for m, s in zip([f // 2 for f in fov], shape))
+              for _ in range(4)]
+    for cls in (ScriptedClient, ScriptedShimClient):
+      client = cls(deltas, fov, seed=trial)
+      c = inference.make_canvas(
+          info, client, np.zeros(shape, np.float32), r.inference_options,
+          counters=inference_utils.Counters(), keep_history=True,
+          movement_policy_fn=movement.get_policy_fn(r, info))
+      c._handle.seg[...] = seg0
+      assert c._native_loop_ok() == (cls is ScriptedShimClient)
+      out = []
+      for start in starts:
+        c._handle.seg[start] = 0
+        n = c.segment_at(start)
+        out.append((n, list(c.history), list(c.history_deleted),
+                    c._min_pos.tolist(), c._max_pos.tolist(),
+                    c._start_logit(start)))
+      runs.append(dict(
+          out=out, trace=list(client.trace), rejects=c.gate_rejects,
+          seed=np.array(c._handle.seed),
+          counters={k: c.counters[k].value for k in (
+              'update_at-calls', 'skip_threshold', 'skip_invalid_pos',
+              'seed_got_too_weak', 'segment_at-loop-calls')}))
+    a, b = runs
+    assert a['trace'] == b['trace']
+    assert a['out'] == b['out']
+    assert a['counters'] == b['counters'] and a['rejects'] == b['rejects']
+    assert np.array_equal(a['seed'], b['seed'], equal_nan=True)
+    total_steps += len(a['trace'])
+    stats = {k: stats.get(k, 0) + v for k, v in a['counters'].items()}
+    stats['rejects'] = stats.get('rejects', 0) + a['rejects']
+  print('\nscripted device %r: %d steps, %r' % (deltas, total_steps, stats))
+  assert total_steps > 200
+  assert stats['skip_threshold'] and stats['skip_invalid_pos'] and stats['rejects']
