@@ -799,7 +799,14 @@ class DeviceCanvas(Canvas):
     """True if `ffn_canvas_segment_at` may run this canvas' segment loop: the
     default movement policy and validity test, nothing hooked in between the
     steps, and an in-thread client (a loop on the executor's server thread
-    would starve the other clients)."""
+    would starve the other clients).
+
+    Timed checkpoints (`checkpoint_interval`) are then taken at the first
+    SEGMENT boundary after the interval has passed (segment_all checks after
+    every segment) instead of after the first FoV step past it: a segment is
+    seconds of GPU time against intervals of minutes (1800 s in the sample
+    config), and a checkpoint taken between segments restores without a
+    partial segment."""
     ok = self.__dict__.get('_native_ok')
     if ok is None:
       cls = type(self)
@@ -808,9 +815,7 @@ class DeviceCanvas(Canvas):
             getattr(self._exec_client, 'in_thread', False) and
             type(self.movement_policy) is movement.FaceMaxMovementPolicy and
             getattr(self.restrictor, 'is_trivial', self.restrictor is None) and
-            cls._segment_at_gen is DeviceCanvas._segment_at_gen and
-            not (self.checkpoint_path is not None and
-                 self.checkpoint_interval_sec > 0))
+            cls._segment_at_gen is DeviceCanvas._segment_at_gen)
       self._native_ok = ok
     # hooks may also be set on the instance (canvas.update_at = ...)
     return (ok and

@@ -365,3 +365,37 @@ def test_randomized_loops_agree_on_scripted_device(shim, deltas, fov):
   print('\nscripted device %r: %d steps, %r' % (deltas, total_steps, stats))
   assert total_steps > 200
   assert stats['skip_threshold'] and stats['skip_invalid_pos'] and stats['rejects']
+
+
+def test_timed_checkpoints_with_the_native_loop(shim, fib25_blob, tmp_path):
+  """checkpoint_interval > 0 keeps the native loop; checkpoints are written at
+  segment boundaries and restore to the same result."""
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  image = synthetic.normalize(g['volume'])
+  path = str(tmp_path / 'ck' / 'seg.cpoint')
+  policy = functools.partial(seed_lib.PolicyFixed, coords=g['seeds'])
+
+  class StopAfterTwo(Exception):
+    pass
+
+  a = _canvas(shim, fib25_blob, image, True, checkpoint_path=path,
+              checkpoint_interval_sec=1e-9)
+  assert a._native_loop_ok()
+  saves = []
+  orig = a.save_checkpoint
+
+  def counting(p, partial_segment_iters=0):
+    saves.append(partial_segment_iters)
+    orig(p, partial_segment_iters=partial_segment_iters)
+    if len(a.origins) >= 2:
+      raise StopAfterTwo()
+
+  a.save_checkpoint = counting
+  with pytest.raises(StopAfterTwo):
+    a.segment_all(seed_policy=policy)
+  assert a._handle.native_calls > 0 and saves and not any(saves)
+
+  b = _canvas(shim, fib25_blob, image, True)
+  assert b.restore_checkpoint(path) == 0
+  b.segment_all(seed_policy=policy)
+  assert np.array_equal(np.asarray(b.segmentation), g['segmentation'])
