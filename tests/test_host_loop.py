@@ -7,7 +7,6 @@ very code libffn_hip.so runs over the HIP canvas is exercised on the CPU."""
 import ctypes
 import functools
 import os
-import subprocess
 
 import numpy as np
 import pytest
@@ -20,102 +19,18 @@ from ffn_amd.inference import movement
 from ffn_amd.inference import request as request_lib
 from ffn_amd.inference import seed as seed_lib
 from ffn_amd.training.model import ModelInfo
-from tests.emulated_device import EmulatedDeviceClient, EmulatedHandle
+from tests.emulated_device import EmulatedDeviceClient
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, 'golden')
 
-_STEP_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(_lib.StepRequest),
-                            ctypes.POINTER(_lib.StepParams),
-                            ctypes.POINTER(_lib.StepResult))
-_READ_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
-                            ctypes.POINTER(ctypes.c_float),
-                            ctypes.POINTER(ctypes.c_int32))
+from tests.native_shim import ShimClient, ShimHandle
 
 
 @pytest.fixture(scope='module')
 def shim(tmp_path_factory):
-  out = str(tmp_path_factory.mktemp('shim') / 'host_loop_shim.so')
-  subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-o',
-                         out, os.path.join(HERE, 'host_loop_shim.cpp')])
-  lib = ctypes.CDLL(out)
-  lib.shim_state_create.restype = ctypes.c_void_p
-  lib.shim_state_destroy.argtypes = [ctypes.c_void_p]
-  lib.shim_segment_at.restype = ctypes.c_int
-  lib.shim_segment_at.argtypes = [
-      ctypes.c_void_p, _STEP_CB, _READ_CB, ctypes.POINTER(ctypes.c_int32),
-      ctypes.POINTER(_lib.SegmentParams), ctypes.c_int,
-      ctypes.POINTER(_lib.SegmentResult)]
-  lib.shim_history.restype = ctypes.c_size_t
-  lib.shim_history.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
-                               ctypes.c_void_p, ctypes.c_size_t]
-  lib.shim_sizeof_params.restype = ctypes.c_size_t
-  lib.shim_sizeof_result.restype = ctypes.c_size_t
-  return lib
-
-
-class ShimHandle(EmulatedHandle):
-  """Emulated canvas + `segment_at` through the C++ loop (what
-  DeviceCanvasHandle.segment_at is on the GPU)."""
-
-  shim = None
-  client = None
-  fail_step = None  # step number at which the device reports FFN_ERR_RANGE once
-
-  def __init__(self, image):
-    super().__init__(image)
-    self._state = self.shim.shim_state_create()
-    self.native_calls = 0
-    self.steps_seen = []
-
-  def segment_at(self, start_pos, params, resume=False):
-    self.native_calls += 1
-
-    def step_cb(req, par, res):
-      if self.fail_step is not None and len(self.steps_seen) == self.fail_step:
-        self.fail_step = None
-        return _lib.ERR_RANGE
-      self.steps_seen.append(tuple(req.contents.pos))
-      out = self.client.step(self, req.contents, par.contents)
-      ctypes.memmove(res, ctypes.addressof(out), ctypes.sizeof(out))
-      return 0
-
-    def read_cb(pos, seed, seg):
-      s, g = self.read_point((pos[0], pos[1], pos[2]))
-      seed[0], seg[0] = s, g
-      return 0
-
-    res = _lib.SegmentResult()
-    start = (ctypes.c_int32 * 3)(*start_pos)
-    rc = self.shim.shim_segment_at(self._state, _STEP_CB(step_cb),
-                                   _READ_CB(read_cb), start,
-                                   ctypes.byref(params), int(resume),
-                                   ctypes.byref(res))
-    if rc == _lib.ERR_RANGE:  # what DeviceCanvasHandle.segment_at does
-      first = _lib.SegmentResult.from_buffer_copy(res)
-      rc = self.shim.shim_segment_at(self._state, _STEP_CB(step_cb),
-                                     _READ_CB(read_cb), start,
-                                     ctypes.byref(params), 1, ctypes.byref(res))
-      for name in ('num_steps', 'skip_threshold', 'skip_invalid_pos',
-                   'gate_rejects'):
-        setattr(res, name, getattr(res, name) + getattr(first, name))
-    assert rc == 0, rc
-    return res
-
-  def segment_history(self):
-    n = self.shim.shim_history(self._state, None, None, 0)
-    pos = np.empty((n, 3), np.int32)
-    deleted = np.empty(n, np.uint32)
-    self.shim.shim_history(self._state, pos.ctypes.data, deleted.ctypes.data, n)
-    return pos, deleted
-
-
-class ShimClient(EmulatedDeviceClient):
-  in_thread = True
-
-  def create_canvas(self, image):
-    ShimHandle.client = self
-    return ShimHandle(image)
+  from tests import native_shim
+  return native_shim.build_shim(tmp_path_factory.mktemp('shim'))
 
 
 def _request():

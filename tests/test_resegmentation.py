@@ -117,13 +117,24 @@ def golden():
   return {k: g[k] for k in g.files}
 
 
-def test_resegmentation_reproduces_reference(golden, fib25_blob, tmp_path):
+@pytest.mark.parametrize('native', [False, True])
+def test_resegmentation_reproduces_reference(golden, fib25_blob, tmp_path,
+                                             tmp_path_factory, native):
+  """native: every segment_at of the point runs in the library's C++ loop
+  (tests/native_shim.py), as it does on the GPU."""
   from tests.emulated_device import EmulatedDeviceClient, EmulatedSeeder
+  from tests import native_shim
   request = build_request(golden, tmp_path)
+  if native:
+    native_shim.ShimHandle.shim = native_shim.build_shim(
+        tmp_path_factory.mktemp('shim'))
+  cls = native_shim.ShimClient if native else EmulatedDeviceClient
+  native_shim.ShimHandle.total_native_calls = 0
+  made = []
 
   def client_fn(counters):
-    return EmulatedDeviceClient(counters, fib25_blob, 12, (33, 33, 33),
-                                (8, 8, 8))
+    made.append(cls(counters, fib25_blob, 12, (33, 33, 33), (8, 8, 8)))
+    return made[-1]
 
   runner = StandInRunner(golden, client_fn, request.inference)
   for n in range(2):
@@ -133,6 +144,9 @@ def test_resegmentation_reproduces_reference(golden, fib25_blob, tmp_path):
   # existing output -> skipped (get_target_path returns None)
   assert resegmentation.get_target_path(request, 0) is None
   assert runner.counters['resegmentation-calls'].value == 2
+  assert len(made) == 2
+  if native:
+    assert native_shim.ShimHandle.total_native_calls >= 4
 
 
 def test_process_many_batches_points_without_changing_results(golden, fib25_blob,
