@@ -472,3 +472,33 @@ def test_update_at_override_is_honoured(fib25_blob):
                                               coords=g['seeds']))
   assert np.array_equal(np.array(seen), g['steps'])
   assert np.array_equal(np.asarray(c.segmentation), g['segmentation'])
+
+
+def test_resegmentation_request_messages_round_trip():
+  """ResegmentationRequest / ResegmentationPoint (inference.proto:296-357):
+  repeated message fields with add(), presence of the optional id_b, and the
+  SerializeToString / ParseFromString pair the result files rely on."""
+  import copy
+  rq = req_lib.ResegmentationRequest()
+  assert len(rq.points) == 0 and not rq.HasField('analysis_radius')
+  p = rq.points.add()
+  p.id_a, p.id_b = 7, 9
+  p.point.x, p.point.y, p.point.z = 1, 2, 3
+  q = rq.points.add(id_a=11)
+  assert not q.HasField('id_b') and q.id_b == 0
+  rq.radius.x = rq.radius.y = rq.radius.z = 24
+  rq.inference.inference_options.move_threshold = 0.9
+  rq.output_directory = '/tmp/out dir'
+  assert rq.max_retry_iters == 1 and rq.subdir_digits == 0  # proto defaults
+  back = req_lib.ResegmentationRequest()
+  assert back.ParseFromString(rq.SerializeToString()) > 0
+  assert back == rq and len(back.points) == 2
+  assert back.points[0].point.z == 3 and not back.points[1].HasField('id_b')
+  assert isinstance(back.points, list) and hasattr(back.points, 'add')
+  clone = copy.deepcopy(rq)
+  clone.points.add(id_a=1)
+  assert len(rq.points) == 2 and len(clone.points) == 3
+  # a plain list assigned to a repeated field gains add()
+  rq.points = [req_lib.ResegmentationPoint(id_a=5)]
+  rq.points.add(id_a=6)
+  assert [pt.id_a for pt in rq.points] == [5, 6]
