@@ -132,13 +132,16 @@ def run_gpu(args, rank, local_rank, world):
   image = synthetic.normalize(vol)
 
   total = args.warmup + args.steps
-  state = {'n': 0, 't0': None, 't1': None, 'vox0': 0, 'vox1': 0}
+  state = {'n': 0, 't0': None, 't1': None, 'vox0': 0, 'vox1': 0,
+           't_run0': None}
 
   class BenchCanvas(inference.DeviceCanvas):
 
     def update_at(self, pos):
       # untimed spin-up before the W warmup steps: host cores and GPU clocks
       # leave their idle states (run-to-run spread of `value` 3 % -> < 1 %)
+      if state['t_run0'] is None:
+        state['t_run0'] = time.perf_counter()
       if state['n'] == 0 and args.prewarm_seconds > 0:
         if state.get('pre_until') is None:
           state['pre_until'] = time.perf_counter() + args.prewarm_seconds
@@ -171,6 +174,8 @@ def run_gpu(args, rank, local_rank, world):
     def _segment_at_native(self, start_pos, max_steps=0, resume=False):
       del max_steps, resume
       done, first = 0, True
+      if state['t_run0'] is None:
+        state['t_run0'] = time.perf_counter()
       while True:
         if state['n'] == 0 and args.prewarm_seconds > 0 and not state.get(
             'prewarm_over'):
@@ -286,10 +291,29 @@ def run_gpu(args, rank, local_rank, world):
       'conv_ms': conv_ms,
       'conv_launches': conv_launches,
       'voxels': state['vox1'] - state['vox0'],
+      # voxels leg: everything this rank did from its first FoV step (prewarm +
+      # warmup + timed steps, segment set-up and commits included) on its own
+      # wall clock -- the K timed steps alone rarely contain a segment commit
+      'voxels_run': state['vox1'],
+      'steps_run': state['n'] + state.get('prewarm_steps', 0),
+      'seconds_run': state['t1_local'] - state['t_run0'],
       'segments': len(canvas.origins),
       'canvas': canvas,
+      'exe': exe,
+      'model': model,
+      'request': request,
+      'image': image,
   }
   if world > 1:
+    vr = torch.tensor([result['voxels_run'], result['steps_run']],
+                      dtype=torch.float64, device='cuda')
+    dist.all_reduce(vr, op=dist.ReduceOp.SUM)
+    sr = torch.tensor([result['seconds_run']], dtype=torch.float64,
+                      device='cuda')
+    dist.all_reduce(sr, op=dist.ReduceOp.MAX)
+    result['voxels_run'] = float(vr[0].item())
+    result['steps_run'] = float(vr[1].item())
+    result['seconds_run'] = float(sr.item())
     dist.barrier()
     dist.destroy_process_group()
   return result
@@ -320,6 +344,8 @@ def cpu_baseline(args):
   class _Stop(Exception):
     pass
 
+  traces = {}
+
   def run(forward_fn, budget_s, max_steps):
     oc = ffn_oracle.OracleCanvas(image, blob, DEPTH, FOV, DELTAS,
                                  ffn_oracle.Options())
@@ -345,6 +371,7 @@ def cpu_baseline(args):
       pass
     steps = n[0] - 1
     dt = time.perf_counter() - t0[0]
+    traces[id(forward_fn) if forward_fn is not None else 0] = list(oc.trace)
     return steps / dt, steps, dt
 
   results = {}
@@ -359,6 +386,7 @@ def cpu_baseline(args):
   ffn_oracle.set_threads(best_thr)
   rate_c, steps_c, dt_c = run(None, args.cpu_seconds / 2, args.cpu_steps)
   results['c_oracle'] = (rate_c, steps_c, dt_c, best_thr)
+  oracle_trace = traces[0]  # (FoV position, queued moves) of the C oracle's run
   try:
     import torch
     best_t, best_rate = None, 0.0
@@ -377,7 +405,7 @@ def cpu_baseline(args):
     pass
   name = max(results, key=lambda k: results[k][0])
   rate, steps, dt, thr = results[name]
-  return {
+  return oracle_trace, {
       'value': round(rate, 3),
       'unit': 'FoV-steps/s',
       'cores': int(thr),
@@ -390,6 +418,93 @@ def cpu_baseline(args):
                  'conv stack on %d threads, %.1f s'
                  % (steps, args.workload, args.volume, name, thr, dt)),
   }
+
+
+def gpu_parity_leg(res, oracle_trace, tol=1e-4):
+  """The first FoV steps of the bench workload once more on the GPU -- a fresh
+  device canvas, same volume / seeds / options, default kernels -- compared
+  step for step with the oracle trajectory the cpu_baseline leg just produced:
+  FoV positions and queued move targets must be equal, move scores (the face
+  maxima of the pasted logits) within `tol`.  Untimed; rank 0 at N = 1 only."""
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from ffn_amd.inference import seed as seed_lib
+
+  n_want = len(oracle_trace)
+  if n_want == 0:
+    return {'parity_steps_checked': 0, 'parity_ok': False}
+  exe, model, request = res['exe'], res['model'], res['request']
+  counters = inference_utils.Counters()
+  canvas = inference.DeviceCanvas(
+      model.info, exe.get_client(counters, direct=True), res['image'],
+      request.inference_options, counters=counters,
+      movement_policy_fn=movement.get_policy_fn(request, model.info))
+  got = []
+  thr = canvas.movement_policy.score_threshold
+  deltas = canvas.movement_policy.deltas
+
+  class _Enough(Exception):
+    pass
+
+  inner = canvas.update_at
+
+  def recording_update(pos):  # an instance hook: the Python loop runs
+    if len(got) >= n_want:
+      raise _Enough()
+    pred = inner(pos)
+    moves = sorted(((s, tuple(int(v) for v in o))
+                    for s, o, _ in pred.scored_move_offsets(deltas, thr)),
+                   reverse=True)
+    got.append((tuple(int(v) for v in pos), moves))
+    return pred
+
+  canvas.update_at = recording_update
+  policy = functools.partial(seed_lib.PolicyGrid3d, step=16,
+                             offsets=(0, 8, 4, 12, 2, 10, 14))
+  try:
+    canvas.segment_all(seed_policy=policy)
+  except _Enough:
+    pass
+  canvas.close()
+  ok = len(got) >= n_want
+  max_err = 0.0
+  first_bad = None
+  for k in range(min(len(got), n_want)):
+    (gp, gm), (op, om) = got[k], oracle_trace[k]
+    same = (gp == tuple(int(v) for v in op) and len(gm) == len(om) and
+            all(tuple(int(v) for v in a[1]) == b[1] for a, b in zip(om, gm)))
+    if same and gm:
+      err = max(abs(a[0] - b[0]) for a, b in zip(om, gm))
+      max_err = max(max_err, err)
+      same = err <= tol
+    if not same:
+      ok = False
+      first_bad = k
+      break
+  return {'parity_steps_checked': min(len(got), n_want), 'parity_ok': bool(ok),
+          'parity_max_move_score_err': max_err, 'parity_tolerance': tol,
+          'parity_first_mismatch_step': first_bad,
+          'parity_what': 'FoV position, queued move targets (equal) and move '
+                         'scores (abs tol) of the first steps of this workload: '
+                         'default GPU path vs the CPU oracle canvas loop'}
+
+
+def _self_launch(args):
+  """`python bench.py --gpus N` outside torch.distributed.run: become
+  `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank
+  per GPU over RCCL); rank 0 of that job prints the one JSON line."""
+  import socket
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+         '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  sys.stdout.flush()
+  os.execve(sys.executable, cmd, env)
 
 
 def main():
@@ -419,10 +534,11 @@ def main():
 
   rank, local_rank, world = _dist_env()
   if world != args.gpus:
-    if args.gpus != 1 or world != 1:
-      raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.'
-                       'distributed.run --nproc-per-node %d' %
-                       (args.gpus, world, args.gpus))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+      _self_launch(args)  # does not return
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.'
+                     'distributed.run --nproc-per-node %d' %
+                     (args.gpus, world, args.gpus))
 
   res = run_gpu(args, rank, local_rank, world)
   if rank != 0:
@@ -435,21 +551,30 @@ def main():
   # (PMC counters need rocprofv3): it is taken from the committed PMC profile of
   # this same command, when present.
   traffic = None
+  traffic_source = None
   try:
     with open(os.path.join(ROOT, 'profiles', 'conv32_pmc_traffic.json')) as f:
-      traffic = json.load(f)['traffic_bytes_per_launch']
+      tj = json.load(f)
+    if tj.get('conv_variant', 4) == res.get('conv_variant', 4):
+      traffic = tj['traffic_bytes_per_launch']
+      traffic_source = ('profiles/conv32_pmc_traffic.json: separate rocprofv3 '
+                        '--pmc FETCH_SIZE / WRITE_SIZE passes of this command '
+                        '(NOT measured in this run)')
   except (OSError, KeyError, ValueError):
     pass
   variant = res.get('conv_variant', 4)
   PEAK_F16_MFMA_TFLOPS = PEAK_BF16_MFMA_TFLOPS  # same dense rate on gfx950
-  if variant in (3, 4):
+  if variant in (3, 4, 5):
     products = BF16X3_PRODUCTS if variant == 3 else 3
-    mfma = ('v_mfma_f32_16x16x32_bf16' if variant == 3 else
-            'v_mfma_f32_16x16x32_f16')
+    mfma = {3: 'v_mfma_f32_16x16x32_bf16', 4: 'v_mfma_f32_16x16x32_f16',
+            5: 'v_mfma_f32_32x32x16_f16'}[variant]
+    shape = ('conv32k (3x3x3 32->32 implicit GEMM, 4-wave workgroups, the 27 taps '
+             'split over the waves' if variant == 5 else
+             'conv32w8 (3x3x3 32->32 implicit GEMM, 8-wave workgroups')
     kernel_name = (
-        'conv32w8 (3x3x3 32->32 implicit GEMM, 8-wave workgroups; f32 operands split %s, %d '
-        'products per f32 product on %s, f32 accumulation)' %
-        ('exactly into 3 bf16 parts' if variant == 3 else
+        '%s; f32 operands split %s, %d products per f32 product on %s, f32 '
+        'accumulation)' %
+        (shape, 'exactly into 3 bf16 parts' if variant == 3 else
          'into fp16 hi + 2^-11-scaled fp16 residual (22 mantissa bits)',
          products, mfma))
     peak = PEAK_F16_MFMA_TFLOPS / products
@@ -493,7 +618,17 @@ def main():
                         if args.host_loop == 'native' else
                         'Python, one ffn_canvas_step per FoV step'),
       },
-      'voxels_segmented_per_s': round(world * res['voxels'] / res['elapsed'], 1),
+      'voxels_segmented_per_s': round(
+          res['voxels_run'] / max(res['seconds_run'], 1e-9), 1),
+      'voxels_leg': {
+          'voxels_segmented': int(res['voxels_run']),
+          'fov_steps': int(res['steps_run']),
+          'seconds': round(res['seconds_run'], 4),
+          'region': 'all ranks, from the first FoV step of the run to the end '
+                    'of the timed region (prewarm + warmup + timed steps, '
+                    'seed set-up and segment commits included); the K timed '
+                    'steps alone held %d voxels' % int(world * res['voxels']),
+      },
       'host_breakdown_us_per_step': {
           'c_abi_step_call': round(1e3 * res['counters'].get(
               'inference-time-ms', 0) / max(res['counters'].get(
@@ -527,6 +662,7 @@ def main():
           'executed_mfma_tflops': round(achieved * executed_ratio, 1),
           'vs_native_f32_mfma_peak': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
           'traffic': traffic,
+          'traffic_source': traffic_source,
           'avg_launch_us': round(avg_conv_ms * 1e3, 3),
           'timing': ('HIP events around the 23-launch conv chain of every %dth '
                      'step, / 23 (includes inter-kernel gaps)' %
@@ -538,7 +674,12 @@ def main():
       },
   }
   if world == 1 and not args.no_cpu_baseline:
-    out['cpu_baseline'] = cpu_baseline(args)
+    oracle_trace, out['cpu_baseline'] = cpu_baseline(args)
+    try:
+      out.update(gpu_parity_leg(res, oracle_trace))
+    except Exception as e:  # pylint:disable=broad-except
+      out.update({'parity_steps_checked': 0, 'parity_ok': False,
+                  'parity_error': repr(e)})
   print(json.dumps(out))
 
 

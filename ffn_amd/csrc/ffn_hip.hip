@@ -89,10 +89,20 @@ struct ffn_engine {
   uint16_t* wpack2h = nullptr;   // fp16 hi / scaled-residual fragments (variant 4)
   size_t wpack2h_layer = 0;
   size_t lds_bytes_h = 0;        // conv32x3<SCHEME 2>: 2 slots x Rc rows x 160 B
+  // conv32k (variant 5): 160-voxel chunks, K split over the waves
+  int nchunks_k = 0, Rc_k = 0;
+  size_t lds_bytes_k = 0;        // 3 slots x Rc_k rows x 144 B
+  uint16_t* wpackk = nullptr;    // fp16 hi / scaled-residual fragments, 32x32x16 order
+  size_t wpackk_layer = 0;
+  bool k_ok = false;             // geometry fits conv32k
+  int ksched_aoff[4 * kKMaxTaps] = {};
+  int ksched_btap[4 * kKMaxTaps] = {};
+  int ksched_ntaps[4] = {};
   unsigned* range_flag = nullptr;  // device word: tag of the last void run
   unsigned range_tag = 0;        // tag of the run being queued
   bool fp16_ok = true;           // every weight inside the fp16 range
-  int conv_variant = 4;       // 0 conv32, 1 conv32p, 2 conv32c, 3 conv32x3 bf16x3, 4 fp16x2
+  int conv_variant = 4;       // 0 conv32, 1 conv32p, 2 conv32c, 3 conv32x3 bf16x3, 4 fp16x2,
+                              // 5 fp16x2 on 32x32x16 with the taps split over the waves
   float* h_io = nullptr;      // pinned staging of ffn_predict: seed, image, logits
   float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
   float* up_seed = nullptr;
@@ -253,6 +263,24 @@ int set_lds_attr_w8(size_t bytes) {
         reinterpret_cast<const void*>(&conv32w8_kernel<RI, RO, SK, 9, true, SCHEME>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   }
+  return FFN_OK;
+}
+
+template <bool RI, bool RO, bool SK>
+int set_lds_attr_k(size_t bytes) {
+#define FFN_K_ATTR(KSV, HEADV)                                                \
+  HIP_TRY(hipFuncSetAttribute(                                                \
+      reinterpret_cast<const void*>(&conv32k_kernel<RI, RO, SK, KSV, HEADV>), \
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes))
+  FFN_K_ATTR(8, false);
+  FFN_K_ATTR(9, false);
+  FFN_K_ATTR(10, false);
+  if (SK) {
+    FFN_K_ATTR(8, true);
+    FFN_K_ATTR(9, true);
+    FFN_K_ATTR(10, true);
+  }
+#undef FFN_K_ATTR
   return FFN_OK;
 }
 
@@ -461,7 +489,37 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
   const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
   a.range_flag = e->range_flag;
   a.range_tag = e->range_tag;
-  if (e->conv_variant >= 3 && e->waves8) {
+  if (e->conv_variant == 5) {
+    // taps split over 4 waves, 32x32x16 MFMA, 160-voxel chunks
+    ConvKArgs ka;
+    ka.c = a;
+    ka.c.wpack = reinterpret_cast<const float*>(e->wpackk +
+                                                (size_t)layer * e->wpackk_layer);
+    ka.c.Rc = e->Rc_k;
+    ka.c.nchunks = e->nchunks_k;
+    ka.c.total_slots = n * e->nchunks_k;
+    ka.c.slots_per_xcd = (ka.c.total_slots + 7) / 8;
+    std::memcpy(ka.aoff, e->ksched_aoff, sizeof(ka.aoff));
+    std::memcpy(ka.btap, e->ksched_btap, sizeof(ka.btap));
+    std::memcpy(ka.ntaps, e->ksched_ntaps, sizeof(ka.ntaps));
+    const dim3 gridk(8 * ka.c.slots_per_xcd), blockk(kKThreads);
+#define FFN_K_LAUNCH(KSV, HEADV)                                              \
+  hipLaunchKernelGGL((conv32k_kernel<RI, RO, SK, KSV, HEADV>), gridk, blockk, \
+                     e->lds_bytes_k, e->stream, ka)
+    const int ks = e->Rc_k / 32;
+    if (head.on) {
+      if constexpr (SK) {
+        if (ks == 8) FFN_K_LAUNCH(8, true);
+        else if (ks == 9) FFN_K_LAUNCH(9, true);
+        else FFN_K_LAUNCH(10, true);
+      }
+    } else {
+      if (ks == 8) FFN_K_LAUNCH(8, false);
+      else if (ks == 9) FFN_K_LAUNCH(9, false);
+      else FFN_K_LAUNCH(10, false);
+    }
+#undef FFN_K_LAUNCH
+  } else if (e->conv_variant >= 3 && e->waves8) {
     // 8-wave workgroups: two waves per SIMD hide each other's operand loads
     const dim3 block8(kW8Threads);
     const bool h = e->conv_variant == 4;
@@ -637,7 +695,7 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   }
   if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   if (head_fused) {
-    e->count_blocks = e->nchunks_c;
+    e->count_blocks = e->conv_variant == 5 ? e->nchunks_k : e->nchunks_c;
   } else {
     e->count_blocks = kHeadBlocks;
     hipLaunchKernelGGL(head_kernel, dim3(kHeadBlocks, n), dim3(256), 0, e->stream,
@@ -825,7 +883,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   // dense -> padded position table and LDS extent of the compact variant
   {
     e->nchunks_c = (g.V + kCChunk - 1) / kCChunk;
-    std::vector<int32_t> pidx((size_t)e->nchunks_c * kCChunk);
+    e->nchunks_k = (g.V + kKChunk - 1) / kKChunk;
+    std::vector<int32_t> pidx(std::max((size_t)e->nchunks_c * kCChunk,
+                                       (size_t)e->nchunks_k * kKChunk));
     for (size_t v = 0; v < pidx.size(); ++v) {
       const int vv = (int)std::min<size_t>(v, (size_t)g.V - 1);
       const int x = vv % g.fx, y = (vv / g.fx) % g.fy, z = vv / (g.fx * g.fy);
@@ -840,6 +900,36 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     e->lds_bytes_c = (size_t)2 * e->Rc * kCLdsStride * sizeof(float);
     e->lds_bytes_x = (size_t)2 * e->Rc * kXRowBytes;
     e->lds_bytes_h = (size_t)2 * e->Rc * kHRowBytes;
+    {
+      int span_k = 0;
+      for (int c = 0; c < e->nchunks_k; ++c)
+        span_k = std::max(span_k, pidx[(size_t)c * kKChunk + kKChunk - 1] -
+                                      pidx[(size_t)c * kKChunk] + 1);
+      e->Rc_k = ((span_k + 2 * (g.XS + 1)) + 31) / 32 * 32;
+      if (e->Rc_k < 256) e->Rc_k = 256;
+      e->k_ok = e->Rc_k <= 320;
+      e->lds_bytes_k = std::max((size_t)3 * e->Rc_k * kKRowB,
+                                (size_t)4 * kKChunk * kKRowB + 64);
+      // tap schedule of the four waves (see conv32k_kernel): two dz = -1 taps
+      // each, then two taps of dz <= 0, then the rest; 7 / 7 / 7 / 6 taps
+      static const int kSched[4][7] = {{0, 1, 8, 9, 16, 18, 19},
+                                       {2, 3, 10, 11, 17, 20, 21},
+                                       {4, 5, 12, 13, 22, 23, 24},
+                                       {6, 7, 14, 15, 25, 26, -1}};
+      for (int w = 0; w < 4; ++w) {
+        int nt = 0;
+        for (int j = 0; j < 7; ++j) {
+          const int s = kSched[w][j];
+          if (s < 0) continue;
+          const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
+          e->ksched_aoff[w * kKMaxTaps + j] =
+              (kz * e->Rc_k + (ky - 1) * g.XS + (kx - 1)) * kKRowB;
+          e->ksched_btap[w * kKMaxTaps + j] = s;
+          ++nt;
+        }
+        e->ksched_ntaps[w] = nt;
+      }
+    }
     E_TRY(hipMalloc(&e->d_dbg, 24 * sizeof(long long)));
     E_TRY(hipMemset(e->d_dbg, 0, 24 * sizeof(long long)));
     E_TRY(hipMalloc(&e->pidx, pidx.size() * sizeof(int32_t)));
@@ -849,6 +939,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     const bool p_ok = g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256;
     const bool c_ok = e->Rc == 256 || e->Rc == 288;
     e->conv_variant = c_ok ? 4 : (p_ok ? 1 : 0);
+    if (e->lds_bytes_k > 160 * 1024) e->k_ok = false;
   }
 
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)
@@ -875,6 +966,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     e->wpack2h_layer = (size_t)27 * 2 * 2 * 64 * 8;
     E_TRY(hipMalloc(&e->wpack2h, e->wpack2h_layer * (2 * depth - 1) *
                                      sizeof(uint16_t)));
+    e->wpackk_layer = (size_t)27 * 2 * 2 * 64 * 8;
+    E_TRY(hipMalloc(&e->wpackk, e->wpackk_layer * (2 * depth - 1) *
+                                    sizeof(uint16_t)));
     E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
     E_TRY(hipMemset(e->range_flag, 0, sizeof(unsigned)));
   }
@@ -904,6 +998,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (!rc) rc = set_lds_attr_w8<false, false, false, 3>(e->lds_bytes_x);
     if (!rc) rc = set_lds_attr_w8<true, true, false, 3>(e->lds_bytes_x);
     if (!rc) rc = set_lds_attr_w8<false, false, true, 3>(e->lds_bytes_x);
+    if (!rc && e->k_ok) rc = set_lds_attr_k<false, false, false>(e->lds_bytes_k);
+    if (!rc && e->k_ok) rc = set_lds_attr_k<true, true, false>(e->lds_bytes_k);
+    if (!rc && e->k_ok) rc = set_lds_attr_k<false, false, true>(e->lds_bytes_k);
     if (!rc) rc = set_lds_attr_p<false, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
@@ -948,6 +1045,7 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->count);
   (void)hipFree(e->wpack3);
   (void)hipFree(e->wpack2h);
+  (void)hipFree(e->wpackk);
   (void)hipFree(e->range_flag);
   (void)hipFree(e->valid);
   (void)hipFree(e->validbits);
@@ -978,6 +1076,7 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   // conv0_a: [27][2][32] + bias, used as stored
   std::vector<uint16_t> host3(e->wpack3_layer * (2 * e->depth - 1));
   std::vector<uint16_t> host2(e->wpack2h_layer * (2 * e->depth - 1));
+  std::vector<uint16_t> hostk(e->wpackk_layer * (2 * e->depth - 1));
   bool weights_in_fp16_range = true;
   std::memcpy(&host[e->w0a_off], src, sizeof(float) * 27 * 2 * F);
   src += 27 * 2 * F;
@@ -1031,6 +1130,23 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
                     part[pl];
             }
     }
+    // conv32k: the same split as the 32x32x16 A operand (rows = cout)
+    //   wpackk[tap][khalf][plane][lane][c] = part(W[tap][16 khalf + 8 (lane >> 5) + c][lane & 31])
+    {
+      uint16_t* wk = &hostk[(size_t)l * e->wpackk_layer];
+      for (int tap = 0; tap < 27; ++tap)
+        for (int kh = 0; kh < 2; ++kh)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int c = 0; c < 8; ++c) {
+              const int ci = 16 * kh + 8 * (lane >> 5) + c, co = lane & 31;
+              const float w = src[((size_t)tap * F + ci) * F + co];
+              uint16_t part[2];
+              split_fp16x2(w, part);
+              for (int pl = 0; pl < 2; ++pl)
+                wk[((((size_t)tap * 2 + kh) * 2 + pl) * 64 + lane) * 8 + c] =
+                    part[pl];
+            }
+    }
     src += 27 * F * F;
     std::memcpy(&host[e->bias_off[l]], src, sizeof(float) * F);
     src += F;
@@ -1039,8 +1155,10 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
                     hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->wpack2h, host2.data(), host2.size() * sizeof(uint16_t),
                     hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->wpackk, hostk.data(), hostk.size() * sizeof(uint16_t),
+                    hipMemcpyHostToDevice));
   e->fp16_ok = weights_in_fp16_range;
-  if (!e->fp16_ok && e->conv_variant == 4) e->conv_variant = 3;
+  if (!e->fp16_ok && e->conv_variant >= 4) e->conv_variant = 3;
   std::memcpy(&host[e->wl_off], src, sizeof(float) * (F + 1));
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipMemcpy(e->weights, host.data(),
@@ -1074,11 +1192,11 @@ int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
   HIP_TRY(hipMemcpyAsync(h_logits, e->logits, bytes, hipMemcpyDeviceToHost,
                          e->stream));
   unsigned flag = 0;
-  if (e->conv_variant == 4)
+  if (e->conv_variant >= 4)
     HIP_TRY(hipMemcpyAsync(&flag, e->range_flag, sizeof(flag),
                            hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  if (e->conv_variant == 4 && flag == e->range_tag) {
+  if (e->conv_variant >= 4 && flag == e->range_tag) {
     // an operand left the fp16 range: this engine stays on the bf16x3 scheme
     e->conv_variant = 3;
     rc = run_stack(e, n, si, std::nanf(""), INFINITY);
@@ -1110,13 +1228,16 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) {
-    if (value < 0 || value > 4) return fail(FFN_ERR_ARG, "conv_variant must be 0..4");
-    if (value == 4 && e->weights_set && !e->fp16_ok)
-      return fail(FFN_ERR_ARG, "conv_variant 4: a weight is outside the fp16 range");
+    if (value < 0 || value > 5) return fail(FFN_ERR_ARG, "conv_variant must be 0..5");
+    if (value >= 4 && e->weights_set && !e->fp16_ok)
+      return fail(FFN_ERR_ARG, "conv_variant %d: a weight is outside the fp16 range",
+                  value);
+    if (value == 5 && !e->k_ok)
+      return fail(FFN_ERR_ARG, "conv_variant 5 unsupported for this fov");
     const Geom& g = e->g;
     if (value == 1 && !(g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256))
       return fail(FFN_ERR_ARG, "conv_variant 1 unsupported for this fov");
-    if (value >= 2 && !(e->Rc == 256 || e->Rc == 288))
+    if (value >= 2 && value <= 4 && !(e->Rc == 256 || e->Rc == 288))
       return fail(FFN_ERR_ARG, "conv_variant %d unsupported for this fov", value);
     e->conv_variant = value;
     return FFN_OK;

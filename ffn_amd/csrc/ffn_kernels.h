@@ -1849,6 +1849,348 @@ __global__ __launch_bounds__(kW8Threads, 2) void conv32w8_kernel(ConvCArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// conv32k: the split-product conv on v_mfma_f32_32x32x16_f16, K split over the
+// waves (conv_variant 5).
+//
+// What bounds conv32w8 is operand delivery, not the matrix pipe: every wave
+// needs the weight fragments of all 27 taps (8 waves x 54 KB through the CU's
+// L1 per launch) and a 16x16x32 MFMA consumes a KB of operands every 16 cycles.
+// Here
+//   * the MFMA is 32x32x16 (twice the MACs per operand byte);
+//   * a workgroup is 4 waves (one per SIMD) that split K, i.e. the 27 TAPS:
+//     wave w contracts its 7 (6) taps for ALL five 32-position tiles of the
+//     chunk, so each tap's weight fragment (4 KB) is fetched by exactly one
+//     wave -- 108 KB per workgroup instead of 432 KB -- and stays in registers
+//     for 30 MFMAs;
+//   * operand roles are swapped (A = weights [cout x cin], B = activations
+//     [cin x position]): a lane's accumulator registers are 4 consecutive
+//     channels of one position, so the four partial sums leave through LDS as
+//     ds_write_b128 / ds_read_b128 and are added in wave order (deterministic).
+// Chunk = 160 consecutive dense voxels (5 tiles of 32; 225 workgroups for the
+// 33^3 FoV, one per CU at batch 1).  The three dz segments are staged as in
+// conv32w8 (f32 -> fp16 hi + 2^-11-scaled residual, ReLU on the way in), but
+// into THREE LDS slots (3 x Rc x 144 B), so no slot is ever re-used and the two
+// in-loop barriers sit at wave-uniform tap counts instead of at segment ends:
+//   taps 0,1 of every wave: dz = -1 only       (dz = 0 is converted meanwhile)
+//   taps 2,3:               dz <= 0            (dz = +1 is converted meanwhile)
+//   taps 4..:               the rest
+// (host-made schedule in ConvKArgs: 7/7/7/6 taps per wave).
+// LDS row = hi plane 64 B | residual plane 64 B | 16 B pad = 144 B: the
+// ds_read_b128 of 32 consecutive rows is bank-conflict free (9 r mod 16).
+// Weight fragments: host-packed [tap][khalf][plane][lane][8] halves with
+//   lane l -> cout l & 31, cin 16 khalf + 8 (l >> 5) + c.
+// ---------------------------------------------------------------------------
+constexpr int kKChunk = 160;
+constexpr int kKTiles = 5;
+constexpr int kKTile = 32;
+constexpr int kKThreads = 256;
+constexpr int kKRowB = 144;
+constexpr int kKMaxTaps = 8;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvKArgs {
+  ConvCArgs c;
+  int aoff[4 * kKMaxTaps];  // [wave][j]: LDS byte offset of the wave's j-th tap
+  int btap[4 * kKMaxTaps];  // [wave][j]: its tap index (weight fragments)
+  int ntaps[4];
+};
+
+template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int KS = 9, bool HEAD = false>
+__global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
+  const ConvCArgs& a = ka.c;
+  typedef f16x8 frag_t;
+  unsigned range_max = 0;  // max |operand| bit pattern seen by this thread
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x;
+  const long long dbg_c0 = a.dbg ? clock64() : 0;
+  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
+  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
+  if (gc >= a.total_slots) return;
+  const int item = gc / a.nchunks;
+  const int chunk = gc - item * a.nchunks;
+  const int v0 = chunk * kKChunk;
+  const int32_t* pidx = a.pidx + v0;
+  int p_first;
+  {
+    int z = (int)((float)v0 / (float)a.fyfx);
+    z -= (z * a.fyfx > v0);
+    z += ((z + 1) * a.fyfx <= v0);
+    const int rem = v0 - z * a.fyfx;
+    int y = (int)((float)rem / (float)a.fx);
+    y -= (y * a.fx > rem);
+    y += ((y + 1) * a.fx <= rem);
+    p_first = __builtin_amdgcn_readfirstlane(z * a.plane + y * a.XS +
+                                             (rem - y * a.fx));
+  }
+  const int p_lo = p_first - (a.XS + 1);  // first staged row of the dz = 0 segment
+  const float* src = a.in + (size_t)item * a.act_stride;
+  const int Rc = a.Rc;  // == 32 * KS
+
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+
+  // LDS byte offset of this lane's position in each tile (+ its k-group)
+  int prow[kKTiles];
+#pragma unroll
+  for (int t = 0; t < kKTiles; ++t)
+    prow[t] = (pidx[t * kKTile + li] - p_lo) * kKRowB + lh * 16;
+  // epilogue pieces: thread -> (position j = (tid >> 3) + 32 k, quad tid & 7)
+  const int q = tid & 7;
+  const int j0 = tid >> 3;
+  int pj[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = j0 + 32 * k;
+    pj[k] = pidx[(v0 + j < a.V) ? j : 0];
+  }
+  // the wave's tap schedule (scalar loads from the kernel arguments)
+  const int nt = ka.ntaps[wave];
+  int aoffs[7], btaps[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    aoffs[j] = ka.aoff[wave * kKMaxTaps + j];
+    btaps[j] = ka.btap[wave * kKMaxTaps + j];
+  }
+
+  struct XFragK { frag_t x[2][2]; };  // activations [khalf][plane]
+  struct WFragK { frag_t w[2][2]; };  // weights     [khalf][plane]
+  const frag_t* wp = reinterpret_cast<const frag_t*>(a.wpack) + lane;
+  auto loadW = [&](int s, WFragK& dst) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        dst.w[kh][pl] = wp[((s * 2 + kh) * 2 + pl) * 64];
+  };
+  // weights of the wave's first two taps BEFORE the staging loads (vmcnt
+  // retires in order)
+  WFragK W0, W1, W2;
+  loadW(btaps[0], W0);
+  loadW(btaps[1], W1);
+
+  // ---- staging: all loads of the three dz segments in flight at once ----
+  f32x4 sv[3][KS];
+#pragma unroll
+  for (int seg = 0; seg < 3; ++seg) {
+    const long p0 = (long)p_lo + (long)(seg - 1) * a.plane;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) sv[seg][k] = s4[tid + k * kKThreads];
+  }
+  auto write_piece = [&](int seg, int k) {
+    const int e = tid + k * kKThreads;
+    f32x4 v = sv[seg][k];
+    if (RELU_IN) {  // tf.nn.relu in front of conv_a (convstack_3d.py:44), as one
+                    // integer max on the bit pattern (negative floats are
+                    // negative ints; -0 -> +0)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int b = __float_as_int(v[c]);
+        v[c] = __int_as_float(b > 0 ? b : 0);
+      }
+    }
+    char* dstrow = ldsb + (seg * Rc + (e >> 3)) * kKRowB + (e & 7) * 8;
+    f32x4 vh = v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const unsigned mbits = __float_as_uint(v[c]) & 0x7fffffffu;
+      range_max = mbits > range_max ? mbits : range_max;
+      vh[c] = mbits < 0x38800000u ? 0.0f : v[c];  // |x| < 2^-14
+    }
+    const f16x4 hi = __builtin_convertvector(vh, f16x4);
+    const f32x4 r1 = (v - __builtin_convertvector(hi, f32x4)) * 2048.0f;
+    const f16x4 res = __builtin_convertvector(r1, f16x4);
+    *reinterpret_cast<f16x4*>(dstrow) = hi;
+    *reinterpret_cast<f16x4*>(dstrow + 64) = res;
+  };
+#pragma unroll
+  for (int k = 0; k < KS; ++k) write_piece(0, k);
+  __syncthreads();
+
+  auto loadX = [&](int t, int off, XFragK& dst) {
+    const char* p = ldsb + prow[t] + off;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        dst.x[kh][pl] = *reinterpret_cast<const frag_t*>(p + pl * 64 + kh * 32);
+  };
+  // acc: products of weight 1; accC: cross products, weight 2^-11
+  f32x16 acc[kKTiles], accC[kKTiles];
+#pragma unroll
+  for (int t = 0; t < kKTiles; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = accC[t][r] = 0.f;
+  auto mma = [](const frag_t& fw, const frag_t& fx, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fx, c, 0, 0, 0);
+  };
+  XFragK X0, X1;
+  const long long dbg_c1 = a.dbg ? clock64() : 0;
+  loadX(0, aoffs[0], X0);
+
+  // one tile of one tap: prefetch the next activation fragments, 6 MFMAs,
+  // optionally one staging piece of the segment being converted
+#define FFN_KTILE(T, XCUR, WCUR, PREFETCH, PIECE)                             \
+  PREFETCH;                                                                   \
+  accC[T] = mma(WCUR.w[0][0], XCUR.x[0][1], accC[T]);                         \
+  acc[T] = mma(WCUR.w[0][0], XCUR.x[0][0], acc[T]);                           \
+  accC[T] = mma(WCUR.w[0][1], XCUR.x[0][0], accC[T]);                         \
+  acc[T] = mma(WCUR.w[1][0], XCUR.x[1][0], acc[T]);                           \
+  accC[T] = mma(WCUR.w[1][0], XCUR.x[1][1], accC[T]);                         \
+  PIECE;                                                                      \
+  accC[T] = mma(WCUR.w[1][1], XCUR.x[1][0], accC[T]);
+  // tap J of the wave (XA holds tile 0's fragments on entry); CONT: prefetch
+  // tile 0 of the next tap at the end (false in front of a barrier); SEG/PB:
+  // staging pieces PB .. PB + 4 of segment SEG ride on the five tiles
+#define FFN_KTAP(J, XA, XB, WCUR, WNEXT2, CONT, SEG, PB)                      \
+  if ((J) < 6 || nt == 7) { /* every wave has 6 or 7 taps */                  \
+    if ((J) + 2 < 7) {                                                        \
+      if ((J) + 2 < 6 || nt == 7) loadW(btaps[((J) + 2) % 7], WNEXT2);        \
+    }                                                                         \
+    const int ao_ = aoffs[J];                                                 \
+    const int an_ = aoffs[((J) + 1) % 7];                                     \
+    FFN_KTILE(0, XA, WCUR, loadX(1, ao_, XB), ilv_piece(SEG, (PB) + 0))       \
+    FFN_KTILE(1, XB, WCUR, loadX(2, ao_, XA), ilv_piece(SEG, (PB) + 1))       \
+    FFN_KTILE(2, XA, WCUR, loadX(3, ao_, XB), ilv_piece(SEG, (PB) + 2))       \
+    FFN_KTILE(3, XB, WCUR, loadX(4, ao_, XA), ilv_piece(SEG, (PB) + 3))       \
+    FFN_KTILE(4, XA, WCUR,                                                    \
+              if ((CONT) && ((J) + 1 < 6 || nt == 7)) loadX(0, an_, XB),      \
+              ilv_piece(SEG, (PB) + 4))                                       \
+  }
+  auto ilv_piece = [&](int seg, int k) {
+    if (seg > 0 && k < KS) write_piece(seg, k);
+  };
+  // 5 tiles per tap: the fragment buffers swap roles from tap to tap
+  FFN_KTAP(0, X0, X1, W0, W2, true, 1, 0)
+  FFN_KTAP(1, X1, X0, W1, W0, false, 1, 5)
+  __syncthreads();  // dz = 0 landed
+  loadX(0, aoffs[2], X0);
+  FFN_KTAP(2, X0, X1, W2, W1, true, 2, 0)
+  FFN_KTAP(3, X1, X0, W0, W2, false, 2, 5)
+  __syncthreads();  // dz = +1 landed
+  // residual input and bias of this thread's epilogue pieces
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
+  unsigned ooff[5];
+  f32x4 skipv[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int j = j0 + 32 * k;
+    const bool ok = v0 + j < a.V;
+    const int p = pj[k];
+    ooff[k] = ok ? ((unsigned)p * kFeatures + q * 4) * 4u : 0x80000000u;
+    skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ADD_SKIP)
+      skipv[k] = *reinterpret_cast<const f32x4*>(
+          a.skip + (size_t)item * a.act_stride + (size_t)p * kFeatures + q * 4);
+  }
+  loadX(0, aoffs[4], X0);
+  FFN_KTAP(4, X0, X1, W1, W0, true, 0, 0)
+  FFN_KTAP(5, X1, X0, W2, W1, true, 0, 0)
+  FFN_KTAP(6, X0, X1, W0, W2, false, 0, 0)
+#undef FFN_KTAP
+#undef FFN_KTILE
+
+  const long long dbg_c2 = a.dbg ? clock64() : 0;
+  // ---- epilogue: the four waves' partial sums meet in LDS ----
+  // P[wave][position 0..159][32 ch] at a 144-B row stride (ds_write_b128 of 8
+  // consecutive positions conflict-free); accumulator register 4 g + i of a lane
+  // is channel 8 g + 4 (lane >> 5) + i of position lane & 31 of the tile.
+  __syncthreads();
+  {
+#pragma unroll
+    for (int t = 0; t < kKTiles; ++t) acc[t] += accC[t] * 4.8828125e-4f;  // 2^-11
+    if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
+      *a.range_flag = a.range_tag;
+    char* P = ldsb + wave * (kKChunk * kKRowB) + li * kKRowB + lh * 16;
+#pragma unroll
+    for (int t = 0; t < kKTiles; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(P + t * (kKTile * kKRowB) + g * 32) =
+            f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2],
+                  acc[t][4 * g + 3]};
+  }
+  __syncthreads();
+  unsigned head_above = 0;
+  {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    float* obase = a.out + (size_t)item * a.act_stride;
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.nbytes, 0x00020000);
+    f32x4 hw4 = {0.f, 0.f, 0.f, 0.f};
+    float hbias = 0.f;
+    if (HEAD) {
+      hw4 = *reinterpret_cast<const f32x4*>(a.head_w + q * 4);
+      hbias = a.head_w[kFeatures];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int j = j0 + 32 * k;
+      const char* pp = ldsb + j * kKRowB + q * 16;
+      f32x4 v = *reinterpret_cast<const f32x4*>(pp);
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        v += *reinterpret_cast<const f32x4*>(pp + w * (kKChunk * kKRowB));
+      v += b4;
+      if (RELU_OUT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
+      }
+      if (ADD_SKIP) v += skipv[k];
+      if (HEAD) {
+        float partial = fmaxf(v[0], 0.f) * hw4[0];
+        partial = __builtin_fmaf(fmaxf(v[1], 0.f), hw4[1], partial);
+        partial = __builtin_fmaf(fmaxf(v[2], 0.f), hw4[2], partial);
+        partial = __builtin_fmaf(fmaxf(v[3], 0.f), hw4[3], partial);
+        partial += __shfl_xor(partial, 1);
+        partial += __shfl_xor(partial, 2);
+        partial += __shfl_xor(partial, 4);
+        bool above = false;
+        if (q == 0 && ooff[k] != 0x80000000u) {
+          const size_t dv = (size_t)item * a.V + (v0 + j);
+          float s = a.seed_raw[dv];
+          if (s != s) s = a.pad_value;
+          const float lg = s + (partial + hbias);
+          a.logits[dv] = lg;
+          above = lg >= a.move_thr;
+        }
+        head_above += (unsigned)__popcll(__ballot(above));  // wave-uniform
+        continue;
+      }
+      if (a.store_policy == 1)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 16);
+      else if (a.store_policy == 2)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 2);
+      else
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
+                                               rs_out, ooff[k], 0, 0);
+    }
+  }
+  if (HEAD) {  // this chunk's count of logits >= move_thr (summed by faces / paste)
+    float* cnt = reinterpret_cast<float*>(ldsb + 4 * kKChunk * kKRowB);
+    if ((tid & 63) == 0) cnt[tid >> 6] = __uint_as_float(head_above);
+    __syncthreads();
+    if (tid == 0)
+      a.head_count[gc] = __float_as_uint(cnt[0]) + __float_as_uint(cnt[1]) +
+                         __float_as_uint(cnt[2]) + __float_as_uint(cnt[3]);
+  }
+  if (a.dbg && gc == 0 && (tid & 63) == 0) {
+    long long* d = a.dbg + wave * 6;
+    d[0] = dbg_c0;
+    d[1] = dbg_c1;
+    d[2] = dbg_c2;
+    d[3] = clock64();
+    d[4] = dbg_w0;
+    d[5] = wall_clock64();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // head: ReLU -> 1x1x1 conv 32->1 + bias; logits = seed + update
 // (reference convstack_3d.py:51-54,91-94; model.py:168-183) and the count of
 // logits >= move_threshold that the disco test needs (inference.py:428-431).
