@@ -130,6 +130,8 @@ SIGNATURES = {
     'ffn_predict': (_I, [_P, _I, _P, _P, _P]),
     'ffn_forward_resident': (_I, [_P, _I, _I]),
     'ffn_canvas_create': (_I, [_P, _P, _I3, ctypes.POINTER(_P)]),
+    'ffn_canvas_create_u8': (_I, [_P, _P, _I3, ctypes.c_float, ctypes.c_float,
+                                  ctypes.POINTER(_P)]),
     'ffn_canvas_destroy': (None, [_P]),
     'ffn_canvas_init_seed': (_I, [_P, _I3, ctypes.c_float]),
     'ffn_canvas_step': (_I, [_P, _I, ctypes.POINTER(_P),

@@ -146,7 +146,9 @@ struct ffn_engine {
 
 struct ffn_canvas {
   ffn_engine* engine = nullptr;
-  float* image = nullptr;
+  float* image = nullptr;        // f32 image; NULL for a uint8 canvas
+  uint8_t* image_u8 = nullptr;   // uint8 canvas: raw image (1 B / voxel) ...
+  float* image_lut = nullptr;    // ... and (v - mean) / stddev for v = 0..255
   float* seed = nullptr;
   int32_t* seg = nullptr;
   int cz = 0, cy = 0, cx = 0;
@@ -176,6 +178,8 @@ int ffn_canvas_view(ffn_canvas* c, FfnCanvasView* out) {
   out->device_id = c->engine->device;
   out->engine_stream = c->engine->stream;
   out->image = c->image;
+  out->image_u8 = c->image_u8;
+  out->image_lut = c->image_lut;
   out->segmentation = c->seg;
   out->shape_zyx[0] = c->cz;
   out->shape_zyx[1] = c->cy;
@@ -502,6 +506,11 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
     std::memcpy(ka.aoff, e->ksched_aoff, sizeof(ka.aoff));
     std::memcpy(ka.btap, e->ksched_btap, sizeof(ka.btap));
     std::memcpy(ka.ntaps, e->ksched_ntaps, sizeof(ka.ntaps));
+    auto magic = [](int d) { return (unsigned)(((1ull << 32) + d - 1) / d); };
+    ka.magic_nchunks = magic(e->nchunks_k);
+    ka.magic_fyfx = magic(e->g.fy * e->g.fx);
+    ka.magic_fx = magic(e->g.fx);
+    ka.dbg_mode = e->dbg_clock == 2;
     const dim3 gridk(8 * ka.c.slots_per_xcd), blockk(kKThreads);
 #define FFN_K_LAUNCH(KSV, HEADV)                                              \
   hipLaunchKernelGGL((conv32k_kernel<RI, RO, SK, KSV, HEADV>), gridk, blockk, \
@@ -714,6 +723,8 @@ int dense_items(ffn_engine* e, int n, StepItems* si) {
     StepItem& it = e->h_items[k];
     std::memset(&it, 0, sizeof(it));
     it.image = e->up_image + (size_t)k * g.V;
+    it.image_u8 = nullptr;
+    it.image_lut = nullptr;
     it.seed = e->up_seed + (size_t)k * g.V;
     it.seg = nullptr;
     it.cz = g.fz;
@@ -769,7 +780,7 @@ int grid_for(long total, int block = 256) {
 
 extern "C" {
 
-int ffn_abi_version(void) { return 3; }
+int ffn_abi_version(void) { return 4; }
 
 const char* ffn_last_error(void) { return g_error.c_str(); }
 
@@ -907,7 +918,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
                                       pidx[(size_t)c * kKChunk] + 1);
       e->Rc_k = ((span_k + 2 * (g.XS + 1)) + 31) / 32 * 32;
       if (e->Rc_k < 256) e->Rc_k = 256;
-      e->k_ok = e->Rc_k <= 320;
+      e->k_ok = e->Rc_k <= 320 && e->nchunks_k >= 2;  // (magic divisions: d >= 2)
       e->lds_bytes_k = std::max((size_t)3 * e->Rc_k * kKRowB,
                                 (size_t)4 * kKChunk * kKRowB + 64);
       // tap schedule of the four waves (see conv32k_kernel): two dz = -1 taps
@@ -1028,9 +1039,13 @@ void ffn_engine_destroy(ffn_engine* e) {
   // ffn_canvas_destroy on an orphan only frees the host struct.
   for (ffn_canvas* c : e->canvases) {
     (void)hipFree(c->image);
+    (void)hipFree(c->image_u8);
+    (void)hipFree(c->image_lut);
     (void)hipFree(c->seed);
     (void)hipFree(c->seg);
     c->image = c->seed = nullptr;
+    c->image_u8 = nullptr;
+    c->image_lut = nullptr;
     c->seg = nullptr;
     c->engine = nullptr;
   }
@@ -1332,12 +1347,19 @@ int ffn_engine_get_profile(ffn_engine* e, double* conv_ms_total,
 
 /* ------------------------------- canvas ---------------------------------- */
 
-int ffn_canvas_create(ffn_engine* e, const float* image_f32,
-                      const int32_t shape_zyx[3], ffn_canvas** out) {
-  if (!e || !image_f32 || !shape_zyx || !out) return fail(FFN_ERR_ARG, "null argument");
+namespace {
+
+// image_f32 (already normalised) or image_u8 + the normalisation constants
+int canvas_create(ffn_engine* e, const float* image_f32, const uint8_t* image_u8,
+                  float mean, float stddev, const int32_t shape_zyx[3],
+                  ffn_canvas** out) {
+  if (!e || (!image_f32 && !image_u8) || !shape_zyx || !out)
+    return fail(FFN_ERR_ARG, "null argument");
   *out = nullptr;
   for (int k = 0; k < 3; ++k)
     if (shape_zyx[k] < 1) return fail(FFN_ERR_ARG, "bad canvas shape");
+  if (image_u8 && !(stddev != 0.0f))
+    return fail(FFN_ERR_ARG, "image_stddev must be non-zero");
   HIP_TRY(hipSetDevice(e->device));
   ffn_canvas* c = new ffn_canvas();
   c->engine = e;
@@ -1345,12 +1367,31 @@ int ffn_canvas_create(ffn_engine* e, const float* image_f32,
   c->cy = shape_zyx[1];
   c->cx = shape_zyx[2];
   c->nvox = (size_t)c->cz * c->cy * c->cx;
-  hipError_t err = hipMalloc(&c->image, c->nvox * sizeof(float));
+  hipError_t err = hipSuccess;
+  if (image_f32) {
+    err = hipMalloc(&c->image, c->nvox * sizeof(float));
+    if (err == hipSuccess)
+      err = hipMemcpy(c->image, image_f32, c->nvox * sizeof(float),
+                      hipMemcpyHostToDevice);
+  } else {
+    // (image.astype(np.float32) - image_mean) / image_stddev (runner.py:383-385):
+    // two correctly rounded f32 operations per value, evaluated here for the
+    // 256 possible inputs -- the device only looks the result up, so a uint8
+    // canvas is bit-identical to the f32 one by construction
+    float lut[256];
+    for (int v = 0; v < 256; ++v) {
+      volatile float d = (float)v - mean;  // volatile: no fused / widened form
+      lut[v] = d / stddev;
+    }
+    err = hipMalloc(&c->image_u8, c->nvox);
+    if (err == hipSuccess) err = hipMalloc(&c->image_lut, sizeof(lut));
+    if (err == hipSuccess)
+      err = hipMemcpy(c->image_u8, image_u8, c->nvox, hipMemcpyHostToDevice);
+    if (err == hipSuccess)
+      err = hipMemcpy(c->image_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
+  }
   if (err == hipSuccess) err = hipMalloc(&c->seed, c->nvox * sizeof(float));
   if (err == hipSuccess) err = hipMalloc(&c->seg, c->nvox * sizeof(int32_t));
-  if (err == hipSuccess)
-    err = hipMemcpy(c->image, image_f32, c->nvox * sizeof(float),
-                    hipMemcpyHostToDevice);
   if (err == hipSuccess) err = hipMemset(c->seg, 0, c->nvox * sizeof(int32_t));
   if (err == hipSuccess) {
     hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, e->stream,
@@ -1367,6 +1408,22 @@ int ffn_canvas_create(ffn_engine* e, const float* image_f32,
   return FFN_OK;
 }
 
+}  // namespace
+
+int ffn_canvas_create(ffn_engine* e, const float* image_f32,
+                      const int32_t shape_zyx[3], ffn_canvas** out) {
+  if (!image_f32) return fail(FFN_ERR_ARG, "null argument");
+  return canvas_create(e, image_f32, nullptr, 0.f, 1.f, shape_zyx, out);
+}
+
+int ffn_canvas_create_u8(ffn_engine* e, const uint8_t* image_u8,
+                         const int32_t shape_zyx[3], float image_mean,
+                         float image_stddev, ffn_canvas** out) {
+  if (!image_u8) return fail(FFN_ERR_ARG, "null argument");
+  return canvas_create(e, nullptr, image_u8, image_mean, image_stddev, shape_zyx,
+                       out);
+}
+
 void ffn_canvas_destroy(ffn_canvas* c) {
   if (!c) return;
   if (c->engine) {
@@ -1376,6 +1433,8 @@ void ffn_canvas_destroy(ffn_canvas* c) {
     e->canvases.erase(std::remove(e->canvases.begin(), e->canvases.end(), c),
                       e->canvases.end());
     (void)hipFree(c->image);
+    (void)hipFree(c->image_u8);
+    (void)hipFree(c->image_lut);
     (void)hipFree(c->seed);
     (void)hipFree(c->seg);
   }
@@ -1462,6 +1521,8 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     }
     StepItem& it = h_items[k];
     it.image = c->image;
+    it.image_u8 = c->image_u8;
+    it.image_lut = c->image_lut;
     it.seed = c->seed;
     it.seg = c->seg;
     it.cz = c->cz;

@@ -11,7 +11,9 @@ int ffn_set_error(int code, const char* fmt, ...)
 struct FfnCanvasView {
   int device_id;
   void* engine_stream;  // hipStream_t of the owning engine
-  const float* image;
+  const float* image;            // f32 canvas image, or NULL for a uint8 canvas:
+  const unsigned char* image_u8;  //   raw image ...
+  const float* image_lut;         //   ... and its 256-entry normalisation table
   const int* segmentation;
   long long shape_zyx[3];
 };

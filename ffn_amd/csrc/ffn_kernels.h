@@ -44,7 +44,9 @@ struct Geom {
 
 // Per-FoV step descriptor read by the gather / paste kernels.
 struct StepItem {
-  const float* image;
+  const float* image;        // f32 canvas image (already normalised), or NULL:
+  const uint8_t* image_u8;   //   raw uint8 image ...
+  const float* image_lut;    //   ... and its 256-entry normalisation table
   float* seed;
   const int32_t* seg;
   int cz, cy, cx;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_kernel(
     if (zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy && xx >= 0 && xx < g.fx) {
       const size_t ci =
           ((size_t)(z0 + zz) * it.cy + (y0 + yy)) * it.cx + (x0 + xx);
-      v.x = it.image[ci];
+      v.x = it.image ? it.image[ci] : it.image_lut[it.image_u8[ci]];
       v.y = it.seed[ci];
       if (hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y && hx >= 1 &&
           hx <= kC0X)  // interior voxel: keep the raw seed (NaN preserved)
@@ -206,7 +208,8 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
     if (zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy && xx >= 0 && xx < g.fx) {
       const size_t ci =
           ((size_t)(z0 + zz) * it.cy + (y0 + yy)) * it.cx + (x0 + xx);
-      vi = it.image[ci];
+      // uint8 canvases: (x - mean) / stddev of runner.py:383-385 is a table look-up
+      vi = it.image ? it.image[ci] : it.image_lut[it.image_u8[ci]];
       vs = it.seed[ci];
       if (hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y && hx >= 1 &&
           hx <= kC0X)  // interior voxel: keep the raw seed (NaN preserved)
@@ -1893,6 +1896,13 @@ struct ConvKArgs {
   int aoff[4 * kKMaxTaps];  // [wave][j]: LDS byte offset of the wave's j-th tap
   int btap[4 * kKMaxTaps];  // [wave][j]: its tap index (weight fragments)
   int ntaps[4];
+  // ceil(2^32 / d) for d = nchunks, fy * fx, fx: exact quotients of the small
+  // dividends met here as one s_mul_hi_u32 (an integer or float division in
+  // front of the staging loads costs ~100 instructions per launch)
+  unsigned magic_nchunks, magic_fyfx, magic_fx;
+  int dbg_mode;  // 0: {entry, loop start, loop end, exit}; 1: {entry, after the
+                 // first barrier, after the dz = 0 barrier, after the dz = +1
+                 // barrier} in clock slots 0..3
 };
 
 template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int KS = 9, bool HEAD = false>
@@ -1907,28 +1917,32 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
   const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
   const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
   if (gc >= a.total_slots) return;
-  const int item = gc / a.nchunks;
+  // the wave's tap schedule first: scalar loads from the kernel arguments that
+  // the weight loads below depend on
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = ka.ntaps[wave];
+  int aoffs[7], btaps[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    aoffs[j] = ka.aoff[wave * kKMaxTaps + j];
+    btaps[j] = ka.btap[wave * kKMaxTaps + j];
+  }
+  const int item = (int)__umulhi((unsigned)gc, ka.magic_nchunks);
   const int chunk = gc - item * a.nchunks;
   const int v0 = chunk * kKChunk;
   const int32_t* pidx = a.pidx + v0;
   int p_first;
   {
-    int z = (int)((float)v0 / (float)a.fyfx);
-    z -= (z * a.fyfx > v0);
-    z += ((z + 1) * a.fyfx <= v0);
+    const int z = (int)__umulhi((unsigned)v0, ka.magic_fyfx);
     const int rem = v0 - z * a.fyfx;
-    int y = (int)((float)rem / (float)a.fx);
-    y -= (y * a.fx > rem);
-    y += ((y + 1) * a.fx <= rem);
-    p_first = __builtin_amdgcn_readfirstlane(z * a.plane + y * a.XS +
-                                             (rem - y * a.fx));
+    const int y = (int)__umulhi((unsigned)rem, ka.magic_fx);
+    p_first = z * a.plane + y * a.XS + (rem - y * a.fx);
   }
   const int p_lo = p_first - (a.XS + 1);  // first staged row of the dz = 0 segment
   const float* src = a.in + (size_t)item * a.act_stride;
   const int Rc = a.Rc;  // == 32 * KS
 
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31;
   const int lh = lane >> 5;
 
@@ -1946,15 +1960,6 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
     const int j = j0 + 32 * k;
     pj[k] = pidx[(v0 + j < a.V) ? j : 0];
   }
-  // the wave's tap schedule (scalar loads from the kernel arguments)
-  const int nt = ka.ntaps[wave];
-  int aoffs[7], btaps[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    aoffs[j] = ka.aoff[wave * kKMaxTaps + j];
-    btaps[j] = ka.btap[wave * kKMaxTaps + j];
-  }
-
   struct XFragK { frag_t x[2][2]; };  // activations [khalf][plane]
   struct WFragK { frag_t w[2][2]; };  // weights     [khalf][plane]
   const frag_t* wp = reinterpret_cast<const frag_t*>(a.wpack) + lane;
@@ -2009,6 +2014,7 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
 #pragma unroll
   for (int k = 0; k < KS; ++k) write_piece(0, k);
   __syncthreads();
+  const long long dbg_b0 = a.dbg ? clock64() : 0;
 
   auto loadX = [&](int t, int off, XFragK& dst) {
     const char* p = ldsb + prow[t] + off;
@@ -2034,7 +2040,9 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
   // one tile of one tap: prefetch the next activation fragments, 6 MFMAs,
   // optionally one staging piece of the segment being converted
 #define FFN_KTILE(T, XCUR, WCUR, PREFETCH, PIECE)                             \
+  __builtin_amdgcn_sched_barrier(0); /* keep the prefetch AHEAD of the MFMAs */ \
   PREFETCH;                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                          \
   accC[T] = mma(WCUR.w[0][0], XCUR.x[0][1], accC[T]);                         \
   acc[T] = mma(WCUR.w[0][0], XCUR.x[0][0], acc[T]);                           \
   accC[T] = mma(WCUR.w[0][1], XCUR.x[0][0], accC[T]);                         \
@@ -2067,10 +2075,12 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
   FFN_KTAP(0, X0, X1, W0, W2, true, 1, 0)
   FFN_KTAP(1, X1, X0, W1, W0, false, 1, 5)
   __syncthreads();  // dz = 0 landed
+  const long long dbg_b1 = a.dbg ? clock64() : 0;
   loadX(0, aoffs[2], X0);
   FFN_KTAP(2, X0, X1, W2, W1, true, 2, 0)
   FFN_KTAP(3, X1, X0, W0, W2, false, 2, 5)
   __syncthreads();  // dz = +1 landed
+  const long long dbg_b2 = a.dbg ? clock64() : 0;
   // residual input and bias of this thread's epilogue pieces
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
   unsigned ooff[5];
@@ -2182,9 +2192,9 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
   if (a.dbg && gc == 0 && (tid & 63) == 0) {
     long long* d = a.dbg + wave * 6;
     d[0] = dbg_c0;
-    d[1] = dbg_c1;
-    d[2] = dbg_c2;
-    d[3] = clock64();
+    d[1] = ka.dbg_mode ? dbg_b0 : dbg_c1;
+    d[2] = ka.dbg_mode ? dbg_b1 : dbg_c2;
+    d[3] = ka.dbg_mode ? dbg_b2 : clock64();
     d[4] = dbg_w0;
     d[5] = wall_clock64();
   }

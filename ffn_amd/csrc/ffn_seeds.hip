@@ -277,6 +277,16 @@ __global__ __launch_bounds__(kThreads) void max7_kernel(
 }
 
 // features of the EDT = voxels where the mask is 0
+// uint8 canvas image -> its normalised f32 form (table of 256 values made by
+// ffn_canvas_create_u8)
+__global__ __launch_bounds__(kThreads) void lut_u8_kernel(
+    const unsigned char* __restrict__ in, const float* __restrict__ lut,
+    float* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)kThreads + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kThreads)
+    out[i] = lut[in[i]];
+}
+
 __global__ __launch_bounds__(kThreads) void mask_to_features_kernel(
     const uint8_t* __restrict__ mask, uint8_t* __restrict__ feat, size_t n) {
   const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
@@ -323,7 +333,7 @@ struct ffn_seeder {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Buf image, fa, fb, edges, thresh, dt, filt, mask, force, d2a, d2b, val, ma,
-      mb, vstack, zstack, coords, small, weights, noise;
+      mb, vstack, zstack, coords, small, weights, noise, canvas_f32;
   size_t noise_n = 0;
   int radius = -1;
   size_t last_n = 0;
@@ -521,7 +531,7 @@ void ffn_seeder_destroy(ffn_seeder* s) {
   for (Buf* b : {&s->image, &s->fa, &s->fb, &s->edges, &s->thresh, &s->dt,
                  &s->filt, &s->mask, &s->force, &s->d2a, &s->d2b, &s->val,
                  &s->ma, &s->mb, &s->vstack, &s->zstack, &s->coords, &s->small,
-                 &s->weights, &s->noise})
+                 &s->weights, &s->noise, &s->canvas_f32})
     if (b->p) (void)hipFree(b->p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -600,7 +610,17 @@ int ffn_seeder_peaks_canvas(ffn_seeder* s, ffn_canvas* canvas,
   const int64_t shape[3] = {v.shape_zyx[0], v.shape_zyx[1], v.shape_zyx[2]};
   size_t n = 0;
   S_OK(check_shape(shape, &n));
-  return run_peaks(s, v.image, nullptr, v.segmentation, nullptr, shape,
+  const float* image = v.image;
+  if (!image) {
+    // uint8 canvas: PolicyPeaks works on the normalised f32 image (seed.py:146);
+    // materialise it for the duration of this call only
+    S_OK(ensure(s->canvas_f32, n * sizeof(float)));
+    hipLaunchKernelGGL(lut_u8_kernel, grid_for(n), dim3(kThreads), 0, s->stream,
+                       v.image_u8, v.image_lut,
+                       static_cast<float*>(s->canvas_f32.p), n);
+    image = static_cast<const float*>(s->canvas_f32.p);
+  }
+  return run_peaks(s, image, nullptr, v.segmentation, nullptr, shape,
                    voxel_size_zyx, cap, coords_zyx, n_peaks, all_edges);
 }
 

@@ -143,8 +143,11 @@ class HipEngine:
     check(self._lib.ffn_forward_resident(self._h, n, repeats))
 
   # -- device canvases -----------------------------------------------------------
-  def create_canvas(self, image_f32: np.ndarray) -> 'DeviceCanvasHandle':
-    return DeviceCanvasHandle(self, image_f32)
+  def create_canvas(self, image) -> 'DeviceCanvasHandle':
+    """image: normalised f32 [z, y, x], or an object with `raw_u8`, `mean`,
+    `stddev` (inference.NormalizedU8Image): the raw uint8 volume, normalised
+    on the device while the FoV is gathered (ffn_canvas_create_u8)."""
+    return DeviceCanvasHandle(self, image)
 
   def step(self, canvases: Sequence['DeviceCanvasHandle'],
            requests: Sequence[StepRequest], params: StepParams):
@@ -223,12 +226,24 @@ class DeviceCanvasHandle:
     self.engine = engine
     self._lib = engine._lib
     self._h = ctypes.c_void_p()
-    image_f32 = _f32(image_f32)
-    if image_f32.ndim != 3:
-      raise ValueError('image must be 3d (z, y, x)')
-    self.shape = tuple(int(s) for s in image_f32.shape)
-    check(self._lib.ffn_canvas_create(engine._h, image_f32.ctypes.data,
-                                      i3(self.shape), ctypes.byref(self._h)))
+    raw = getattr(image_f32, 'raw_u8', None)
+    if raw is not None:  # uint8 canvas: 1 B / voxel in HBM, no f32 host copy
+      raw = np.ascontiguousarray(raw, dtype=np.uint8)
+      if raw.ndim != 3:
+        raise ValueError('image must be 3d (z, y, x)')
+      self.shape = tuple(int(s) for s in raw.shape)
+      self.is_u8 = True
+      check(self._lib.ffn_canvas_create_u8(
+          engine._h, raw.ctypes.data, i3(self.shape), float(image_f32.mean),
+          float(image_f32.stddev), ctypes.byref(self._h)))
+    else:
+      image_f32 = _f32(image_f32)
+      if image_f32.ndim != 3:
+        raise ValueError('image must be 3d (z, y, x)')
+      self.shape = tuple(int(s) for s in image_f32.shape)
+      self.is_u8 = False
+      check(self._lib.ffn_canvas_create(engine._h, image_f32.ctypes.data,
+                                        i3(self.shape), ctypes.byref(self._h)))
     self._pt = (ctypes.c_int32 * 3)()
     self._pt_seed = ctypes.c_float()
     self._pt_seg = ctypes.c_int32()

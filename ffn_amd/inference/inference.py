@@ -62,6 +62,42 @@ def _logit_options(options) -> InferenceOptions:
   return out
 
 
+class NormalizedU8Image:
+  """A raw uint8 image that stands for `(raw.astype(np.float32) - mean) /
+  stddev`, the normalised image Runner.make_canvas hands to the Canvas
+  (reference runner.py:383-385).
+
+  A DeviceCanvas uploads `raw_u8` as it is (1 byte per voxel in HBM) and the
+  normalisation happens in the FoV gather (ffn_canvas_create_u8), bit-identical
+  to the f32 path; host-side consumers (seed policies, a host Canvas, save_raw)
+  index or convert it like the f32 array and get the same values."""
+
+  dtype = np.dtype(np.float32)
+  ndim = 3
+
+  def __init__(self, raw_u8, mean, stddev):
+    self.raw_u8 = np.asarray(raw_u8)
+    if self.raw_u8.dtype != np.uint8 or self.raw_u8.ndim != 3:
+      raise ValueError('raw_u8 must be a 3d uint8 array')
+    self.mean = float(np.float32(mean))
+    self.stddev = float(np.float32(stddev))
+    self.shape = tuple(self.raw_u8.shape)
+
+  def _norm(self, raw):
+    return ((np.asarray(raw).astype(np.float32) - np.float32(self.mean)) /
+            np.float32(self.stddev))
+
+  def __getitem__(self, key):
+    return self._norm(self.raw_u8[key])
+
+  def __array__(self, dtype=None, copy=None):
+    out = self._norm(self.raw_u8)
+    return out if dtype is None else out.astype(dtype)
+
+  def __len__(self):
+    return self.shape[0]
+
+
 class Canvas:
   """Tracks state of the inference progress and results within a subvolume."""
 
@@ -660,7 +696,10 @@ class DeviceCanvas(Canvas):
 
   def _alloc_state(self, storage_cls):
     del storage_cls
-    image = np.ascontiguousarray(self.image, dtype=np.float32)
+    if isinstance(self.image, NormalizedU8Image):
+      image = self.image  # uploaded raw; normalised in the FoV gather
+    else:
+      image = np.ascontiguousarray(self.image, dtype=np.float32)
     self._handle = self._exec_client.create_canvas(image)
     self.seed = _DeviceArray(self, 'seed')
     self.segmentation = _DeviceArray(self, 'seg')
@@ -728,7 +767,7 @@ class DeviceCanvas(Canvas):
     if h[4]:
       c['movement_policy-calls'].IncrementBy(h[4])
       c['movement_policy-time-ms'].IncrementBy(h[5] * MSEC_IN_SEC)
-    self._hot = [0, 0.0, 0.0, 0.0, 0, 0.0]
+    h[:] = [0, 0.0, 0.0, 0.0, 0, 0.0]  # in place: the segment loop holds a reference
 
   def _prepare_step(self, pos):
     """Fills the step request: FoV centre, segment start, queue-head points."""

@@ -38,6 +38,9 @@ class Runner:
   """Helper for managing FFN inference runs."""
 
   ALL_MASKED = 1
+  #: raw uint8 subvolumes are uploaded as they are and normalised on the device
+  #: (ffn_canvas_create_u8); False = normalise on the host as the reference does
+  DEVICE_U8 = True
 
   def __init__(self, device_id: int = 0):
     self.counters = inference_utils.Counters()
@@ -172,13 +175,20 @@ class Runner:
     if restrictor == self.ALL_MASKED:
       return None, None
 
-    # (u8 -> f32 - mean) / stddev in f32, exactly as reference runner.py:383-385.
-    image = (image.astype(np.float32) -
-             self.request.image_mean) / self.request.image_stddev
-
     exc = self.executor
     if exc is None:
       raise executor.TerminationException
+
+    # (u8 -> f32 - mean) / stddev in f32, exactly as reference runner.py:383-385
+    # -- on the device when the canvas lives there and the data is raw uint8 (the
+    # image then stays 1 B / voxel in HBM and no f32 copy is made on the host)
+    if (image.dtype == np.uint8 and self.DEVICE_U8 and
+        hasattr(exc, 'engine') and 'storage_cls' not in canvas_kwargs):
+      image = inference.NormalizedU8Image(image, self.request.image_mean,
+                                          self.request.image_stddev)
+    else:
+      image = (image.astype(np.float32) -
+               self.request.image_mean) / self.request.image_stddev
 
     canvas = inference.make_canvas(
         self._model_info,

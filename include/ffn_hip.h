@@ -150,6 +150,15 @@ int ffn_forward_resident(ffn_engine* engine, int n, int repeats);
  * segmentation i32, all kept in HBM for the whole subvolume. */
 int ffn_canvas_create(ffn_engine* engine, const float* image_f32,
                       const int32_t shape_zyx[3], ffn_canvas** out);
+/* The same from the RAW uint8 image: Runner.make_canvas' normalisation
+ * (image.astype(np.float32) - image_mean) / image_stddev (runner.py:383-385)
+ * moves into the FoV gather of the first conv (a 256-entry table made with the
+ * same two f32 operations), the image stays 1 byte per voxel in HBM (1024^3:
+ * 1.07 GB instead of 4.29 GB) and no normalised f32 copy is made on the host.
+ * Every result is bit-identical to ffn_canvas_create on the normalised image. */
+int ffn_canvas_create_u8(ffn_engine* engine, const uint8_t* image_u8,
+                         const int32_t shape_zyx[3], float image_mean,
+                         float image_stddev, ffn_canvas** out);
 void ffn_canvas_destroy(ffn_canvas* canvas);
 
 /* Canvas.init_seed (inference.py:443-450): seed[:] = NaN; seed[pos] = value. */

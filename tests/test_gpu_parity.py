@@ -433,19 +433,14 @@ def test_batched_device_canvases_through_threaded_executor(fib25_model):
   assert counters['executor-inference-calls'].value < total_steps
 
 
-def test_runner_end_to_end_writes_reference_format(fib25_model, tmp_path):
-  """run_inference.py flow: InferenceRequest (text format) -> Runner.start ->
-  Runner.run -> seg-*.npz with the reference's keys; the segmentation equals
-  the reference-minted fixture; a second run() skips the finished subvolume."""
+def _runner_request_text(g, tmp_path, out_dir):
+  """The sample config's request (configs/inference_training_sample2.pbtxt) on
+  an `npy:` volume with the fixture's fixed seeds, parsed from text format."""
   import json as _json
   from ffn_amd.inference import request as req_lib
-  from ffn_amd.inference import runner as runner_lib
-  from ffn_amd.inference import storage
-  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells56.npz'))
   vol_path = str(tmp_path / 'vol.npy')
   np.save(vol_path, g['volume'])
   weights = os.path.join(GOLDEN, 'fib25_weights.npz')
-  out_dir = str(tmp_path / 'out')
   seeds = _json.dumps({'coords': g['seeds'].tolist()}).replace('"', '\\"')
   text = '''
     image { npy: "%s" }
@@ -466,7 +461,19 @@ def test_runner_end_to_end_writes_reference_format(fib25_model, tmp_path):
       segment_threshold: 0.6
       min_segment_size: 1000
     }''' % (vol_path, seeds, weights, out_dir)
-  request = req_lib.request_from_text(text)
+  return req_lib.request_from_text(text)
+
+
+def test_runner_end_to_end_writes_reference_format(fib25_model, tmp_path):
+  """run_inference.py flow: InferenceRequest (text format) -> Runner.start ->
+  Runner.run -> seg-*.npz with the reference's keys; the segmentation equals
+  the reference-minted fixture; a second run() skips the finished subvolume."""
+  import json as _json
+  from ffn_amd.inference import runner as runner_lib
+  from ffn_amd.inference import storage
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells56.npz'))
+  out_dir = str(tmp_path / 'out')
+  request = _runner_request_text(g, tmp_path, out_dir)
   runner = runner_lib.Runner()
   runner.start(request)
   canvas = runner.run((0, 0, 0), tuple(g['volume'].shape))

@@ -1,0 +1,394 @@
+"""GPU tests added in round 2: parity at the BASELINE size, uint8 canvases,
+checkpoint resume on the device, the CLI end to end.  All through the C-ABI.
+"""
+
+import functools
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _request():
+  from ffn_amd.inference import request as req_lib
+  r = req_lib.InferenceRequest()
+  r.image_mean = 128
+  r.image_stddev = 33
+  o = r.inference_options
+  o.init_activation = 0.95
+  o.pad_value = 0.05
+  o.move_threshold = 0.9
+  o.segment_threshold = 0.6
+  o.min_segment_size = 1000
+  o.min_boundary_dist.x = 1
+  o.min_boundary_dist.y = 1
+  o.min_boundary_dist.z = 1
+  return r
+
+
+@pytest.fixture(scope='module')
+def hip_exe(fib25_model):
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference_utils
+  exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
+                                  fib25_model.info, None,
+                                  inference_utils.Counters(), 1, device_id=0)
+  yield exe
+  exe.engine.close()
+
+
+def _device_canvas(exe, model, image, **kwargs):
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  r = _request()
+  counters = inference_utils.Counters()
+  return inference.DeviceCanvas(
+      model.info, exe.get_client(counters, direct=True), image,
+      r.inference_options, counters=counters,
+      movement_policy_fn=movement.get_policy_fn(r, model.info), **kwargs)
+
+
+# ---------------------------------------------------------------------------
+# N1: the BASELINE-size workload against a reference-minted fixture
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('variant', [2, 4, 5])
+def test_cells250_matches_reference_minted_run(hip_exe, fib25_model, variant):
+  """configs[1] at full size: the 250^3 phantom bench.py runs, first row of its
+  seed grid, 3,658 FoV steps.  The fixture was minted by the reference's own
+  Canvas with the oracle forward (tools/make_golden.py --only cells250); the
+  GPU must visit the same FoV positions in the same order, queue the same
+  moves, commit the same segment ids voxel for voxel (IoU 1.0) -- with the
+  exact-f32 kernel (variant 2) AND with the split-product kernels (4, 5)."""
+  path = os.path.join(GOLDEN, 'ref_canvas_cells250.npz')
+  if not os.path.exists(path):
+    pytest.skip('fixture not minted')
+  import hashlib
+  from ffn_amd import synthetic
+  from ffn_amd.inference import seed as seed_lib
+  g = np.load(path)
+  vol = synthetic.cells_volume((250, 250, 250), seed=1234)
+  assert hashlib.sha256(vol.tobytes()).hexdigest() == str(g['volume_sha256'])
+  eng = hip_exe.engine
+  eng.set_option('conv_variant', variant)
+  try:
+    canvas = _device_canvas(hip_exe, fib25_model, synthetic.normalize(vol))
+    got_steps, got_moves = [], []
+    thr = canvas.movement_policy.score_threshold
+    deltas = canvas.movement_policy.deltas
+    inner = canvas.update_at
+
+    def recording_update(pos):
+      pred = inner(pos)
+      got_steps.append(tuple(int(v) for v in pos))
+      got_moves.append(sorted(
+          ((s, tuple(int(v) + int(p) for v, p in zip(o, pos)))
+           for s, o, _ in pred.scored_move_offsets(deltas, thr)), reverse=True))
+      return pred
+
+    canvas.update_at = recording_update
+    canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                     coords=g['seeds']))
+    want_steps = [tuple(int(v) for v in p) for p in g['steps']]
+    n = min(len(got_steps), len(want_steps))
+    first_bad = next((k for k in range(n) if got_steps[k] != want_steps[k]),
+                     None)
+    margin = None
+    if first_bad is not None:
+      # the real tolerance statement: where, and how close the call was
+      k0 = int(np.sum(g['n_moves'][:first_bad - 1])) if first_bad else 0
+      margin = [float(s) - thr for s in
+                g['move_scores'][k0:k0 + int(g['n_moves'][max(first_bad - 1, 0)])]]
+    assert first_bad is None and len(got_steps) == len(want_steps), (
+        'variant %d: trajectory leaves the reference at step %s of %d / %d '
+        '(move-score margins over the threshold there: %s)' %
+        (variant, first_bad, len(got_steps), len(want_steps), margin))
+    # queued moves: same targets, scores within the logit tolerance
+    off = 0
+    max_err = 0.0
+    for k, moves in enumerate(got_moves):
+      nm = int(g['n_moves'][k])
+      assert len(moves) == nm, k
+      for j, (s, c) in enumerate(moves):
+        assert c == tuple(int(v) for v in g['move_coords'][off + j]), (k, j)
+        max_err = max(max_err, abs(s - float(g['move_scores'][off + j])))
+      off += nm
+    assert max_err <= TOL
+    seg = np.asarray(canvas.segmentation)
+    want = g['segmentation'].astype(np.int32)
+    inter = np.sum((seg > 0) & (want > 0) & (seg == want))
+    union = np.sum((seg > 0) | (want > 0))
+    assert inter == union, 'IoU %.6f' % (inter / max(union, 1))
+    assert np.array_equal(seg, want)  # the -1 markers too
+    ref_c = json.loads(str(g['counters']))
+    for key in ('update_at-calls', 'voxels-segmented', 'voxels-overlapping',
+                'skip_invalid_pos', 'segment_at-loop-calls'):
+      assert canvas.counters[key].value == ref_c[key], key
+    origins = json.loads(str(g['origins']))
+    assert {int(k): [list(v.start_zyx), v.iters]
+            for k, v in canvas.origins.items()} == {
+                int(k): v for k, v in origins.items()}
+    sample = np.asarray(canvas.seed[0:33, 0:33, 192:225])
+    want_s = g['final_seed_sample']
+    assert np.array_equal(np.isnan(sample), np.isnan(want_s))
+    assert np.nanmax(np.abs(sample - want_s)) <= TOL
+    print('variant %d: %d steps, max move-score err %.3g' %
+          (variant, len(got_steps), max_err))
+    canvas.close()
+  finally:
+    eng.set_option('conv_variant', 4)
+
+
+def test_cells250_native_loop_same_result(hip_exe, fib25_model):
+  """The same workload through ffn_canvas_segment_at (the default drive of
+  bench.py / Runner.run): final segmentation, origins and counters of the
+  reference-minted run."""
+  path = os.path.join(GOLDEN, 'ref_canvas_cells250.npz')
+  if not os.path.exists(path):
+    pytest.skip('fixture not minted')
+  from ffn_amd import synthetic
+  from ffn_amd.inference import seed as seed_lib
+  g = np.load(path)
+  vol = synthetic.cells_volume((250, 250, 250), seed=1234)
+  canvas = _device_canvas(hip_exe, fib25_model, synthetic.normalize(vol))
+  assert canvas._native_loop_ok()
+  canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                   coords=g['seeds']))
+  assert np.array_equal(np.asarray(canvas.segmentation),
+                        g['segmentation'].astype(np.int32))
+  ref_c = json.loads(str(g['counters']))
+  for key in ('update_at-calls', 'voxels-segmented', 'voxels-overlapping',
+              'skip_invalid_pos', 'segment_at-loop-calls'):
+    assert canvas.counters[key].value == ref_c[key], key
+  origins = json.loads(str(g['origins']))
+  assert {int(k): [list(v.start_zyx), v.iters]
+          for k, v in canvas.origins.items()} == {
+              int(k): v for k, v in origins.items()}
+  canvas.close()
+
+
+# ---------------------------------------------------------------------------
+# uint8 canvases (ffn_canvas_create_u8)
+# ---------------------------------------------------------------------------
+def test_u8_canvas_bit_identical_to_f32_canvas(hip_exe, fib25_model):
+  """Normalisation in the FoV gather == normalisation on the host
+  (runner.py:383-385): same step results, same seed array, same PolicyPeaks
+  seeds, bit for bit -- for a mean / stddev that are not exact in f32 too."""
+  from ffn_amd import _lib
+  from ffn_amd import seeding
+  from ffn_amd import synthetic
+  from ffn_amd.inference import inference
+  from oracle import ffn_oracle
+  eng = hip_exe.engine
+  vol = synthetic.cells_volume((64, 72, 80), seed=9)
+  for mean, std in ((128.0, 33.0), (127.3, 28.9)):
+    img = (vol.astype(np.float32) - mean) / std
+    a = eng.create_canvas(img)
+    b = eng.create_canvas(inference.NormalizedU8Image(vol, mean, std))
+    assert b.is_u8 and not a.is_u8
+    params = _lib.StepParams(ffn_oracle.f32_logit(0.05),
+                             ffn_oracle.f32_logit(0.9), 0.0)
+    pos0 = (30, 36, 40)
+    for h in (a, b):
+      h.init_seed(pos0, ffn_oracle.f32_logit(0.95))
+    for pos in (pos0, (30, 36, 48), (38, 36, 40), (30, 44, 44)):
+      req = _lib.StepRequest()
+      req.pos[:] = pos
+      req.start_pos[:] = pos0
+      req.num_candidates = 0
+      ra = eng.step1(a, req, params)
+      fa = (list(ra.face_score), list(ra.face_index), ra.start_logit,
+            ra.num_above_move)
+      rb = eng.step1(b, req, params)
+      fb = (list(rb.face_score), list(rb.face_index), rb.start_logit,
+            rb.num_above_move)
+      assert fa == fb, pos
+    sa, sb = a.read_seed(), b.read_seed()
+    assert np.array_equal(sa, sb, equal_nan=True)
+    assert np.sum(~np.isnan(sa)) > 33**3
+    s = seeding.default_seeder(0)
+    pa = s.peaks_canvas(a)
+    pb = s.peaks_canvas(b)
+    assert len(pa) > 10 and np.array_equal(pa, pb)
+    a.close()
+    b.close()
+
+
+def test_runner_uses_u8_canvas_for_raw_volumes(fib25_model, tmp_path):
+  """Runner.make_canvas hands raw uint8 data to the device (DEVICE_U8) and the
+  result is the one of the host-normalised path."""
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import runner as runner_lib
+  from tests.test_gpu_parity import _runner_request_text
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells56.npz'))
+  segs = []
+  for device_u8 in (True, False):
+    out_dir = str(tmp_path / ('out%d' % device_u8))
+    request = _runner_request_text(g, tmp_path, out_dir)
+    runner = runner_lib.Runner()
+    runner.DEVICE_U8 = device_u8
+    runner.start(request)
+    canvas = runner.run((0, 0, 0), tuple(g['volume'].shape))
+    assert isinstance(canvas.image, inference.NormalizedU8Image) == device_u8
+    segs.append(np.asarray(canvas.segmentation).copy())
+    runner.stop_executor()
+  assert np.array_equal(segs[0], segs[1])
+  assert np.array_equal(segs[0], g['segmentation'])
+
+
+# ---------------------------------------------------------------------------
+# .cpoint on the real device (f3)
+# ---------------------------------------------------------------------------
+def test_mid_segment_checkpoint_resume_on_device(hip_exe, fib25_model, tmp_path):
+  """Saved mid-segment from the device canvas, the canvas destroyed, restored
+  into a fresh DeviceCanvas, finished: equal to the uninterrupted run and to
+  the reference-minted fixture (inference.py:728-843, runner.py:505-519)."""
+  from ffn_amd import synthetic
+  from tests import resume_case
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  image = synthetic.normalize(g['volume'])
+
+  def make(path, interval):
+    return _device_canvas(hip_exe, fib25_model, image, checkpoint_path=path,
+                          checkpoint_interval_sec=interval)
+
+  a, b, meta = resume_case.run_resume_case(make, g['seeds'], 30, tmp_path)
+  assert meta['partial_segment_iters'] > 0
+  resume_case.assert_same_final_state(a, b)
+  assert np.array_equal(np.asarray(b.segmentation), g['segmentation'])
+  a.close()
+  b.close()
+
+
+def test_runner_resumes_from_cpoint_and_removes_it(fib25_model, tmp_path):
+  """Runner.run: an existing .cpoint is restored, the run finishes with the
+  uninterrupted result and the checkpoint file is removed (runner.py:505-542)."""
+  from ffn_amd.inference import runner as runner_lib
+  from ffn_amd.inference import seed as seed_lib
+  from ffn_amd.inference import storage
+  from tests.test_gpu_parity import _runner_request_text
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  out_dir = str(tmp_path / 'out')
+  request = _runner_request_text(g, tmp_path, out_dir)
+  runner = runner_lib.Runner()
+  runner.start(request)
+  # leg 1: a canvas killed after 30 FoV steps, checkpointing every step
+  canvas, _ = runner.make_canvas((0, 0, 0), tuple(g['volume'].shape))
+  canvas.checkpoint_interval_sec = 1e-9
+  steps = [0]
+  inner = canvas.update_at
+
+  class _Kill(Exception):
+    pass
+
+  def hooked(pos):
+    if steps[0] >= 30:
+      raise _Kill()
+    steps[0] += 1
+    return inner(pos)
+
+  canvas.update_at = hooked
+  with pytest.raises(_Kill):
+    canvas.segment_all(seed_policy=runner.get_seed_policy(
+        (0, 0, 0), tuple(g['volume'].shape)))
+  canvas.close()
+  cpoint = storage.checkpoint_path(out_dir, (0, 0, 0))
+  assert os.path.exists(cpoint)
+  # leg 2: Runner.run picks the file up
+  done = runner.run((0, 0, 0), tuple(g['volume'].shape))
+  assert done is not None and not os.path.exists(cpoint)
+  with np.load(storage.segmentation_path(out_dir, (0, 0, 0)),
+               allow_pickle=True) as d:
+    want = g['segmentation'].copy()
+    want[want < 0] = 0
+    assert np.array_equal(d['segmentation'], want)
+  runner.stop_executor()
+  del seed_lib
+
+
+# ---------------------------------------------------------------------------
+# CLI (a22)
+# ---------------------------------------------------------------------------
+def _cli_args(g, tmp_path, out_dir):
+  vol_path = str(tmp_path / 'vol.npy')
+  np.save(vol_path, g['volume'])
+  weights = os.path.join(GOLDEN, 'fib25_weights.npz')
+  seeds = json.dumps({'coords': g['seeds'].tolist()}).replace('"', '\\"')
+  request = '''
+    image { npy: "%s" }
+    image_mean: 128
+    image_stddev: 33
+    checkpoint_interval: 1800
+    seed_policy: "PolicyFixed"
+    seed_policy_args: "%s"
+    model_checkpoint_path: "%s"
+    model_name: "convstack_3d.ConvStack3DFFNModel"
+    model_args: "{\\"depth\\": 12, \\"fov_size\\": [33, 33, 33], \\"deltas\\": [8, 8, 8]}"
+    segmentation_output_dir: "%s"
+    inference_options {
+      init_activation: 0.95
+      pad_value: 0.05
+      move_threshold: 0.9
+      min_boundary_dist { x: 1 y: 1 z: 1}
+      segment_threshold: 0.6
+      min_segment_size: 1000
+    }''' % (vol_path, seeds, weights, out_dir)
+  z, y, x = g['volume'].shape
+  bbox = 'start { x:0 y:0 z:0 } size { x:%d y:%d z:%d }' % (x, y, z)
+  return request, bbox
+
+
+def test_run_inference_main_end_to_end(tmp_path):
+  """run_inference.main([...]) -- the reference's CLI flow (run_inference.py:
+  38-56): flags -> request -> Runner -> seg-*.npz + counters.txt."""
+  import run_inference
+  from ffn_amd.inference import storage
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  out_dir = str(tmp_path / 'out')
+  request, bbox = _cli_args(g, tmp_path, out_dir)
+  run_inference.main(['--inference_request', request, '--bounding_box', bbox])
+  path = storage.segmentation_path(out_dir, (0, 0, 0))
+  with np.load(path, allow_pickle=True) as d:
+    want = g['segmentation'].copy()
+    want[want < 0] = 0
+    assert np.array_equal(d['segmentation'], want)
+    counters = json.loads(str(d['counters']))
+    assert counters['update_at-calls'] == len(g['steps'])
+  ctr = os.path.join(out_dir, 'counters.txt')
+  assert os.path.exists(ctr)
+  text = open(ctr).read()
+  assert 'update_at-calls' in text
+
+
+def test_run_inference_main_sharded_assemble(tmp_path):
+  """--subvolume_size ... --assemble: sub-boxes advance concurrently on the
+  GPU, one global label volume is assembled and reconciled."""
+  import run_inference
+  from ffn_amd import synthetic
+  vol = synthetic.cells_volume((80, 96, 112), seed=21, membrane_dilate=2)
+  g = {'volume': vol,
+       'seeds': np.array([[z, y, x] for z in (20, 40, 60)
+                          for y in (24, 48, 72) for x in (24, 56, 88)])}
+  out_dir = str(tmp_path / 'out')
+  request, bbox = _cli_args(g, tmp_path, out_dir)
+  request = request.replace('seed_policy: "PolicyFixed"',
+                            'seed_policy: "PolicyPeaks"')
+  request = '\n'.join(l for l in request.split('\n')
+                      if 'seed_policy_args' not in l)
+  merged_path = str(tmp_path / 'merged.npy')
+  run_inference.main(['--inference_request', request, '--bounding_box', bbox,
+                      '--subvolume_size', '72,64,56', '--batch_size', '4',
+                      '--assemble', merged_path])
+  merged = np.load(merged_path)
+  assert merged.shape == vol.shape
+  ids = np.unique(merged)
+  assert len(ids) > 3 and ids[0] == 0
+  assert np.mean(merged > 0) > 0.2
+  assert os.path.exists(os.path.join(out_dir, 'counters.txt'))

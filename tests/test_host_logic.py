@@ -237,6 +237,50 @@ def test_device_canvas_checkpoint_roundtrip(fib25_blob, tmp_path):
   assert b._max_id == a._max_id and set(b.origins) == set(a.origins)
 
 
+def test_mid_segment_checkpoint_resume_emulated_device(fib25_blob, tmp_path):
+  """Killed in the middle of a segment, continued from the .cpoint in a fresh
+  canvas: same final state as the uninterrupted run (inference.py:728-843)."""
+  from tests import resume_case
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  r = _request()
+  info = _info()
+  image = synthetic.normalize(g['volume'])
+
+  def make(path, interval):
+    client = EmulatedDeviceClient(inference_utils.Counters(), fib25_blob, 12,
+                                  (33, 33, 33), (8, 8, 8))
+    return inference.make_canvas(info, client, image, r.inference_options,
+                                 movement_policy_fn=movement.get_policy_fn(
+                                     r, info),
+                                 checkpoint_path=path,
+                                 checkpoint_interval_sec=interval)
+
+  # (the uninterrupted run is the reference-minted fixture itself)
+  _, b, meta = resume_case.run_resume_case(make, g['seeds'], 30, tmp_path,
+                                           run_uninterrupted=False)
+  assert meta['partial_segment_iters'] > 0  # it really was mid-segment
+  assert np.array_equal(np.asarray(b.segmentation), g['segmentation'])
+  assert np.array_equal(np.asarray(b.seed), g['seed_logits'], equal_nan=True)
+  origins = json.loads(str(g['origins']))
+  assert {int(k): [list(v.start_zyx), v.iters]
+          for k, v in b.origins.items()} == {int(k): v
+                                             for k, v in origins.items()}
+  assert b.counters['update_at-calls'].value == len(g['steps'])
+
+
+def test_normalized_u8_image_equals_host_normalisation():
+  """NormalizedU8Image stands for (u8 -> f32 - mean) / stddev (runner.py:383-385)."""
+  rng = np.random.RandomState(0)
+  raw = rng.randint(0, 256, (9, 10, 11)).astype(np.uint8)
+  for mean, std in ((128, 33), (127.3, 28.9)):
+    want = (raw.astype(np.float32) - mean) / std
+    img = inference.NormalizedU8Image(raw, mean, std)
+    assert img.shape == raw.shape and img.dtype == np.float32
+    assert np.array_equal(np.asarray(img), want)
+    assert np.array_equal(img[2:5, 1:, ::2], want[2:5, 1:, ::2])
+    assert want.dtype == np.float32
+
+
 def test_threaded_executor_protocol_batches_and_terminates():
   """The reference's queue protocol: N clients > batch_size, partial batches are
   not padded, server exits once every expected client came and went."""

@@ -75,6 +75,16 @@ def main():
             'cycles; wall %.0f ns -> %.2f GHz; %.2f cyc/MFMA' % (
                 v, w, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1], c[w, 3] - c[w, 2],
                 tot, wall, tot / max(wall, 1), (c[w, 2] - c[w, 1]) / nmfma))
+  if 5 in args.variants:
+    # conv32k phase stamps: entry -> first barrier -> dz = 0 barrier -> dz = +1
+    # barrier (-> loop end / exit are in the table above)
+    eng.set_option('debug_clock', 2)
+    eng.set_option('conv_variant', 5)
+    eng.forward_resident(1, 3)
+    c = eng.debug_clocks()
+    for w in range(4):
+      print('variant 5 wave %d: entry -> B0 %d  -> B1 %d  -> B2 %d shader cycles' %
+            (w, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1], c[w, 3] - c[w, 2]))
   eng.set_option('debug_clock', 0)
   eng.close()
 

@@ -15,6 +15,9 @@ Outputs (committed):
   tests/golden/ref_canvas_*.npz    Canvas.segment_all runs: per-step FoV
                                    positions + queued moves, final
                                    segmentation, counters, origins
+  tests/golden/ref_canvas_cells250.npz   (--only cells250, ~15 min) the same at
+                                   the BASELINE size: 3,658 FoV steps on the
+                                   250^3 bench volume
 
 Usage:  python tools/make_golden.py [--only weights|movement|misc|canvas]
 """
@@ -240,6 +243,50 @@ def make_canvas_case(name, shape, seed, depth_weights, grid_step, grid_offsets,
   print(name, 'steps', len(steps), 'segments', len(origins), 'counters', keep)
 
 
+def make_cells250(blob, depth):
+  """BASELINE configs[1] at its full size: the 250^3 cells phantom of bench.py
+  (synthetic.cells_volume seed 1234), the first row of the bench's seed grid
+  (14 seeds, 5 of which start a segment) -> 3,658 FoV steps through the
+  reference's Canvas with the oracle forward.  The volume is NOT stored (it is
+  regenerated from its seed; a checksum pins it).  About 15 minutes on 8 cores."""
+  import hashlib
+  import time
+  shape = (250, 250, 250)
+  vol = synthetic.cells_volume(shape, seed=1234)
+  image = synthetic.normalize(vol)
+  seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))[:14]
+  ffn_oracle.set_threads(os.cpu_count() or 1)
+  t0 = time.time()
+  canvas, trace, counters = run_reference_canvas(image, blob, depth,
+                                                 (33, 33, 33), (8, 8, 8), seeds)
+  wall = time.time() - t0
+  seg = np.array(canvas.segmentation)
+  steps = np.array([t[0] for t in trace], np.int16).reshape(-1, 3)
+  n_moves = np.array([len(t[1]) for t in trace], np.int8)
+  move_scores = np.array([s for t in trace for s, _ in t[1]], np.float32)
+  move_coords = np.array([c for t in trace for _, c in t[1]],
+                         np.int16).reshape(-1, 3)
+  origins = {
+      int(k): [list(int(x) for x in v.start_zyx), int(v.iters)]
+      for k, v in canvas.origins.items()
+  }
+  cdict = {k: c.value for k, c in counters}
+  keep = {k: v for k, v in cdict.items() if not k.endswith('-time-ms')}
+  final_seed = np.array(canvas.seed)
+  np.savez_compressed(
+      os.path.join(GOLD, 'ref_canvas_cells250.npz'),
+      volume_sha256=hashlib.sha256(vol.tobytes()).hexdigest(), seeds=seeds,
+      segmentation=seg.astype(np.int8), steps=steps, n_moves=n_moves,
+      move_scores=move_scores, move_coords=move_coords,
+      origins=json.dumps(origins), counters=json.dumps(keep), depth=depth,
+      # the seed array after the LAST segment, around its start (a 33^3 sample
+      # of logits; the full 62 MB array is not stored)
+      final_seed_sample=final_seed[0:33, 0:33, 192:225],
+      mint_wall_seconds=wall)
+  print('cells250 steps', len(steps), 'segments', len(origins), 'wall %.0f s'
+        % wall, 'counters', keep)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--only', default='')
@@ -256,6 +303,9 @@ def main():
     blob = ffn_oracle.weights_blob(v, 12)
     make_canvas_case('cells56', (56, 56, 56), 11, (blob, 12), 16, (0, 8), 1)
     make_canvas_case('cells72', (72, 64, 80), 5, (blob, 12), 16, (0,), 2)
+  if args.only == 'cells250':  # slow: only on request
+    v = tf_checkpoint.load_checkpoint(CKPT)
+    make_cells250(ffn_oracle.weights_blob(v, 12), 12)
 
 
 if __name__ == '__main__':
