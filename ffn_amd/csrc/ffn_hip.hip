@@ -511,6 +511,7 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
     ka.magic_fyfx = magic(e->g.fy * e->g.fx);
     ka.magic_fx = magic(e->g.fx);
     ka.dbg_mode = e->dbg_clock == 2;
+    ka.ablate = e->ablate;
     const dim3 gridk(8 * ka.c.slots_per_xcd), blockk(kKThreads);
 #define FFN_K_LAUNCH(KSV, HEADV)                                              \
   hipLaunchKernelGGL((conv32k_kernel<RI, RO, SK, KSV, HEADV>), gridk, blockk, \

@@ -1900,6 +1900,9 @@ struct ConvKArgs {
   // dividends met here as one s_mul_hi_u32 (an integer or float division in
   // front of the staging loads costs ~100 instructions per launch)
   unsigned magic_nchunks, magic_fyfx, magic_fx;
+  int ablate;    // timing experiments only (results are wrong): 1 = no activation
+                 // fragment reads after the first, 2 = no staging conversion in
+                 // the loop, 4 = no weight loads after the first two taps
   int dbg_mode;  // 0: {entry, loop start, loop end, exit}; 1: {entry, after the
                  // first barrier, after the dz = 0 barrier, after the dz = +1
                  // barrier} in clock slots 0..3
@@ -2017,6 +2020,7 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
   const long long dbg_b0 = a.dbg ? clock64() : 0;
 
   auto loadX = [&](int t, int off, XFragK& dst) {
+    if (ka.ablate & 1) return;
     const char* p = ldsb + prow[t] + off;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -2034,6 +2038,14 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fx, c, 0, 0, 0);
   };
   XFragK X0, X1;
+  if (ka.ablate & 1) {  // (timing experiment: the fragments must not be undefined)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) X0.x[kh][pl][c] = X1.x[kh][pl][c] = (_Float16)0;
+  }
   const long long dbg_c1 = a.dbg ? clock64() : 0;
   loadX(0, aoffs[0], X0);
 
@@ -2056,7 +2068,8 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
 #define FFN_KTAP(J, XA, XB, WCUR, WNEXT2, CONT, SEG, PB)                      \
   if ((J) < 6 || nt == 7) { /* every wave has 6 or 7 taps */                  \
     if ((J) + 2 < 7) {                                                        \
-      if ((J) + 2 < 6 || nt == 7) loadW(btaps[((J) + 2) % 7], WNEXT2);        \
+      if (((J) + 2 < 6 || nt == 7) && !(abl & 4))                             \
+        loadW(btaps[((J) + 2) % 7], WNEXT2);                                  \
     }                                                                         \
     const int ao_ = aoffs[J];                                                 \
     const int an_ = aoffs[((J) + 1) % 7];                                     \
@@ -2068,8 +2081,9 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
               if ((CONT) && ((J) + 1 < 6 || nt == 7)) loadX(0, an_, XB),      \
               ilv_piece(SEG, (PB) + 4))                                       \
   }
+  const int abl = ka.ablate;
   auto ilv_piece = [&](int seg, int k) {
-    if (seg > 0 && k < KS) write_piece(seg, k);
+    if (seg > 0 && k < KS && !(abl & 2)) write_piece(seg, k);
   };
   // 5 tiles per tap: the fragment buffers swap roles from tap to tap
   FFN_KTAP(0, X0, X1, W0, W2, true, 1, 0)

@@ -183,8 +183,18 @@ class _UnionFind:
         self.parent[rx] = ry
 
 
+#: Merge criterion defaults, conservative on purpose: an object pair is joined
+#: across a cut only if the two labellings agree on at least half of the
+#: smaller one's margin voxels AND on a minimum voxel count.  A single shared
+#: voxel must not be an edge -- the union-find is transitive, so one spurious
+#: contact would chain distinct neurites into a global merger.
+MIN_OVERLAP_VOXELS = 64
+MIN_OVERLAP_FRACTION = 0.5
+
+
 def margin_edges(ops, seg_global_ids, assembled_box, core_lo, core_hi,
-                 min_overlap_voxels=1, min_overlap_fraction=0.0):
+                 min_overlap_voxels=MIN_OVERLAP_VOXELS,
+                 min_overlap_fraction=MIN_OVERLAP_FRACTION):
   """Merge candidates between one sub-box's own labels and the assembled
   volume over the sub-box's margin (everything outside its core).
 
@@ -241,8 +251,10 @@ def _all_gather_rows(rows: np.ndarray, world: int, device):
 
 
 def reconcile_segmentations(local_results, shape_zyx, rank: int, world: int,
-                            device=None, min_overlap_voxels: int = 1,
-                            min_overlap_fraction: float = 0.0, ops=None):
+                            device=None,
+                            min_overlap_voxels: int = MIN_OVERLAP_VOXELS,
+                            min_overlap_fraction: float = MIN_OVERLAP_FRACTION,
+                            ops=None):
   """merge_segmentations + union-find reconciliation of objects that cross a
   cut between sub-boxes (doc/manual.md:119-127).
 
@@ -289,8 +301,9 @@ def reconcile_segmentations(local_results, shape_zyx, rank: int, world: int,
 def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
                    rank: int = 0, world: int = 1, device=None,
                    batch_size=None, reconcile: bool = True,
-                   min_overlap_voxels: int = 1,
-                   min_overlap_fraction: float = 0.0, save: bool = True):
+                   min_overlap_voxels: int = MIN_OVERLAP_VOXELS,
+                   min_overlap_fraction: float = MIN_OVERLAP_FRACTION,
+                   save: bool = True):
   """Segments a whole bounding box on `world` GPUs (BASELINE configs C4 / C5).
 
   One process per GPU calls this with its rank.  The box is cut into
@@ -318,19 +331,20 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
   # FoV could not host a single seed
   boxes = tile_volume(size_zyx, sub_size_zyx, overlap_zyx, back_shift=True)
   mine = assign_round_robin(boxes, rank, world)
-  canvases = runner.run_many(
-      [(tuple(c + o for c, o in zip(corner_zyx, b.corner)), b.size)
-       for b in mine], batch_size=batch_size, save=save)
-  results = []
-  for b, canvas in zip(mine, canvases):
-    if canvas is None:
-      raise RuntimeError('sub-box %r was skipped (output exists / masked); '
-                         'assemble from the saved files instead' % (b,))
+  results = [None] * len(mine)
+
+  def collect(index, canvas):  # the canvas is closed right after this call
     seg = np.array(np.asarray(canvas.segmentation), np.int32)
     seg[seg < 0] = 0  # the -1 "excluded" markers (runner.py:452)
-    results.append((b, seg))
-    if hasattr(canvas, 'close'):
-      canvas.close()
+    results[index] = (mine[index], seg)
+
+  runner.run_many(
+      [(tuple(c + o for c, o in zip(corner_zyx, b.corner)), b.size)
+       for b in mine], batch_size=batch_size, save=save, on_done=collect)
+  for b, r in zip(mine, results):
+    if r is None:
+      raise RuntimeError('sub-box %r was skipped (output exists / masked); '
+                         'assemble from the saved files instead' % (b,))
   info = {'boxes': boxes, 'mine': mine}
   if reconcile:
     merged, offsets, edges, roots = reconcile_segmentations(

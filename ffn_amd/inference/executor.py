@@ -455,11 +455,9 @@ class HipBatchExecutor(ThreadingBatchExecutor):
         pending = list(steps)
         while pending:
           p0 = pending[0][3]
-          key = (p0.pad_value, p0.move_threshold, p0.disco_seed_threshold)
-          group = [s for s in pending
-                   if (s[3].pad_value, s[3].move_threshold,
-                       s[3].disco_seed_threshold) == key]
-          pending = [s for s in pending if s not in group]
+          key = bytes(p0)  # every field, deleted_threshold (maybe NaN) included
+          group = [s for s in pending if bytes(s[3]) == key]
+          pending = [s for s in pending if bytes(s[3]) != key]
           with self.engine_lock:
             res = self.engine.step([s[1] for s in group],
                                    [s[2] for s in group], p0)

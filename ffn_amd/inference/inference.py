@@ -30,6 +30,7 @@ import logging
 import os
 import struct
 import threading
+import weakref
 import time
 
 import numpy as np
@@ -585,7 +586,10 @@ class _DeviceArray:
   """
 
   def __init__(self, canvas: 'DeviceCanvas', which: str):
-    self._c = canvas
+    # a proxy, not a reference: canvas <-> array would be a cycle, and a cycle
+    # keeps a finished subvolume's HBM (12 B / voxel) alive until the cyclic
+    # collector happens to run
+    self._c = weakref.proxy(canvas)
     self._which = which
     self.shape = canvas.shape
     self.dtype = np.dtype(np.float32 if which == 'seed' else np.int32)
@@ -712,9 +716,18 @@ class DeviceCanvas(Canvas):
     return self._exec_client.canvas_call(fn, *args, **kwargs)
 
   def close(self):
+    """Frees the canvas' device memory now (it is also freed when the last
+    reference to the canvas goes away)."""
     if self._handle is not None:
       self._call(self._handle.close)
       self._handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint:disable=broad-except
+      pass
+    super().__del__()
 
   # -- cached point reads ------------------------------------------------------------
   def _invalidate_cache(self):
@@ -1099,20 +1112,43 @@ class MultiCanvasDriver:
     self.calls = 0
     self.steps = 0
 
-  def run(self, jobs):
+  def run(self, jobs, window=None, on_done=None):
     """jobs: iterable of (DeviceCanvas, seed_policy_factory) -- a whole
     `segment_all` per canvas -- or (DeviceCanvas, generator) for any other
-    step-yielding task on that canvas (e.g. a resegmentation point)."""
+    step-yielding task on that canvas (e.g. a resegmentation point, or a
+    `segment_all` resumed from a checkpoint).
+
+    `jobs` is consumed LAZILY: at most `window` canvases are open at any time
+    (None = all at once); when one finishes, `on_done(canvas)` is called -- the
+    place to save and close it -- and the next job is pulled.  A device canvas
+    holds 12 B / voxel of HBM plus its host image, so a long job list must not
+    be materialised up front."""
+    jobs = iter(jobs)
     ready = collections.deque()  # [canvas, generator, pending request, steps]
-    for canvas, seed_policy in jobs:
-      if inspect.isgenerator(seed_policy):
-        gen = seed_policy
-      else:
-        gen = canvas._segment_all_gen(seed_policy)
-      try:
-        ready.append([canvas, gen, next(gen), 0])
-      except StopIteration:
-        pass
+    state = {'open': 0, 'exhausted': False}
+
+    def finished(canvas):
+      state['open'] -= 1
+      if on_done is not None:
+        on_done(canvas)
+
+    def refill():
+      while not state['exhausted'] and (window is None or
+                                        state['open'] < window):
+        try:
+          canvas, task = next(jobs)
+        except StopIteration:
+          state['exhausted'] = True
+          return
+        gen = (task if inspect.isgenerator(task) else
+               canvas._segment_all_gen(task))
+        state['open'] += 1
+        try:
+          ready.append([canvas, gen, next(gen), 0])
+        except StopIteration:
+          finished(canvas)
+
+    refill()
     limit = self.max_steps_per_canvas
     inflight = collections.deque()  # (ticket, batch)
     depth = 2 if self.overlap else 1
@@ -1124,7 +1160,19 @@ class MultiCanvasDriver:
           n = min(self.batch_size, max(1, (live + 1) // 2), len(ready))
         else:
           n = min(self.batch_size, len(ready))
-        batch = [ready.popleft() for _ in range(n)]
+        # one engine call = one set of step parameters: canvases that differ
+        # (keep_history / other options, e.g. resegmentation canvases next to
+        # plain ones) wait for a batch of their own kind
+        key = bytes(ready[0][0]._step_params)
+        batch, others = [], []
+        while ready and len(batch) < n:
+          entry = ready.popleft()
+          if bytes(entry[0]._step_params) == key:
+            batch.append(entry)
+          else:
+            others.append(entry)
+        ready.extendleft(reversed(others))
+        n = len(batch)
         ticket = engine.step_submit([b[0]._handle for b in batch],
                                     [b[2] for b in batch],
                                     batch[0][0]._step_params)
@@ -1137,12 +1185,15 @@ class MultiCanvasDriver:
         try:
           entry[2] = entry[1].send(res[k])
         except StopIteration:
+          finished(entry[0])
           continue
         entry[3] += 1
         if limit is not None and entry[3] >= limit:
           entry[1].close()
+          finished(entry[0])
           continue
         ready.append(entry)
+      refill()
 
 
 def make_canvas(model_info, exec_client, image, options, **kwargs) -> Canvas:

@@ -290,7 +290,7 @@ class Runner:
     return canvas
 
   def run_many(self, subvolumes, batch_size=None, reset_counters=True,
-               save=True):
+               save=True, window=None, on_done=None, keep_open=False):
     """Segments several subvolumes CONCURRENTLY on this GPU (BASELINE config C3).
 
     The reference gets this from one thread per subvolume calling `run()` on a
@@ -299,42 +299,72 @@ class Runner:
     `ffn_canvas_step(n, ...)` (`inference.MultiCanvasDriver`).  Needs a Runner
     started with direct=True and batch_size >= the wanted concurrency.
 
+    Like `run()`, a subvolume whose result exists is skipped, an existing
+    `.cpoint` is restored first and removed after the result is written.  At
+    most `window` canvases are open at once (each holds image + seed +
+    segmentation in HBM and its image on the host): a subvolume is created when
+    a slot frees up, and saved and closed the moment it finishes.
+
     Args:
       subvolumes: iterable of (corner_zyx, size_zyx)
       batch_size: FoV steps per engine call (default: the engine's max batch)
       save: write each result like `run()` does (segmentation npz [+ prob])
+      window: canvases open at once (default 2 x batch_size: two groups of
+        batch_size keep two steps in flight)
+      on_done: called as on_done(index, canvas) when subvolume `index` is
+        finished and saved, before its canvas is closed
+      keep_open: leave finished canvases open (the caller closes them)
 
     Returns:
       list of canvases (None where the output already existed / all masked),
-      in the order of `subvolumes`.
+      in the order of `subvolumes`; closed unless `keep_open`.
     """
     if not self._direct:
       raise ValueError('run_many needs Runner.start(..., direct=True)')
     if reset_counters:
       self.counters.reset()
     out_dir = self.request.segmentation_output_dir
-    canvases, jobs, meta = [], [], []
-    for corner, size in subvolumes:
-      corner = tuple(int(c) for c in corner)
-      size = tuple(int(s) for s in size)
-      seg_path = storage.segmentation_path(out_dir, corner)
-      if save and os.path.exists(seg_path):
-        canvases.append(None)
-        continue
-      canvas, alignment = self.make_canvas(corner, size)
-      canvases.append(canvas)
-      if canvas is None:
-        continue
-      self.canvases[corner] = canvas
-      jobs.append((canvas, self.get_seed_policy(corner, size)))
-      meta.append((canvas, alignment, corner))
+    subvolumes = [(tuple(int(c) for c in corner), tuple(int(s) for s in size))
+                  for corner, size in subvolumes]
+    canvases = [None] * len(subvolumes)
+    meta = {}
     driver = inference.MultiCanvasDriver(self.executor.engine, batch_size)
-    driver.run(jobs)
-    for canvas, alignment, corner in meta:
+    if window is None:
+      window = 2 * driver.batch_size
+
+    def jobs():
+      for index, (corner, size) in enumerate(subvolumes):
+        seg_path = storage.segmentation_path(out_dir, corner)
+        if save and os.path.exists(seg_path):
+          continue
+        canvas, alignment = self.make_canvas(corner, size)
+        if canvas is None:
+          continue
+        cpoint_path = storage.checkpoint_path(out_dir, corner)
+        partial = 0
+        if os.path.exists(cpoint_path):
+          partial = canvas.restore_checkpoint(cpoint_path)
+        canvases[index] = canvas
+        self.canvases[corner] = canvas
+        meta[id(canvas)] = (index, alignment, corner, cpoint_path)
+        yield canvas, canvas._segment_all_gen(
+            self.get_seed_policy(corner, size), partial)
+
+    def finished(canvas):
+      index, alignment, corner, cpoint_path = meta.pop(id(canvas))
       if save:
         self.save_segmentation(canvas, alignment,
                                storage.segmentation_path(out_dir, corner),
                                storage.object_prob_path(out_dir, corner))
+        try:
+          os.remove(cpoint_path)
+        except OSError:
+          pass
       del self.canvases[corner]
-    return canvases
+      if on_done is not None:
+        on_done(index, canvas)
+      if not keep_open and hasattr(canvas, 'close'):
+        canvas.close()
 
+    driver.run(jobs(), window=window, on_done=finished)
+    return canvases

@@ -139,10 +139,17 @@ def list_variables(prefix: str) -> Dict[str, dict]:
     for key, value in _block_entries(_read_block(data, off, size)):
       if key == b'':
         continue  # BundleHeaderProto
-      info = {'dtype': None, 'shape': (), 'shard': 0, 'offset': 0, 'size': 0}
+      info = {'dtype': None, 'dtype_enum': 0, 'shape': (), 'shard': 0,
+              'offset': 0, 'size': 0, 'sliced': False}
       for field, _, val in _parse_proto(value):
         if field == 1:
-          info['dtype'] = _DTYPES[val]
+          # unknown dtypes (DT_STRING object graphs of TF2 checkpoints, half,
+          # bfloat16 ...) are recorded, not rejected: only a tensor that is
+          # actually requested must be readable
+          info['dtype_enum'] = val
+          info['dtype'] = _DTYPES.get(val)
+        elif field == 7:
+          info['sliced'] = True  # BundleEntryProto.slices: partitioned variable
         elif field == 2:
           info['shape'] = _parse_shape(val)
         elif field == 3:
@@ -155,9 +162,29 @@ def list_variables(prefix: str) -> Dict[str, dict]:
   return entries
 
 
-def load_checkpoint(prefix: str) -> Dict[str, np.ndarray]:
-  """Loads every tensor of a TensorBundle checkpoint into numpy arrays."""
+def load_checkpoint(prefix: str, names=None) -> Dict[str, np.ndarray]:
+  """Loads the tensors of a TensorBundle checkpoint into numpy arrays.
+
+  names: tensors to load (KeyError / ValueError if one is missing, of an
+    unsupported dtype or sliced); default: every tensor this reader can
+    represent -- entries of other dtypes (e.g. the DT_STRING
+    `_CHECKPOINTABLE_OBJECT_GRAPH` of object-based checkpoints) and sliced
+    (partitioned) entries are skipped."""
   entries = list_variables(prefix)
+  if names is not None:
+    wanted = {}
+    for n in names:
+      e = entries[n]
+      if e['dtype'] is None:
+        raise ValueError('%s: unsupported tensor dtype enum %d' %
+                         (n, e['dtype_enum']))
+      if e['sliced']:
+        raise ValueError('%s: sliced (partitioned) tensors are not supported' % n)
+      wanted[n] = e
+    entries = wanted
+  else:
+    entries = {n: e for n, e in entries.items()
+               if e['dtype'] is not None and not e['sliced']}
   num_shards = 1 + max((e['shard'] for e in entries.values()), default=0)
   shards = {}
   out = {}

@@ -44,8 +44,10 @@ def main(argv=None):
                   'by sub-box borders) and save it here (.npy, rank 0).  The '
                   "sub-boxes of a rank then advance concurrently on its GPU "
                   '(--batch_size of them per engine call).')
-  ap.add_argument('--min_overlap_voxels', type=int, default=64)
-  ap.add_argument('--min_overlap_fraction', type=float, default=0.25)
+  ap.add_argument('--min_overlap_voxels', type=int,
+                  default=ffn_dist.MIN_OVERLAP_VOXELS)
+  ap.add_argument('--min_overlap_fraction', type=float,
+                  default=ffn_dist.MIN_OVERLAP_FRACTION)
   args = ap.parse_args(argv)
   logging.basicConfig(level=logging.INFO)
 

@@ -190,7 +190,7 @@ def test_reconcile_single_process_restores_objects():
   results = _sub_results(truth, boxes)
   merged, offsets, edges, roots = ffn_dist.reconcile_segmentations(
       results, shape, 0, 1, device='cpu', min_overlap_voxels=8,
-      ops=EmulatedLabelOps())
+      min_overlap_fraction=0.0, ops=EmulatedLabelOps())
   assert _partition_equal(merged, truth)
   want, want_edges, want_roots = labels_oracle.reconcile(results, shape, 8)
   assert np.array_equal(merged, want)
@@ -198,6 +198,41 @@ def test_reconcile_single_process_restores_objects():
   # without reconciliation the cut objects stay split
   plain, _ = ffn_dist.merge_segmentations(results, shape, 0, 1)
   assert not _partition_equal(plain, truth)
+
+
+def test_reconcile_defaults_do_not_merge_touching_objects():
+  """Two DISTINCT objects that merely touch inside the overlap zone of a cut
+  (one labelling bleeds a thin sliver into the other) are not joined by the
+  default criterion; one object cut in two still is."""
+  shape = (40, 40, 72)
+  truth = np.zeros(shape, np.int32)
+  truth[8:32, 8:32, 4:30] = 1   # object A, left of the cut (x = 36)
+  truth[8:32, 8:32, 30:68] = 2  # object B, touching A inside the overlap zone
+  truth[2:6, 2:38, 4:68] = 3    # object C crosses the cut: must be re-joined
+  boxes = ffn_dist.tile_volume(shape, (40, 40, 44), (0, 0, 16))
+  assert len(boxes) == 2
+  results = _sub_results(truth, boxes)
+  # the left canvas over-segments: A leaks one voxel layer into B
+  b0, s0 = results[0]
+  leak = (truth[:, :, :44] == 2)
+  leak[:, :, 31:] = False
+  a_local = int(s0[20, 20, 10])
+  s0 = s0.copy()
+  s0[leak] = a_local
+  results[0] = (b0, s0)
+  merged, _, edges, _ = ffn_dist.reconcile_segmentations(
+      results, shape, 0, 1, device='cpu', ops=EmulatedLabelOps())
+  ids_a = set(np.unique(merged[truth == 1]).tolist()) - {0}
+  ids_b = set(np.unique(merged[:, :, 40:][truth[:, :, 40:] == 2]).tolist()) - {0}
+  assert ids_a.isdisjoint(ids_b), (ids_a, ids_b, edges)
+  assert len(set(np.unique(merged[truth == 3]).tolist()) - {0}) == 1
+  # the permissive criterion of round 1 (1 voxel, no fraction) does chain them
+  loose, _, _, _ = ffn_dist.reconcile_segmentations(
+      results, shape, 0, 1, device='cpu', min_overlap_voxels=1,
+      min_overlap_fraction=0.0, ops=EmulatedLabelOps())
+  la = set(np.unique(loose[truth == 1]).tolist()) - {0}
+  lb = set(np.unique(loose[:, :, 40:][truth[:, :, 40:] == 2]).tolist()) - {0}
+  assert not la.isdisjoint(lb)
 
 
 def _reconcile_worker(rank, world, port, tmpdir):
@@ -212,7 +247,7 @@ def _reconcile_worker(rank, world, port, tmpdir):
   results = _sub_results(truth, mine)
   merged, _, edges, _ = ffn_dist.reconcile_segmentations(
       results, shape, rank, world, device='cpu', min_overlap_voxels=8,
-      ops=EmulatedLabelOps(seed=rank))
+      min_overlap_fraction=0.0, ops=EmulatedLabelOps(seed=rank))
   np.save(os.path.join(tmpdir, 'rec_%d.npy' % rank), merged)
   np.save(os.path.join(tmpdir, 'edges_%d.npy' % rank), edges)
   dist.barrier()

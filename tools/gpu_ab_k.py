@@ -25,6 +25,7 @@ def main():
   ap.add_argument('--rounds', type=int, default=5)
   ap.add_argument('--repeats', type=int, default=40)
   ap.add_argument('--variants', type=int, nargs='+', default=[4, 5])
+  ap.add_argument('--ablate', action='store_true')
   args = ap.parse_args()
   model = convstack_3d.ConvStack3DFFNModel(fov_size=[33, 33, 33],
                                            deltas=[8, 8, 8], depth=12)
@@ -75,6 +76,28 @@ def main():
             'cycles; wall %.0f ns -> %.2f GHz; %.2f cyc/MFMA' % (
                 v, w, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1], c[w, 3] - c[w, 2],
                 tot, wall, tot / max(wall, 1), (c[w, 2] - c[w, 1]) / nmfma))
+  if 5 in args.variants and args.ablate:
+    # issue experiments on conv32k (results are wrong, timing only)
+    eng.set_option('debug_clock', 1)
+    eng.set_option('conv_variant', 5)
+    eng.set_option('fuse_head', 0)
+    for abl in (0, 1, 2, 3, 4, 7):
+      eng.set_option('ablate', abl)
+      eng.forward_resident(1, 3)
+      eng.synchronize()
+      t0 = time.perf_counter()
+      eng.forward_resident(1, args.repeats)
+      eng.synchronize()
+      dt = (time.perf_counter() - t0) / args.repeats
+      eng.forward_resident(1, 2)
+      c = eng.debug_clocks()
+      w = 0
+      print('variant 5 ablate %d (1 no X reads, 2 no conversion, 4 no W loads): '
+            '%7.1f us/stack; wave 0 stage %d loop %d epilogue %d' %
+            (abl, dt * 1e6, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1],
+             c[w, 3] - c[w, 2]))
+    eng.set_option('ablate', 0)
+    eng.set_option('fuse_head', 1)
   if 5 in args.variants:
     # conv32k phase stamps: entry -> first barrier -> dz = 0 barrier -> dz = +1
     # barrier (-> loop end / exit are in the table above)
