@@ -82,6 +82,7 @@ struct ffn_engine {
   int store_policy = 1;  // conv32c epilogue stores: sc1 write-through (-1.4 % per stack)
   long long* d_dbg = nullptr;  // debug clocks of conv32c WG 0 (24 values)
   int dbg_clock = 0;
+  int dbg_layer = 3;      // the launch whose clocks are recorded (3 = a conv_a)
   size_t lds_bytes_c = 0;
   size_t lds_bytes_x = 0;        // conv32x3: 2 slots x Rc rows x 224 B
   uint16_t* wpack3 = nullptr;    // bf16 hi/mid/lo weight fragments, all layers
@@ -98,11 +99,24 @@ struct ffn_engine {
   int ksched_aoff[4 * kKMaxTaps] = {};
   int ksched_btap[4 * kKMaxTaps] = {};
   int ksched_ntaps[4] = {};
+  // conv32d (variant 6): conv32k's chunks / schedule, split-plane activations,
+  // LDS-DMA staging.  rawT / rawX / rawS: the three activation allocations
+  float* rawT = nullptr;
+  float* rawX = nullptr;
+  float* rawS = nullptr;
+  bool d_ok = false;
+  bool d_weights_ok = true;      // every |weight| x 2^11 inside the fp16 range
+  uint16_t* wpackd = nullptr;    // [28][khalf][plane hi, res][64][8] fp16 per layer
+  size_t wpackd_layer = 0;       // halves per layer
+  size_t lds_bytes_d = 0;        // 3 slots x 8 planes x Rc_k rows x 16 B
+  int dsched_aoff[4 * 8] = {};
+  int dsched_btap[4 * 8] = {};
   unsigned* range_flag = nullptr;  // device word: tag of the last void run
   unsigned range_tag = 0;        // tag of the run being queued
   bool fp16_ok = true;           // every weight inside the fp16 range
   int conv_variant = 4;       // 0 conv32, 1 conv32p, 2 conv32c, 3 conv32x3 bf16x3, 4 fp16x2,
-                              // 5 fp16x2 on 32x32x16 with the taps split over the waves
+                              // 5 fp16x2 on 32x32x16 with the taps split over the waves,
+                              // 6 the same on producer-split planes + LDS-DMA staging
   float* h_io = nullptr;      // pinned staging of ffn_predict: seed, image, logits
   float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
   float* up_seed = nullptr;
@@ -285,6 +299,25 @@ int set_lds_attr_k(size_t bytes) {
     FFN_K_ATTR(10, true);
   }
 #undef FFN_K_ATTR
+  return FFN_OK;
+}
+
+int set_lds_attr_d(size_t bytes) {
+#define FFN_D_ATTR(KIND, SK, KSV, HEADV)                                          \
+  HIP_TRY(hipFuncSetAttribute(                                                    \
+      reinterpret_cast<const void*>(&conv32d_kernel<KIND, SK, KSV, HEADV>),       \
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes))
+#define FFN_D_ATTRS(KSV)            \
+  FFN_D_ATTR(0, false, KSV, false); \
+  FFN_D_ATTR(1, false, KSV, false); \
+  FFN_D_ATTR(1, true, KSV, false);  \
+  FFN_D_ATTR(1, false, KSV, true);  \
+  FFN_D_ATTR(1, true, KSV, true)
+  FFN_D_ATTRS(8);
+  FFN_D_ATTRS(9);
+  FFN_D_ATTRS(10);
+#undef FFN_D_ATTRS
+#undef FFN_D_ATTR
   return FFN_OK;
 }
 
@@ -475,7 +508,7 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
   a.nbytes = (unsigned)((size_t)e->g.nchunks * kChunk * kFeatures * sizeof(float));
   a.store_policy = e->store_policy;
   // clocks of ONE mid-stack launch (a conv_a: ReLU in and out, no residual)
-  a.dbg = (e->dbg_clock && layer == 3) ? e->d_dbg : nullptr;
+  a.dbg = (e->dbg_clock && layer == e->dbg_layer) ? e->d_dbg : nullptr;
   a.head_w = e->weights + e->wl_off;
   a.seed_raw = e->seed_raw;
   a.logits = e->logits;
@@ -628,6 +661,87 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
   return FFN_OK;
 }
 
+// The split-plane layout of variant 6 and the f32 layout of the others keep their
+// zero padding in different bytes of the same allocations: re-zero on a change.
+int switch_variant(ffn_engine* e, int value) {
+  if ((value == 6) != (e->conv_variant == 6)) {
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(e->act_base, 0,
+                           (size_t)3 * e->max_batch * e->g.act_stride * sizeof(float),
+                           e->stream));
+  }
+  e->conv_variant = value;
+  return FFN_OK;
+}
+
+// conv32d launch: KIND 0 conv_a (T' = split(relu(conv(X') + b))), KIND 1 conv_b
+// (X = conv(T') + b [+ X]; X' = split(relu(X))), or the fused head
+template <int KIND, bool SK>
+int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
+                   int layer, const HeadFusion& head = HeadFusion()) {
+  const Geom& g = e->g;
+  const long positions = g.act_stride / kFeatures;
+  ConvDArgs a;
+  a.in_sp = reinterpret_cast<const char*>(raw_in) + (size_t)g.guard * 16;
+  a.out_sp = reinterpret_cast<char*>(raw_out) + (size_t)g.guard * 16;
+  a.x_f32 = e->rawX + (size_t)g.guard * 4;
+  a.wpack = reinterpret_cast<const char*>(e->wpackd + (size_t)layer * e->wpackd_layer);
+  a.bias = e->weights + e->bias_off[layer];
+  a.item_bytes = g.act_stride * (long)sizeof(float);
+  a.sp_plane_bytes = positions * 16;
+  a.XS = g.XS;
+  a.plane = g.plane;
+  a.nchunks = e->nchunks_k;
+  a.V = g.V;
+  a.fx = g.fx;
+  a.fyfx = g.fy * g.fx;
+  a.total_slots = n * e->nchunks_k;
+  a.slots_per_xcd = (a.total_slots + 7) / 8;
+  auto magic = [](int d) { return (unsigned)(((1ull << 32) + d - 1) / d); };
+  a.magic_nchunks = magic(e->nchunks_k);
+  a.magic_fyfx = magic(g.fy * g.fx);
+  a.magic_fx = magic(g.fx);
+  a.sp_bytes = (unsigned)((size_t)g.act_stride * sizeof(float) - (size_t)g.guard * 32);
+  std::memcpy(a.aoff, e->dsched_aoff, sizeof(a.aoff));
+  std::memcpy(a.btap, e->dsched_btap, sizeof(a.btap));
+  a.dbg = (e->dbg_clock && layer == e->dbg_layer) ? e->d_dbg : nullptr;
+  a.head_w = e->weights + e->wl_off;
+  a.seed_raw = e->seed_raw;
+  a.logits = e->logits;
+  a.head_count = e->count;
+  a.pad_value = head.pad_value;
+  a.move_thr = head.move_thr;
+  a.range_flag = e->range_flag;
+  a.range_tag = e->range_tag;
+  const bool prof = e->prof_now;
+  if (prof) {
+    if (e->events_used + 2 > (int)e->events.size()) {
+      int rc = flush_events(e);
+      if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  }
+  const dim3 grid(8 * a.slots_per_xcd), block(kDThreads);
+  const int ks = e->Rc_k / 32;
+#define FFN_D_LAUNCH(KSV, HEADV)                                                 \
+  hipLaunchKernelGGL((conv32d_kernel<KIND, SK, KSV, HEADV>), grid, block,        \
+                     e->lds_bytes_d, e->stream, a)
+  if (head.on) {
+    if constexpr (KIND == 1) {
+      if (ks == 8) FFN_D_LAUNCH(8, true);
+      else if (ks == 9) FFN_D_LAUNCH(9, true);
+      else FFN_D_LAUNCH(10, true);
+    }
+  } else {
+    if (ks == 8) FFN_D_LAUNCH(8, false);
+    else if (ks == 9) FFN_D_LAUNCH(9, false);
+    else FFN_D_LAUNCH(10, false);
+  }
+#undef FFN_D_LAUNCH
+  if (prof) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  return FFN_OK;
+}
+
 // FoVs described by `si` -> logits (+ count of logits >= move_thr, + seed_raw)
 int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
               float move_thr) {
@@ -644,11 +758,22 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     hipLaunchKernelGGL(conv0a_kernel, dim3(tz * ty * tx, n), dim3(kC0Threads), 0,
                        e->stream, si, pad_value, W + e->w0a_off, W + e->b0a_off,
                        e->bufT, e->seed_raw, g, ty, tx);
-  else
-    hipLaunchKernelGGL(conv0a_mfma_kernel, dim3(tz * ty * tx, n),
+  else if (e->conv_variant == 6) {
+    Conv0SplitOut so;
+    so.out_sp = reinterpret_cast<char*>(e->rawT) + (size_t)g.guard * 16;
+    so.sp_plane_bytes = (g.act_stride / kFeatures) * 16;
+    so.item_bytes = g.act_stride * (long)sizeof(float);
+    so.range_flag = e->range_flag;
+    so.range_tag = e->range_tag;
+    hipLaunchKernelGGL(conv0a_mfma_kernel<true>, dim3(tz * ty * tx, n),
                        dim3(kC0Threads), 0, e->stream, si, pad_value,
                        W + e->w0a_off, W + e->b0a_off, e->bufT, e->seed_raw, g,
-                       ty, tx);
+                       ty, tx, so);
+  } else
+    hipLaunchKernelGGL(conv0a_mfma_kernel<false>, dim3(tz * ty * tx, n),
+                       dim3(kC0Threads), 0, e->stream, si, pad_value,
+                       W + e->w0a_off, W + e->b0a_off, e->bufT, e->seed_raw, g,
+                       ty, tx, Conv0SplitOut());
   int rc;
   const float* head_in;
   bool head_fused = false;
@@ -660,7 +785,25 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     e->chain_launches_pending.push_back(2 * e->depth - 1);
     HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   }
-  if (e->conv_variant == 0) {
+  if (e->conv_variant == 6) {
+    // T' -> (X, X') -> T' -> ... ; the head is always fused into the last conv_b
+    rc = launch_conv32d<1, false>(e, n, e->rawT, e->rawS, 0);
+    if (rc) return rc;
+    for (int i = 1; i < e->depth; ++i) {
+      rc = launch_conv32d<0, false>(e, n, e->rawS, e->rawT, 2 * i - 1);
+      if (rc) return rc;
+      HeadFusion hf;
+      hf.on = i == e->depth - 1;
+      hf.pad_value = pad_value;
+      hf.move_thr = move_thr;
+      rc = launch_conv32d<1, true>(e, n, e->rawT, e->rawS, 2 * i, hf);
+      if (rc) return rc;
+      head_fused = hf.on;
+    }
+    if (e->depth == 1)
+      return fail(FFN_ERR_ARG, "conv_variant 6 needs depth >= 2 (fused head)");
+    head_in = e->bufX;
+  } else if (e->conv_variant == 0) {
     rc = launch_conv32<false, false, false>(e, n, e->bufT, e->bufX, nullptr, 0);
     if (rc) return rc;
     for (int i = 1; i < e->depth; ++i) {
@@ -705,7 +848,7 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   }
   if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   if (head_fused) {
-    e->count_blocks = e->conv_variant == 5 ? e->nchunks_k : e->nchunks_c;
+    e->count_blocks = e->conv_variant >= 5 ? e->nchunks_k : e->nchunks_c;
   } else {
     e->count_blocks = kHeadBlocks;
     hipLaunchKernelGGL(head_kernel, dim3(kHeadBlocks, n), dim3(256), 0, e->stream,
@@ -850,11 +993,14 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   } while (0)
 
   E_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  const size_t act_bytes = (size_t)2 * max_batch * g.act_stride * sizeof(float);
+  const size_t act_bytes = (size_t)3 * max_batch * g.act_stride * sizeof(float);
   E_TRY(hipMalloc(&e->act_base, act_bytes));
   E_TRY(hipMemset(e->act_base, 0, act_bytes));
-  e->bufT = e->act_base + (size_t)g.guard * kFeatures;
-  e->bufX = e->bufT + (size_t)max_batch * g.act_stride;
+  e->rawT = e->act_base;
+  e->rawX = e->rawT + (size_t)max_batch * g.act_stride;
+  e->rawS = e->rawX + (size_t)max_batch * g.act_stride;
+  e->bufT = e->rawT + (size_t)g.guard * kFeatures;
+  e->bufX = e->rawX + (size_t)g.guard * kFeatures;
   const size_t vbytes = (size_t)max_batch * g.V * sizeof(float);
   E_TRY(hipMalloc(&e->up_image, vbytes));
   E_TRY(hipMalloc(&e->up_seed, vbytes));
@@ -941,6 +1087,21 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
         }
         e->ksched_ntaps[w] = nt;
       }
+      // conv32d: the same schedule in the plane-major LDS image (8 planes x Rc_k
+      // rows x 16 B per segment); wave 3's seventh tap is the all-zero tap 27
+      e->lds_bytes_d = std::max((size_t)3 * 128 * e->Rc_k,
+                                (size_t)4 * kDChunk * kDRowB + 64);
+      for (int w = 0; w < 4; ++w)
+        for (int j = 0; j < 7; ++j) {
+          int s = kSched[w][j];
+          const bool dummy = s < 0;
+          if (dummy) s = kSched[w][j - 1];
+          const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
+          e->dsched_aoff[w * 8 + j] =
+              kz * 128 * e->Rc_k + ((ky - 1) * g.XS + (kx - 1)) * 16;
+          e->dsched_btap[w * 8 + j] = dummy ? 27 : s;
+        }
+      e->d_ok = e->k_ok && e->lds_bytes_d <= 160 * 1024 && depth >= 2;
     }
     E_TRY(hipMalloc(&e->d_dbg, 24 * sizeof(long long)));
     E_TRY(hipMemset(e->d_dbg, 0, 24 * sizeof(long long)));
@@ -979,6 +1140,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     E_TRY(hipMalloc(&e->wpack2h, e->wpack2h_layer * (2 * depth - 1) *
                                      sizeof(uint16_t)));
     e->wpackk_layer = (size_t)27 * 2 * 2 * 64 * 8;
+    e->wpackd_layer = (size_t)kDTaps * 2 * 2 * 64 * 8;  // + the all-zero tap
+    E_TRY(hipMalloc(&e->wpackd, e->wpackd_layer * (2 * depth - 1) *
+                                    sizeof(uint16_t)));
     E_TRY(hipMalloc(&e->wpackk, e->wpackk_layer * (2 * depth - 1) *
                                     sizeof(uint16_t)));
     E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
@@ -1013,6 +1177,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (!rc && e->k_ok) rc = set_lds_attr_k<false, false, false>(e->lds_bytes_k);
     if (!rc && e->k_ok) rc = set_lds_attr_k<true, true, false>(e->lds_bytes_k);
     if (!rc && e->k_ok) rc = set_lds_attr_k<false, false, true>(e->lds_bytes_k);
+    if (!rc && e->d_ok) rc = set_lds_attr_d(e->lds_bytes_d);
     if (!rc) rc = set_lds_attr_p<false, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
@@ -1062,6 +1227,7 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->wpack3);
   (void)hipFree(e->wpack2h);
   (void)hipFree(e->wpackk);
+  (void)hipFree(e->wpackd);
   (void)hipFree(e->range_flag);
   (void)hipFree(e->valid);
   (void)hipFree(e->validbits);
@@ -1093,6 +1259,8 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   std::vector<uint16_t> host3(e->wpack3_layer * (2 * e->depth - 1));
   std::vector<uint16_t> host2(e->wpack2h_layer * (2 * e->depth - 1));
   std::vector<uint16_t> hostk(e->wpackk_layer * (2 * e->depth - 1));
+  std::vector<uint16_t> hostd(e->wpackd_layer * (2 * e->depth - 1));  // zero tap 27
+  bool d_weights_ok = true;
   bool weights_in_fp16_range = true;
   std::memcpy(&host[e->w0a_off], src, sizeof(float) * 27 * 2 * F);
   src += 27 * 2 * F;
@@ -1163,6 +1331,25 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
                     part[pl];
             }
     }
+    // conv32d: the same A operand (+ an all-zero tap 27); the kernel also uses
+    // 2^11 hi, so |w| must stay below 2^5
+    //   wpackd[tap][khalf][plane hi, res][lane][c]
+    {
+      uint16_t* wd = &hostd[(size_t)l * e->wpackd_layer];
+      for (int tap = 0; tap < 27; ++tap)
+        for (int kh = 0; kh < 2; ++kh)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int c = 0; c < 8; ++c) {
+              const int ci = 16 * kh + 8 * (lane >> 5) + c, co = lane & 31;
+              const float w = src[((size_t)tap * F + ci) * F + co];
+              if (!(std::fabs(w) <= 31.0f)) d_weights_ok = false;
+              uint16_t part[2];
+              split_fp16x2(w, part);
+              const size_t base = ((((size_t)tap * 2 + kh) * 2) * 64 + lane) * 8 + c;
+              wd[base] = part[0];
+              wd[base + 64 * 8] = part[1];
+            }
+    }
     src += 27 * F * F;
     std::memcpy(&host[e->bias_off[l]], src, sizeof(float) * F);
     src += F;
@@ -1173,8 +1360,15 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
                     hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->wpackk, hostk.data(), hostk.size() * sizeof(uint16_t),
                     hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->wpackd, hostd.data(), hostd.size() * sizeof(uint16_t),
+                    hipMemcpyHostToDevice));
+  e->d_weights_ok = d_weights_ok;
   e->fp16_ok = weights_in_fp16_range;
-  if (!e->fp16_ok && e->conv_variant >= 4) e->conv_variant = 3;
+  if ((!e->fp16_ok && e->conv_variant >= 4) ||
+      (!e->d_weights_ok && e->conv_variant == 6)) {
+    int rc = switch_variant(e, 3);
+    if (rc) return rc;
+  }
   std::memcpy(&host[e->wl_off], src, sizeof(float) * (F + 1));
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipMemcpy(e->weights, host.data(),
@@ -1214,7 +1408,8 @@ int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (e->conv_variant >= 4 && flag == e->range_tag) {
     // an operand left the fp16 range: this engine stays on the bf16x3 scheme
-    e->conv_variant = 3;
+    rc = switch_variant(e, 3);
+    if (rc) return rc;
     rc = run_stack(e, n, si, std::nanf(""), INFINITY);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h_logits, e->logits, bytes, hipMemcpyDeviceToHost,
@@ -1244,19 +1439,22 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) {
-    if (value < 0 || value > 5) return fail(FFN_ERR_ARG, "conv_variant must be 0..5");
+    if (value < 0 || value > 6) return fail(FFN_ERR_ARG, "conv_variant must be 0..6");
     if (value >= 4 && e->weights_set && !e->fp16_ok)
       return fail(FFN_ERR_ARG, "conv_variant %d: a weight is outside the fp16 range",
                   value);
     if (value == 5 && !e->k_ok)
       return fail(FFN_ERR_ARG, "conv_variant 5 unsupported for this fov");
+    if (value == 6 && !e->d_ok)
+      return fail(FFN_ERR_ARG, "conv_variant 6 unsupported for this fov / depth");
+    if (value == 6 && e->weights_set && !e->d_weights_ok)
+      return fail(FFN_ERR_ARG, "conv_variant 6: a weight x 2^11 is outside the fp16 range");
     const Geom& g = e->g;
     if (value == 1 && !(g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256))
       return fail(FFN_ERR_ARG, "conv_variant 1 unsupported for this fov");
     if (value >= 2 && value <= 4 && !(e->Rc == 256 || e->Rc == 288))
       return fail(FFN_ERR_ARG, "conv_variant %d unsupported for this fov", value);
-    e->conv_variant = value;
-    return FFN_OK;
+    return switch_variant(e, value);
   }
   if (std::strcmp(name, "profile_every") == 0) {
     if (value < 1) return fail(FFN_ERR_ARG, "profile_every must be >= 1");
@@ -1270,6 +1468,10 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   }
   if (std::strcmp(name, "debug_clock") == 0) {
     e->dbg_clock = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "debug_layer") == 0) {
+    e->dbg_layer = value;
     return FFN_OK;
   }
   if (std::strcmp(name, "ablate") == 0) {

@@ -165,12 +165,28 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_kernel(
 // ds_read_b32 per k-step straight from the (image, seed) tile (lane group g
 // reads channel g & 1 of tap 2s + (g >> 1)); B operand: the [54][32] weights,
 // 28 registers per lane, loaded once.  5x fewer issue cycles than the VALU form.
+// SPLIT (conv_variant 6): the output leaves as "split planes" (fp16 hi + scaled
+// residual, 16 B per position and chunk plane; see conv32d) instead of f32.
+struct Conv0SplitOut {
+  char* out_sp;            // position 0 of plane 0, item 0
+  long sp_plane_bytes;     // positions x 16
+  long item_bytes;
+  unsigned* range_flag;
+  unsigned range_tag;
+};
+typedef _Float16 f16x8_c0 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_c0 __attribute__((ext_vector_type(4)));
+
+template <bool SPLIT>
 __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
     StepItems si, float pad_value, const float* __restrict__ w /*[27][2][32]*/,
     const float* __restrict__ bias, float* __restrict__ out,
-    float* __restrict__ seed_raw, Geom g, int tiles_y, int tiles_x) {
+    float* __restrict__ seed_raw, Geom g, int tiles_y, int tiles_x,
+    Conv0SplitOut so) {
   constexpr int HZ = kC0Z + 2, HY = kC0Y + 2, HX = kC0X + 2;
   __shared__ float tile[HZ * HY * HX * 2];  // (image, seed) interleaved
+  // SPLIT: the block's 256 x 32 outputs, transposed through LDS (36-float rows)
+  __shared__ __attribute__((aligned(16))) float otile[SPLIT ? 256 * 36 : 4];
   const int item = blockIdx.y;
   const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
   int b = blockIdx.x;
@@ -244,6 +260,11 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int op = (wave * 2 + m) * kTile + grp * 4 + r;
+      if constexpr (SPLIT) {
+        otile[op * 36 + i] = fmaxf(acc0[r], 0.0f);
+        otile[op * 36 + 16 + i] = fmaxf(acc1[r], 0.0f);
+        continue;
+      }
       const int ox_ = op % kC0X;
       const int oy_ = (op / kC0X) % kC0Y;
       const int oz_ = op / (kC0X * kC0Y);
@@ -254,6 +275,49 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
       o[i] = fmaxf(acc0[r], 0.0f);
       o[16 + i] = fmaxf(acc1[r], 0.0f);
     }
+  }
+  if constexpr (SPLIT) {
+    __syncthreads();
+    unsigned range_max = 0;
+    char* ob = so.out_sp + (long)item * so.item_bytes;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = threadIdx.x + kC0Threads * k;  // (chunk plane c, position op)
+      const int c = e >> 8, op = e & 255;
+      const int ox_ = op % kC0X;
+      const int oy_ = (op / kC0X) % kC0Y;
+      const int oz_ = op / (kC0X * kC0Y);
+      const int z = oz + oz_, y = oy + oy_, x = ox + ox_;
+      if (z >= g.fz || y >= g.fy || x >= g.fx) continue;
+      const long p = (long)z * g.plane + (long)y * g.XS + x;
+      const f32x4 va = *reinterpret_cast<const f32x4*>(otile + op * 36 + c * 8);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(otile + op * 36 + c * 8 + 4);
+      f16x8_c0 hi, res;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 v = h ? vb : va;
+        f32x4 vh = v;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const unsigned mbits = __float_as_uint(v[cc]) & 0x7fffffffu;
+          range_max = mbits > range_max ? mbits : range_max;
+          vh[cc] = mbits < 0x38800000u ? 0.0f : v[cc];  // |x| < 2^-14
+        }
+        const f16x4_c0 h4 = __builtin_convertvector(vh, f16x4_c0);
+        const f32x4 r1 = (v - __builtin_convertvector(h4, f32x4)) * 2048.0f;
+        const f16x4_c0 r4 = __builtin_convertvector(r1, f16x4_c0);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          hi[4 * h + cc] = h4[cc];
+          res[4 * h + cc] = r4[cc];
+        }
+      }
+      *reinterpret_cast<f16x8_c0*>(ob + (long)c * so.sp_plane_bytes + p * 16) = hi;
+      *reinterpret_cast<f16x8_c0*>(ob + (long)(4 + c) * so.sp_plane_bytes + p * 16) =
+          res;
+    }
+    if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
+      *so.range_flag = so.range_tag;
   }
 }
 
@@ -2209,6 +2273,505 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
     d[1] = ka.dbg_mode ? dbg_b0 : dbg_c1;
     d[2] = ka.dbg_mode ? dbg_b1 : dbg_c2;
     d[3] = ka.dbg_mode ? dbg_b2 : clock64();
+    d[4] = dbg_w0;
+    d[5] = wall_clock64();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// conv32d (conv_variant 6): conv32k with the operand split done ONCE by the
+// producer, the staging done by LDS-DMA and ONE accumulator per tile.
+//
+// conv32w8 / conv32k stage f32 activations through registers and split every
+// value into fp16 hi + scaled residual on the way into LDS -- 5.3x redundantly
+// (three dz segments of 256-288 rows per 144-160 outputs) and with ~9 VALU
+// instructions per value in front of or between the MFMAs (conv32k: 3.3 K of
+// its 14.4 K loop cycles, profiles/r02_conv32k_ablations.txt).  Here
+//   * every layer WRITES its output already split: "split planes" in HBM,
+//       plane cp (0..3: hi of channels 8cp..8cp+7, 4..7: scaled residual of
+//       channels 8(cp-4)..) = [padded position] x 16 B, same zero guards / zero
+//       padding positions as the f32 layout, same 128 B per position in total;
+//     ReLU (conv_a's input, convstack_3d.py:44) is applied by the producer too:
+//       conv_a writes  T' = split(relu(conv + b))
+//       conv_b writes  X  = conv + b + X (f32 residual stream, planes
+//                      [8][position][4 ch]: 16 B per position and plane as
+//                      well, so every store instruction of the epilogue writes
+//                      one contiguous KiB) and X' = split(relu(X));
+//   * a dz segment is then 8 contiguous runs of R x 16 B in HBM and lands in LDS
+//     with global_load_lds_dwordx4 (1 KiB per wave instruction, no VGPRs, no
+//     VALU): 3 KS DMA instructions per wave, all issued at kernel entry, the
+//     dz = -1 segment in front of everything else in the memory queue;
+//   * the LDS image is plane-major ([chunk plane][row] x 16 B): the
+//     ds_read_b128 of 32 consecutive rows is one contiguous 512 B -- bank
+//     conflict free without padding, which is what makes the DMA's lane-linear
+//     destination usable;
+//   * the three products of the split share ONE accumulator: the weights come
+//     in three fp16 planes, hs = 2^11 hi, hi and res (x w ~= 2^-11 (hs x_hi +
+//     hi x_res + res x_hi), every product exact in f32, the 2^-11 applied once
+//     in the epilogue).  Dependent MFMAs issue back to back at the full rate
+//     (profiles/r02_ubench_mfma_dep.txt), and a third of conv32k's accumulator
+//     read-out is left.
+// Chunks (160 dense voxels), wave roles (the 27 taps split 7/7/7/6 over the four
+// waves, + one all-zero tap so that every wave runs the same straight-line code)
+// and the fused head are conv32k's.
+// The compiler does not see the DMAs nor the loads of the first four weight
+// taps (inline asm), so their s_waitcnt vmcnt are placed by hand.  vmcnt
+// retires in order; what a workgroup pulls through its CU's 64 B/clk vector
+// memory path per launch (110 KB of activations + 112 KB of weight fragments)
+// takes 3.5 K cycles to ISSUE, so only what the first taps need is issued in
+// front of the first barrier and the rest rides on the MFMAs of taps 0 and 1:
+//     W0 (4) | DMA dz=-1 (KS) | W1 (4)          -> barrier 0: vmcnt(4)
+//     tap 0: DMA dz=0 (KS), W2 W3 (8), W4 (4, compiler)
+//     tap 1: DMA dz=+1 (KS), W5 (4, compiler)  -> barrier 1: vmcnt(KS + 8)
+//     tap 2: W6 (4, compiler); tap 3            -> barrier 2: vmcnt(8)
+// (No memory operation of the compiler's precedes a DMA it must not wait for:
+// its own vmcnt for such a load would count none of them and drain the queue.)
+// The 2^11-scaled weight plane is made in registers (v_pk_mul_f16, exact).
+// ---------------------------------------------------------------------------
+constexpr int kDChunk = 160;
+constexpr int kDTiles = 5;
+constexpr int kDThreads = 256;
+constexpr int kDRowB = 144;   // epilogue: row stride of the partial sums in LDS
+constexpr int kDTaps = 28;    // 27 + the all-zero tap
+constexpr int kDTapBytes = 2 * 2 * 1024;  // weight fragments of one tap (hi, res)
+
+struct ConvDArgs {
+  const char* in_sp;     // split planes read (position 0 of plane 0, item 0)
+  char* out_sp;          // split planes written (T' or X')
+  float* x_f32;          // residual stream, f32 planes [8][position][4] (position 0 of plane 0)
+  const char* wpack;     // [28][khalf][plane hi, res][64 lanes][8] fp16 (tap 27 = zeros)
+  const float* bias;
+  long item_bytes;       // bytes per item of an activation buffer (split or f32)
+  long sp_plane_bytes;   // positions x 16: one chunk plane of the split layout
+  int XS, plane, nchunks, V, fx, fyfx, total_slots, slots_per_xcd;
+  unsigned magic_nchunks, magic_fyfx, magic_fx;
+  unsigned sp_bytes;     // bytes of a split / f32 buffer past position 0 (store range)
+  int aoff[4 * 8];       // [wave][j]: LDS byte offset of the wave's j-th tap
+  int btap[4 * 8];       // [wave][j]: its tap index (weight fragments)
+  long long* dbg;
+  const float* head_w;
+  const float* seed_raw;
+  float* logits;
+  unsigned* head_count;
+  float pad_value, move_thr;
+  unsigned* range_flag;
+  unsigned range_tag;
+};
+
+// one LDS-DMA wave instruction: 64 lanes x 16 B, global (sbase + voff) -> LDS
+// (lds_dst + 16 lane); invisible to the compiler's vmcnt bookkeeping
+__device__ __forceinline__ void lds_dma16(const char* sbase, unsigned voff,
+                                          unsigned lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
+// a 16-B load the compiler does not count either (waited for by hand)
+template <int OFF>
+__device__ __forceinline__ f16x8 hidden_load16(const char* sbase, unsigned voff) {
+  f16x8 d;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+               : "=v"(d)
+               : "v"(voff), "s"(sbase), "n"(OFF)
+               : "memory");
+  return d;
+}
+
+// v ~= hi + 2^-11 res (both fp16), 8 values -> one 16-B hi and one 16-B residual
+// fragment; the running maximum of |v| feeds the fp16 range check
+__device__ __forceinline__ void split8_fp16(const f32x4& v0, const f32x4& v1,
+                                            f16x8& hi, f16x8& res,
+                                            unsigned& range_max) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 v = h ? v1 : v0;
+    f32x4 vh = v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const unsigned mbits = __float_as_uint(v[c]) & 0x7fffffffu;
+      range_max = mbits > range_max ? mbits : range_max;
+      vh[c] = mbits < 0x38800000u ? 0.0f : v[c];  // |x| < 2^-14: all in the residual
+    }
+    const f16x4 h4 = __builtin_convertvector(vh, f16x4);
+    const f32x4 r1 = (v - __builtin_convertvector(h4, f32x4)) * 2048.0f;
+    const f16x4 r4 = __builtin_convertvector(r1, f16x4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      hi[4 * h + c] = h4[c];
+      res[4 * h + c] = r4[c];
+    }
+  }
+}
+
+// KIND 0: conv_a (out = split(relu(conv + b)));  KIND 1: conv_b (x = conv + b
+// [+ x]; out = split(relu(x)));  HEAD (KIND 1 only): the network's head instead
+// of any activation output.
+template <int KIND, bool ADD_SKIP, int KS, bool HEAD>
+__global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
+  typedef f16x8 frag_t;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int R = 32 * KS;     // rows per dz segment
+  constexpr int R16 = R * 16;    // bytes of one chunk plane of a segment in LDS
+  constexpr int SEG = 8 * R16;   // bytes of a segment slot
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x;
+  const long long dbg_c0 = a.dbg ? clock64() : 0;
+  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
+  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
+  if (gc >= a.total_slots) return;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int aoffs[7], btaps[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    aoffs[j] = a.aoff[wave * 8 + j];
+    btaps[j] = a.btap[wave * 8 + j];
+  }
+  const int item = (int)__umulhi((unsigned)gc, a.magic_nchunks);
+  const int chunk = gc - item * a.nchunks;
+  const int v0 = chunk * kDChunk;
+  // dense FoV index -> padded position, by arithmetic: a table look-up would be
+  // a memory operation of the compiler's in front of the DMAs (see above)
+  auto padded = [&](int v) {
+    v = v < a.V ? v : a.V - 1;
+    const int z = (int)__umulhi((unsigned)v, a.magic_fyfx);
+    const int rem = v - z * a.fyfx;
+    const int y = (int)__umulhi((unsigned)rem, a.magic_fx);
+    return z * a.plane + y * a.XS + (rem - y * a.fx);
+  };
+  const int p_first = __builtin_amdgcn_readfirstlane(padded(v0));
+  const int p_lo = p_first - (a.XS + 1);  // first staged row of the dz = 0 segment
+
+  const int lane = tid & 63;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+
+  struct XFragD { frag_t x[2][2]; };  // activations [khalf][plane hi, res]
+  struct WFragD { frag_t w[2][3]; };  // weights     [khalf][plane hs, hi, res]
+  WFragD W0, W1, W2, W3, W4;
+  auto hiddenW = [&](int s, WFragD& dst) {
+    const char* b0 = a.wpack + (long)s * kDTapBytes;
+    const unsigned vo = (unsigned)lane * 16;
+    dst.w[0][1] = hidden_load16<0>(b0, vo);
+    dst.w[0][2] = hidden_load16<1024>(b0, vo);
+    dst.w[1][1] = hidden_load16<2048>(b0, vo);
+    dst.w[1][2] = hidden_load16<3072>(b0, vo);
+  };
+  // hs = 2^11 hi (exact: |w| <= 31 is checked on the host)
+  auto scaleW = [](WFragD& w) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) w.w[kh][0] = w.w[kh][1] * (_Float16)2048.0f;
+  };
+  auto pinW = [&](WFragD& w) {  // "the data is here": consumers stay below
+    asm volatile(""
+                 : "+v"(w.w[0][1]), "+v"(w.w[0][2]), "+v"(w.w[1][1]),
+                   "+v"(w.w[1][2]));
+    scaleW(w);
+  };
+  const frag_t* wp = reinterpret_cast<const frag_t*>(a.wpack) + lane;
+  auto loadW = [&](int s, WFragD& dst) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        dst.w[kh][1 + pl] = wp[((s * 2 + kh) * 2 + pl) * 64];
+  };
+
+  // ---- staging: 3 x KS LDS-DMA instructions per wave; only dz = -1 and the
+  // first two weight taps in front of the first barrier ----
+  const unsigned lbase =
+      (unsigned)(size_t)(__attribute__((address_space(3))) char*)ldsb;
+  const char* g0 = a.in_sp + (long)item * a.item_bytes + (long)p_lo * 16;
+  unsigned voff[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int u = 64 * (wave + 4 * k) + lane;  // 16-B unit of the segment image
+    const int cp = u / R;
+    voff[k] = (unsigned)(cp * (int)a.sp_plane_bytes + (u - cp * R) * 16);
+  }
+  auto dma_piece = [&](int seg, int k) {
+    lds_dma16(g0 + (long)(seg - 1) * a.plane * 16, voff[k],
+              lbase + seg * SEG + (wave + 4 * k) * 1024);
+  };
+  hiddenW(btaps[0], W0);
+#pragma unroll
+  for (int k = 0; k < KS; ++k) dma_piece(0, k);
+  hiddenW(btaps[1], W1);
+  // LDS byte offset of this lane's (position, k-group) in each tile
+  int xb[kDTiles];
+#pragma unroll
+  for (int t = 0; t < kDTiles; ++t)
+    xb[t] = (padded(v0 + t * 32 + li) - p_lo) * 16 + lh * R16;
+  // epilogue pieces
+  //   normal: item e = tid + 256 k -> (chunk plane c = e / 160, position j = e % 160)
+  //   HEAD:   position j = (tid >> 3) + 32 k, channel quad tid & 7
+  constexpr int NE = HEAD ? 5 : 3;
+  int ej[NE], ec[NE], ep[NE];
+  bool eok[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    if constexpr (HEAD) {
+      ej[k] = (tid >> 3) + 32 * k;
+      ec[k] = tid & 7;
+      eok[k] = v0 + ej[k] < a.V;
+    } else {
+      const int e = tid + 256 * k;
+      ec[k] = e >= 480 ? 3 : e >= 320 ? 2 : e >= 160 ? 1 : 0;
+      ej[k] = e - 160 * ec[k];
+      eok[k] = e < 640 && v0 + ej[k] < a.V;
+      if (e >= 640) { ej[k] = 0; ec[k] = 0; }
+    }
+    ep[k] = padded(v0 + ej[k]);
+  }
+
+  auto loadX = [&](int t, int off, XFragD& dst) {
+    const char* p = ldsb + xb[t] + off;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+        dst.x[kh][pl] =
+            *reinterpret_cast<const frag_t*>(p + (pl * 4 + kh * 2) * R16);
+  };
+  // acc = 2^11 x (the convolution): hs x_hi + hi x_res + res x_hi
+  f32x16 acc[kDTiles];
+#pragma unroll
+  for (int t = 0; t < kDTiles; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  auto mma = [](const frag_t& fw, const frag_t& fx, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fx, c, 0, 0, 0);
+  };
+  XFragD X0, X1;
+
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // W0, dz = -1 landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  pinW(W0);
+  const long long dbg_c1 = a.dbg ? clock64() : 0;
+  loadX(0, aoffs[0], X0);
+
+  // EXTRA: memory instructions riding on the tile (issued behind its prefetch)
+#define FFN_DTILE(T, XCUR, WCUR, PREFETCH, EXTRA)                             \
+  __builtin_amdgcn_sched_barrier(0); /* keep the prefetch AHEAD of the MFMAs */ \
+  PREFETCH;                                                                   \
+  EXTRA;                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                          \
+  acc[T] = mma(WCUR.w[0][1], XCUR.x[0][1], acc[T]);                           \
+  acc[T] = mma(WCUR.w[0][2], XCUR.x[0][0], acc[T]);                           \
+  acc[T] = mma(WCUR.w[0][0], XCUR.x[0][0], acc[T]);                           \
+  acc[T] = mma(WCUR.w[1][1], XCUR.x[1][1], acc[T]);                           \
+  acc[T] = mma(WCUR.w[1][2], XCUR.x[1][0], acc[T]);                           \
+  acc[T] = mma(WCUR.w[1][0], XCUR.x[1][0], acc[T]);
+  // tap J of the wave (XA holds tile 0's fragments on entry); CONT: prefetch
+  // tile 0 of the next tap under the last tile (false in front of a barrier);
+  // E0..E4: the extra memory instructions of its five tiles
+#define FFN_DTAP(J, XA, XB, WCUR, CONT, E0, E1, E2, E3, E4)                   \
+  {                                                                           \
+    const int ao_ = aoffs[J];                                                 \
+    const int an_ = aoffs[((J) + 1) % 7];                                     \
+    FFN_DTILE(0, XA, WCUR, loadX(1, ao_, XB), E0)                             \
+    FFN_DTILE(1, XB, WCUR, loadX(2, ao_, XA), E1)                             \
+    FFN_DTILE(2, XA, WCUR, loadX(3, ao_, XB), E2)                             \
+    FFN_DTILE(3, XB, WCUR, loadX(4, ao_, XA), E3)                             \
+    FFN_DTILE(4, XA, WCUR, if (CONT) loadX(0, an_, XB), E4)                   \
+  }
+  auto dma_range = [&](int seg, int k0, int k1) {
+#pragma unroll
+    for (int k = k0; k < k1 && k < KS; ++k) dma_piece(seg, k);
+  };
+  // tap 0: the dz = 0 segment, W2, W3 (hidden), then W4
+  FFN_DTAP(0, X0, X1, W0, true, dma_range(1, 0, 3), dma_range(1, 3, 6),
+           dma_range(1, 6, KS), hiddenW(btaps[2], W2),
+           { hiddenW(btaps[3], W3); loadW(btaps[4], W4); })
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS + 12) : "memory");  // W1 landed
+  pinW(W1);
+  // tap 1: the dz = +1 segment, then W5
+  FFN_DTAP(1, X1, X0, W1, false, dma_range(2, 0, 3), dma_range(2, 3, 6),
+           dma_range(2, 6, KS), loadW(btaps[5], W0), (void)0)
+  // dz = 0, W2, W3 landed: newer are the dz = +1 DMAs and the two compiler taps
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS + 8) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  pinW(W2);
+  pinW(W3);
+  loadX(0, aoffs[2], X0);
+  FFN_DTAP(2, X0, X1, W2, true, loadW(btaps[6], W1), (void)0, (void)0, (void)0,
+           (void)0)
+  FFN_DTAP(3, X1, X0, W3, false, (void)0, (void)0, (void)0, (void)0, (void)0)
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // dz = +1 landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  loadX(0, aoffs[4], X0);
+  // residual input and bias of this thread's epilogue pieces
+  f32x4 skipv[NE][2], biasv[NE][2];
+  float seedv[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    skipv[k][0] = skipv[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    seedv[k] = 0.f;
+    if constexpr (HEAD) {
+      if ((tid & 7) == 0 && eok[k])
+        seedv[k] = a.seed_raw[(size_t)item * a.V + (v0 + ej[k])];
+    }
+    if constexpr (HEAD) {
+      biasv[k][0] = biasv[k][1] =
+          *reinterpret_cast<const f32x4*>(a.bias + (tid & 7) * 4);
+    } else {
+      biasv[k][0] = *reinterpret_cast<const f32x4*>(a.bias + ec[k] * 8);
+      biasv[k][1] = *reinterpret_cast<const f32x4*>(a.bias + ec[k] * 8 + 4);
+    }
+    if (ADD_SKIP) {
+      const float* xs = a.x_f32 + (long)item * (a.item_bytes >> 2);
+      if constexpr (HEAD) {
+        const int q = ec[k];
+        skipv[k][0] = *reinterpret_cast<const f32x4*>(
+            xs + (long)q * (a.sp_plane_bytes >> 2) + (long)ep[k] * 4);
+      } else {
+        const float* s =
+            xs + (long)(2 * ec[k]) * (a.sp_plane_bytes >> 2) + (long)ep[k] * 4;
+        skipv[k][0] = *reinterpret_cast<const f32x4*>(s);
+        skipv[k][1] = *reinterpret_cast<const f32x4*>(s + (a.sp_plane_bytes >> 2));
+      }
+    }
+  }
+  scaleW(W4);
+  FFN_DTAP(4, X0, X1, W4, true, (void)0, (void)0, (void)0, (void)0, (void)0)
+  scaleW(W0);
+  FFN_DTAP(5, X1, X0, W0, true, (void)0, (void)0, (void)0, (void)0, (void)0)
+  scaleW(W1);
+  FFN_DTAP(6, X0, X1, W1, false, (void)0, (void)0, (void)0, (void)0, (void)0)
+#undef FFN_DTAP
+#undef FFN_DTILE
+
+  const long long dbg_c2 = a.dbg ? clock64() : 0;
+  // ---- epilogue: the four waves' partial sums meet in LDS ----
+  // P[wave][position 0..159][32 ch] at a 144-B row stride; accumulator register
+  // 4 g + i of a lane is channel 8 g + 4 (lane >> 5) + i of position lane & 31.
+  __builtin_amdgcn_sched_barrier(0);  // (no accumulator leaves the AGPRs early)
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    char* P = ldsb + wave * (kDChunk * kDRowB) + li * kDRowB + lh * 16;
+#pragma unroll
+    for (int t = 0; t < kDTiles; ++t) {
+      // tile by tile (the scheduler would otherwise pull every accumulator out
+      // of the AGPRs at once and spill the kernel's long-lived values)
+      asm volatile("" : "+a"(acc[t]));  // still AGPRs here
+      const f32x16 s = acc[t];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(P + t * (32 * kDRowB) + g * 32) =
+            f32x4{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  constexpr float kScale = 4.8828125e-4f;  // 2^-11
+  unsigned range_max = 0;
+  unsigned head_above = 0;
+  if constexpr (HEAD) {
+    const int q = tid & 7;
+    const f32x4 hw4 = *reinterpret_cast<const f32x4*>(a.head_w + q * 4);
+    const float hbias = a.head_w[kFeatures];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int j = ej[k];
+      const char* pp = ldsb + j * kDRowB + q * 16;
+      f32x4 v = *reinterpret_cast<const f32x4*>(pp);
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        v += *reinterpret_cast<const f32x4*>(pp + w * (kDChunk * kDRowB));
+      v = v * kScale + biasv[k][0];
+      if (ADD_SKIP) v += skipv[k][0];
+      float partial = fmaxf(v[0], 0.f) * hw4[0];
+      partial = __builtin_fmaf(fmaxf(v[1], 0.f), hw4[1], partial);
+      partial = __builtin_fmaf(fmaxf(v[2], 0.f), hw4[2], partial);
+      partial = __builtin_fmaf(fmaxf(v[3], 0.f), hw4[3], partial);
+      partial += __shfl_xor(partial, 1);
+      partial += __shfl_xor(partial, 2);
+      partial += __shfl_xor(partial, 4);
+      bool above = false;
+      if (q == 0 && eok[k]) {
+        const size_t dv = (size_t)item * a.V + (v0 + j);
+        float s = seedv[k];
+        if (s != s) s = a.pad_value;
+        const float lg = s + (partial + hbias);
+        a.logits[dv] = lg;
+        above = lg >= a.move_thr;
+      }
+      head_above += (unsigned)__popcll(__ballot(above));  // wave-uniform
+    }
+    float* cnt = reinterpret_cast<float*>(ldsb + 4 * kDChunk * kDRowB);
+    if ((tid & 63) == 0) cnt[tid >> 6] = __uint_as_float(head_above);
+    __syncthreads();
+    if (tid == 0)
+      a.head_count[gc] = __float_as_uint(cnt[0]) + __float_as_uint(cnt[1]) +
+                         __float_as_uint(cnt[2]) + __float_as_uint(cnt[3]);
+  } else {
+    const __amdgpu_buffer_rsrc_t rs_sp = __builtin_amdgcn_make_buffer_rsrc(
+        a.out_sp + (long)item * a.item_bytes, 0, a.sp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(a.x_f32) + (long)item * a.item_bytes, 0, a.sp_bytes,
+        0x00020000);
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int j = ej[k], c = ec[k];
+      const char* pp = ldsb + j * kDRowB + c * 32;
+      f32x4 va = *reinterpret_cast<const f32x4*>(pp);
+      f32x4 vb = *reinterpret_cast<const f32x4*>(pp + 16);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        va += *reinterpret_cast<const f32x4*>(pp + w * (kDChunk * kDRowB));
+        vb += *reinterpret_cast<const f32x4*>(pp + w * (kDChunk * kDRowB) + 16);
+      }
+      va = va * kScale + biasv[k][0];
+      vb = vb * kScale + biasv[k][1];
+      if (KIND == 1) {
+        if (ADD_SKIP) {
+          va += skipv[k][0];
+          vb += skipv[k][1];
+        }
+        // the residual stream stays f32 (write-through: nothing dirty is left
+        // in L2 for the kernel boundary)
+        const unsigned xo = eok[k] ? (unsigned)(2 * c * (int)a.sp_plane_bytes +
+                                                ep[k] * 16)
+                                   : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, va),
+                                               rs_x, xo, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb),
+                                               rs_x, xo, (int)a.sp_plane_bytes, 16);
+      }
+      // what the next conv consumes: ReLU (conv_a's own, or the one in front of
+      // the next conv_a), then the split
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        va[cc] = va[cc] > 0.0f ? va[cc] : 0.0f;
+        vb[cc] = vb[cc] > 0.0f ? vb[cc] : 0.0f;
+      }
+      f16x8 hi, res;
+      split8_fp16(va, vb, hi, res, range_max);
+      const unsigned so = eok[k] ? (unsigned)(c * (int)a.sp_plane_bytes + ep[k] * 16)
+                                 : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rs_sp,
+                                             so, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, res), rs_sp,
+                                             so, (int)(4 * a.sp_plane_bytes), 16);
+    }
+    // an operand of the next layer left the fp16 range: the step is void, the
+    // host re-runs it with the bf16x3 scheme (ffn_step_result.range_error)
+    if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
+      *a.range_flag = a.range_tag;
+  }
+  if (a.dbg && gc == 0 && (tid & 63) == 0) {
+    long long* d = a.dbg + wave * 6;
+    d[0] = dbg_c0;
+    d[1] = dbg_c1;
+    d[2] = dbg_c2;
+    d[3] = clock64();
     d[4] = dbg_w0;
     d[5] = wall_clock64();
   }

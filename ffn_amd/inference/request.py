@@ -24,16 +24,29 @@ _SCALARS = (float, int, str, bool)
 class _Repeated(list):
   """Repeated field: a list with protobuf's `add()` for message elements."""
 
-  __slots__ = ('_ftype',)
+  __slots__ = ('_ftype', '_owner')
 
   def __init__(self, ftype, items=()):
     super().__init__(items)
     self._ftype = ftype
+    self._owner = None  # the message to mark present when an element is added
+
+  def _touch(self):
+    if self._owner is not None:
+      self._owner._attach()
 
   def add(self, **kwargs):
     item = self._ftype(**kwargs)
     self.append(item)
     return item
+
+  def append(self, item):
+    super().append(item)
+    self._touch()
+
+  def extend(self, items):
+    super().extend(items)
+    self._touch()
 
   def __deepcopy__(self, memo):
     return _Repeated(self._ftype, (copy.deepcopy(v, memo) for v in self))
@@ -65,6 +78,9 @@ class Message:
     ftype, default, repeated = fields[name]
     if repeated:
       values[name] = _Repeated(ftype)
+      # adding to a repeated field of a not-yet-present sub-message makes the
+      # sub-message present (protobuf semantics: c.image.channels.add())
+      values[name]._owner = self
       return values[name]
     if isinstance(ftype, type) and issubclass(ftype, Message):
       # Reading an unset sub-message yields a default instance that becomes
@@ -196,6 +212,48 @@ class DecoratedVolume(Message):
     return self.WhichOneof('volume_path')
 
 
+class MaskChannelConfig(Message):
+  """inference.proto:60-66: min_value <= channel <= max_value, or isin(values)."""
+  FIELDS = {
+      'channel': (int, 0, False),
+      'min_value': (float, 0.0, False),
+      'max_value': (float, 0.0, False),
+      'values': (int, None, True),
+      'invert': (bool, False, False),
+  }
+
+
+class ImageMaskOptions(Message):
+  FIELDS = {'channels': (MaskChannelConfig, None, True)}
+
+
+class VolumeMaskOptions(Message):
+  FIELDS = {
+      'mask': (DecoratedVolume, None, False),
+      'channels': (MaskChannelConfig, None, True),
+  }
+
+
+class CoordinateExpressionOptions(Message):
+  """inference.proto:77-86: a numpy expression over z, y, x index arrays (eval)."""
+  FIELDS = {'expression': (str, '', False)}
+
+
+class MaskConfig(Message):
+  """inference.proto:96-103."""
+  FIELDS = {
+      'volume': (VolumeMaskOptions, None, False),
+      'image': (ImageMaskOptions, None, False),
+      'coordinate_expression': (CoordinateExpressionOptions, None, False),
+      'invert': (bool, False, False),
+  }
+  ONEOFS = {'source': ('volume', 'image', 'coordinate_expression')}
+
+
+class MaskConfigs(Message):
+  FIELDS = {'masks': (MaskConfig, None, True)}
+
+
 class InferenceOptions(Message):
   FIELDS = {
       'init_activation': (float, 0.0, False),
@@ -226,12 +284,13 @@ class AlignmentOptions(Message):
 
 
 class SegmentationSource(Message):
-  """inference.proto:111-127 (the `mask` field is out of scope)."""
+  """inference.proto:111-127."""
   FIELDS = {
       'directory': (str, '', False),
       'threshold': (float, 0.0, False),
       'split_cc': (bool, False, False),
       'min_size': (int, 0, False),
+      'mask': (MaskConfigs, None, False),
   }
 
 
@@ -272,6 +331,9 @@ class InferenceRequest(Message):
       'seed_policy_args': (str, '', False),
       'alignment_options': (AlignmentOptions, None, False),
       'init_segmentation': (DecoratedVolume, None, False),
+      # exclusion masks (inference.proto:198-205)
+      'masks': (MaskConfig, None, True),
+      'seed_masks': (MaskConfig, None, True),
   }
 
   def __setattr__(self, name, value):

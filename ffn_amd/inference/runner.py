@@ -34,6 +34,16 @@ from . import storage
 from .inference_utils import timer_counter
 
 
+class _Box:
+  """start / size / end in XYZ (the part of bounding_box.BoundingBox that
+  MovementRestrictor reads: movement.py:283-284)."""
+
+  def __init__(self, start, size):
+    self.start = np.array(start)
+    self.size = np.array(size)
+    self.end = self.start + self.size
+
+
 class Runner:
   """Helper for managing FFN inference runs."""
 
@@ -123,9 +133,11 @@ class Runner:
             request.init_segmentation)
       else:
         self.init_seg_volume = None
+      self._mask_volumes = {}
+      self._shift_mask_volume = None
       if (request.HasField('shift_mask') and
           request.shift_mask.which_volume() is not None):
-        raise NotImplementedError('shift masks are out of scope (SURVEY 8a16)')
+        self._shift_mask_volume = storage.decorated_volume(request.shift_mask)
       alignment_options = request.alignment_options
       if alignment_options.type != alignment_options.NO_ALIGNMENT:
         raise NotImplementedError('Only NO_ALIGNMENT is implemented')
@@ -135,9 +147,63 @@ class Runner:
       self.executor.start_server()
 
   def make_restrictor(self, corner, subvol_size, image, alignment):
-    """Masks are not on the hot path (all-pass restrictor)."""
-    del corner, subvol_size, image, alignment
-    return None
+    """Builds a MovementRestrictor from the request's masks, seed masks and
+    shift mask (reference runner.py:218-305); None without any of them,
+    ALL_MASKED if nothing is left to segment."""
+    kwargs = {}
+    request = self.request
+    if len(request.masks):
+      with timer_counter(self.counters, 'load-mask'):
+        final_mask = storage.build_mask(request.masks, corner, subvol_size,
+                                        self._mask_volumes, image, alignment)
+        if np.all(final_mask):
+          logging.info('Everything masked.')
+          return self.ALL_MASKED
+        kwargs['mask'] = final_mask
+    if len(request.seed_masks):
+      with timer_counter(self.counters, 'load-seed-mask'):
+        seed_mask = storage.build_mask(request.seed_masks, corner, subvol_size,
+                                       self._mask_volumes, image, alignment)
+        if np.all(seed_mask):
+          logging.info('All seeds masked.')
+          return self.ALL_MASKED
+        kwargs['seed_mask'] = seed_mask
+    if self._shift_mask_volume is not None:
+      with timer_counter(self.counters, 'load-shift-mask'):
+        s = request.shift_mask_scale
+        scale = np.array((1, s, s))
+        shift_corner = np.array(corner) // scale
+        shift_size = -(-np.array(subvol_size) // scale)
+        shift_alignment = alignment.rescaled(np.array((1.0, 1.0, 1.0)) / scale)
+        src_corner, src_size = shift_alignment.expand_bounds(
+            shift_corner, shift_size, forward=False)
+        src_corner, src_size = storage.clip_subvolume_to_bounds(
+            src_corner, src_size, self._shift_mask_volume)
+        src_end = np.array(src_corner) + np.array(src_size)
+        expanded = np.asarray(self._shift_mask_volume[
+            0:2, int(src_corner[0]):int(src_end[0]),
+            int(src_corner[1]):int(src_end[1]),
+            int(src_corner[2]):int(src_end[2])])
+        shift_mask = np.array([
+            shift_alignment.align_and_crop(src_corner, expanded[i],
+                                           shift_corner, shift_size)
+            for i in range(2)])
+        shift_mask = alignment.transform_shift_mask(corner, s, shift_mask)
+        if request.HasField('shift_mask_fov'):
+          fov = request.shift_mask_fov
+          shift_mask_fov = _Box(
+              (fov.start.x, fov.start.y, fov.start.z),
+              (fov.size.x, fov.size.y, fov.size.z))
+        else:
+          diameter = np.array(self._model_info.input_image_size)
+          shift_mask_fov = _Box(-(diameter // 2), diameter)
+        kwargs.update({
+            'shift_mask': shift_mask,
+            'shift_mask_fov': shift_mask_fov,
+            'shift_mask_scale': request.shift_mask_scale,
+            'shift_mask_threshold': request.shift_mask_threshold,
+        })
+    return movement.MovementRestrictor(**kwargs) if kwargs else None
 
   def make_canvas(self, corner, subvol_size, **canvas_kwargs):
     """Builds the Canvas for a subvolume (reference runner.py:307-414)."""

@@ -214,6 +214,86 @@ def threshold_segmentation(segmentation_dir, corner, labels, threshold):
     labels[prob < threshold] = 0
 
 
+def build_mask(masks, corner, subvol_size, mask_volume_map=None, image=None,
+               alignment=None):
+  """Boolean exclusion mask of a subvolume (reference storage.py:323-411).
+
+  Args:
+    masks: iterable of MaskConfig messages
+    corner, subvol_size: the subvolume (z, y, x)
+    mask_volume_map: optional cache {serialized volume message: open volume}
+    image: the subvolume's image (zyx), needed by `image` mask sources
+    alignment: optional Alignment (identity if omitted)
+
+  Returns:
+    bool ndarray of `subvol_size`: the logical OR of every config's mask (each
+    the OR of its channel masks, optionally inverted); None without configs.
+  """
+  from . import align  # pylint:disable=g-import-not-at-top
+  final_mask = None
+  if mask_volume_map is None:
+    mask_volume_map = {}
+  corner = tuple(int(c) for c in corner)
+  subvol_size = tuple(int(c) for c in subvol_size)
+  if alignment is None:
+    alignment = align.Alignment(corner, subvol_size)  # identity
+  src_corner, src_size = alignment.expand_bounds(corner, subvol_size,
+                                                 forward=False)
+  for config in masks:
+    curr_mask = np.zeros(subvol_size, dtype=bool)
+    source_type = config.WhichOneof('source')
+    if source_type == 'coordinate_expression':
+      # pylint:disable=eval-used,unused-variable,possibly-unused-variable
+      z, y, x = np.mgrid[src_corner[0]:src_corner[0] + src_size[0],
+                         src_corner[1]:src_corner[1] + src_size[1],
+                         src_corner[2]:src_corner[2] + src_size[2]]
+      bool_mask = eval(config.coordinate_expression.expression)  # as the reference
+      # pylint:enable=eval-used,unused-variable,possibly-unused-variable
+      curr_mask |= alignment.align_and_crop(src_corner, bool_mask, corner,
+                                            subvol_size)
+    else:
+      if source_type == 'image':
+        assert image is not None
+        channels = config.image.channels
+        mask = np.asarray(image)[np.newaxis, ...]
+      elif source_type == 'volume':
+        channels = config.volume.channels
+        volume_key = config.volume.mask.SerializeToString()
+        if volume_key not in mask_volume_map:
+          mask_volume_map[volume_key] = decorated_volume(config.volume.mask)
+        volume = mask_volume_map[volume_key]
+        clipped_corner, clipped_size = clip_subvolume_to_bounds(
+            src_corner, src_size, volume)
+        clipped_end = np.array(clipped_corner) + np.array(clipped_size)
+        sel = tuple(slice(int(a), int(b))
+                    for a, b in zip(clipped_corner, clipped_end))
+        if volume.ndim == 4:
+          mask = np.asarray(volume[np.index_exp[:] + sel])
+        else:  # a 3-d volume is its own single channel
+          mask = np.asarray(volume[sel])[np.newaxis, ...]
+      else:
+        raise ValueError('Unsupported mask source: %s' % source_type)
+      for chan_config in channels:
+        channel_mask = mask[chan_config.channel, ...]
+        channel_mask = alignment.align_and_crop(src_corner, channel_mask,
+                                                corner, subvol_size)
+        if len(chan_config.values):
+          bool_mask = np.isin(channel_mask, list(chan_config.values))
+        else:
+          bool_mask = ((channel_mask >= chan_config.min_value) &
+                       (channel_mask <= chan_config.max_value))
+        if chan_config.invert:
+          bool_mask = np.logical_not(bool_mask)
+        curr_mask |= bool_mask
+    if config.invert:
+      curr_mask = np.logical_not(curr_mask)
+    if final_mask is None:
+      final_mask = curr_mask
+    else:
+      final_mask |= curr_mask
+  return final_mask
+
+
 def load_segmentation(segmentation_dir, corner, allow_cpoint=False,
                       threshold=None, split_cc=True, min_size=0,
                       mask_config=None):
@@ -222,8 +302,6 @@ def load_segmentation(segmentation_dir, corner, allow_cpoint=False,
   Returns (uint64 zyx array, {segment id: origin info}).  Connected-component
   splitting and dust removal run on the GPU (segmentation.clean_up).
   """
-  if mask_config is not None:
-    raise NotImplementedError('masks are out of scope (SURVEY.md 8)')
   target_path = get_existing_subvolume_path(segmentation_dir, corner,
                                             allow_cpoint)
   if target_path is None:
@@ -240,6 +318,10 @@ def load_segmentation(segmentation_dir, corner, allow_cpoint=False,
   output = seg.astype(np.uint64)
   if threshold is not None:
     threshold_segmentation(segmentation_dir, corner, output, threshold)
+  if mask_config is not None:  # exclusion mask (reference storage.py:470-472)
+    mask = build_mask(mask_config.masks, corner, seg.shape)
+    if mask is not None:
+      output[mask] = 0
   if split_cc or min_size:
     # (the reference passes min_size in clean_up's `connectivity` slot,
     # storage.py:476-478; 6-connectivity is what its callers get for the
@@ -264,6 +346,8 @@ def load_segmentation_from_source(source, corner):
     kwargs['split_cc'] = source.split_cc
   if source.HasField('min_size'):
     kwargs['min_size'] = source.min_size
+  if source.HasField('mask'):
+    kwargs['mask_config'] = source.mask
   return load_segmentation(source.directory, corner, **kwargs)
 
 

@@ -148,11 +148,13 @@ def forward(image, seed, blob, depth, features=32, stop_after=-1):
   return out[0] if squeeze else out
 
 
-def forward_torch(image, seed, variables, depth, threads=None):
+def forward_torch(image, seed, variables, depth, threads=None, f64=False):
   """The same forward pass restated on torch-CPU (oneDNN conv3d, f32): an
   independent implementation used to cross-check `forward` and as the stronger
   CPU baseline (BASELINE.md section 3 names it as the stand-in for the
-  reference's TF CPU path, TensorFlow being unavailable)."""
+  reference's TF CPU path, TensorFlow being unavailable).  f64: the whole
+  stack in double precision (f32 inputs and weights, logits rounded to f32 at
+  the end) -- the arithmetic every f32 implementation approximates."""
   import torch
   import torch.nn.functional as F
   if threads:
@@ -162,7 +164,7 @@ def forward_torch(image, seed, variables, depth, threads=None):
   squeeze = image.ndim == 3
   if squeeze:
     image, seed = image[None], seed[None]
-  cache = variables.setdefault('__torch__', {})
+  cache = variables.setdefault('__torch64__' if f64 else '__torch__', {})
 
   def wb(name):
     if name not in cache:
@@ -170,12 +172,17 @@ def forward_torch(image, seed, variables, depth, threads=None):
           variables['seed_update/%s/weights' % name])).permute(4, 3, 0, 1, 2)
       b = torch.from_numpy(np.ascontiguousarray(
           variables['seed_update/%s/biases' % name]))
+      if f64:
+        w, b = w.double(), b.double()
       cache[name] = (w.contiguous(), b)
     return cache[name]
 
   with torch.no_grad():
     s = torch.from_numpy(seed)
-    x = torch.stack([torch.from_numpy(image), s], dim=1)
+    im = torch.from_numpy(image)
+    if f64:
+      s, im = s.double(), im.double()
+    x = torch.stack([im, s], dim=1)
     net = torch.relu(F.conv3d(x, *wb('conv0_a'), padding=1))
     net = F.conv3d(net, *wb('conv0_b'), padding=1)
     for i in range(1, depth):
@@ -185,7 +192,7 @@ def forward_torch(image, seed, variables, depth, threads=None):
       net = F.conv3d(net, *wb('conv%d_b' % i), padding=1) + skip
     net = torch.relu(net)
     out = s + F.conv3d(net, *wb('conv_lom'))[:, 0]
-  out = out.numpy()
+  out = out.float().numpy()
   return out[0] if squeeze else out
 
 

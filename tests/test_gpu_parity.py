@@ -42,12 +42,13 @@ def _fov_inputs(rng, n=1):
 
 @pytest.mark.parametrize('variant,fuse_head,waves8', [
     (0, 1, 1), (1, 1, 1), (2, 1, 1), (2, 0, 1), (3, 1, 1), (3, 0, 1), (4, 1, 1),
-    (4, 0, 1), (3, 1, 0), (4, 1, 0), (4, 0, 0), (4, 1, 2), (4, 0, 2), (5, 1, 2), (5, 0, 2)])
+    (4, 0, 1), (3, 1, 0), (4, 1, 0), (4, 0, 0), (4, 1, 2), (4, 0, 2), (5, 1, 2), (5, 0, 2), (6, 1, 2)])
 def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head, waves8):
   """conv_variant 0 simple f32 MFMA, 1 padded pipelined, 2 compact (exact f32
   MFMA), 3 compact with bf16x3 split products, 4 with fp16 hi + scaled
   residual, 5 the same products on 32x32x16 MFMAs with the taps split over the
-  waves (conv32k); with the 1x1x1 head fused into the last conv or as its own
+  waves (conv32k), 6 the same on producer-split planes staged by LDS-DMA
+  (conv32d); with the 1x1x1 head fused into the last conv or as its own
   launch."""
   from oracle import ffn_oracle
   engine.set_option('conv_variant', variant)
@@ -89,7 +90,7 @@ def test_predict_is_deterministic_and_variants_agree(engine):
   a = engine.predict(seed, img)
   b = engine.predict(seed, img)
   assert np.array_equal(a, b)
-  for variant in (0, 1, 2, 3, 4, 5):
+  for variant in (0, 1, 2, 3, 4, 5, 6):
     engine.set_option('conv_variant', variant)
     c = engine.predict(seed, img)
     assert np.abs(a - c).max() <= 2e-5, variant
@@ -138,7 +139,7 @@ def test_anisotropic_fov(fib25_model):
   img = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
   seed = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
   blob = ffn_oracle.weights_blob(variables, 2)
-  for variant in (0, 1, 2, 3, 4):
+  for variant in (0, 1, 2, 3, 4, 5, 6):
     eng.set_option('conv_variant', variant)
     got = eng.predict(seed, img)
     want = ffn_oracle.forward(img, seed, blob, 2)

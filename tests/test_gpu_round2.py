@@ -59,7 +59,7 @@ def _device_canvas(exe, model, image, **kwargs):
 # ---------------------------------------------------------------------------
 # N1: the BASELINE-size workload against a reference-minted fixture
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize('variant', [2, 4, 5])
+@pytest.mark.parametrize('variant', [2, 4, 5, 6])
 def test_cells250_matches_reference_minted_run(hip_exe, fib25_model, variant):
   """configs[1] at full size: the 250^3 phantom bench.py runs, first row of its
   seed grid, 3,658 FoV steps.  The fixture was minted by the reference's own

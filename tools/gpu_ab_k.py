@@ -64,18 +64,22 @@ def main():
             (b, v, med, t.min(), med / 23 / b * (23.0 / 25.0),
              b * flop / (med * 1e-6) / 1e12))
   eng.set_option('debug_clock', 1)
-  for v, nmfma in ((4, 13.5 * 27.0), (5, 210.0)):
+  for v, nmfma in ((4, 13.5 * 27.0), (5, 210.0), (6, 210.0)):
     if v not in args.variants:
       continue
     eng.set_option('conv_variant', v)
-    eng.forward_resident(1, 3)
-    c = eng.debug_clocks()
-    for w in range(4):
-      tot, wall = c[w, 3] - c[w, 0], (c[w, 5] - c[w, 4]) * 10.0
-      print('variant %d wave %d: stage %d  loop %d  epilogue %d  total %d shader '
-            'cycles; wall %.0f ns -> %.2f GHz; %.2f cyc/MFMA' % (
-                v, w, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1], c[w, 3] - c[w, 2],
-                tot, wall, tot / max(wall, 1), (c[w, 2] - c[w, 1]) / nmfma))
+    for layer in ((3, 4, 22) if v == 6 else (3,)):  # conv_a, conv_b, fused head
+      eng.set_option('debug_layer', layer)
+      eng.forward_resident(1, 3)
+      c = eng.debug_clocks()
+      for w in range(4):
+        tot, wall = c[w, 3] - c[w, 0], (c[w, 5] - c[w, 4]) * 10.0
+        print('variant %d layer %d wave %d: stage %d  loop %d  epilogue %d  total %d '
+              'shader cycles; wall %.0f ns -> %.2f GHz; %.2f cyc/MFMA' % (
+                  v, layer, w, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1],
+                  c[w, 3] - c[w, 2], tot, wall, tot / max(wall, 1),
+                  (c[w, 2] - c[w, 1]) / nmfma))
+    eng.set_option('debug_layer', 3)
   if 5 in args.variants and args.ablate:
     # issue experiments on conv32k (results are wrong, timing only)
     eng.set_option('debug_clock', 1)

@@ -15,11 +15,18 @@ Outputs (committed):
   tests/golden/ref_canvas_*.npz    Canvas.segment_all runs: per-step FoV
                                    positions + queued moves, final
                                    segmentation, counters, origins
+  tests/golden/ref_masks.npz       storage.build_mask KATs and a Canvas run
+                                   under a MovementRestrictor (mask, seed
+                                   mask, shift mask)
   tests/golden/ref_canvas_cells250.npz   (--only cells250, ~15 min) the same at
                                    the BASELINE size: 3,658 FoV steps on the
                                    250^3 bench volume
+  tests/golden/ref_canvas_cells250_{onednn,f64}.npz   (--only cells250
+                                   --forward onednn|f64) the same run with the
+                                   torch-CPU f32 / f64 conv stack behind the
+                                   reference Canvas (3,725 steps)
 
-Usage:  python tools/make_golden.py [--only weights|movement|misc|canvas]
+Usage:  python tools/make_golden.py [--only weights|movement|misc|canvas|masks]
 """
 
 import argparse
@@ -152,10 +159,11 @@ def make_misc():
 class OracleClient(ref_executor.ExecutorClient):
   """ExecutorClient (executor.py:85-108) backed by the oracle forward."""
 
-  def __init__(self, blob, depth, log):
+  def __init__(self, blob, depth, log, forward_fn=None):
     self.blob = blob
     self.depth = depth
     self.log = log
+    self.forward_fn = forward_fn  # f(image, seed) -> logits; default: C oracle
 
   def start(self):
     return 0
@@ -164,12 +172,17 @@ class OracleClient(ref_executor.ExecutorClient):
     pass
 
   def predict(self, seed, image, fetches):
-    out = ffn_oracle.forward(image, seed, self.blob, self.depth)
+    if self.forward_fn is not None:
+      out = self.forward_fn(image[..., 0] if image.ndim == 5 else image,
+                            seed[..., 0] if seed.ndim == 5 else seed)
+    else:
+      out = ffn_oracle.forward(image, seed, self.blob, self.depth)
     return {'logits': out[..., None]}
 
 
 def run_reference_canvas(image_f32, blob, depth, fov, deltas, seeds,
-                         min_segment_size=1000):
+                         min_segment_size=1000, forward_fn=None,
+                         restrictor=None):
   """Drives the reference Canvas exactly as Runner does (runner.py:392-408)."""
   info = ref_model.ModelInfo(
       deltas=np.array(deltas[::-1]), pred_mask_size=np.array(fov[::-1]),
@@ -187,7 +200,8 @@ def run_reference_canvas(image_f32, blob, depth, fov, deltas, seeds,
   counters = ref_utils.Counters()
   trace = []
   canvas = ref_inference.Canvas(
-      info, OracleClient(blob, depth, trace), image_f32, o, counters=counters,
+      info, OracleClient(blob, depth, trace, forward_fn), image_f32, o,
+      counters=counters, restrictor=restrictor,
       movement_policy_fn=ref_movement.get_policy_fn(request, info))
 
   # Record each FoV step: position + the moves the policy queued.
@@ -243,7 +257,83 @@ def make_canvas_case(name, shape, seed, depth_weights, grid_step, grid_offsets,
   print(name, 'steps', len(steps), 'segments', len(origins), 'counters', keep)
 
 
-def make_cells250(blob, depth):
+def make_masks(blob, depth):
+  """Exclusion masks: storage.build_mask KATs (reference storage.py:323-411) and
+  a Canvas run restricted by a MovementRestrictor with a mask, a seed mask and a
+  shift mask (reference movement.py:247-336, inference.py:497-499,573-577)."""
+  from ffn.utils import bounding_box as ref_bbox
+  out = {}
+  rng = np.random.RandomState(5)
+  corner, size = (5, 7, 9), (20, 24, 28)
+  image = rng.randint(0, 256, size).astype(np.uint8)
+  labels = rng.randint(0, 6, (2,) + tuple(c + s + 3 for c, s in zip(corner, size))
+                       ).astype(np.uint64)  # a 4-d "volume" mask source
+  configs = []
+  c = inference_pb2.MaskConfig()
+  c.coordinate_expression.expression = '(x + 2 * y > 60) & (z % 3 == 0)'
+  configs.append(c)
+  c = inference_pb2.MaskConfig()
+  ch = c.image.channels.add()
+  ch.channel = 0
+  ch.min_value = 100
+  ch.max_value = 140
+  ch = c.image.channels.add()
+  ch.channel = 0
+  ch.values.extend([3, 250])
+  ch.invert = False
+  configs.append(c)
+  c = inference_pb2.MaskConfig()
+  c.volume.mask.hdf5 = 'unused:unused'
+  ch = c.volume.channels.add()
+  ch.channel = 1
+  ch.values.extend([2, 5])
+  ch = c.volume.channels.add()
+  ch.channel = 0
+  ch.min_value = 0
+  ch.max_value = 1
+  ch.invert = True
+  c.invert = True
+  configs.append(c)
+  vol_map = {configs[2].volume.mask.SerializeToString(): labels}
+  for i, sel in enumerate(([0], [1], [2], [0, 1, 2])):
+    m = ref_storage.build_mask([configs[k] for k in sel], corner, size,
+                               dict(vol_map), image)
+    out['build_mask_%d' % i] = np.asarray(m, bool)
+  out['bm_corner'] = np.array(corner)
+  out['bm_size'] = np.array(size)
+  out['bm_image'] = image
+  out['bm_labels'] = labels
+
+  # a restricted Canvas run on the cells72 phantom (94 steps unrestricted)
+  shape = (72, 64, 80)
+  vol = synthetic.cells_volume(shape, seed=5, membrane_dilate=2)
+  img = synthetic.normalize(vol)
+  seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16), step=16, offsets=(0,))
+  zz, yy, xx = np.mgrid[0:72, 0:64, 0:80]
+  mask = (xx > 50) & (yy < 30)              # no FoV centred here
+  seed_mask = (zz < 24) & (xx < 30)         # no segment started here
+  shift = np.zeros((2, 72, 32, 40), np.float32)  # scale 2 in y, x
+  shift[0, 40:43, 14:16, 18:20] = 7.0
+  shift[1, 24:26, 9:10, 24:26] = -5.0
+  restrictor = ref_movement.MovementRestrictor(
+      mask=mask, seed_mask=seed_mask, shift_mask=shift,
+      shift_mask_fov=ref_bbox.BoundingBox(start=(-6, -6, -4), size=(13, 13, 9)),
+      shift_mask_threshold=4, shift_mask_scale=2)
+  canvas, trace, counters = run_reference_canvas(
+      img, blob, depth, (33, 33, 33), (8, 8, 8), seeds, restrictor=restrictor)
+  cdict = {k: c.value for k, c in counters}
+  out.update(
+      run_volume=vol, run_seeds=seeds, run_mask=mask, run_seed_mask=seed_mask,
+      run_shift=shift, run_segmentation=np.array(canvas.segmentation),
+      run_steps=np.array([t[0] for t in trace], np.int32).reshape(-1, 3),
+      run_counters=json.dumps({k: v for k, v in cdict.items()
+                               if not k.endswith('-time-ms')}))
+  np.savez_compressed(os.path.join(GOLD, 'ref_masks.npz'), **out)
+  print('masks: run of', len(trace), 'steps; counters',
+        {k: v for k, v in cdict.items() if k.startswith('skip')})
+
+
+def make_cells250(blob, depth, forward='oracle', variables=None):
   """BASELINE configs[1] at its full size: the 250^3 cells phantom of bench.py
   (synthetic.cells_volume seed 1234), the first row of the bench's seed grid
   (14 seeds, 5 of which start a segment) -> 3,658 FoV steps through the
@@ -257,8 +347,19 @@ def make_cells250(blob, depth):
   seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))[:14]
   ffn_oracle.set_threads(os.cpu_count() or 1)
   t0 = time.time()
+  forward_fn, suffix = None, ''
+  if forward != 'oracle':
+    # the same run with another CORRECT implementation of the conv stack:
+    # 'onednn' = torch-CPU f32 (blocked / vectorised sums, the kind of kernel
+    # TensorFlow's CPU path also uses), 'f64' = double precision throughout
+    import functools
+    forward_fn = functools.partial(ffn_oracle.forward_torch, variables=variables,
+                                   depth=depth, threads=os.cpu_count() or 1,
+                                   f64=forward == 'f64')
+    suffix = '_' + forward
   canvas, trace, counters = run_reference_canvas(image, blob, depth,
-                                                 (33, 33, 33), (8, 8, 8), seeds)
+                                                 (33, 33, 33), (8, 8, 8), seeds,
+                                                 forward_fn=forward_fn)
   wall = time.time() - t0
   seg = np.array(canvas.segmentation)
   steps = np.array([t[0] for t in trace], np.int16).reshape(-1, 3)
@@ -274,8 +375,8 @@ def make_cells250(blob, depth):
   keep = {k: v for k, v in cdict.items() if not k.endswith('-time-ms')}
   final_seed = np.array(canvas.seed)
   np.savez_compressed(
-      os.path.join(GOLD, 'ref_canvas_cells250.npz'),
-      volume_sha256=hashlib.sha256(vol.tobytes()).hexdigest(), seeds=seeds,
+      os.path.join(GOLD, 'ref_canvas_cells250%s.npz' % suffix),
+      forward=forward, volume_sha256=hashlib.sha256(vol.tobytes()).hexdigest(), seeds=seeds,
       segmentation=seg.astype(np.int8), steps=steps, n_moves=n_moves,
       move_scores=move_scores, move_coords=move_coords,
       origins=json.dumps(origins), counters=json.dumps(keep), depth=depth,
@@ -290,6 +391,11 @@ def make_cells250(blob, depth):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--only', default='')
+  ap.add_argument('--forward', default='oracle',
+                  choices=['oracle', 'onednn', 'f64'],
+                  help='cells250: the conv-stack implementation behind the '
+                  "reference Canvas (default: the C oracle's sequential f32 "
+                  'fmaf chain)')
   args = ap.parse_args()
   os.makedirs(GOLD, exist_ok=True)
   if args.only in ('', 'weights'):
@@ -303,9 +409,12 @@ def main():
     blob = ffn_oracle.weights_blob(v, 12)
     make_canvas_case('cells56', (56, 56, 56), 11, (blob, 12), 16, (0, 8), 1)
     make_canvas_case('cells72', (72, 64, 80), 5, (blob, 12), 16, (0,), 2)
+  if args.only in ('', 'masks'):
+    v = tf_checkpoint.load_checkpoint(CKPT)
+    make_masks(ffn_oracle.weights_blob(v, 12), 12)
   if args.only == 'cells250':  # slow: only on request
     v = tf_checkpoint.load_checkpoint(CKPT)
-    make_cells250(ffn_oracle.weights_blob(v, 12), 12)
+    make_cells250(ffn_oracle.weights_blob(v, 12), 12, args.forward, v)
 
 
 if __name__ == '__main__':
