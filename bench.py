@@ -42,6 +42,50 @@ VOXELS = FOV[0] * FOV[1] * FOV[2]
 # count 2 * 27 taps * 32 cin * 32 cout per voxel x 35,937 voxels.
 CONV32_FLOPS = 2.0 * 27 * 32 * 32 * VOXELS
 STEP_FLOPS = 2.0 * (2 * 27 * 32 + 23 * 27 * 32 * 32 + 32) * VOXELS
+CONFIG = 'c1'
+VOLUME_ZYX = (250, 250, 250)
+
+
+def configure(args):
+  """--config c1 (default): BASELINE configs[1].  c5: the anisotropic hi-res
+  model of configs[4] -- depth 18, FoV zyx (21, 41, 41), deltas (5, 10, 10),
+  68.4 GFLOP per FoV step -- with random weights (no checkpoint of that shape
+  ships with the reference) on one (128, 384, 384) tile of its volume."""
+  global FOV, DELTAS, DEPTH, VOXELS, CONV32_FLOPS, STEP_FLOPS, CONFIG, VOLUME_ZYX
+  CONFIG = args.config
+  if args.config == 'c5':
+    FOV, DELTAS, DEPTH = (21, 41, 41), (5, 10, 10), 18
+    VOLUME_ZYX = (128, 384, 384) if args.volume == 250 else (
+        max(args.volume // 3, 64), args.volume, args.volume)
+  else:
+    VOLUME_ZYX = (args.volume,) * 3
+  VOXELS = FOV[0] * FOV[1] * FOV[2]
+  CONV32_FLOPS = 2.0 * 27 * 32 * 32 * VOXELS
+  STEP_FLOPS = 2.0 * (2 * 27 * 32 + (2 * DEPTH - 1) * 27 * 32 * 32 + 32) * VOXELS
+
+
+def model_variables():
+  """TF-named weight arrays: the reference's FIB-25 checkpoint (c1), or -- c5 --
+  seeded random weights (normal, std 0.02) with a head bias that makes the
+  object map grow, so that the flood fill keeps producing FoV steps."""
+  if CONFIG == 'c1':
+    with np.load(os.path.join(ROOT, 'tests', 'golden', 'fib25_weights.npz')) as d:
+      return {k: d[k] for k in d.files}
+  rng = np.random.RandomState(18)
+  v = {}
+
+  def conv(name, cin, cout, k=3, bias=0.0):
+    v['seed_update/%s/weights' % name] = rng.normal(
+        0, 0.02, (k, k, k, cin, cout)).astype(np.float32)
+    v['seed_update/%s/biases' % name] = np.full((cout,), bias, np.float32)
+
+  conv('conv0_a', 2, FEATURES)
+  conv('conv0_b', FEATURES, FEATURES)
+  for i in range(1, DEPTH):
+    conv('conv%d_a' % i, FEATURES, FEATURES)
+    conv('conv%d_b' % i, FEATURES, FEATURES)
+  conv('conv_lom', FEATURES, 1, k=1, bias=5.5)  # pad (-2.94) + 5.5 > move threshold
+  return v
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA
 # conv32x3 (default): every f32 product = 6 exact bf16 x bf16 products on the
@@ -86,8 +130,7 @@ def load_model():
   model = convstack_3d.ConvStack3DFFNModel(
       fov_size=list(FOV[::-1]), deltas=list(DELTAS[::-1]), batch_size=1,
       depth=DEPTH, features=FEATURES)
-  model.load_checkpoint(os.path.join(ROOT, 'tests', 'golden',
-                                     'fib25_weights.npz'))
+  model.set_variables(model_variables())
   return model
 
 
@@ -124,7 +167,7 @@ def run_gpu(args, rank, local_rank, world):
   if args.sync_mode is not None:
     eng.set_option('sync_mode', args.sync_mode)
 
-  shape = (args.volume,) * 3
+  shape = VOLUME_ZYX
   if args.workload == 'cells':
     vol = synthetic.cells_volume(shape, seed=1234 + rank)
   else:
@@ -319,6 +362,158 @@ def run_gpu(args, rank, local_rank, world):
   return result
 
 
+def run_sharded(args, rank, local_rank, world):
+  """--mode sharded: BASELINE configs[3] in shape -- ONE volume, cut into
+  overlapping sub-boxes by `tile_volume` (ffn/utils/bounding_box.py:250-412),
+  dealt round-robin to the ranks, every rank advancing its sub-boxes
+  concurrently (`Runner.run_many`, one batched engine call per round), then the
+  TIMED assembly on the devices: id offsets (all_gather), owned cores into one
+  int32 volume, all_reduce(MAX) over RCCL, margin histograms, union-find
+  edges (all_gather), relabel.  No voxel crosses PCIe before the result is
+  asked for."""
+  import tempfile
+  import torch
+  import torch.distributed as dist
+  from ffn_amd import distributed as ffn_dist
+  from ffn_amd import synthetic
+  from ffn_amd.inference import runner as runner_lib
+
+  if not torch.cuda.is_available():
+    raise RuntimeError('bench.py needs an MI355X: no CPU fallback exists')
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  if world > 1:
+    dist.init_process_group('nccl', device_id=device)
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  n = args.sharded_volume
+  shape = (n, n, n)
+  vol = synthetic.cells_volume(shape, seed=4321)  # the SAME volume on every rank
+  request = make_request()
+  request.seed_policy = 'PolicyPeaks'
+  out_dir = tempfile.mkdtemp(prefix='ffn_sharded_%d_' % rank)
+  request.segmentation_output_dir = out_dir
+  request.model_checkpoint_path = os.path.join(ROOT, 'tests', 'golden',
+                                               'fib25_weights.npz')
+  run = runner_lib.Runner(device_id=local_rank)
+  run.start(request, batch_size=args.sharded_batch, direct=True,
+            image_volume=vol)
+  sub = (args.sharded_sub,) * 3
+  ov = tuple(FOV)
+  boxes = ffn_dist.tile_volume(shape, sub, ov, back_shift=True)
+  mine = ffn_dist.assign_round_robin(boxes, rank, world)
+  asm = ffn_dist._assembly_for(device)
+  results = [None] * len(mine)
+
+  def collect(index, canvas):
+    results[index] = (mine[index], asm.labels(canvas.segmentation))
+
+  barrier()
+  t0 = time.perf_counter()
+  run.run_many([(b.corner, b.size) for b in mine],
+               batch_size=args.sharded_batch, save=False, on_done=collect)
+  torch.cuda.synchronize()
+  t_seg_local = time.perf_counter() - t0
+  barrier()
+  t_seg = time.perf_counter() - t0
+  steps = run.counters['update_at-calls'].value
+  voxels = run.counters['voxels-segmented'].value
+  # timed assembly, in two parts (after one untimed pass: allocations, code
+  # objects and the RCCL communicator are set up by the first call)
+  merged, _, _, _ = ffn_dist.merge_segmentations(
+      results, shape, rank, world, device, assembly=asm, keep_on_device=True)
+  del merged
+  barrier()
+  tm = time.perf_counter()
+  merged, offsets, held, _ = ffn_dist.merge_segmentations(
+      results, shape, rank, world, device, assembly=asm, keep_on_device=True)
+  barrier()
+  merge_ms = (time.perf_counter() - tm) * 1e3
+  plain_ids = int(torch.unique(merged).numel()) - 1
+  del merged
+  barrier()
+  tr = time.perf_counter()
+  merged, offsets, edges, roots = ffn_dist.reconcile_segmentations(
+      results, shape, rank, world, device, keep_on_device=True, assembly=asm)
+  barrier()
+  reconcile_total_ms = (time.perf_counter() - tr) * 1e3
+  final_ids = int(torch.unique(merged).numel()) - 1
+  tot = torch.tensor([float(steps), float(voxels), t_seg_local],
+                     dtype=torch.float64, device=device)
+  if world > 1:
+    part = tot.clone()
+    dist.all_reduce(tot[:2], op=dist.ReduceOp.SUM)
+    dist.all_reduce(part[2:], op=dist.ReduceOp.MAX)
+    tot[2] = part[2]
+  check = None
+  if world == 1 and not args.no_cpu_baseline:
+    # checker leg (untimed): the assembly against its numpy specification
+    from oracle import labels_oracle
+    host_results = [(b, seg.cpu().numpy()) for b, seg in held]
+    want, want_edges, _ = labels_oracle.reconcile(
+        host_results, shape, ffn_dist.MIN_OVERLAP_VOXELS,
+        ffn_dist.MIN_OVERLAP_FRACTION)
+    got = merged.cpu().numpy()
+    check = {'ids_expected': int(len(np.unique(want)) - 1),
+             'ids_got': int(len(np.unique(got)) - 1),
+             'volume_equal': bool(np.array_equal(got, want)),
+             'edges_equal': bool(np.array_equal(edges, want_edges))}
+  run.stop_executor()
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+  if rank != 0:
+    return
+  steps_all, voxels_all, t_seg_max = (float(v) for v in tot.tolist())
+  out = {
+      'metric': 'FoV-steps/sec (one %d^3 volume sharded by sub-box over %d GPU(s))'
+                % (n, world),
+      'value': round(steps_all / t_seg, 2),
+      'unit': 'FoV-steps/s',
+      'n_gpus': world,
+      'steps': int(steps_all),
+      'warmup': 0,
+      'ms_per_step': round(1e3 * t_seg / max(steps_all, 1), 4),
+      'higher_is_better': True,
+      'scaling': 'strong',
+      'vs_baseline': None,
+      'dtype': 'f32 (split products on the fp16 MFMA)',
+      'data': 'synthetic',
+      'config': {
+          'workload': ('configs[3]-shaped: ONE synthetic cells %d^3 uint8 volume, '
+                       '%d overlapping sub-boxes of %d^3 (overlap = FoV) dealt '
+                       'round-robin, %d concurrent canvases per GPU, GPU '
+                       'PolicyPeaks seeds, FIB-25 weights; assembly on the devices'
+                       % (n, len(boxes), args.sharded_sub, args.sharded_batch)),
+          'volume': list(shape),
+          'sub_boxes': len(boxes),
+          'parallelism': 'sub-boxes sharded over ranks; collectives only in the '
+                         'final assembly (RCCL)',
+      },
+      'segmentation_seconds': round(t_seg, 3),
+      'voxels_segmented_per_s': round(voxels_all / t_seg, 1),
+      'merge_ms': round(merge_ms, 2),
+      'reconcile_ms': round(reconcile_total_ms - merge_ms, 2),
+      'assembly': {
+          'merge_ms': round(merge_ms, 2),
+          'merge_plus_reconcile_ms': round(reconcile_total_ms, 2),
+          'how': 'all_gather(id offsets) + cores -> one device int32 volume + '
+                 'all_reduce(MAX) over RCCL; then margin pair histograms on the '
+                 'GPU, all_gather(edges), union-find, table relabel in place; '
+                 'wall clock between barriers, max over ranks',
+          'ids_before_reconcile': plain_ids,
+          'ids_after_reconcile': final_ids,
+          'merge_edges': int(len(edges)),
+          'check_vs_specification': check,
+      },
+  }
+  print(json.dumps(out))
+
+
 def cpu_baseline(args):
   """Oracle port on a bounded sample of the same workload, on this host's cores.
 
@@ -329,16 +524,15 @@ def cpu_baseline(args):
   The faster is reported as `value`."""
   from ffn_amd import synthetic
   from oracle import ffn_oracle
-  with np.load(os.path.join(ROOT, 'tests', 'golden', 'fib25_weights.npz')) as d:
-    variables = {k: d[k] for k in d.files}
+  variables = model_variables()
   blob = ffn_oracle.weights_blob(variables, DEPTH)
-  shape = (args.volume,) * 3
+  shape = VOLUME_ZYX
   if args.workload == 'cells':
     vol = synthetic.cells_volume(shape, seed=1234)
   else:
     vol = synthetic.noise_volume(shape, seed=0)
   image = synthetic.normalize(vol)
-  seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))
+  seeds = ffn_oracle.grid_seeds(shape, tuple(f // 2 for f in FOV))
   ncpu = os.cpu_count() or 1
 
   class _Stop(Exception):
@@ -517,6 +711,15 @@ def main():
                   help='untimed spin-up (extra FoV steps) before the warmup '
                   'steps are counted')
   ap.add_argument('--volume', type=int, default=250)
+  ap.add_argument('--mode', choices=['stream', 'sharded'], default='stream',
+                  help='stream: the headline (one seed stream per GPU); sharded: '
+                  'one volume tiled into sub-boxes, timed assembly (configs[3])')
+  ap.add_argument('--sharded-volume', type=int, default=320)
+  ap.add_argument('--sharded-sub', type=int, default=176)
+  ap.add_argument('--sharded-batch', type=int, default=8)
+  ap.add_argument('--config', choices=['c1', 'c5'], default='c1',
+                  help='c1: BASELINE configs[1] (the headline); c5: the depth-18 '
+                  'anisotropic model of configs[4], random weights')
   ap.add_argument('--workload', choices=['cells', 'noise'], default='cells')
   ap.add_argument('--conv-variant', type=int, default=None)
   ap.add_argument('--profile-every', type=int, default=8)
@@ -531,6 +734,7 @@ def main():
                   'loop inside the library; python: one ffn_canvas_step call '
                   'per step from the interpreter')
   args = ap.parse_args()
+  configure(args)
 
   rank, local_rank, world = _dist_env()
   if world != args.gpus:
@@ -540,6 +744,9 @@ def main():
                      'distributed.run --nproc-per-node %d' %
                      (args.gpus, world, args.gpus))
 
+  if args.mode == 'sharded':
+    run_sharded(args, rank, local_rank, world)
+    return
   res = run_gpu(args, rank, local_rank, world)
   if rank != 0:
     return
@@ -564,11 +771,14 @@ def main():
     pass
   variant = res.get('conv_variant', 4)
   PEAK_F16_MFMA_TFLOPS = PEAK_BF16_MFMA_TFLOPS  # same dense rate on gfx950
-  if variant in (3, 4, 5):
+  if variant in (3, 4, 5, 6):
     products = BF16X3_PRODUCTS if variant == 3 else 3
     mfma = {3: 'v_mfma_f32_16x16x32_bf16', 4: 'v_mfma_f32_16x16x32_f16',
-            5: 'v_mfma_f32_32x32x16_f16'}[variant]
-    shape = ('conv32k (3x3x3 32->32 implicit GEMM, 4-wave workgroups, the 27 taps '
+            5: 'v_mfma_f32_32x32x16_f16', 6: 'v_mfma_f32_32x32x16_f16'}[variant]
+    shape = ('conv32d (3x3x3 32->32 implicit GEMM on producer-split fp16 planes '
+             'staged by LDS-DMA, 4-wave workgroups, the 27 taps split over the '
+             'waves, one accumulator per tile' if variant == 6 else
+             'conv32k (3x3x3 32->32 implicit GEMM, 4-wave workgroups, the 27 taps '
              'split over the waves' if variant == 5 else
              'conv32w8 (3x3x3 32->32 implicit GEMM, 8-wave workgroups')
     kernel_name = (
@@ -593,7 +803,9 @@ def main():
     executed_ratio = 1
     dtype = 'f32'
   out = {
-      'metric': 'FoV-steps/sec (flood-filling inference loop, 250^3 volume)',
+      'metric': ('FoV-steps/sec (flood-filling inference loop, 250^3 volume)'
+                 if CONFIG == 'c1' else
+                 'FoV-steps/sec (flood-filling inference loop, configs[4] model)'),
       'value': round(steps_per_s, 2),
       'unit': 'FoV-steps/s',
       'n_gpus': world,
@@ -608,11 +820,16 @@ def main():
       'dtype': dtype,
       'data': 'synthetic',
       'config': {
-          'workload': ('configs[1] single-seed single-GPU: depth=12 fov=33^3 '
-                       'deltas=8, synthetic %s %d^3 uint8 volume per GPU, '
-                       'FIB-25 weights, device-resident canvas, batch 1'
-                       % (args.workload, args.volume)),
-          'volume': [args.volume] * 3,
+          'workload': (
+              'configs[1] single-seed single-GPU: depth=12 fov=33^3 '
+              'deltas=8, synthetic %s %d^3 uint8 volume per GPU, '
+              'FIB-25 weights, device-resident canvas, batch 1'
+              % (args.workload, args.volume) if CONFIG == 'c1' else
+              'configs[4] model on one tile: depth=18 fov zyx %s deltas %s, '
+              'synthetic %s %s uint8 volume per GPU, random weights, '
+              'device-resident canvas, batch 1 (NOT the headline config)'
+              % (list(FOV), list(DELTAS), args.workload, list(VOLUME_ZYX))),
+          'volume': list(VOLUME_ZYX),
           'parallelism': 'independent volume per rank (no data-path collective)',
           'host_loop': ('ffn_canvas_segment_at (segment loop inside the library)'
                         if args.host_loop == 'native' else
@@ -664,9 +881,10 @@ def main():
           'traffic': traffic,
           'traffic_source': traffic_source,
           'avg_launch_us': round(avg_conv_ms * 1e3, 3),
-          'timing': ('HIP events around the 23-launch conv chain of every %dth '
-                     'step, / 23 (includes inter-kernel gaps)' %
-                     args.profile_every if args.profile_mode == 2 else
+          'timing': ('HIP events around the %d-launch conv chain of every %dth '
+                     'step, / %d (includes inter-kernel gaps)' %
+                     (2 * DEPTH - 1, args.profile_every, 2 * DEPTH - 1)
+                     if args.profile_mode == 2 else
                      'HIP event pair around each conv launch of every %dth step'
                      % args.profile_every),
           'launches': int(res['conv_launches']),

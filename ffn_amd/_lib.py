@@ -178,6 +178,20 @@ SIGNATURES = {
              ctypes.POINTER(ctypes.c_int64)]),
     'ffn_labels_last_timing': (_I, [_P, ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(ctypes.c_double)]),
+    'ffn_labels_copy_device': (_I, [_P, _P, ctypes.c_size_t, _P]),
+    'ffn_labels_copy_canvas': (_I, [_P, _P, _P]),
+    'ffn_labels_place_core_device': (
+        _I, [_P, _P, ctypes.POINTER(ctypes.c_int64),
+             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+             ctypes.c_int32, _P, ctypes.POINTER(ctypes.c_int64),
+             ctypes.POINTER(ctypes.c_int64)]),
+    'ffn_labels_margin_pairs_device': (
+        _I, [_P, _P, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32,
+             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _P,
+             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+             ctypes.c_size_t, _P, _P, _P, ctypes.POINTER(ctypes.c_size_t)]),
+    'ffn_labels_remap_device': (_I, [_P, _P, ctypes.c_size_t, ctypes.c_size_t,
+                                     _P, _P]),
     # include/ffn_seeds.h
     'ffn_seeder_create': (_I, [_I, ctypes.POINTER(_P)]),
     'ffn_seeder_destroy': (None, [_P]),

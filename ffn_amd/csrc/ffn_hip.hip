@@ -105,6 +105,13 @@ struct ffn_engine {
   float* rawX = nullptr;
   float* rawS = nullptr;
   bool d_ok = false;
+  // conv32d with 96-voxel chunks, two workgroups per CU (variant 7)
+  bool e_ok = false;
+  int batch_chunks = 1;   // option: variant 6 uses the 96-voxel form for n >= 2
+  bool small_now = false; // the stack being queued uses the 96-voxel form
+  int nchunks_e = 0;
+  size_t lds_bytes_e = 0;
+  int esched_aoff[4 * 8] = {};
   bool d_weights_ok = true;      // every |weight| x 2^11 inside the fp16 range
   uint16_t* wpackd = nullptr;    // [28][khalf][plane hi, res][64][8] fp16 per layer
   size_t wpackd_layer = 0;       // halves per layer
@@ -116,7 +123,8 @@ struct ffn_engine {
   bool fp16_ok = true;           // every weight inside the fp16 range
   int conv_variant = 4;       // 0 conv32, 1 conv32p, 2 conv32c, 3 conv32x3 bf16x3, 4 fp16x2,
                               // 5 fp16x2 on 32x32x16 with the taps split over the waves,
-                              // 6 the same on producer-split planes + LDS-DMA staging
+                              // 6 the same on producer-split planes + LDS-DMA staging,
+                              // 7 = 6 with 96-voxel chunks, two workgroups per CU
   float* h_io = nullptr;      // pinned staging of ffn_predict: seed, image, logits
   float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
   float* up_seed = nullptr;
@@ -318,6 +326,23 @@ int set_lds_attr_d(size_t bytes) {
   FFN_D_ATTRS(10);
 #undef FFN_D_ATTRS
 #undef FFN_D_ATTR
+  return FFN_OK;
+}
+
+constexpr int kERows = 208, kETiles = 3, kEPieces = 7;
+
+int set_lds_attr_e(size_t bytes) {
+#define FFN_E_ATTR(KIND, SK, HEADV)                                               \
+  HIP_TRY(hipFuncSetAttribute(                                                    \
+      reinterpret_cast<const void*>(                                              \
+          &conv32d_kernel<KIND, SK, kEPieces, HEADV, kETiles, kERows, 2>),        \
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes))
+  FFN_E_ATTR(0, false, false);
+  FFN_E_ATTR(1, false, false);
+  FFN_E_ATTR(1, true, false);
+  FFN_E_ATTR(1, false, true);
+  FFN_E_ATTR(1, true, true);
+#undef FFN_E_ATTR
   return FFN_OK;
 }
 
@@ -664,7 +689,7 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
 // The split-plane layout of variant 6 and the f32 layout of the others keep their
 // zero padding in different bytes of the same allocations: re-zero on a change.
 int switch_variant(ffn_engine* e, int value) {
-  if ((value == 6) != (e->conv_variant == 6)) {
+  if ((value >= 6) != (e->conv_variant >= 6)) {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemsetAsync(e->act_base, 0,
                            (size_t)3 * e->max_batch * e->g.act_stride * sizeof(float),
@@ -691,18 +716,20 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   a.sp_plane_bytes = positions * 16;
   a.XS = g.XS;
   a.plane = g.plane;
-  a.nchunks = e->nchunks_k;
+  const bool small = e->small_now;  // 96-voxel chunks, 2 workgroups / CU
+  const int nchunks = small ? e->nchunks_e : e->nchunks_k;
+  a.nchunks = nchunks;
   a.V = g.V;
   a.fx = g.fx;
   a.fyfx = g.fy * g.fx;
-  a.total_slots = n * e->nchunks_k;
+  a.total_slots = n * nchunks;
   a.slots_per_xcd = (a.total_slots + 7) / 8;
   auto magic = [](int d) { return (unsigned)(((1ull << 32) + d - 1) / d); };
-  a.magic_nchunks = magic(e->nchunks_k);
+  a.magic_nchunks = magic(nchunks);
   a.magic_fyfx = magic(g.fy * g.fx);
   a.magic_fx = magic(g.fx);
   a.sp_bytes = (unsigned)((size_t)g.act_stride * sizeof(float) - (size_t)g.guard * 32);
-  std::memcpy(a.aoff, e->dsched_aoff, sizeof(a.aoff));
+  std::memcpy(a.aoff, small ? e->esched_aoff : e->dsched_aoff, sizeof(a.aoff));
   std::memcpy(a.btap, e->dsched_btap, sizeof(a.btap));
   a.dbg = (e->dbg_clock && layer == e->dbg_layer) ? e->d_dbg : nullptr;
   a.head_w = e->weights + e->wl_off;
@@ -726,7 +753,17 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
 #define FFN_D_LAUNCH(KSV, HEADV)                                                 \
   hipLaunchKernelGGL((conv32d_kernel<KIND, SK, KSV, HEADV>), grid, block,        \
                      e->lds_bytes_d, e->stream, a)
-  if (head.on) {
+#define FFN_E_LAUNCH(HEADV)                                                      \
+  hipLaunchKernelGGL(                                                            \
+      (conv32d_kernel<KIND, SK, kEPieces, HEADV, kETiles, kERows, 2>), grid,     \
+      block, e->lds_bytes_e, e->stream, a)
+  if (small) {
+    if (head.on) {
+      if constexpr (KIND == 1) FFN_E_LAUNCH(true);
+    } else {
+      FFN_E_LAUNCH(false);
+    }
+  } else if (head.on) {
     if constexpr (KIND == 1) {
       if (ks == 8) FFN_D_LAUNCH(8, true);
       else if (ks == 9) FFN_D_LAUNCH(9, true);
@@ -738,6 +775,7 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
     else FFN_D_LAUNCH(10, false);
   }
 #undef FFN_D_LAUNCH
+#undef FFN_E_LAUNCH
   if (prof) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   return FFN_OK;
 }
@@ -758,7 +796,7 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     hipLaunchKernelGGL(conv0a_kernel, dim3(tz * ty * tx, n), dim3(kC0Threads), 0,
                        e->stream, si, pad_value, W + e->w0a_off, W + e->b0a_off,
                        e->bufT, e->seed_raw, g, ty, tx);
-  else if (e->conv_variant == 6) {
+  else if (e->conv_variant >= 6) {
     Conv0SplitOut so;
     so.out_sp = reinterpret_cast<char*>(e->rawT) + (size_t)g.guard * 16;
     so.sp_plane_bytes = (g.act_stride / kFeatures) * 16;
@@ -785,7 +823,13 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     e->chain_launches_pending.push_back(2 * e->depth - 1);
     HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   }
-  if (e->conv_variant == 6) {
+  // conv32d: one workgroup per CU (160-voxel chunks) for a single FoV; with
+  // several FoVs in flight the 96-voxel form (two workgroups per CU, the same
+  // arithmetic bit for bit) overlaps one workgroup's MFMAs with the other's
+  // staging and epilogue
+  e->small_now = e->conv_variant == 7 ||
+                 (e->conv_variant == 6 && e->batch_chunks && n >= 2 && e->e_ok);
+  if (e->conv_variant >= 6) {
     // T' -> (X, X') -> T' -> ... ; the head is always fused into the last conv_b
     rc = launch_conv32d<1, false>(e, n, e->rawT, e->rawS, 0);
     if (rc) return rc;
@@ -848,7 +892,8 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   }
   if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   if (head_fused) {
-    e->count_blocks = e->conv_variant >= 5 ? e->nchunks_k : e->nchunks_c;
+    e->count_blocks = e->small_now ? e->nchunks_e
+                      : e->conv_variant >= 5 ? e->nchunks_k : e->nchunks_c;
   } else {
     e->count_blocks = kHeadBlocks;
     hipLaunchKernelGGL(head_kernel, dim3(kHeadBlocks, n), dim3(256), 0, e->stream,
@@ -924,7 +969,7 @@ int grid_for(long total, int block = 256) {
 
 extern "C" {
 
-int ffn_abi_version(void) { return 4; }
+int ffn_abi_version(void) { return 5; }
 
 const char* ffn_last_error(void) { return g_error.c_str(); }
 
@@ -1010,7 +1055,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   E_TRY(hipMemset(e->up_image, 0, vbytes));
   E_TRY(hipMemset(e->up_seed, 0, vbytes));
   E_TRY(hipMalloc(&e->count, sizeof(unsigned) * max_batch *
-                                  std::max<size_t>(kHeadBlocks, (g.V + kCChunk - 1) / kCChunk)));
+                                  std::max<size_t>(kHeadBlocks, (g.V + 95) / 96)));
   E_TRY(hipMalloc(&e->d_items, sizeof(StepItem) * 2 * max_batch));
   E_TRY(hipHostMalloc(&e->h_items, sizeof(StepItem) * 2 * max_batch,
                       hipHostMallocDefault));
@@ -1102,6 +1147,32 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
           e->dsched_btap[w * 8 + j] = dummy ? 27 : s;
         }
       e->d_ok = e->k_ok && e->lds_bytes_d <= 160 * 1024 && depth >= 2;
+      // variant 7: 96-voxel chunks in kERows rows, three slots in 80 KB
+      {
+        const int ce = 32 * kETiles;
+        e->nchunks_e = (g.V + ce - 1) / ce;
+        int span_e = 0;
+        for (int c = 0; c < e->nchunks_e; ++c) {
+          const int v_lo = c * ce, v_hi = std::min(g.V, v_lo + ce) - 1;
+          auto pad = [&](int v) {
+            const int x = v % g.fx, y = (v / g.fx) % g.fy, z = v / (g.fx * g.fy);
+            return z * g.plane + y * g.XS + x;
+          };
+          span_e = std::max(span_e, pad(v_hi) - pad(v_lo) + 1);
+        }
+        e->lds_bytes_e = std::max((size_t)3 * 128 * kERows,
+                                  (size_t)4 * ce * kDRowB + 64);
+        e->e_ok = e->d_ok && span_e + 2 * (g.XS + 1) <= kERows &&
+                  e->nchunks_e >= 2 && e->lds_bytes_e <= 80 * 1024;
+        for (int w = 0; w < 4; ++w)
+          for (int j = 0; j < 7; ++j) {
+            int s = kSched[w][j];
+            if (s < 0) s = kSched[w][j - 1];
+            const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
+            e->esched_aoff[w * 8 + j] =
+                kz * 128 * kERows + ((ky - 1) * g.XS + (kx - 1)) * 16;
+          }
+      }
     }
     E_TRY(hipMalloc(&e->d_dbg, 24 * sizeof(long long)));
     E_TRY(hipMemset(e->d_dbg, 0, 24 * sizeof(long long)));
@@ -1111,8 +1182,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     // variants 1 / 2 need 7*256 <= R*8 <= 8*256 resp. Rc in {256, 288}
     const bool p_ok = g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256;
     const bool c_ok = e->Rc == 256 || e->Rc == 288;
-    e->conv_variant = c_ok ? 4 : (p_ok ? 1 : 0);
     if (e->lds_bytes_k > 160 * 1024) e->k_ok = false;
+    // default: conv32d where the geometry allows it, else conv32w8, ...
+    e->conv_variant = e->d_ok ? 6 : c_ok ? 4 : (p_ok ? 1 : 0);
   }
 
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)
@@ -1178,6 +1250,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (!rc && e->k_ok) rc = set_lds_attr_k<true, true, false>(e->lds_bytes_k);
     if (!rc && e->k_ok) rc = set_lds_attr_k<false, false, true>(e->lds_bytes_k);
     if (!rc && e->d_ok) rc = set_lds_attr_d(e->lds_bytes_d);
+    if (!rc && e->e_ok) rc = set_lds_attr_e(e->lds_bytes_e);
     if (!rc) rc = set_lds_attr_p<false, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
@@ -1331,8 +1404,7 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
                     part[pl];
             }
     }
-    // conv32d: the same A operand (+ an all-zero tap 27); the kernel also uses
-    // 2^11 hi, so |w| must stay below 2^5
+    // conv32d: the same A operand (+ an all-zero tap 27)
     //   wpackd[tap][khalf][plane hi, res][lane][c]
     {
       uint16_t* wd = &hostd[(size_t)l * e->wpackd_layer];
@@ -1342,7 +1414,6 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
             for (int c = 0; c < 8; ++c) {
               const int ci = 16 * kh + 8 * (lane >> 5) + c, co = lane & 31;
               const float w = src[((size_t)tap * F + ci) * F + co];
-              if (!(std::fabs(w) <= 31.0f)) d_weights_ok = false;
               uint16_t part[2];
               split_fp16x2(w, part);
               const size_t base = ((((size_t)tap * 2 + kh) * 2) * 64 + lane) * 8 + c;
@@ -1365,7 +1436,7 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   e->d_weights_ok = d_weights_ok;
   e->fp16_ok = weights_in_fp16_range;
   if ((!e->fp16_ok && e->conv_variant >= 4) ||
-      (!e->d_weights_ok && e->conv_variant == 6)) {
+      (!e->d_weights_ok && e->conv_variant >= 6)) {
     int rc = switch_variant(e, 3);
     if (rc) return rc;
   }
@@ -1439,7 +1510,7 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) {
-    if (value < 0 || value > 6) return fail(FFN_ERR_ARG, "conv_variant must be 0..6");
+    if (value < 0 || value > 7) return fail(FFN_ERR_ARG, "conv_variant must be 0..7");
     if (value >= 4 && e->weights_set && !e->fp16_ok)
       return fail(FFN_ERR_ARG, "conv_variant %d: a weight is outside the fp16 range",
                   value);
@@ -1447,7 +1518,9 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
       return fail(FFN_ERR_ARG, "conv_variant 5 unsupported for this fov");
     if (value == 6 && !e->d_ok)
       return fail(FFN_ERR_ARG, "conv_variant 6 unsupported for this fov / depth");
-    if (value == 6 && e->weights_set && !e->d_weights_ok)
+    if (value == 7 && !e->e_ok)
+      return fail(FFN_ERR_ARG, "conv_variant 7 unsupported for this fov / depth");
+    if (value >= 6 && e->weights_set && !e->d_weights_ok)
       return fail(FFN_ERR_ARG, "conv_variant 6: a weight x 2^11 is outside the fp16 range");
     const Geom& g = e->g;
     if (value == 1 && !(g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256))
@@ -1468,6 +1541,10 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   }
   if (std::strcmp(name, "debug_clock") == 0) {
     e->dbg_clock = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "batch_chunks") == 0) {
+    e->batch_chunks = value != 0;
     return FFN_OK;
   }
   if (std::strcmp(name, "debug_layer") == 0) {

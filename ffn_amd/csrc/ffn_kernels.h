@@ -2280,7 +2280,7 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
 
 // ---------------------------------------------------------------------------
 // conv32d (conv_variant 6): conv32k with the operand split done ONCE by the
-// producer, the staging done by LDS-DMA and ONE accumulator per tile.
+// producer and the staging done by LDS-DMA.
 //
 // conv32w8 / conv32k stage f32 activations through registers and split every
 // value into fp16 hi + scaled residual on the way into LDS -- 5.3x redundantly
@@ -2305,15 +2305,16 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
 //     ds_read_b128 of 32 consecutive rows is one contiguous 512 B -- bank
 //     conflict free without padding, which is what makes the DMA's lane-linear
 //     destination usable;
-//   * the three products of the split share ONE accumulator: the weights come
-//     in three fp16 planes, hs = 2^11 hi, hi and res (x w ~= 2^-11 (hs x_hi +
-//     hi x_res + res x_hi), every product exact in f32, the 2^-11 applied once
-//     in the epilogue).  Dependent MFMAs issue back to back at the full rate
-//     (profiles/r02_ubench_mfma_dep.txt), and a third of conv32k's accumulator
-//     read-out is left.
-// Chunks (160 dense voxels), wave roles (the 27 taps split 7/7/7/6 over the four
-// waves, + one all-zero tap so that every wave runs the same straight-line code)
-// and the fused head are conv32k's.
+// Arithmetic, summation order, chunks (160 dense voxels), wave roles (the 27
+// taps split 7/7/7/6 over the four waves, + one all-zero tap so that every wave
+// runs the same straight-line code) and the fused head are conv32k's: the
+// logits are BIT-IDENTICAL to conv_variant 5.  (A single accumulator per tile
+// with a 2^11-scaled weight plane was built and measured: one third less
+// accumulator read-out, but the cross terms then lose bits against the large
+// accumulator, and on the 250^3 fixture the run left the oneDNN / f64
+// trajectory at step 430 -- see tests/test_gpu_round2.py -- so it is not used.
+// Dependent MFMAs issue back to back at the full rate either way,
+// profiles/r02_ubench_mfma_dep.txt.)
 // The compiler does not see the DMAs nor the loads of the first four weight
 // taps (inline asm), so their s_waitcnt vmcnt are placed by hand.  vmcnt
 // retires in order; what a workgroup pulls through its CU's 64 B/clk vector
@@ -2326,7 +2327,6 @@ __global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
 //     tap 2: W6 (4, compiler); tap 3            -> barrier 2: vmcnt(8)
 // (No memory operation of the compiler's precedes a DMA it must not wait for:
 // its own vmcnt for such a load would count none of them and drain the queue.)
-// The 2^11-scaled weight plane is made in registers (v_pk_mul_f16, exact).
 // ---------------------------------------------------------------------------
 constexpr int kDChunk = 160;
 constexpr int kDTiles = 5;
@@ -2409,11 +2409,20 @@ __device__ __forceinline__ void split8_fp16(const f32x4& v0, const f32x4& v1,
 // KIND 0: conv_a (out = split(relu(conv + b)));  KIND 1: conv_b (x = conv + b
 // [+ x]; out = split(relu(x)));  HEAD (KIND 1 only): the network's head instead
 // of any activation output.
-template <int KIND, bool ADD_SKIP, int KS, bool HEAD>
-__global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
+// NT = 32-position tiles per workgroup (chunk = 32 NT dense voxels), R = rows per
+// dz segment, WPS = workgroups the kernel is built to co-host per CU (waves per
+// SIMD).  (5, 32 KS, 1): one workgroup per CU, the batch-1 form.  (3, 208, 2):
+// 96-voxel chunks whose three slots fit in 80 KB, so that TWO workgroups share
+// a CU and one's MFMAs run under the other's staging / epilogue -- the same
+// arithmetic in the same order, bit-identical results (conv_variant 7).
+template <int KIND, bool ADD_SKIP, int KS, bool HEAD, int NT = 5, int R = 32 * KS,
+          int WPS = 1>
+__global__ __launch_bounds__(kDThreads, WPS) void conv32d_kernel(ConvDArgs a) {
   typedef f16x8 frag_t;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  constexpr int R = 32 * KS;     // rows per dz segment
+  static_assert(NT == 5 || NT == 3, "tile loop is written for 5 or 3 tiles");
+  static_assert(4 * KS * 64 >= 8 * R && R % 8 == 0, "KS pieces per wave cover a slot");
+  constexpr int kChunkD = 32 * NT;  // dense voxels per workgroup
   constexpr int R16 = R * 16;    // bytes of one chunk plane of a segment in LDS
   constexpr int SEG = 8 * R16;   // bytes of a segment slot
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2432,7 +2441,7 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
   }
   const int item = (int)__umulhi((unsigned)gc, a.magic_nchunks);
   const int chunk = gc - item * a.nchunks;
-  const int v0 = chunk * kDChunk;
+  const int v0 = chunk * kChunkD;
   // dense FoV index -> padded position, by arithmetic: a table look-up would be
   // a memory operation of the compiler's in front of the DMAs (see above)
   auto padded = [&](int v) {
@@ -2450,26 +2459,20 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
   const int lh = lane >> 5;
 
   struct XFragD { frag_t x[2][2]; };  // activations [khalf][plane hi, res]
-  struct WFragD { frag_t w[2][3]; };  // weights     [khalf][plane hs, hi, res]
+  struct WFragD { frag_t w[2][2]; };  // weights     [khalf][plane hi, res]
   WFragD W0, W1, W2, W3, W4;
   auto hiddenW = [&](int s, WFragD& dst) {
     const char* b0 = a.wpack + (long)s * kDTapBytes;
     const unsigned vo = (unsigned)lane * 16;
-    dst.w[0][1] = hidden_load16<0>(b0, vo);
-    dst.w[0][2] = hidden_load16<1024>(b0, vo);
-    dst.w[1][1] = hidden_load16<2048>(b0, vo);
-    dst.w[1][2] = hidden_load16<3072>(b0, vo);
-  };
-  // hs = 2^11 hi (exact: |w| <= 31 is checked on the host)
-  auto scaleW = [](WFragD& w) {
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) w.w[kh][0] = w.w[kh][1] * (_Float16)2048.0f;
+    dst.w[0][0] = hidden_load16<0>(b0, vo);
+    dst.w[0][1] = hidden_load16<1024>(b0, vo);
+    dst.w[1][0] = hidden_load16<2048>(b0, vo);
+    dst.w[1][1] = hidden_load16<3072>(b0, vo);
   };
   auto pinW = [&](WFragD& w) {  // "the data is here": consumers stay below
     asm volatile(""
-                 : "+v"(w.w[0][1]), "+v"(w.w[0][2]), "+v"(w.w[1][1]),
-                   "+v"(w.w[1][2]));
-    scaleW(w);
+                 : "+v"(w.w[0][0]), "+v"(w.w[0][1]), "+v"(w.w[1][0]),
+                   "+v"(w.w[1][1]));
   };
   const frag_t* wp = reinterpret_cast<const frag_t*>(a.wpack) + lane;
   auto loadW = [&](int s, WFragD& dst) {
@@ -2477,7 +2480,7 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
-        dst.w[kh][1 + pl] = wp[((s * 2 + kh) * 2 + pl) * 64];
+        dst.w[kh][pl] = wp[((s * 2 + kh) * 2 + pl) * 64];
   };
 
   // ---- staging: 3 x KS LDS-DMA instructions per wave; only dz = -1 and the
@@ -2488,27 +2491,42 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
   unsigned voff[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
-    const int u = 64 * (wave + 4 * k) + lane;  // 16-B unit of the segment image
+    // 16-B unit of the segment image (pieces past the slot's end re-copy its
+    // first units: the same bytes to the same place)
+    int u = 64 * (wave + 4 * k) + lane;
+    u = u >= 8 * R ? u - 8 * R : u;
     const int cp = u / R;
     voff[k] = (unsigned)(cp * (int)a.sp_plane_bytes + (u - cp * R) * 16);
   }
   auto dma_piece = [&](int seg, int k) {
+    const int u0 = 64 * (wave + 4 * k);  // wave-uniform; wraps with the units
     lds_dma16(g0 + (long)(seg - 1) * a.plane * 16, voff[k],
-              lbase + seg * SEG + (wave + 4 * k) * 1024);
+              lbase + seg * SEG + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
   };
+  // WPS == 2: a neighbour workgroup's MFMAs cover this one's issue time, so
+  // EVERYTHING is queued up front and the later barriers never wait for a DMA
+  constexpr bool kEarly = WPS > 1;
   hiddenW(btaps[0], W0);
 #pragma unroll
   for (int k = 0; k < KS; ++k) dma_piece(0, k);
   hiddenW(btaps[1], W1);
-  // LDS byte offset of this lane's (position, k-group) in each tile
-  int xb[kDTiles];
+  if constexpr (kEarly) {
 #pragma unroll
-  for (int t = 0; t < kDTiles; ++t)
+    for (int k = 0; k < KS; ++k) dma_piece(1, k);
+    hiddenW(btaps[2], W2);
+    hiddenW(btaps[3], W3);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) dma_piece(2, k);
+  }
+  // LDS byte offset of this lane's (position, k-group) in each tile
+  int xb[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
     xb[t] = (padded(v0 + t * 32 + li) - p_lo) * 16 + lh * R16;
   // epilogue pieces
   //   normal: item e = tid + 256 k -> (chunk plane c = e / 160, position j = e % 160)
   //   HEAD:   position j = (tid >> 3) + 32 k, channel quad tid & 7
-  constexpr int NE = HEAD ? 5 : 3;
+  constexpr int NE = HEAD ? NT : (4 * kChunkD + 255) / 256;
   int ej[NE], ec[NE], ep[NE];
   bool eok[NE];
 #pragma unroll
@@ -2519,10 +2537,10 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
       eok[k] = v0 + ej[k] < a.V;
     } else {
       const int e = tid + 256 * k;
-      ec[k] = e >= 480 ? 3 : e >= 320 ? 2 : e >= 160 ? 1 : 0;
-      ej[k] = e - 160 * ec[k];
-      eok[k] = e < 640 && v0 + ej[k] < a.V;
-      if (e >= 640) { ej[k] = 0; ec[k] = 0; }
+      ec[k] = e >= 3 * kChunkD ? 3 : e >= 2 * kChunkD ? 2 : e >= kChunkD ? 1 : 0;
+      ej[k] = e - kChunkD * ec[k];
+      eok[k] = e < 4 * kChunkD && v0 + ej[k] < a.V;
+      if (e >= 4 * kChunkD) { ej[k] = 0; ec[k] = 0; }
     }
     ep[k] = padded(v0 + ej[k]);
   }
@@ -2536,18 +2554,19 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
         dst.x[kh][pl] =
             *reinterpret_cast<const frag_t*>(p + (pl * 4 + kh * 2) * R16);
   };
-  // acc = 2^11 x (the convolution): hs x_hi + hi x_res + res x_hi
-  f32x16 acc[kDTiles];
+  // acc: products of weight 1 (hi x hi); accC: cross products, weight 2^-11
+  f32x16 acc[NT], accC[NT];
 #pragma unroll
-  for (int t = 0; t < kDTiles; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[t][r] = accC[t][r] = 0.f;
   auto mma = [](const frag_t& fw, const frag_t& fx, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fx, c, 0, 0, 0);
   };
   XFragD X0, X1;
 
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // W0, dz = -1 landed
+  // W0, dz = -1 landed (newer: W1 [, dz = 0, W2, W3, dz = +1])
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEarly ? 2 * KS + 12 : 4) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   pinW(W0);
@@ -2560,12 +2579,12 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
   PREFETCH;                                                                   \
   EXTRA;                                                                      \
   __builtin_amdgcn_sched_barrier(0);                                          \
-  acc[T] = mma(WCUR.w[0][1], XCUR.x[0][1], acc[T]);                           \
-  acc[T] = mma(WCUR.w[0][2], XCUR.x[0][0], acc[T]);                           \
+  accC[T] = mma(WCUR.w[0][0], XCUR.x[0][1], accC[T]);                         \
   acc[T] = mma(WCUR.w[0][0], XCUR.x[0][0], acc[T]);                           \
-  acc[T] = mma(WCUR.w[1][1], XCUR.x[1][1], acc[T]);                           \
-  acc[T] = mma(WCUR.w[1][2], XCUR.x[1][0], acc[T]);                           \
-  acc[T] = mma(WCUR.w[1][0], XCUR.x[1][0], acc[T]);
+  accC[T] = mma(WCUR.w[0][1], XCUR.x[0][0], accC[T]);                         \
+  acc[T] = mma(WCUR.w[1][0], XCUR.x[1][0], acc[T]);                           \
+  accC[T] = mma(WCUR.w[1][0], XCUR.x[1][1], accC[T]);                         \
+  accC[T] = mma(WCUR.w[1][1], XCUR.x[1][0], accC[T]);
   // tap J of the wave (XA holds tile 0's fragments on entry); CONT: prefetch
   // tile 0 of the next tap under the last tile (false in front of a barrier);
   // E0..E4: the extra memory instructions of its five tiles
@@ -2575,19 +2594,30 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
     const int an_ = aoffs[((J) + 1) % 7];                                     \
     FFN_DTILE(0, XA, WCUR, loadX(1, ao_, XB), E0)                             \
     FFN_DTILE(1, XB, WCUR, loadX(2, ao_, XA), E1)                             \
-    FFN_DTILE(2, XA, WCUR, loadX(3, ao_, XB), E2)                             \
-    FFN_DTILE(3, XB, WCUR, loadX(4, ao_, XA), E3)                             \
-    FFN_DTILE(4, XA, WCUR, if (CONT) loadX(0, an_, XB), E4)                   \
+    if constexpr (NT == 3) {                                                  \
+      FFN_DTILE(2, XA, WCUR, if (CONT) loadX(0, an_, XB), { E2; E3; E4; })    \
+    } else {                                                                  \
+      FFN_DTILE(2, XA, WCUR, loadX(3, ao_, XB), E2)                           \
+      FFN_DTILE(3, XB, WCUR, loadX(4, ao_, XA), E3)                           \
+      FFN_DTILE(4, XA, WCUR, if (CONT) loadX(0, an_, XB), E4)                 \
+    }                                                                         \
   }
   auto dma_range = [&](int seg, int k0, int k1) {
+    if constexpr (!kEarly) {
 #pragma unroll
-    for (int k = k0; k < k1 && k < KS; ++k) dma_piece(seg, k);
+      for (int k = k0; k < k1 && k < KS; ++k) dma_piece(seg, k);
+    }
+  };
+  auto hiddenW_late = [&](int s, WFragD& dst) {
+    if constexpr (!kEarly) hiddenW(s, dst);
   };
   // tap 0: the dz = 0 segment, W2, W3 (hidden), then W4
   FFN_DTAP(0, X0, X1, W0, true, dma_range(1, 0, 3), dma_range(1, 3, 6),
-           dma_range(1, 6, KS), hiddenW(btaps[2], W2),
-           { hiddenW(btaps[3], W3); loadW(btaps[4], W4); })
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS + 12) : "memory");  // W1 landed
+           dma_range(1, 6, KS), hiddenW_late(btaps[2], W2),
+           { hiddenW_late(btaps[3], W3); loadW(btaps[4], W4); })
+  // W1 landed (newer: dz = 0, W2, W3 [, dz = +1], W4)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEarly ? 2 * KS + 12 : KS + 12)
+               : "memory");
   pinW(W1);
   // tap 1: the dz = +1 segment, then W5
   FFN_DTAP(1, X1, X0, W1, false, dma_range(2, 0, 3), dma_range(2, 3, 6),
@@ -2602,7 +2632,8 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
   FFN_DTAP(2, X0, X1, W2, true, loadW(btaps[6], W1), (void)0, (void)0, (void)0,
            (void)0)
   FFN_DTAP(3, X1, X0, W3, false, (void)0, (void)0, (void)0, (void)0, (void)0)
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // dz = +1 landed
+  // dz = +1 landed (newer: W5, W6 [, W4])
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEarly ? 12 : 8) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   loadX(0, aoffs[4], X0);
@@ -2638,11 +2669,8 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
       }
     }
   }
-  scaleW(W4);
   FFN_DTAP(4, X0, X1, W4, true, (void)0, (void)0, (void)0, (void)0, (void)0)
-  scaleW(W0);
   FFN_DTAP(5, X1, X0, W0, true, (void)0, (void)0, (void)0, (void)0, (void)0)
-  scaleW(W1);
   FFN_DTAP(6, X0, X1, W1, false, (void)0, (void)0, (void)0, (void)0, (void)0)
 #undef FFN_DTAP
 #undef FFN_DTILE
@@ -2655,13 +2683,13 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
   __syncthreads();
   __builtin_amdgcn_sched_barrier(0);
   {
-    char* P = ldsb + wave * (kDChunk * kDRowB) + li * kDRowB + lh * 16;
+    char* P = ldsb + wave * (kChunkD * kDRowB) + li * kDRowB + lh * 16;
 #pragma unroll
-    for (int t = 0; t < kDTiles; ++t) {
+    for (int t = 0; t < NT; ++t) {
       // tile by tile (the scheduler would otherwise pull every accumulator out
       // of the AGPRs at once and spill the kernel's long-lived values)
-      asm volatile("" : "+a"(acc[t]));  // still AGPRs here
-      const f32x16 s = acc[t];
+      asm volatile("" : "+a"(acc[t]), "+a"(accC[t]));  // still AGPRs here
+      const f32x16 s = acc[t] + accC[t] * 4.8828125e-4f;  // 2^-11
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<f32x4*>(P + t * (32 * kDRowB) + g * 32) =
@@ -2670,7 +2698,6 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
     }
   }
   __syncthreads();
-  constexpr float kScale = 4.8828125e-4f;  // 2^-11
   unsigned range_max = 0;
   unsigned head_above = 0;
   if constexpr (HEAD) {
@@ -2684,8 +2711,8 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
       f32x4 v = *reinterpret_cast<const f32x4*>(pp);
 #pragma unroll
       for (int w = 1; w < 4; ++w)
-        v += *reinterpret_cast<const f32x4*>(pp + w * (kDChunk * kDRowB));
-      v = v * kScale + biasv[k][0];
+        v += *reinterpret_cast<const f32x4*>(pp + w * (kChunkD * kDRowB));
+      v += biasv[k][0];
       if (ADD_SKIP) v += skipv[k][0];
       float partial = fmaxf(v[0], 0.f) * hw4[0];
       partial = __builtin_fmaf(fmaxf(v[1], 0.f), hw4[1], partial);
@@ -2705,7 +2732,7 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
       }
       head_above += (unsigned)__popcll(__ballot(above));  // wave-uniform
     }
-    float* cnt = reinterpret_cast<float*>(ldsb + 4 * kDChunk * kDRowB);
+    float* cnt = reinterpret_cast<float*>(ldsb + 4 * kChunkD * kDRowB);
     if ((tid & 63) == 0) cnt[tid >> 6] = __uint_as_float(head_above);
     __syncthreads();
     if (tid == 0)
@@ -2725,11 +2752,11 @@ __global__ __launch_bounds__(kDThreads, 1) void conv32d_kernel(ConvDArgs a) {
       f32x4 vb = *reinterpret_cast<const f32x4*>(pp + 16);
 #pragma unroll
       for (int w = 1; w < 4; ++w) {
-        va += *reinterpret_cast<const f32x4*>(pp + w * (kDChunk * kDRowB));
-        vb += *reinterpret_cast<const f32x4*>(pp + w * (kDChunk * kDRowB) + 16);
+        va += *reinterpret_cast<const f32x4*>(pp + w * (kChunkD * kDRowB));
+        vb += *reinterpret_cast<const f32x4*>(pp + w * (kChunkD * kDRowB) + 16);
       }
-      va = va * kScale + biasv[k][0];
-      vb = vb * kScale + biasv[k][1];
+      va += biasv[k][0];
+      vb += biasv[k][1];
       if (KIND == 1) {
         if (ADD_SKIP) {
           va += skipv[k][0];

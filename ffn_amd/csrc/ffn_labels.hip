@@ -411,6 +411,69 @@ __global__ __launch_bounds__(kThreads) void cc_output_kernel(
   }
 }
 
+// ---- device-resident assembly of sub-box results -----------------------------
+
+struct Box3 {
+  long long lo[3], hi[3];     // core of the sub-box, sub-box coordinates
+  long long src_shape[3];
+  long long dst_shape[3];
+  long long corner[3];        // the sub-box inside the assembled volume
+};
+
+// dst[n] = src[n] > 0 ? src[n] : 0 (the -1 "excluded" markers of a canvas)
+__global__ __launch_bounds__(kThreads) void copy_labels_kernel(
+    const int32_t* __restrict__ src, size_t n, int32_t* __restrict__ dst) {
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    const int32_t v = src[i];
+    dst[i] = v > 0 ? v : 0;
+  }
+}
+
+// assembled[corner + v] = src[v] > 0 ? src[v] + off : 0 over the core; one block
+// row of threads per x-run (coalesced on both sides)
+__global__ __launch_bounds__(kThreads) void place_core_kernel(
+    const int32_t* __restrict__ src, int32_t off, int32_t* __restrict__ dst,
+    Box3 b) {
+  const long long nx = b.hi[2] - b.lo[2], ny = b.hi[1] - b.lo[1];
+  const long long rows = (b.hi[0] - b.lo[0]) * ny;
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const long long z = b.lo[0] + r / ny, y = b.lo[1] + r % ny;
+    const int32_t* s = src + (z * b.src_shape[1] + y) * b.src_shape[2] + b.lo[2];
+    int32_t* d = dst + ((z + b.corner[0]) * b.dst_shape[1] + (y + b.corner[1])) *
+                           b.dst_shape[2] + b.corner[2] + b.lo[2];
+    for (long long x = threadIdx.x; x < nx; x += kThreads) {
+      const int32_t v = s[x];
+      d[x] = v > 0 ? v + off : 0;
+    }
+  }
+}
+
+// the two label volumes of a sub-box's MARGIN (everything outside its core):
+// a = own label + off, b = assembled label; both 0 inside the core
+__global__ __launch_bounds__(kThreads) void margin_gather_kernel(
+    const int32_t* __restrict__ own, int32_t off,
+    const int32_t* __restrict__ assembled, u32* __restrict__ a,
+    u32* __restrict__ bb, Box3 b) {
+  const long long nx = b.src_shape[2], ny = b.src_shape[1];
+  const long long rows = b.src_shape[0] * ny;
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const long long z = r / ny, y = r % ny;
+    const bool row_in_core = z >= b.lo[0] && z < b.hi[0] && y >= b.lo[1] &&
+                             y < b.hi[1];
+    const int32_t* s = own + r * nx;
+    const int32_t* g = assembled + ((z + b.corner[0]) * b.dst_shape[1] +
+                                    (y + b.corner[1])) * b.dst_shape[2] +
+                       b.corner[2];
+    for (long long x = threadIdx.x; x < nx; x += kThreads) {
+      const bool core = row_in_core && x >= b.lo[2] && x < b.hi[2];
+      const int32_t v = s[x];
+      a[r * nx + x] = core ? 0u : (v > 0 ? (u32)(v + off) : 0u);
+      bb[r * nx + x] = core ? 0u : (u32)g[x];
+    }
+  }
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -874,6 +937,159 @@ int ffn_labels_connected_components(ffn_labels* h, const void* in,
   if ((first_index || sizes) && *n_components > cap)
     return ffn_set_error(FFN_ERR_ARG, "%llu components exceed cap %zu",
                          (unsigned long long)*n_components, cap);
+  return FFN_OK;
+}
+
+namespace {
+int fill_box(Box3* b, const int64_t src_shape[3], const int64_t core_lo[3],
+             const int64_t core_hi[3], const int64_t dst_shape[3],
+             const int64_t corner[3]) {
+  for (int k = 0; k < 3; ++k) {
+    b->lo[k] = core_lo[k];
+    b->hi[k] = core_hi[k];
+    b->src_shape[k] = src_shape[k];
+    b->dst_shape[k] = dst_shape[k];
+    b->corner[k] = corner[k];
+    if (core_lo[k] < 0 || core_hi[k] > src_shape[k] || core_lo[k] > core_hi[k] ||
+        corner[k] < 0 || corner[k] + src_shape[k] > dst_shape[k])
+      return ffn_set_error(FFN_ERR_ARG, "sub-box / core outside its volume (axis %d)", k);
+  }
+  return FFN_OK;
+}
+}  // namespace
+
+int ffn_labels_copy_device(ffn_labels* h, const int32_t* src_dev, size_t n,
+                           int32_t* dst_dev) {
+  if (!h || (n && (!src_dev || !dst_dev)))
+    return ffn_set_error(FFN_ERR_ARG, "NULL argument");
+  L_TRY(hipSetDevice(h->device_id));
+  if (n)
+    hipLaunchKernelGGL(copy_labels_kernel, dim3(grid_for(n, kThreads * 8)),
+                       dim3(kThreads), 0, h->stream, src_dev, n, dst_dev);
+  L_TRY(hipGetLastError());
+  L_TRY(hipStreamSynchronize(h->stream));
+  return FFN_OK;
+}
+
+int ffn_labels_copy_canvas(ffn_labels* h, ffn_canvas* canvas, int32_t* dst_dev) {
+  if (!h || !canvas || !dst_dev) return ffn_set_error(FFN_ERR_ARG, "NULL argument");
+  FfnCanvasView v;
+  L_OK(ffn_canvas_view(canvas, &v));
+  if (v.device_id != h->device_id)
+    return ffn_set_error(FFN_ERR_ARG, "canvas lives on device %d, labels on %d",
+                         v.device_id, h->device_id);
+  L_TRY(hipSetDevice(h->device_id));
+  // the canvas' own stream may still be committing the last segment
+  L_TRY(hipStreamSynchronize(static_cast<hipStream_t>(v.engine_stream)));
+  const size_t n = (size_t)v.shape_zyx[0] * v.shape_zyx[1] * v.shape_zyx[2];
+  return ffn_labels_copy_device(h, v.segmentation, n, dst_dev);
+}
+
+int ffn_labels_place_core_device(ffn_labels* h, const int32_t* src_dev,
+                                 const int64_t src_shape_zyx[3],
+                                 const int64_t core_lo[3], const int64_t core_hi[3],
+                                 int32_t id_offset, int32_t* dst_dev,
+                                 const int64_t dst_shape_zyx[3],
+                                 const int64_t corner_zyx[3]) {
+  if (!h || !src_dev || !dst_dev || !src_shape_zyx || !core_lo || !core_hi ||
+      !dst_shape_zyx || !corner_zyx)
+    return ffn_set_error(FFN_ERR_ARG, "NULL argument");
+  L_TRY(hipSetDevice(h->device_id));
+  Box3 b;
+  L_OK(fill_box(&b, src_shape_zyx, core_lo, core_hi, dst_shape_zyx, corner_zyx));
+  const long long rows = (b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]);
+  if (rows > 0 && b.hi[2] > b.lo[2])
+    hipLaunchKernelGGL(place_core_kernel,
+                       dim3((unsigned)std::min<long long>(rows, 1 << 20)),
+                       dim3(kThreads), 0, h->stream, src_dev, id_offset, dst_dev, b);
+  L_TRY(hipGetLastError());
+  L_TRY(hipStreamSynchronize(h->stream));
+  return FFN_OK;
+}
+
+int ffn_labels_margin_pairs_device(ffn_labels* h, const int32_t* own_dev,
+                                   const int64_t own_shape_zyx[3],
+                                   int32_t id_offset, const int64_t core_lo[3],
+                                   const int64_t core_hi[3],
+                                   const int32_t* assembled_dev,
+                                   const int64_t assembled_shape_zyx[3],
+                                   const int64_t corner_zyx[3], size_t cap,
+                                   uint64_t* pair_a, uint64_t* pair_b,
+                                   uint64_t* pair_count, size_t* n_pairs) {
+  if (!h || !own_dev || !assembled_dev || !own_shape_zyx || !core_lo ||
+      !core_hi || !assembled_shape_zyx || !corner_zyx || !pair_a || !pair_b ||
+      !pair_count || !n_pairs)
+    return ffn_set_error(FFN_ERR_ARG, "NULL argument");
+  L_TRY(hipSetDevice(h->device_id));
+  Box3 b;
+  L_OK(fill_box(&b, own_shape_zyx, core_lo, core_hi, assembled_shape_zyx,
+                corner_zyx));
+  const size_t n = (size_t)own_shape_zyx[0] * own_shape_zyx[1] * own_shape_zyx[2];
+  h->pairs_valid = false;
+  *n_pairs = 0;
+  if (n == 0) return FFN_OK;
+  h->n = n;
+  h->elem_bytes = 4;
+  h->have_b = true;
+  L_OK(ensure(h->a, n * 4));
+  L_OK(ensure(h->b, n * 4));
+  const long long rows = own_shape_zyx[0] * own_shape_zyx[1];
+  hipLaunchKernelGGL(margin_gather_kernel,
+                     dim3((unsigned)std::min<long long>(rows, 1 << 20)),
+                     dim3(kThreads), 0, h->stream, own_dev, id_offset,
+                     assembled_dev, static_cast<u32*>(h->a.p),
+                     static_cast<u32*>(h->b.p), b);
+  L_TRY(hipGetLastError());
+  std::vector<uint32_t> slots(cap ? cap : 1);
+  return pair_counts_impl<uint32_t>(h, n, cap, pair_a, pair_b, pair_count,
+                                    slots.data(), n_pairs);
+}
+
+int ffn_labels_remap_device(ffn_labels* h, int32_t* vol_dev, size_t n,
+                            size_t n_keys, const uint64_t* keys,
+                            const uint64_t* values) {
+  if (!h || (n && !vol_dev) || (n_keys && (!keys || !values)))
+    return ffn_set_error(FFN_ERR_ARG, "NULL argument");
+  if (n_keys >= (1u << 29)) return ffn_set_error(FFN_ERR_ARG, "too many keys");
+  L_TRY(hipSetDevice(h->device_id));
+  h->pairs_valid = false;
+  if (n == 0 || n_keys == 0) return FFN_OK;
+  L_OK(ensure(h->small, 64));
+  int* overflow = static_cast<int*>(h->small.p);
+  u32 nslots = table_size_for(n_keys);
+  L_OK(ensure(h->aux0, n_keys * 8));
+  L_OK(ensure(h->aux1, n_keys * 8));
+  L_TRY(hipMemcpyAsync(h->aux0.p, keys, n_keys * 8, hipMemcpyHostToDevice,
+                       h->stream));
+  L_TRY(hipMemcpyAsync(h->aux1.p, values, n_keys * 8, hipMemcpyHostToDevice,
+                       h->stream));
+  for (;;) {
+    L_OK(alloc_table(h, nslots, false));
+    L_TRY(hipMemsetAsync(h->small.p, 0, 64, h->stream));
+    hipLaunchKernelGGL(map_build_kernel, dim3((n_keys + 255) / 256), dim3(256), 0,
+                       h->stream, static_cast<const u64*>(h->aux0.p),
+                       static_cast<const u64*>(h->aux1.p), (u32)n_keys,
+                       static_cast<u64*>(h->keys.p),
+                       static_cast<u64*>(h->slot_label.p), nslots - 1, overflow);
+    L_TRY(hipGetLastError());
+    int ov = 0;
+    L_TRY(hipMemcpyAsync(&ov, overflow, sizeof(int), hipMemcpyDeviceToHost,
+                         h->stream));
+    L_TRY(hipStreamSynchronize(h->stream));
+    if (!ov) break;
+    if (nslots >= (1u << 30))
+      return ffn_set_error(FFN_ERR_ARG, "remap table overflow");
+    nslots <<= 2;
+  }
+  h->nslots = nslots;
+  h->n = n;
+  h->elem_bytes = 4;
+  h->have_b = false;
+  L_OK(start_timer(h));
+  // in place: every voxel reads its own label and writes its own slot
+  L_OK(apply_impl<uint32_t>(h, reinterpret_cast<const uint32_t*>(vol_dev), nullptr,
+                            n, 1, reinterpret_cast<uint32_t*>(vol_dev)));
+  L_OK(stop_timer(h, (double)n * 4 * 2));
   return FFN_OK;
 }
 

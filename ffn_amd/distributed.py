@@ -103,8 +103,156 @@ def assign_round_robin(boxes: Sequence[SubBox], rank: int,
   return [b for b in boxes if b.index % world == rank]
 
 
+class _HostAssembly:
+  """Assembly on host arrays (numpy; collectives on CPU tensors / gloo): the
+  device-free path, also the specification of `_DeviceAssembly`."""
+
+  on_device = False
+
+  def __init__(self, device=None, ops=None):
+    self.device = device
+    self._ops = ops
+
+  def labels(self, seg):
+    seg = np.asarray(seg)
+    out = np.array(seg, np.int32)
+    out[out < 0] = 0
+    return out
+
+  def max_id(self, seg):
+    return int(seg.max()) if seg.size else 0
+
+  def zeros(self, shape):
+    return np.zeros(tuple(int(v) for v in shape), np.int32)
+
+  def place_core(self, out, box, seg, off):
+    lo = [c - b for c, b in zip(box.core_lo, box.corner)]
+    hi = [c - b for c, b in zip(box.core_hi, box.corner)]
+    core = seg[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+    out[box.core_lo[0]:box.core_hi[0], box.core_lo[1]:box.core_hi[1],
+        box.core_lo[2]:box.core_hi[2]] = np.where(core > 0, core + off, 0)
+
+  def all_reduce_max(self, out, world):
+    if world > 1:
+      import torch  # pylint:disable=g-import-not-at-top
+      import torch.distributed as dist  # pylint:disable=g-import-not-at-top
+      t = torch.from_numpy(out)  # shares memory: reduced in place (gloo)
+      if self.device is not None and str(self.device) != 'cpu':
+        t = t.to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out[...] = t.cpu().numpy()
+      else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return out
+
+  def margin_pairs(self, box, seg, off, merged):
+    own = np.where(seg > 0, seg.astype(np.int64) + off, 0).astype(np.uint32)
+    sel = tuple(slice(c, c + n) for c, n in zip(box.corner, box.size))
+    g = np.array(merged[sel], np.uint32)
+    core = tuple(slice(int(l - b), int(h - b))
+                 for l, h, b in zip(box.core_lo, box.core_hi, box.corner))
+    own[core] = 0
+    g[core] = 0
+    if self._ops is not None:
+      pa, pb, cnt, _ = self._ops.pair_counts(own, g)
+      return pa, pb, cnt
+    keys, cnt = np.unique(own.astype(np.uint64).ravel() |
+                          (g.astype(np.uint64).ravel() << np.uint64(32)),
+                          return_counts=True)
+    return (keys & np.uint64(0xffffffff), keys >> np.uint64(32),
+            cnt.astype(np.uint64))
+
+  def remap(self, merged, keys, vals):
+    if self._ops is not None:
+      return self._ops.remap(merged, keys, vals, keep_missing=True)
+    lut = dict(zip(keys.tolist(), vals.tolist()))
+    out = merged.copy()
+    for k, v in lut.items():
+      out[merged == k] = v
+    return out
+
+  def to_host(self, merged):
+    return merged
+
+
+class _DeviceAssembly:
+  """Assembly on the GPU: sub-box labels, the assembled volume and the RCCL
+  all-reduce buffer are ONE set of device arrays (torch owns the memory, the
+  label kernels of libffn_hip.so work on the raw pointers); no voxel crosses
+  PCIe until the caller asks for the result."""
+
+  on_device = True
+
+  def __init__(self, device, ops=None):
+    import torch  # pylint:disable=g-import-not-at-top
+    self.torch = torch
+    self.device = torch.device(device)
+    if ops is None:
+      from . import labels  # pylint:disable=g-import-not-at-top
+      ops = labels.default_ops(self.device.index or 0)
+    self._ops = ops
+
+  def labels(self, seg):
+    """int32 device labels (>= 0) of a sub-box: from a device canvas (copied on
+    the device), a device tensor, or host data (one upload)."""
+    torch = self.torch
+    handle = getattr(seg, 'canvas_handle', None)
+    if handle is not None:  # the segmentation of a live DeviceCanvas
+      out = torch.empty(tuple(seg.shape), dtype=torch.int32, device=self.device)
+      self._ops.copy_canvas(handle(), out.data_ptr())
+      return out
+    if isinstance(seg, torch.Tensor):
+      return seg.to(self.device, torch.int32).clamp_(min=0)
+    host = np.array(np.asarray(seg), np.int32)
+    host[host < 0] = 0
+    return torch.from_numpy(host).to(self.device)
+
+  def max_id(self, seg):
+    return int(seg.max().item()) if seg.numel() else 0
+
+  def zeros(self, shape):
+    return self.torch.zeros(tuple(int(v) for v in shape), dtype=self.torch.int32,
+                            device=self.device)
+
+  def place_core(self, out, box, seg, off):
+    self.torch.cuda.synchronize(self.device)
+    lo = [c - b for c, b in zip(box.core_lo, box.corner)]
+    hi = [c - b for c, b in zip(box.core_hi, box.corner)]
+    self._ops.place_core_device(seg.data_ptr(), seg.shape, lo, hi, off,
+                                out.data_ptr(), out.shape, box.corner)
+
+  def all_reduce_max(self, out, world):
+    if world > 1:
+      import torch.distributed as dist  # pylint:disable=g-import-not-at-top
+      dist.all_reduce(out, op=dist.ReduceOp.MAX)  # RCCL, in place
+      self.torch.cuda.synchronize(self.device)
+    return out
+
+  def margin_pairs(self, box, seg, off, merged):
+    self.torch.cuda.synchronize(self.device)
+    lo = [c - b for c, b in zip(box.core_lo, box.corner)]
+    hi = [c - b for c, b in zip(box.core_hi, box.corner)]
+    return self._ops.margin_pairs_device(seg.data_ptr(), seg.shape, off, lo, hi,
+                                         merged.data_ptr(), merged.shape,
+                                         box.corner)
+
+  def remap(self, merged, keys, vals):
+    self.torch.cuda.synchronize(self.device)
+    self._ops.remap_device(merged.data_ptr(), merged.numel(), keys, vals)
+    return merged
+
+  def to_host(self, merged):
+    return merged.cpu().numpy()
+
+
+def _assembly_for(device, ops=None):
+  if device is not None and str(device) != 'cpu' and str(device).startswith('cuda'):
+    return _DeviceAssembly(device, ops)
+  return _HostAssembly(device, ops)
+
+
 def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
-                        device=None):
+                        device=None, assembly=None, keep_on_device=False):
   """Assembles one global int32 label volume from per-rank sub-box results.
 
   Args:
@@ -114,7 +262,14 @@ def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
     rank, world: torch.distributed rank / world size (world == 1: no
       collective at all)
     device: torch device for the collective buffers ('cuda:k' with the nccl
-      backend, 'cpu' with gloo)
+      backend, 'cpu' with gloo).  With a cuda device the whole assembly stays
+      in HBM (`_DeviceAssembly`): the sub-box labels (device canvases are
+      copied on the device, host arrays uploaded once), the assembled volume
+      and the all-reduce buffer; with 'cpu' / None it runs on numpy arrays
+      (`_HostAssembly`, the device-free path).
+    assembly: an assembly object to use instead (tests)
+    keep_on_device: return (assembled volume as the assembly holds it, offsets,
+      the sub-box labels as the assembly holds them, the assembly) instead
 
   Returns:
     (global int32 ndarray, list of per-sub-box id offsets of this rank)
@@ -122,11 +277,14 @@ def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
   import torch
   import torch.distributed as dist
 
+  asm = assembly if assembly is not None else _assembly_for(device)
+  local_results = [(box, asm.labels(seg)) for box, seg in local_results]
   # 1. global id space: offsets by exclusive scan over (rank, sub-box) order
-  local_max = [int(seg.max()) if seg.size else 0 for _, seg in local_results]
+  local_max = [asm.max_id(seg) for _, seg in local_results]
   my_total = int(sum(local_max))
   if world > 1:
-    t = torch.tensor([my_total], dtype=torch.int64, device=device)
+    t = torch.tensor([my_total], dtype=torch.int64,
+                     device=device if asm.on_device else None)
     gathered = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
     totals = [int(g.item()) for g in gathered]
@@ -141,21 +299,13 @@ def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
     raise OverflowError('global id space exceeds int32')
 
   # 2. owned cores into a zero-filled volume, then union by all_reduce(MAX)
-  out = np.zeros(tuple(shape_zyx), dtype=np.int32)
+  out = asm.zeros(shape_zyx)
   for (box, seg), off in zip(local_results, offsets):
-    lo = [c - b for c, b in zip(box.core_lo, box.corner)]
-    hi = [c - b for c, b in zip(box.core_hi, box.corner)]
-    core = seg[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].astype(np.int32)
-    core = np.where(core > 0, core + off, 0).astype(np.int32)
-    out[box.core_lo[0]:box.core_hi[0], box.core_lo[1]:box.core_hi[1],
-        box.core_lo[2]:box.core_hi[2]] = core
-  if world > 1:
-    t = torch.from_numpy(out)
-    if device is not None and str(device) != 'cpu':
-      t = t.to(device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    out = t.cpu().numpy()
-  return out, offsets
+    asm.place_core(out, box, seg, off)
+  out = asm.all_reduce_max(out, world)
+  if keep_on_device:
+    return out, offsets, local_results, asm
+  return asm.to_host(out), offsets
 
 
 class _UnionFind:
@@ -215,9 +365,17 @@ def margin_edges(ops, seg_global_ids, assembled_box, core_lo, core_hi,
   a[core] = 0
   g[core] = 0
   pa, pb, cnt, _ = ops.pair_counts(a, g)
+  return _edges_from_pairs(pa, pb, cnt, min_overlap_voxels,
+                           min_overlap_fraction)
+
+
+def _edges_from_pairs(pa, pb, cnt, min_overlap_voxels, min_overlap_fraction):
+  """(own id, assembled id, voxels) pairs of a margin -> merge edges."""
+  pa = np.asarray(pa, np.uint64)
+  pb = np.asarray(pb, np.uint64)
   if pa.size == 0:
     return np.zeros((0, 3), np.int64)
-  cnt = cnt.astype(np.int64)
+  cnt = np.asarray(cnt).astype(np.int64)
   ua, ia = np.unique(pa, return_inverse=True)
   ub, ib = np.unique(pb, return_inverse=True)
   size_a = np.zeros(ua.size, np.int64)
@@ -254,7 +412,7 @@ def reconcile_segmentations(local_results, shape_zyx, rank: int, world: int,
                             device=None,
                             min_overlap_voxels: int = MIN_OVERLAP_VOXELS,
                             min_overlap_fraction: float = MIN_OVERLAP_FRACTION,
-                            ops=None):
+                            ops=None, keep_on_device=False, assembly=None):
   """merge_segmentations + union-find reconciliation of objects that cross a
   cut between sub-boxes (doc/manual.md:119-127).
 
@@ -268,23 +426,18 @@ def reconcile_segmentations(local_results, shape_zyx, rank: int, world: int,
      int64 [k, 3] array of all merge edges, {id: root id} for every id that
      took part in an edge)
   """
-  merged, offsets = merge_segmentations(local_results, shape_zyx, rank, world,
-                                        device)
-  if ops is None:
-    from . import labels  # pylint:disable=g-import-not-at-top
-    index = getattr(device, 'index', None)
-    ops = labels.default_ops(index if index is not None else 0)
+  asm = assembly if assembly is not None else _assembly_for(device, ops)
+  merged, offsets, held, asm = merge_segmentations(
+      local_results, shape_zyx, rank, world, device, assembly=asm,
+      keep_on_device=True)
   mine = []
-  for (box, seg), off in zip(local_results, offsets):
-    own = np.where(seg > 0, seg.astype(np.int64) + off, 0)
-    sel = tuple(slice(c, c + n) for c, n in zip(box.corner, box.size))
-    lo = [c - b for c, b in zip(box.core_lo, box.corner)]
-    hi = [c - b for c, b in zip(box.core_hi, box.corner)]
-    mine.append(margin_edges(ops, own, merged[sel], lo, hi,
-                             min_overlap_voxels, min_overlap_fraction))
+  for (box, seg), off in zip(held, offsets):
+    pa, pb, cnt = asm.margin_pairs(box, seg, off, merged)
+    mine.append(_edges_from_pairs(pa, pb, cnt, min_overlap_voxels,
+                                  min_overlap_fraction))
   edges = (np.concatenate(mine) if mine else np.zeros((0, 3), np.int64))
   if world > 1:
-    edges = _all_gather_rows(edges, world, device)
+    edges = _all_gather_rows(edges, world, device if asm.on_device else None)
   if edges.shape[0]:
     edges = edges[np.lexsort((edges[:, 2], edges[:, 1], edges[:, 0]))]
   uf = _UnionFind()
@@ -294,8 +447,10 @@ def reconcile_segmentations(local_results, shape_zyx, rank: int, world: int,
   keys = np.array(sorted(k for k, v in roots.items() if k != v), np.uint64)
   if keys.size:
     vals = np.array([roots[int(k)] for k in keys], np.uint64)
-    merged = ops.remap(merged, keys, vals, keep_missing=True)
-  return merged, offsets, edges, roots
+    merged = asm.remap(merged, keys, vals)
+  if keep_on_device:
+    return merged, offsets, edges, roots
+  return asm.to_host(merged), offsets, edges, roots
 
 
 def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
@@ -332,11 +487,12 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
   boxes = tile_volume(size_zyx, sub_size_zyx, overlap_zyx, back_shift=True)
   mine = assign_round_robin(boxes, rank, world)
   results = [None] * len(mine)
+  asm = _assembly_for(device)
 
   def collect(index, canvas):  # the canvas is closed right after this call
-    seg = np.array(np.asarray(canvas.segmentation), np.int32)
-    seg[seg < 0] = 0  # the -1 "excluded" markers (runner.py:452)
-    results[index] = (mine[index], seg)
+    # the -1 "excluded" markers (runner.py:452) are dropped; on a GPU the
+    # labels go from the canvas into the assembly's own device array
+    results[index] = (mine[index], asm.labels(canvas.segmentation))
 
   runner.run_many(
       [(tuple(c + o for c, o in zip(corner_zyx, b.corner)), b.size)
@@ -346,15 +502,20 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
       raise RuntimeError('sub-box %r was skipped (output exists / masked); '
                          'assemble from the saved files instead' % (b,))
   info = {'boxes': boxes, 'mine': mine}
+  import time  # pylint:disable=g-import-not-at-top
+  t0 = time.perf_counter()
   if reconcile:
     merged, offsets, edges, roots = reconcile_segmentations(
         results, size_zyx, rank, world, device, min_overlap_voxels,
-        min_overlap_fraction)
+        min_overlap_fraction, keep_on_device=True, assembly=asm)
     info.update(offsets=offsets, edges=edges, roots=roots)
   else:
-    merged, offsets = merge_segmentations(results, size_zyx, rank, world,
-                                          device)
+    merged, offsets, _, _ = merge_segmentations(
+        results, size_zyx, rank, world, device, assembly=asm,
+        keep_on_device=True)
     info.update(offsets=offsets, edges=np.zeros((0, 3), np.int64), roots={})
+  info['assemble_seconds'] = time.perf_counter() - t0
   info['local_results'] = results
-  return merged, info
+  info['merged_device'] = merged if asm.on_device else None
+  return asm.to_host(merged), info
 

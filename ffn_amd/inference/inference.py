@@ -595,6 +595,11 @@ class _DeviceArray:
     self.dtype = np.dtype(np.float32 if which == 'seed' else np.int32)
     self.ndim = 3
 
+  def canvas_handle(self):
+    """The ffn_canvas* behind this array (device-side consumers: the assembly
+    of sub-box results copies the segmentation inside HBM)."""
+    return self._c._handle._h
+
   def _box(self, key):
     if key is Ellipsis:
       key = (slice(None),) * 3

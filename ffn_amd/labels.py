@@ -150,6 +150,63 @@ class LabelOps:
     k = int(ncomp.value)
     return out, first[:k], sizes[:k], int(fz.value)
 
+  # -- device-resident assembly (raw device pointers, int32 labels) ----------------
+  @staticmethod
+  def _i64x3(v):
+    return (ctypes.c_int64 * 3)(*[int(x) for x in v])
+
+  def copy_device(self, src_ptr: int, n: int, dst_ptr: int):
+    """dst[i] = max(src[i], 0): a canvas segmentation without its -1 markers."""
+    check(self._lib.ffn_labels_copy_device(self._h, ctypes.c_void_p(src_ptr),
+                                           int(n), ctypes.c_void_p(dst_ptr)))
+
+  def copy_canvas(self, canvas_handle, dst_ptr: int):
+    """The segmentation of a live device canvas (ffn_canvas*), negatives
+    dropped, into a device buffer -- no trip through the host."""
+    check(self._lib.ffn_labels_copy_canvas(self._h, canvas_handle,
+                                           ctypes.c_void_p(dst_ptr)))
+
+  def place_core_device(self, src_ptr, src_shape, core_lo, core_hi, id_offset,
+                        dst_ptr, dst_shape, corner):
+    """Core of a sub-box (ids + id_offset) into the assembled device volume."""
+    check(self._lib.ffn_labels_place_core_device(
+        self._h, ctypes.c_void_p(src_ptr), self._i64x3(src_shape),
+        self._i64x3(core_lo), self._i64x3(core_hi), int(id_offset),
+        ctypes.c_void_p(dst_ptr), self._i64x3(dst_shape), self._i64x3(corner)))
+
+  def margin_pairs_device(self, own_ptr, own_shape, id_offset, core_lo, core_hi,
+                          assembled_ptr, assembled_shape, corner):
+    """(own id + offset, assembled id, voxels) over a sub-box's margin."""
+    cap = 1 << 16
+    while True:
+      pa = np.empty(cap, np.uint64)
+      pb = np.empty(cap, np.uint64)
+      pc = np.empty(cap, np.uint64)
+      found = ctypes.c_size_t(0)
+      rc = self._lib.ffn_labels_margin_pairs_device(
+          self._h, ctypes.c_void_p(own_ptr), self._i64x3(own_shape),
+          int(id_offset), self._i64x3(core_lo), self._i64x3(core_hi),
+          ctypes.c_void_p(assembled_ptr), self._i64x3(assembled_shape),
+          self._i64x3(corner), cap, pa.ctypes.data, pb.ctypes.data,
+          pc.ctypes.data, ctypes.byref(found))
+      if rc != 0 and found.value > cap:
+        cap = found.value
+        continue
+      check(rc)
+      break
+    self._resident = None
+    m = found.value
+    return pa[:m], pb[:m], pc[:m]
+
+  def remap_device(self, vol_ptr: int, n: int, keys, values):
+    """In place on a device int32 volume: ids in `keys` -> `values`."""
+    keys = np.ascontiguousarray(keys, np.uint64)
+    values = np.ascontiguousarray(values, np.uint64)
+    check(self._lib.ffn_labels_remap_device(
+        self._h, ctypes.c_void_p(vol_ptr), int(n), keys.size, keys.ctypes.data,
+        values.ctypes.data))
+    self._resident = None
+
   def last_timing(self) -> Tuple[float, float]:
     """(kernel milliseconds, algorithmic HBM bytes) of the last call."""
     ms = ctypes.c_double(0)

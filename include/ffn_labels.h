@@ -33,6 +33,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "ffn_hip.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -79,6 +81,51 @@ int ffn_labels_connected_components(ffn_labels* h, const void* in,
                                     uint64_t* n_components, size_t cap,
                                     uint64_t* first_index, uint64_t* sizes,
                                     int64_t* first_zero_index);
+
+/* ---- device-resident assembly (the final segmentation merge) ----
+ * The same operations on DEVICE pointers (int32 labels, e.g. a canvas'
+ * segmentation from ffn_canvas_view or the data_ptr of the tensor RCCL reduces),
+ * so that assembling the sub-boxes of a volume moves no voxel through the
+ * host.  Every call returns with its kernels complete (stream synchronised);
+ * the caller synchronises whatever produced the inputs. */
+
+/* dst[i] = src[i] > 0 ? src[i] : 0 (a canvas' -1 "excluded" markers dropped). */
+int ffn_labels_copy_device(ffn_labels* h, const int32_t* src_dev, size_t n,
+                           int32_t* dst_dev);
+
+/* The same from a live device canvas (Canvas.segmentation, inference.py:224-232)
+ * straight out of its HBM: dst_dev holds cz * cy * cx int32. */
+int ffn_labels_copy_canvas(ffn_labels* h, ffn_canvas* canvas, int32_t* dst_dev);
+
+/* Writes the CORE [core_lo, core_hi) (sub-box coordinates) of a sub-box's
+ * labels, globally offset (v > 0 ? v + id_offset : 0), into the assembled
+ * volume, in which the sub-box sits at corner_zyx
+ * (ffn/utils/bounding_box.py:250-412 tiling; doc/manual.md:107-127). */
+int ffn_labels_place_core_device(ffn_labels* h, const int32_t* src_dev,
+                                 const int64_t src_shape_zyx[3],
+                                 const int64_t core_lo[3], const int64_t core_hi[3],
+                                 int32_t id_offset, int32_t* dst_dev,
+                                 const int64_t dst_shape_zyx[3],
+                                 const int64_t corner_zyx[3]);
+
+/* Joint histogram over a sub-box's MARGIN (everything outside its core) of
+ * (own label + id_offset, assembled label): the overlap table of the
+ * union-find reconciliation (doc/manual.md:119-127).  Output as
+ * ffn_labels_pair_counts (pairs with a 0 member included; unsorted). */
+int ffn_labels_margin_pairs_device(ffn_labels* h, const int32_t* own_dev,
+                                   const int64_t own_shape_zyx[3],
+                                   int32_t id_offset, const int64_t core_lo[3],
+                                   const int64_t core_hi[3],
+                                   const int32_t* assembled_dev,
+                                   const int64_t assembled_shape_zyx[3],
+                                   const int64_t corner_zyx[3], size_t cap,
+                                   uint64_t* pair_a, uint64_t* pair_b,
+                                   uint64_t* pair_count, size_t* n_pairs);
+
+/* In place: vol[i] = values[j] where vol[i] == keys[j], unchanged otherwise. */
+int ffn_labels_remap_device(ffn_labels* h, int32_t* vol_dev, size_t n,
+                            size_t n_keys, const uint64_t* keys,
+                            const uint64_t* values);
 
 /* HIP-event time of the kernels (no host<->device copies) of the last call on
  * this handle, and the HBM bytes they are specified to move (algorithmic):

@@ -73,12 +73,13 @@ def main(argv=None):
           [int(v) for v in fov])
     if args.assemble:
       import numpy as np  # pylint:disable=g-import-not-at-top
-      device = None
+      # the assembly (id offsets, cores into one volume, all-reduce over RCCL,
+      # margin histograms, relabel) runs on the GPU that segmented
+      import torch  # pylint:disable=g-import-not-at-top
+      torch.cuda.set_device(local_rank)
+      device = torch.device('cuda', local_rank)
       if world > 1:
-        import torch  # pylint:disable=g-import-not-at-top
         import torch.distributed as dist  # pylint:disable=g-import-not-at-top
-        torch.cuda.set_device(local_rank)
-        device = torch.device('cuda', local_rank)
         dist.init_process_group('nccl', device_id=device)
       merged, info = ffn_dist.segment_volume(
           runner, start_zyx, size_zyx, sub, ov, rank, world, device,

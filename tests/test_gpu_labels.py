@@ -210,12 +210,60 @@ def test_reconcile_on_gpu_matches_specification():
   truth = tl._objects_volume(shape, 5)
   boxes = ffn_dist.tile_volume(shape, (32, 36, 40), (12, 12, 12))
   results = tl._sub_results(truth, boxes)
-  merged, _, edges, roots = ffn_dist.reconcile_segmentations(
-      results, shape, 0, 1, min_overlap_voxels=8, min_overlap_fraction=0.1)
   want, want_edges, want_roots = labels_oracle.reconcile(results, shape, 8, 0.1)
+  # (a) everything in HBM: sub-box labels, assembled volume, margin histogram,
+  # relabel -- torch owns the memory, libffn_hip.so's kernels the arithmetic
+  merged, _, edges, roots = ffn_dist.reconcile_segmentations(
+      results, shape, 0, 1, device='cuda:0', min_overlap_voxels=8,
+      min_overlap_fraction=0.1)
   assert np.array_equal(merged, want)
   assert np.array_equal(edges, want_edges) and roots == want_roots
   assert tl._partition_equal(merged, truth)
+  # the assembled volume can stay on the device
+  dev, _, _, _ = ffn_dist.reconcile_segmentations(
+      results, shape, 0, 1, device='cuda:0', min_overlap_voxels=8,
+      min_overlap_fraction=0.1, keep_on_device=True)
+  assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), want)
+  # (b) host arrays, GPU label kernels through host buffers
+  from ffn_amd import labels
+  merged_b, _, edges_b, roots_b = ffn_dist.reconcile_segmentations(
+      results, shape, 0, 1, min_overlap_voxels=8, min_overlap_fraction=0.1,
+      ops=labels.default_ops(0))
+  assert np.array_equal(merged_b, want) and np.array_equal(edges_b, want_edges)
+  assert roots_b == want_roots
+  # (c) the device-free path (numpy only)
+  merged_c, _, edges_c, _ = ffn_dist.reconcile_segmentations(
+      results, shape, 0, 1, min_overlap_voxels=8, min_overlap_fraction=0.1)
+  assert np.array_equal(merged_c, want) and np.array_equal(edges_c, want_edges)
+
+
+def test_device_assembly_primitives(ops):
+  """place_core / margin_pairs / remap on device pointers == the numpy forms."""
+  import torch
+  from ffn_amd import distributed as ffn_dist
+  rng = np.random.RandomState(3)
+  shape = (40, 44, 52)
+  boxes = ffn_dist.tile_volume(shape, (28, 30, 36), (10, 10, 12))
+  host = ffn_dist._HostAssembly()
+  dev = ffn_dist._DeviceAssembly('cuda:0', ops)
+  out_h, out_d = host.zeros(shape), dev.zeros(shape)
+  segs = []
+  for k, box in enumerate(boxes):
+    seg = rng.randint(-1, 5, box.size).astype(np.int32)
+    segs.append(seg)
+    host.place_core(out_h, box, host.labels(seg), 10 * k)
+    dev.place_core(out_d, box, dev.labels(seg), 10 * k)
+  assert np.array_equal(out_d.cpu().numpy(), out_h)
+  for k, box in enumerate(boxes[:3]):
+    ph = host.margin_pairs(box, host.labels(segs[k]), 10 * k, out_h)
+    pd = dev.margin_pairs(box, dev.labels(segs[k]), 10 * k, out_d)
+    th = sorted(zip(*[np.asarray(v).tolist() for v in ph]))
+    td = sorted(zip(*[np.asarray(v).tolist() for v in pd]))
+    assert th == td
+  keys = np.array([3, 11, 24], np.uint64)
+  vals = np.array([1, 1, 7], np.uint64)
+  assert np.array_equal(dev.remap(out_d, keys, vals).cpu().numpy(),
+                        host.remap(out_h, keys, vals))
 
 
 def test_labels_abi_rejects_bad_arguments(ops):

@@ -17,7 +17,7 @@ from tests.conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-DEFAULT_VARIANT = 4
+DEFAULT_VARIANT = 6
 DEFAULT_WAVES8 = 2  # what ffn_engine_create selects for the 33^3 FoV
 TOL = 1e-4
 
@@ -42,14 +42,14 @@ def _fov_inputs(rng, n=1):
 
 @pytest.mark.parametrize('variant,fuse_head,waves8', [
     (0, 1, 1), (1, 1, 1), (2, 1, 1), (2, 0, 1), (3, 1, 1), (3, 0, 1), (4, 1, 1),
-    (4, 0, 1), (3, 1, 0), (4, 1, 0), (4, 0, 0), (4, 1, 2), (4, 0, 2), (5, 1, 2), (5, 0, 2), (6, 1, 2)])
+    (4, 0, 1), (3, 1, 0), (4, 1, 0), (4, 0, 0), (4, 1, 2), (4, 0, 2), (5, 1, 2), (5, 0, 2), (6, 1, 2), (7, 1, 2)])
 def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head, waves8):
   """conv_variant 0 simple f32 MFMA, 1 padded pipelined, 2 compact (exact f32
   MFMA), 3 compact with bf16x3 split products, 4 with fp16 hi + scaled
   residual, 5 the same products on 32x32x16 MFMAs with the taps split over the
   waves (conv32k), 6 the same on producer-split planes staged by LDS-DMA
-  (conv32d); with the 1x1x1 head fused into the last conv or as its own
-  launch."""
+  (conv32d), 7 = 6 with 96-voxel chunks for two workgroups per CU; with the
+  1x1x1 head fused into the last conv or as its own launch."""
   from oracle import ffn_oracle
   engine.set_option('conv_variant', variant)
   engine.set_option('fuse_head', fuse_head)
@@ -90,11 +90,43 @@ def test_predict_is_deterministic_and_variants_agree(engine):
   a = engine.predict(seed, img)
   b = engine.predict(seed, img)
   assert np.array_equal(a, b)
-  for variant in (0, 1, 2, 3, 4, 5, 6):
+  by_variant = {}
+  for variant in (0, 1, 2, 3, 4, 5, 6, 7):
     engine.set_option('conv_variant', variant)
     c = engine.predict(seed, img)
     assert np.abs(a - c).max() <= 2e-5, variant
+    by_variant[variant] = c
+  # conv32d = conv32k's arithmetic and summation order on producer-split planes,
+  # whatever the chunk size
+  assert np.array_equal(by_variant[5], by_variant[6])
+  assert np.array_equal(by_variant[6], by_variant[7])
   engine.set_option('conv_variant', DEFAULT_VARIANT)
+
+
+def test_c5_model_full_depth(fib25_model):
+  """BASELINE configs[4] model at its FULL depth: 18 residual modules, FoV zyx
+  (21, 41, 41), deltas (5, 10, 10), random weights -- every conv variant that
+  supports the geometry against the oracle."""
+  from ffn_amd import engine as hip_engine
+  from ffn_amd.training.models import convstack_3d
+  from oracle import ffn_oracle
+  variables = ffn_oracle.random_weights(18, seed=18, stddev=0.03)
+  m = convstack_3d.ConvStack3DFFNModel(fov_size=[41, 41, 21],
+                                       deltas=[10, 10, 5], depth=18)
+  m.set_variables(variables)
+  eng = hip_engine.HipEngine.from_model(m, max_batch=2)
+  rng = np.random.RandomState(4)
+  img = rng.normal(0, 1, (2, 21, 41, 41)).astype(np.float32)
+  seed = rng.normal(0, 2, (2, 21, 41, 41)).astype(np.float32)
+  blob = ffn_oracle.weights_blob(variables, 18)
+  want = ffn_oracle.forward(img, seed, blob, 18)
+  for variant in (2, 3, 4, 5, 6):
+    eng.set_option('conv_variant', variant)
+    got = eng.predict(seed, img)
+    err = np.abs(got - want).max()
+    print('c5 depth 18 variant %d: max |err| %.3g' % (variant, err))
+    assert err <= TOL, (variant, err)
+  eng.close()
 
 
 def test_predict_nan_seed_propagates_like_reference(engine):
@@ -636,6 +668,11 @@ def test_sharded_volume_end_to_end(fib25_model, tmp_path):
   plain, _ = ffn_dist.merge_segmentations(info['local_results'], shape, 0, 1)
   assert len(info['edges']) > 0
   assert len(np.unique(merged)) < len(np.unique(plain))
+  # (4) the same assembly with everything resident on the device
+  on_dev, _, edges_dev, _ = ffn_dist.reconcile_segmentations(
+      info['local_results'], shape, 0, 1, device='cuda:0', min_overlap_voxels=32,
+      min_overlap_fraction=0.2)
+  assert np.array_equal(on_dev, want) and np.array_equal(edges_dev, want_edges)
 
 
 def test_anisotropic_canvas_step_matches_oracle():
@@ -795,19 +832,21 @@ def test_large_canvas_offsets_beyond_2gib(engine, fib25_blob):
   canvas.close()
 
 
-def test_fp16_range_fallback(fib25_model, fib25_blob):
-  """conv_variant 4 keeps operands in fp16: a value beyond 65504 must void the
-  run (nothing pasted) and repeat it with the bf16x3 scheme -- silently for
+@pytest.mark.parametrize('fast', [6, 4])
+def test_fp16_range_fallback(fib25_model, fib25_blob, fast):
+  """conv_variants 4 / 6 keep operands in fp16: a value beyond 65504 must void
+  the run (nothing pasted) and repeat it with the bf16x3 scheme -- silently for
   ffn_predict, through FFN_ERR_RANGE + retry for canvas steps."""
   from ffn_amd import _lib
   from ffn_amd import engine as hip_engine
   from oracle import ffn_oracle
   eng = hip_engine.HipEngine.from_model(fib25_model, max_batch=1)
-  assert eng.get_option('conv_variant') == 4
+  assert eng.get_option('conv_variant') == DEFAULT_VARIANT
+  eng.set_option('conv_variant', fast)
   rng = np.random.RandomState(12)
   img, seed = _fov_inputs(rng, 1)
   ok = eng.predict(seed, img)
-  assert eng.get_option('conv_variant') == 4  # ordinary data stays on fp16x2
+  assert eng.get_option('conv_variant') == fast  # ordinary data stays on fp16x2
   big = (img * 3e5).astype(np.float32)  # conv0_a outputs far beyond 65504
   got = eng.predict(seed, big)
   assert eng.get_option('conv_variant') == 3
@@ -817,7 +856,7 @@ def test_fp16_range_fallback(fib25_model, fib25_blob):
   assert np.array_equal(eng.predict(seed, img), eng.predict(seed, img))
   assert np.abs(eng.predict(seed, img) - ok).max() <= 2e-5
   # canvas step: the voided step must leave the canvas untouched, then repeat
-  eng.set_option('conv_variant', 4)
+  eng.set_option('conv_variant', fast)
   vol = np.zeros((40, 40, 40), np.float32)
   vol[4:37, 4:37, 4:37] = big[0]
   canvas = eng.create_canvas(vol)
@@ -837,7 +876,7 @@ def test_fp16_range_fallback(fib25_model, fib25_blob):
   assert rc == _lib.ERR_RANGE and res[0].range_error == 1
   seed_now = canvas.read_seed()
   assert np.isnan(seed_now).sum() == seed_now.size - 1  # nothing was pasted
-  eng.set_option('conv_variant', 4)
+  eng.set_option('conv_variant', fast)
   r = eng.step1(canvas, req, params)  # Python handle: retries with bf16x3
   assert eng.range_fallbacks == 1 and eng.get_option('conv_variant') == 3
   assert r.range_error == 0 and np.isfinite(r.start_logit)

@@ -546,3 +546,22 @@ def test_resegmentation_request_messages_round_trip():
   rq.points = [req_lib.ResegmentationPoint(id_a=5)]
   rq.points.add(id_a=6)
   assert [pt.id_a for pt in rq.points] == [5, 6]
+
+
+def test_update_seed_pads_a_smaller_prediction_around_the_centre():
+  """FFNModel.update_seed (reference model.py:168-183): pred == seed adds in
+  place; pred < seed zero-pads the update dz // 2 in front, the rest behind."""
+  info = ffn_model.ModelInfo(np.array([8, 8, 8]), np.array([5, 7, 4]),  # xyz
+                             np.array([8, 8, 7]), np.array([8, 8, 7]))
+  m = ffn_model.FFNModel(info)
+  seed = np.zeros((1, 7, 8, 8, 1), np.float32)
+  upd = np.ones((1, 4, 7, 5, 1), np.float32)
+  out = m.update_seed(seed, upd)
+  assert out is seed and out.sum() == upd.size
+  # dz = 3 -> 1 in front, 2 behind; dy = 1 -> 0 / 1; dx = 3 -> 1 / 2
+  assert np.all(seed[0, 1:5, 0:7, 1:6, 0] == 1)
+  assert seed[0, 0].sum() == 0 and seed[0, 5:].sum() == 0
+  assert seed[0, :, 7].sum() == 0 and seed[0, :, :, 0].sum() == 0
+  same = ffn_model.FFNModel(_info())
+  s2 = np.full((33, 33, 33), 2.0, np.float32)
+  assert np.all(same.update_seed(s2, np.ones_like(s2)) == 3.0)

@@ -35,6 +35,7 @@ def main():
   rng = np.random.RandomState(0)
   img = rng.normal(0, 1, (maxb, 33, 33, 33)).astype(np.float32)
   seed = rng.normal(0, 1, (maxb, 33, 33, 33)).astype(np.float32)
+  eng.set_option('batch_chunks', 0)  # variant 6 / 7 are compared in their pure forms
   eng.set_option('conv_variant', 2)
   ref = eng.predict(seed[:2], img[:2])
   for v in args.variants:
@@ -64,11 +65,11 @@ def main():
             (b, v, med, t.min(), med / 23 / b * (23.0 / 25.0),
              b * flop / (med * 1e-6) / 1e12))
   eng.set_option('debug_clock', 1)
-  for v, nmfma in ((4, 13.5 * 27.0), (5, 210.0), (6, 210.0)):
+  for v, nmfma in ((4, 13.5 * 27.0), (5, 210.0), (6, 210.0), (7, 126.0)):
     if v not in args.variants:
       continue
     eng.set_option('conv_variant', v)
-    for layer in ((3, 4, 22) if v == 6 else (3,)):  # conv_a, conv_b, fused head
+    for layer in ((3, 4, 22) if v >= 6 else (3,)):  # conv_a, conv_b, fused head
       eng.set_option('debug_layer', layer)
       eng.forward_resident(1, 3)
       c = eng.debug_clocks()
