@@ -402,6 +402,9 @@ def run_sharded(args, rank, local_rank, world):
   run = runner_lib.Runner(device_id=local_rank)
   run.start(request, batch_size=args.sharded_batch, direct=True,
             image_volume=vol)
+  if args.conv_variant is not None:
+    run.executor.engine.set_option('conv_variant', args.conv_variant)
+  conv_variant = run.executor.engine.get_option('conv_variant')
   sub = (args.sharded_sub,) * 3
   ov = tuple(FOV)
   boxes = ffn_dist.tile_volume(shape, sub, ov, back_shift=True)
@@ -491,6 +494,7 @@ def run_sharded(args, rank, local_rank, world):
                        % (n, len(boxes), args.sharded_sub, args.sharded_batch)),
           'volume': list(shape),
           'sub_boxes': len(boxes),
+          'conv_variant': conv_variant,
           'parallelism': 'sub-boxes sharded over ranks; collectives only in the '
                          'final assembly (RCCL)',
       },

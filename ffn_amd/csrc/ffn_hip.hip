@@ -109,6 +109,10 @@ struct ffn_engine {
   bool e_ok = false;
   int batch_chunks = 1;   // option: variant 6 uses the 96-voxel form for n >= 2
   bool small_now = false; // the stack being queued uses the 96-voxel form
+  // conv32m (variant 8): M split over the waves, weights through an LDS ring
+  bool m_ok = false;
+  bool m_now = false;
+  int nchunks_m = 0;
   int nchunks_e = 0;
   size_t lds_bytes_e = 0;
   int esched_aoff[4 * 8] = {};
@@ -330,6 +334,20 @@ int set_lds_attr_d(size_t bytes) {
 }
 
 constexpr int kERows = 208, kETiles = 3, kEPieces = 7;
+
+int set_lds_attr_m() {
+#define FFN_M_ATTR(KIND, SK, HEADV)                                               \
+  HIP_TRY(hipFuncSetAttribute(                                                    \
+      reinterpret_cast<const void*>(&conv32m_kernel<KIND, SK, HEADV>),            \
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMLdsBytes))
+  FFN_M_ATTR(0, false, false);
+  FFN_M_ATTR(1, false, false);
+  FFN_M_ATTR(1, true, false);
+  FFN_M_ATTR(1, false, true);
+  FFN_M_ATTR(1, true, true);
+#undef FFN_M_ATTR
+  return FFN_OK;
+}
 
 int set_lds_attr_e(size_t bytes) {
 #define FFN_E_ATTR(KIND, SK, HEADV)                                               \
@@ -717,7 +735,8 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   a.XS = g.XS;
   a.plane = g.plane;
   const bool small = e->small_now;  // 96-voxel chunks, 2 workgroups / CU
-  const int nchunks = small ? e->nchunks_e : e->nchunks_k;
+  const bool msplit = e->m_now;     // conv32m: 128-voxel chunks, M split
+  const int nchunks = msplit ? e->nchunks_m : small ? e->nchunks_e : e->nchunks_k;
   a.nchunks = nchunks;
   a.V = g.V;
   a.fx = g.fx;
@@ -757,7 +776,16 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   hipLaunchKernelGGL(                                                            \
       (conv32d_kernel<KIND, SK, kEPieces, HEADV, kETiles, kERows, 2>), grid,     \
       block, e->lds_bytes_e, e->stream, a)
-  if (small) {
+  if (msplit) {
+    if (head.on) {
+      if constexpr (KIND == 1)
+        hipLaunchKernelGGL((conv32m_kernel<KIND, SK, true>), grid, block,
+                           kMLdsBytes, e->stream, a);
+    } else {
+      hipLaunchKernelGGL((conv32m_kernel<KIND, SK, false>), grid, block,
+                         kMLdsBytes, e->stream, a);
+    }
+  } else if (small) {
     if (head.on) {
       if constexpr (KIND == 1) FFN_E_LAUNCH(true);
     } else {
@@ -828,7 +856,9 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   // arithmetic bit for bit) overlaps one workgroup's MFMAs with the other's
   // staging and epilogue
   e->small_now = e->conv_variant == 7 ||
-                 (e->conv_variant == 6 && e->batch_chunks && n >= 2 && e->e_ok);
+                 (e->conv_variant == 6 && e->batch_chunks == 1 && n >= 2 && e->e_ok);
+  e->m_now = e->conv_variant == 8 ||
+             (e->conv_variant == 6 && e->batch_chunks == 2 && n >= 2 && e->m_ok);
   if (e->conv_variant >= 6) {
     // T' -> (X, X') -> T' -> ... ; the head is always fused into the last conv_b
     rc = launch_conv32d<1, false>(e, n, e->rawT, e->rawS, 0);
@@ -892,7 +922,7 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   }
   if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   if (head_fused) {
-    e->count_blocks = e->small_now ? e->nchunks_e
+    e->count_blocks = e->m_now ? e->nchunks_m : e->small_now ? e->nchunks_e
                       : e->conv_variant >= 5 ? e->nchunks_k : e->nchunks_c;
   } else {
     e->count_blocks = kHeadBlocks;
@@ -1164,6 +1194,18 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
                                   (size_t)4 * ce * kDRowB + 64);
         e->e_ok = e->d_ok && span_e + 2 * (g.XS + 1) <= kERows &&
                   e->nchunks_e >= 2 && e->lds_bytes_e <= 80 * 1024;
+        // variant 8: 128-voxel chunks in kMRows rows
+        e->nchunks_m = (g.V + kMChunk - 1) / kMChunk;
+        int span_m = 0;
+        auto padm = [&](int v) {
+          const int x = v % g.fx, y = (v / g.fx) % g.fy, z = v / (g.fx * g.fy);
+          return z * g.plane + y * g.XS + x;
+        };
+        for (int c = 0; c < e->nchunks_m; ++c) {
+          const int v_lo = c * kMChunk, v_hi = std::min(g.V, v_lo + kMChunk) - 1;
+          span_m = std::max(span_m, padm(v_hi) - padm(v_lo) + 1);
+        }
+        e->m_ok = e->d_ok && span_m + 2 * (g.XS + 1) <= kMRows && e->nchunks_m >= 2;
         for (int w = 0; w < 4; ++w)
           for (int j = 0; j < 7; ++j) {
             int s = kSched[w][j];
@@ -1251,6 +1293,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (!rc && e->k_ok) rc = set_lds_attr_k<false, false, true>(e->lds_bytes_k);
     if (!rc && e->d_ok) rc = set_lds_attr_d(e->lds_bytes_d);
     if (!rc && e->e_ok) rc = set_lds_attr_e(e->lds_bytes_e);
+    if (!rc && e->m_ok) rc = set_lds_attr_m();
     if (!rc) rc = set_lds_attr_p<false, false, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<true, true, false>(e->lds_bytes);
     if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
@@ -1510,7 +1553,7 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) {
-    if (value < 0 || value > 7) return fail(FFN_ERR_ARG, "conv_variant must be 0..7");
+    if (value < 0 || value > 8) return fail(FFN_ERR_ARG, "conv_variant must be 0..8");
     if (value >= 4 && e->weights_set && !e->fp16_ok)
       return fail(FFN_ERR_ARG, "conv_variant %d: a weight is outside the fp16 range",
                   value);
@@ -1520,6 +1563,8 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
       return fail(FFN_ERR_ARG, "conv_variant 6 unsupported for this fov / depth");
     if (value == 7 && !e->e_ok)
       return fail(FFN_ERR_ARG, "conv_variant 7 unsupported for this fov / depth");
+    if (value == 8 && !e->m_ok)
+      return fail(FFN_ERR_ARG, "conv_variant 8 unsupported for this fov / depth");
     if (value >= 6 && e->weights_set && !e->d_weights_ok)
       return fail(FFN_ERR_ARG, "conv_variant 6: a weight x 2^11 is outside the fp16 range");
     const Geom& g = e->g;
@@ -1544,7 +1589,10 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     return FFN_OK;
   }
   if (std::strcmp(name, "batch_chunks") == 0) {
-    e->batch_chunks = value != 0;
+    // steps with >= 2 FoVs under conv_variant 6: 0 = the same kernel, 1 = its
+    // 96-voxel form (bit-identical), 2 = conv32m (another summation order)
+    if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "batch_chunks 0..2");
+    e->batch_chunks = value;
     return FFN_OK;
   }
   if (std::strcmp(name, "debug_layer") == 0) {

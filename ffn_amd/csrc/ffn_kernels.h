@@ -2805,6 +2805,358 @@ __global__ __launch_bounds__(kDThreads, WPS) void conv32d_kernel(ConvDArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// conv32m (conv_variant 8): the same split-product conv, M split over the waves.
+//
+// conv32d splits K (the taps) over the four waves so that a lone workgroup per CU
+// fetches every weight fragment once; the price is the epilogue (four partial
+// sums per output meet in LDS: a third of the kernel) and 110 KB of LDS, i.e.
+// one workgroup per CU and nothing to run under its prologue and epilogue.
+// When several FoVs are in flight there ARE other workgroups, so here
+//   * a workgroup = 128 dense voxels, wave w owns tile w (32 positions) for ALL
+//     27 taps: no cross-wave reduction, the epilogue goes straight from the
+//     accumulators to memory (no LDS, no barrier);
+//   * the weights are shared through LDS instead: each tap's 4 KB of fragments
+//     is copied ONCE per workgroup by LDS-DMA into a ring of five taps (one
+//     1-KiB piece per wave, issued four taps ahead) and read by all four waves;
+//   * the waves walk the taps in lock step (one barrier per tap), so the dz = +1
+//     segment can take the LDS slot of dz = -1 once every wave is past tap 8:
+//     two slots of 240 rows + a ring of five taps = 80 KB, TWO workgroups per
+//     CU, <= 156 registers per lane (the accumulators stay in VGPRs: no
+//     accumulator read-out) -- one workgroup's MFMAs run under the other's
+//     prologue, barriers and epilogue.
+// Activations, weights, split planes, staging by DMA, range check, fused head:
+// conv32d's.  Every wave accumulates its outputs over all taps in tap order
+// (hi x hi, and the two cross products in a second accumulator): the summation
+// ORDER differs from conv32d's (partial sums per wave, then added), so the
+// logits agree to ~1e-6 but not bit for bit.
+// All global loads are inline asm (hidden from the compiler), so every
+// s_waitcnt vmcnt is written by hand from the fixed issue order
+//   W0 .. W3 | dz=-1 (8) | dz=0 (8) | tap s: W(s+4) [s = 9: dz=+1 (8)]
+//   [s = 22: the epilogue operands (NEPI)]
+// tap s waits for W(s+1) (prefetched into registers during tap s); the counts
+// are computed at compile time from that order (m_wait).
+// ---------------------------------------------------------------------------
+constexpr int kMChunk = 128;
+constexpr int kMRows = 240;
+constexpr int kMPieces = 8;                    // DMA pieces per wave and segment
+constexpr int kMSeg = 8 * kMRows * 16;         // bytes of a segment slot
+constexpr int kMRing = 2 * kMSeg;              // LDS offset of the weight ring
+constexpr int kMRingTaps = 5;                  // taps resident in the weight ring
+constexpr int kMLdsBytes = kMRing + kMRingTaps * 4096;  // 81,920: two per CU
+
+// vmcnt for tap S's wait (-1: nothing to wait for): operations issued before it
+// that are NEWER than W(S+1).  D = ring depth: W0 .. W(D-2) are queued in front
+// of the segments, tap t queues W(t+D-1) [t = 9: then the dz = +1 DMAs; t =
+// 27 - D: then the NEPI epilogue operands].
+constexpr int m_wait(int S, int D, int NEPI) {
+  if (S == 0) return kMPieces;      // dz = 0's DMAs are newer than dz = -1 / W1
+  if (S + 1 > 26) return -1;
+  if (S + 1 <= D - 2) return -1;    // queued in front of everything: landed
+  const int tr = S + 2 - D;         // the tap that queued W(S+1)
+  int n = 0;
+  for (int t = tr + 1; t <= S - 1; ++t) n += (t <= 27 - D) ? 1 : 0;
+  if (tr <= 9 && 9 <= S - 1) n += kMPieces;
+  if (tr <= 27 - D && 27 - D <= S - 1) n += NEPI;
+  return n;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int OFF>
+__device__ __forceinline__ f32x4 hidden_load16f(const char* sbase, unsigned voff) {
+  f32x4 d;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+               : "=v"(d)
+               : "v"(voff), "s"(sbase), "n"(OFF)
+               : "memory");
+  return d;
+}
+
+template <int KIND, bool ADD_SKIP, bool HEAD>
+__global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
+  typedef f16x8 frag_t;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  constexpr int R = kMRows;
+  constexpr int R16 = R * 16;
+  constexpr int NEPI = HEAD ? (ADD_SKIP ? 13 : 9) : (ADD_SKIP ? 8 : 4);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x;
+  const long long dbg_c0 = a.dbg ? clock64() : 0;
+  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
+  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
+  if (gc >= a.total_slots) return;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int item = (int)__umulhi((unsigned)gc, a.magic_nchunks);
+  const int chunk = gc - item * a.nchunks;
+  const int v0 = chunk * kMChunk;
+  auto padded = [&](int v) {
+    v = v < a.V ? v : a.V - 1;
+    const int z = (int)__umulhi((unsigned)v, a.magic_fyfx);
+    const int rem = v - z * a.fyfx;
+    const int y = (int)__umulhi((unsigned)rem, a.magic_fx);
+    return z * a.plane + y * a.XS + (rem - y * a.fx);
+  };
+  const int p_first = __builtin_amdgcn_readfirstlane(padded(v0));
+  const int p_lo = p_first - (a.XS + 1);
+  const int lane = tid & 63;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const unsigned lbase =
+      (unsigned)(size_t)(__attribute__((address_space(3))) char*)ldsb;
+
+  // ---- weight ring: tap s -> slot s % D, this wave copies piece `wave` ----
+  constexpr int D = kMRingTaps;
+  auto dma_w = [&](int s) {
+    lds_dma16(a.wpack + (long)s * kDTapBytes + wave * 1024, (unsigned)lane * 16,
+              lbase + kMRing + (s % D) * 4096 + wave * 1024);
+  };
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) dma_w(s);
+  // ---- activations: dz = -1 -> slot 0, dz = 0 -> slot 1 (dz = +1 later -> slot 0)
+  const char* g0 = a.in_sp + (long)item * a.item_bytes + (long)p_lo * 16;
+  unsigned voff[kMPieces];
+#pragma unroll
+  for (int k = 0; k < kMPieces; ++k) {
+    int u = 64 * (wave + 4 * k) + lane;
+    u = u >= 8 * R ? u - 8 * R : u;
+    const int cp = u / R;
+    voff[k] = (unsigned)(cp * (int)a.sp_plane_bytes + (u - cp * R) * 16);
+  }
+  auto dma_seg = [&](int seg) {  // seg 0, 1, 2 = dz -1, 0, +1
+#pragma unroll
+    for (int k = 0; k < kMPieces; ++k) {
+      const int u0 = 64 * (wave + 4 * k);
+      lds_dma16(g0 + (long)(seg - 1) * a.plane * 16, voff[k],
+                lbase + (seg & 1) * kMSeg + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
+    }
+  };
+  dma_seg(0);
+  dma_seg(1);
+
+  // this lane's position (its tile = its wave) and its place in the LDS image
+  const int jpos = wave * 32 + li;
+  const bool ok = v0 + jpos < a.V;
+  const int ppos = padded(v0 + jpos);
+  const int xb = (ppos - p_lo) * 16 + lh * R16;
+
+  struct Frag { frag_t x[2][2]; frag_t w[2][2]; };  // [khalf][plane hi, res]
+  auto load_frags = [&](int s, Frag& f) {
+    const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
+    const char* px = ldsb + xb + (kz & 1) * kMSeg + ((ky - 1) * a.XS + (kx - 1)) * 16;
+    const char* pw = ldsb + kMRing + (s % D) * 4096 + lane * 16;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        f.x[kh][pl] = *reinterpret_cast<const frag_t*>(px + (pl * 4 + kh * 2) * R16);
+        f.w[kh][pl] = *reinterpret_cast<const frag_t*>(pw + (kh * 2 + pl) * 1024);
+      }
+  };
+  f32x16 acc, accC;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = accC[r] = 0.f;
+  auto mma = [](const frag_t& fw, const frag_t& fx, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fx, c, 0, 0, 0);
+  };
+  // epilogue operands (hidden loads, issued at tap 23)
+  f32x4 bias4[4], skip4[4], hw4[4];
+  float seedv = 0.f, hbias = 0.f;
+
+  Frag F0, F1;
+  wait_vmcnt<kMPieces>();  // W0 .. W(D-2), dz = -1 landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const long long dbg_c1 = a.dbg ? clock64() : 0;
+  dma_w(D - 1);
+  load_frags(0, F0);
+
+  // tap S: (wait for W(S+1), barrier, queue W(S+3)), prefetch tap S+1's
+  // fragments, 6 MFMAs on the current ones
+#define FFN_MTAP(S, FCUR, FNEXT)                                                \
+  {                                                                             \
+    if ((S) > 0) {                                                              \
+      if constexpr (m_wait(S, D, NEPI) >= 0) wait_vmcnt<m_wait(S, D, NEPI)>();  \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
+      __builtin_amdgcn_s_barrier();                                             \
+      asm volatile("" ::: "memory");                                            \
+      if ((S) + D - 1 <= 26) dma_w((S) + D - 1);                                \
+      if ((S) == 9) dma_seg(2);                                                 \
+      if ((S) == 27 - D) issue_epilogue_loads();                                \
+    }                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    if ((S) + 1 <= 26) load_frags((S) + 1, FNEXT);                              \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    accC = mma(FCUR.w[0][0], FCUR.x[0][1], accC);                               \
+    acc = mma(FCUR.w[0][0], FCUR.x[0][0], acc);                                 \
+    accC = mma(FCUR.w[0][1], FCUR.x[0][0], accC);                               \
+    acc = mma(FCUR.w[1][0], FCUR.x[1][0], acc);                                 \
+    accC = mma(FCUR.w[1][0], FCUR.x[1][1], accC);                               \
+    accC = mma(FCUR.w[1][1], FCUR.x[1][0], accC);                               \
+  }
+  auto issue_epilogue_loads = [&]() {
+    const unsigned vb = (unsigned)lh * 16;  // channels 8 g + 4 lh .. + 3
+    const char* bp = reinterpret_cast<const char*>(a.bias);
+    bias4[0] = hidden_load16f<0>(bp, vb);
+    bias4[1] = hidden_load16f<32>(bp, vb);
+    bias4[2] = hidden_load16f<64>(bp, vb);
+    bias4[3] = hidden_load16f<96>(bp, vb);
+    if constexpr (ADD_SKIP) {
+      // f32 plane 2 g + lh, 16 B per position
+      const char* xs = reinterpret_cast<const char*>(a.x_f32) + (long)item * a.item_bytes;
+      const unsigned vs = (unsigned)(lh * (int)a.sp_plane_bytes + ppos * 16);
+      skip4[0] = hidden_load16f<0>(xs, vs);
+      skip4[1] = hidden_load16f<0>(xs + 2 * a.sp_plane_bytes, vs);
+      skip4[2] = hidden_load16f<0>(xs + 4 * a.sp_plane_bytes, vs);
+      skip4[3] = hidden_load16f<0>(xs + 6 * a.sp_plane_bytes, vs);
+    }
+    if constexpr (HEAD) {
+      const char* hp = reinterpret_cast<const char*>(a.head_w);
+      hw4[0] = hidden_load16f<0>(hp, vb);
+      hw4[1] = hidden_load16f<32>(hp, vb);
+      hw4[2] = hidden_load16f<64>(hp, vb);
+      hw4[3] = hidden_load16f<96>(hp, vb);
+      const char* sp = reinterpret_cast<const char*>(a.seed_raw + (size_t)item * a.V);
+      asm volatile("global_load_dword %0, %1, %2"
+                   : "=v"(seedv)
+                   : "v"((unsigned)((ok ? v0 + jpos : 0) * 4)), "s"(sp)
+                   : "memory");
+    }
+  };
+  FFN_MTAP(0, F0, F1)
+  FFN_MTAP(1, F1, F0)
+  FFN_MTAP(2, F0, F1)
+  FFN_MTAP(3, F1, F0)
+  FFN_MTAP(4, F0, F1)
+  FFN_MTAP(5, F1, F0)
+  FFN_MTAP(6, F0, F1)
+  FFN_MTAP(7, F1, F0)
+  FFN_MTAP(8, F0, F1)
+  FFN_MTAP(9, F1, F0)
+  FFN_MTAP(10, F0, F1)
+  FFN_MTAP(11, F1, F0)
+  FFN_MTAP(12, F0, F1)
+  FFN_MTAP(13, F1, F0)
+  FFN_MTAP(14, F0, F1)
+  FFN_MTAP(15, F1, F0)
+  FFN_MTAP(16, F0, F1)
+  FFN_MTAP(17, F1, F0)
+  FFN_MTAP(18, F0, F1)
+  FFN_MTAP(19, F1, F0)
+  FFN_MTAP(20, F0, F1)
+  FFN_MTAP(21, F1, F0)
+  FFN_MTAP(22, F0, F1)
+  FFN_MTAP(23, F1, F0)
+  FFN_MTAP(24, F0, F1)
+  FFN_MTAP(25, F1, F0)
+  FFN_MTAP(26, F0, F1)
+#undef FFN_MTAP
+  const long long dbg_c2 = a.dbg ? clock64() : 0;
+
+  // ---- epilogue: straight from the accumulators (lane = position jpos,
+  // register 4 g + i = channel 8 g + 4 lh + i) ----
+  wait_vmcnt<0>();
+  asm volatile(""
+               : "+v"(bias4[0]), "+v"(bias4[1]), "+v"(bias4[2]), "+v"(bias4[3]));
+  if constexpr (ADD_SKIP)
+    asm volatile(""
+                 : "+v"(skip4[0]), "+v"(skip4[1]), "+v"(skip4[2]), "+v"(skip4[3]));
+  if constexpr (HEAD)
+    asm volatile(""
+                 : "+v"(hw4[0]), "+v"(hw4[1]), "+v"(hw4[2]), "+v"(hw4[3]),
+                   "+v"(seedv));
+  const f32x16 s = acc + accC * 4.8828125e-4f;  // 2^-11
+  unsigned range_max = 0;
+  if constexpr (HEAD) {
+    hbias = a.head_w[kFeatures];
+    float partial = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = f32x4{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
+      v += bias4[g];
+      if (ADD_SKIP) v += skip4[g];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        partial = __builtin_fmaf(fmaxf(v[i], 0.f), hw4[g][i], partial);
+    }
+    partial += __shfl_xor(partial, 32);  // the other 16 channels of the position
+    bool above = false;
+    if (lh == 0 && ok) {
+      const size_t dv = (size_t)item * a.V + (v0 + jpos);
+      float sd = seedv;
+      if (sd != sd) sd = a.pad_value;
+      const float lg = sd + (partial + hbias);
+      a.logits[dv] = lg;
+      above = lg >= a.move_thr;
+    }
+    const unsigned mine = (unsigned)__popcll(__ballot(above));
+    // (LDS is free: every wave is past its last fragment read only after the
+    // barrier below)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* cnt = reinterpret_cast<float*>(ldsb);
+    if (lane == 0) cnt[wave] = __uint_as_float(mine);
+    __syncthreads();
+    if (tid == 0)
+      a.head_count[gc] = __float_as_uint(cnt[0]) + __float_as_uint(cnt[1]) +
+                         __float_as_uint(cnt[2]) + __float_as_uint(cnt[3]);
+  } else {
+    const __amdgpu_buffer_rsrc_t rs_sp = __builtin_amdgcn_make_buffer_rsrc(
+        a.out_sp + (long)item * a.item_bytes, 0, a.sp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(a.x_f32) + (long)item * a.item_bytes, 0, a.sp_bytes,
+        0x00020000);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = f32x4{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
+      v += bias4[g];
+      if (KIND == 1) {
+        if (ADD_SKIP) v += skip4[g];
+        const unsigned xo =
+            ok ? (unsigned)((2 * g + lh) * (int)a.sp_plane_bytes + ppos * 16)
+               : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_x,
+                                               xo, 0, 16);
+      }
+      f32x4 vh;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int bits = __float_as_int(v[cc]);  // ReLU (-0 -> +0, NaN stays)
+        v[cc] = __int_as_float(bits > 0 ? bits : 0);
+        const unsigned mbits = __float_as_uint(v[cc]);
+        range_max = mbits > range_max ? mbits : range_max;
+        vh[cc] = mbits < 0x38800000u ? 0.0f : v[cc];  // < 2^-14: all residual
+      }
+      const f16x4 h4 = __builtin_convertvector(vh, f16x4);
+      const f32x4 r1 = (v - __builtin_convertvector(h4, f32x4)) * 2048.0f;
+      const f16x4 r4 = __builtin_convertvector(r1, f16x4);
+      const unsigned so =
+          ok ? (unsigned)(g * (int)a.sp_plane_bytes + ppos * 16 + lh * 8)
+             : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h4), rs_sp, so,
+                                            0, 16);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, r4), rs_sp, so,
+                                            (int)(4 * a.sp_plane_bytes), 16);
+    }
+    if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
+      *a.range_flag = a.range_tag;
+  }
+  if (a.dbg && gc == 0 && lane == 0) {
+    long long* d = a.dbg + wave * 6;
+    d[0] = dbg_c0;
+    d[1] = dbg_c1;
+    d[2] = dbg_c2;
+    d[3] = clock64();
+    d[4] = dbg_w0;
+    d[5] = wall_clock64();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // head: ReLU -> 1x1x1 conv 32->1 + bias; logits = seed + update
 // (reference convstack_3d.py:51-54,91-94; model.py:168-183) and the count of
 // logits >= move_threshold that the disco test needs (inference.py:428-431).

@@ -42,14 +42,15 @@ def _fov_inputs(rng, n=1):
 
 @pytest.mark.parametrize('variant,fuse_head,waves8', [
     (0, 1, 1), (1, 1, 1), (2, 1, 1), (2, 0, 1), (3, 1, 1), (3, 0, 1), (4, 1, 1),
-    (4, 0, 1), (3, 1, 0), (4, 1, 0), (4, 0, 0), (4, 1, 2), (4, 0, 2), (5, 1, 2), (5, 0, 2), (6, 1, 2), (7, 1, 2)])
+    (4, 0, 1), (3, 1, 0), (4, 1, 0), (4, 0, 0), (4, 1, 2), (4, 0, 2), (5, 1, 2), (5, 0, 2), (6, 1, 2), (7, 1, 2), (8, 1, 2)])
 def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head, waves8):
   """conv_variant 0 simple f32 MFMA, 1 padded pipelined, 2 compact (exact f32
   MFMA), 3 compact with bf16x3 split products, 4 with fp16 hi + scaled
   residual, 5 the same products on 32x32x16 MFMAs with the taps split over the
   waves (conv32k), 6 the same on producer-split planes staged by LDS-DMA
-  (conv32d), 7 = 6 with 96-voxel chunks for two workgroups per CU; with the
-  1x1x1 head fused into the last conv or as its own launch."""
+  (conv32d), 7 = 6 with 96-voxel chunks for two workgroups per CU, 8 = the M-split
+  form with the weights in an LDS ring (conv32m); with the 1x1x1 head fused into
+  the last conv or as its own launch."""
   from oracle import ffn_oracle
   engine.set_option('conv_variant', variant)
   engine.set_option('fuse_head', fuse_head)
@@ -91,7 +92,7 @@ def test_predict_is_deterministic_and_variants_agree(engine):
   b = engine.predict(seed, img)
   assert np.array_equal(a, b)
   by_variant = {}
-  for variant in (0, 1, 2, 3, 4, 5, 6, 7):
+  for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):
     engine.set_option('conv_variant', variant)
     c = engine.predict(seed, img)
     assert np.abs(a - c).max() <= 2e-5, variant
