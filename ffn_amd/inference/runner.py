@@ -52,7 +52,11 @@ class Runner:
   #: (ffn_canvas_create_u8); False = normalise on the host as the reference does
   DEVICE_U8 = True
 
-  def __init__(self, device_id: int = 0):
+  def __init__(self, device_id: int = 0, conv_variant: Optional[int] = None):
+    """conv_variant: None = the engine's default (conv32d; 2 = the exact-f32
+    kernel in the oracle's summation order, 8 = the M-split kernel for batched
+    drives: include/ffn_hip.h)."""
+    self.conv_variant = conv_variant
     self.counters = inference_utils.Counters()
     self.executor = None
     self._exec_interface = executor.ExecutorInterface()
@@ -98,6 +102,8 @@ class Runner:
     self.executor = executor.HipBatchExecutor(
         self._exec_interface, model, model.info, None, self.counters,
         batch_size, device_id=self.device_id)
+    if self.conv_variant is not None:
+      self.executor.engine.set_option('conv_variant', int(self.conv_variant))
     return model
 
   def start(self, request, batch_size: int = 1, session=None, direct=None,

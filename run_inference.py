@@ -38,6 +38,10 @@ def main(argv=None):
                   'the whole bounding box on one rank).')
   ap.add_argument('--overlap', default='', help='x,y,z overlap of sub-boxes.')
   ap.add_argument('--batch_size', type=int, default=1)
+  ap.add_argument('--conv_variant', type=int, default=None,
+                  help='kernel behind the 32->32 convs (default: conv32d; 2 = exact '
+                  'f32 in the oracle\'s summation order; 8 = M-split, for batched '
+                  'runs); see DESIGN.md section 3')
   ap.add_argument('--assemble', default='',
                   help='With sharding: also assemble ONE global label volume '
                   '(RCCL all-reduce + union-find reconciliation of objects cut '
@@ -61,7 +65,7 @@ def main(argv=None):
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
 
-  runner = runner_lib.Runner(device_id=local_rank)
+  runner = runner_lib.Runner(device_id=local_rank, conv_variant=args.conv_variant)
   runner.start(request, batch_size=args.batch_size,
                direct=True if args.assemble else None)
 
