@@ -1225,8 +1225,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     const bool p_ok = g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256;
     const bool c_ok = e->Rc == 256 || e->Rc == 288;
     if (e->lds_bytes_k > 160 * 1024) e->k_ok = false;
-    // default: conv32d where the geometry allows it, else conv32w8, ...
-    e->conv_variant = e->d_ok ? 6 : c_ok ? 4 : (p_ok ? 1 : 0);
+    // default: conv32m where the geometry allows it (33^3: yes), else conv32d,
+    // else conv32w8, ...
+    e->conv_variant = e->m_ok ? 8 : e->d_ok ? 6 : c_ok ? 4 : (p_ok ? 1 : 0);
   }
 
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)

@@ -2975,8 +2975,36 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
   dma_w(D - 1);
   load_frags(0, F0);
 
-  // tap S: (wait for W(S+1), barrier, queue W(S+3)), prefetch tap S+1's
-  // fragments, 6 MFMAs on the current ones
+  // tap S: wait for W(S+1), barrier; then the 6 MFMAs of the current fragments
+  // with everything else between them, in the shadow of the matrix pipe: the
+  // queueing of W(S+D-1) [, the dz = +1 DMAs, the epilogue operands] and the 8
+  // fragment reads of tap S+1
+  auto load_part = [&](int s, int part, Frag& f) {  // 2 of the 8 reads of tap s
+    const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
+    const char* px = ldsb + xb + (kz & 1) * kMSeg + ((ky - 1) * a.XS + (kx - 1)) * 16;
+    const char* pw = ldsb + kMRing + (s % D) * 4096 + lane * 16;
+    const int kh = part & 1;
+    if (part < 2) {
+      f.w[kh][0] = *reinterpret_cast<const frag_t*>(pw + (kh * 2 + 0) * 1024);
+      f.w[kh][1] = *reinterpret_cast<const frag_t*>(pw + (kh * 2 + 1) * 1024);
+    } else {
+      f.x[kh][0] = *reinterpret_cast<const frag_t*>(px + (0 * 4 + kh * 2) * R16);
+      f.x[kh][1] = *reinterpret_cast<const frag_t*>(px + (1 * 4 + kh * 2) * R16);
+    }
+  };
+  auto dma_seg_part = [&](int k0, int k1) {  // pieces [k0, k1) of dz = +1 -> slot 0
+#pragma unroll
+    for (int k = k0; k < k1; ++k) {
+      const int u0 = 64 * (wave + 4 * k);
+      lds_dma16(g0 + (long)a.plane * 16, voff[k],
+                lbase + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
+    }
+  };
+#define FFN_MGAP(S, PART, FNEXT)                                                \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  if ((S) + 1 <= 26) load_part((S) + 1, PART, FNEXT);                           \
+  if ((S) == 9) dma_seg_part(2 * (PART), 2 * (PART) + 2);                       \
+  __builtin_amdgcn_sched_barrier(0);
 #define FFN_MTAP(S, FCUR, FNEXT)                                                \
   {                                                                             \
     if ((S) > 0) {                                                              \
@@ -2984,19 +3012,24 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
       __builtin_amdgcn_s_barrier();                                             \
       asm volatile("" ::: "memory");                                            \
-      if ((S) + D - 1 <= 26) dma_w((S) + D - 1);                                \
-      if ((S) == 9) dma_seg(2);                                                 \
-      if ((S) == 27 - D) issue_epilogue_loads();                                \
     }                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                          \
-    if ((S) + 1 <= 26) load_frags((S) + 1, FNEXT);                              \
-    __builtin_amdgcn_sched_barrier(0);                                          \
     accC = mma(FCUR.w[0][0], FCUR.x[0][1], accC);                               \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    if ((S) > 0 && (S) + D - 1 <= 26) dma_w((S) + D - 1);                       \
+    __builtin_amdgcn_sched_barrier(0);                                          \
     acc = mma(FCUR.w[0][0], FCUR.x[0][0], acc);                                 \
+    FFN_MGAP(S, 0, FNEXT)                                                       \
     accC = mma(FCUR.w[0][1], FCUR.x[0][0], accC);                               \
+    FFN_MGAP(S, 1, FNEXT)                                                       \
     acc = mma(FCUR.w[1][0], FCUR.x[1][0], acc);                                 \
+    FFN_MGAP(S, 2, FNEXT)                                                       \
     accC = mma(FCUR.w[1][0], FCUR.x[1][1], accC);                               \
+    FFN_MGAP(S, 3, FNEXT)                                                       \
     accC = mma(FCUR.w[1][1], FCUR.x[1][0], accC);                               \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    if ((S) == 27 - D) issue_epilogue_loads();                                  \
+    __builtin_amdgcn_sched_barrier(0);                                          \
   }
   auto issue_epilogue_loads = [&]() {
     const unsigned vb = (unsigned)lh * 16;  // channels 8 g + 4 lh .. + 3
@@ -3055,6 +3088,7 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
   FFN_MTAP(25, F1, F0)
   FFN_MTAP(26, F0, F1)
 #undef FFN_MTAP
+#undef FFN_MGAP
   const long long dbg_c2 = a.dbg ? clock64() : 0;
 
   // ---- epilogue: straight from the accumulators (lane = position jpos,

@@ -17,7 +17,7 @@ from tests.conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-DEFAULT_VARIANT = 6
+DEFAULT_VARIANT = 8
 DEFAULT_WAVES8 = 2  # what ffn_engine_create selects for the 33^3 FoV
 TOL = 1e-4
 
@@ -833,9 +833,9 @@ def test_large_canvas_offsets_beyond_2gib(engine, fib25_blob):
   canvas.close()
 
 
-@pytest.mark.parametrize('fast', [6, 4])
+@pytest.mark.parametrize('fast', [8, 6, 4])
 def test_fp16_range_fallback(fib25_model, fib25_blob, fast):
-  """conv_variants 4 / 6 keep operands in fp16: a value beyond 65504 must void
+  """conv_variants 4 / 6 / 8 keep operands in fp16: a value beyond 65504 must void
   the run (nothing pasted) and repeat it with the bf16x3 scheme -- silently for
   ffn_predict, through FFN_ERR_RANGE + retry for canvas steps."""
   from ffn_amd import _lib

@@ -166,7 +166,7 @@ def test_cells250_matches_reference_minted_run(hip_exe, fib25_model, variant):
           (variant, len(got_steps), max_err))
     canvas.close()
   finally:
-    eng.set_option('conv_variant', 6)
+    eng.set_option('conv_variant', 8)
 
 
 def test_cells250_logit_tolerance_on_canvas_states(hip_exe, fib25_model):
@@ -225,7 +225,7 @@ def test_cells250_logit_tolerance_on_canvas_states(hip_exe, fib25_model):
     print('max |logit - exact f32 kernel| on canvas states:', worst)
     assert max(worst.values()) <= 2e-5, worst
   finally:
-    eng.set_option('conv_variant', 6)
+    eng.set_option('conv_variant', 8)
 
 
 def test_cells250_native_loop_same_result(hip_exe, fib25_model):

@@ -8,7 +8,7 @@ echo "== rocprof stats"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats
 tail -1 gpurun_out/rocprof.log | cut -c1-200
 for f in $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); do cp $f gpurun_out/r02_default_kernel_stats.csv; head -9 $f | cut -c1-160; done
 rm -rf gpurun_out/prof
-echo "== SQ"; bash tools/gpu_pmc_sq.sh 2>&1 | tee gpurun_out/r02_pmc_sq_conv32d.txt | head -40
+echo "== SQ"; bash tools/gpu_pmc_sq.sh 2>&1 | tee gpurun_out/r02_pmc_sq_default.txt | head -40
 rm -rf gpurun_out/pmc_SQ
 echo "== traffic"; bash tools/gpu_pmc.sh 2>&1 | tee gpurun_out/r02_pmc_fetch_write.txt
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
