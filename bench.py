@@ -775,12 +775,19 @@ def main():
     pass
   variant = res.get('conv_variant', 4)
   PEAK_F16_MFMA_TFLOPS = PEAK_BF16_MFMA_TFLOPS  # same dense rate on gfx950
-  if variant in (3, 4, 5, 6, 7, 8):
+  if variant in (3, 4, 5, 6, 7, 8, 9):
     products = BF16X3_PRODUCTS if variant == 3 else 3
     mfma = {3: 'v_mfma_f32_16x16x32_bf16', 4: 'v_mfma_f32_16x16x32_f16',
             5: 'v_mfma_f32_32x32x16_f16', 6: 'v_mfma_f32_32x32x16_f16',
-            7: 'v_mfma_f32_32x32x16_f16', 8: 'v_mfma_f32_32x32x16_f16'}[variant]
-    shape = ('conv32m (3x3x3 32->32 implicit GEMM on producer-split fp16 planes '
+            7: 'v_mfma_f32_32x32x16_f16', 8: 'v_mfma_f32_32x32x16_f16',
+            9: 'v_mfma_f32_32x32x16_f16'}[variant]
+    shape = ('conv32mt (3x3x3 32->32 implicit GEMM on producer-split fp16 planes '
+             'staged by LDS-DMA: 256 conv32m workgroups of 128 voxels, one per '
+             'CU -- one 32-position tile per wave for all 27 taps, weights '
+             'through an LDS-DMA ring -- and the remaining voxels in 32-voxel '
+             'tail workgroups whose taps are split over the four waves'
+             if variant == 9 else
+             'conv32m (3x3x3 32->32 implicit GEMM on producer-split fp16 planes '
              'staged by LDS-DMA, 4-wave workgroups of 128 voxels, one 32-position '
              'tile per wave for all 27 taps, weights through an LDS-DMA ring, two '
              'workgroups per CU' if variant == 8 else

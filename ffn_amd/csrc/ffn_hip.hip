@@ -112,6 +112,14 @@ struct ffn_engine {
   // conv32m (variant 8): M split over the waves, weights through an LDS ring
   bool m_ok = false;
   bool m_now = false;
+  // conv32mt (variant 9): conv32m for the first n_main <= 256 chunks, 32-voxel
+  // K-split tail workgroups for the rest
+  bool t_ok = false;
+  bool t_now = false;
+  int tail_batched = 0;  // option: steps with >= 2 FoVs take the tail form too
+  int n_main = 0, n_tail = 0, n_tail3 = 0;  // tail workgroups of 32 / 96 voxels
+  int tsched_aoff[4 * 8] = {};
+  int t3sched_aoff[4 * 8] = {};
   int nchunks_m = 0;
   int nchunks_e = 0;
   size_t lds_bytes_e = 0;
@@ -346,6 +354,19 @@ int set_lds_attr_m() {
   FFN_M_ATTR(1, false, true);
   FFN_M_ATTR(1, true, true);
 #undef FFN_M_ATTR
+#define FFN_MT_ATTR(KIND, SK, HEADV)                                              \
+  HIP_TRY(hipFuncSetAttribute(                                                    \
+      reinterpret_cast<const void*>(&conv32mt_kernel<KIND, SK, HEADV, 1>),        \
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMLdsBytes));              \
+  HIP_TRY(hipFuncSetAttribute(                                                    \
+      reinterpret_cast<const void*>(&conv32mt_kernel<KIND, SK, HEADV, 3>),        \
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMLdsBytes))
+  FFN_MT_ATTR(0, false, false);
+  FFN_MT_ATTR(1, false, false);
+  FFN_MT_ATTR(1, true, false);
+  FFN_MT_ATTR(1, false, true);
+  FFN_MT_ATTR(1, true, true);
+#undef FFN_MT_ATTR
   return FFN_OK;
 }
 
@@ -776,7 +797,32 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   hipLaunchKernelGGL(                                                            \
       (conv32d_kernel<KIND, SK, kEPieces, HEADV, kETiles, kERows, 2>), grid,     \
       block, e->lds_bytes_e, e->stream, a)
-  if (msplit) {
+  if (e->t_now) {
+    // one FoV: 32-voxel tail workgroups (balance over the CUs); several: the
+    // same voxels in 96-voxel ones (cost per voxel) -- the same bits
+    const bool one = n == 1;
+    ConvTailMap mp;
+    mp.n = n;
+    mp.n_main = e->n_main;
+    mp.n_tail = one ? e->n_tail : e->n_tail3;
+    mp.mains_per_xcd = (mp.n_main + 7) / 8;
+    mp.tails_per_xcd = (mp.n_tail + 7) / 8;
+    std::memcpy(mp.taoff, one ? e->tsched_aoff : e->t3sched_aoff, sizeof(mp.taoff));
+    const dim3 tgrid(8 * n * (mp.mains_per_xcd + mp.tails_per_xcd));
+#define FFN_MT_LAUNCH(HEADV)                                                      \
+  if (one)                                                                        \
+    hipLaunchKernelGGL((conv32mt_kernel<KIND, SK, HEADV, 1>), tgrid, block,       \
+                       kMLdsBytes, e->stream, a, mp);                             \
+  else                                                                            \
+    hipLaunchKernelGGL((conv32mt_kernel<KIND, SK, HEADV, 3>), tgrid, block,       \
+                       kMLdsBytes, e->stream, a, mp)
+    if (head.on) {
+      if constexpr (KIND == 1) { FFN_MT_LAUNCH(true); }
+    } else {
+      FFN_MT_LAUNCH(false);
+    }
+#undef FFN_MT_LAUNCH
+  } else if (msplit) {
     if (head.on) {
       if constexpr (KIND == 1)
         hipLaunchKernelGGL((conv32m_kernel<KIND, SK, true>), grid, block,
@@ -857,8 +903,12 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   // staging and epilogue
   e->small_now = e->conv_variant == 7 ||
                  (e->conv_variant == 6 && e->batch_chunks == 1 && n >= 2 && e->e_ok);
-  e->m_now = e->conv_variant == 8 ||
+  e->m_now = e->conv_variant >= 8 ||
              (e->conv_variant == 6 && e->batch_chunks == 2 && n >= 2 && e->m_ok);
+  // variant 9: a single FoV runs conv32mt (balance over the CUs: +14 %); steps
+  // with several FoVs run plain conv32m (cost per voxel: the K-split tail costs
+  // 5-10 % there) unless tail_batched asks for the single-FoV bits
+  e->t_now = e->conv_variant == 9 && (n == 1 || e->tail_batched != 0);
   if (e->conv_variant >= 6) {
     // T' -> (X, X') -> T' -> ... ; the head is always fused into the last conv_b
     rc = launch_conv32d<1, false>(e, n, e->rawT, e->rawS, 0);
@@ -922,7 +972,8 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   }
   if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   if (head_fused) {
-    e->count_blocks = e->m_now ? e->nchunks_m : e->small_now ? e->nchunks_e
+    e->count_blocks = e->t_now ? e->n_main + (n == 1 ? e->n_tail : e->n_tail3)
+                      : e->m_now ? e->nchunks_m : e->small_now ? e->nchunks_e
                       : e->conv_variant >= 5 ? e->nchunks_k : e->nchunks_c;
   } else {
     e->count_blocks = kHeadBlocks;
@@ -1085,7 +1136,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   E_TRY(hipMemset(e->up_image, 0, vbytes));
   E_TRY(hipMemset(e->up_seed, 0, vbytes));
   E_TRY(hipMalloc(&e->count, sizeof(unsigned) * max_batch *
-                                  std::max<size_t>(kHeadBlocks, (g.V + 95) / 96)));
+                                  std::max<size_t>(kHeadBlocks, (g.V + 31) / 32)));
   E_TRY(hipMalloc(&e->d_items, sizeof(StepItem) * 2 * max_batch));
   E_TRY(hipHostMalloc(&e->h_items, sizeof(StepItem) * 2 * max_batch,
                       hipHostMallocDefault));
@@ -1206,6 +1257,39 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
           span_m = std::max(span_m, padm(v_hi) - padm(v_lo) + 1);
         }
         e->m_ok = e->d_ok && span_m + 2 * (g.XS + 1) <= kMRows && e->nchunks_m >= 2;
+        // variant 9: the chunks past the 256th become 32-voxel tail workgroups,
+        // as long as all of one FoV's workgroups find a slot at once (two per CU)
+        if (e->m_ok && e->nchunks_m > 256) {
+          e->n_main = 256;
+          e->n_tail = (g.V - 256 * kMChunk + 31) / 32;
+          e->n_tail3 = (g.V - 256 * kMChunk + 95) / 96;
+          int span_t = 0, span_t3 = 0;
+          for (int c = 0; c < e->n_tail; ++c) {
+            const int v_lo = 256 * kMChunk + c * 32, v_hi = std::min(g.V, v_lo + 32) - 1;
+            span_t = std::max(span_t, padm(v_hi) - padm(v_lo) + 1);
+          }
+          for (int c = 0; c < e->n_tail3; ++c) {
+            const int v_lo = 256 * kMChunk + c * 96, v_hi = std::min(g.V, v_lo + 96) - 1;
+            span_t3 = std::max(span_t3, padm(v_hi) - padm(v_lo) + 1);
+          }
+          static_assert((size_t)3 * 128 * kTRows <= kMLdsBytes &&
+                            (size_t)4 * 32 * kDRowB + 64 <= kMLdsBytes &&
+                            (size_t)3 * 128 * kT3Rows <= kMLdsBytes &&
+                            (size_t)4 * 96 * kDRowB + 64 <= kMLdsBytes,
+                        "a tail workgroup fits conv32m's LDS");
+          e->t_ok = span_t + 2 * (g.XS + 1) <= kTRows &&
+                    span_t3 + 2 * (g.XS + 1) <= kT3Rows && e->n_tail <= 256;
+          for (int w = 0; w < 4; ++w)
+            for (int j = 0; j < 7; ++j) {
+              int s = kSched[w][j];
+              if (s < 0) s = kSched[w][j - 1];
+              const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
+              e->tsched_aoff[w * 8 + j] =
+                  kz * 128 * kTRows + ((ky - 1) * g.XS + (kx - 1)) * 16;
+              e->t3sched_aoff[w * 8 + j] =
+                  kz * 128 * kT3Rows + ((ky - 1) * g.XS + (kx - 1)) * 16;
+            }
+        }
         for (int w = 0; w < 4; ++w)
           for (int j = 0; j < 7; ++j) {
             int s = kSched[w][j];
@@ -1227,7 +1311,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (e->lds_bytes_k > 160 * 1024) e->k_ok = false;
     // default: conv32m where the geometry allows it (33^3: yes), else conv32d,
     // else conv32w8, ...
-    e->conv_variant = e->m_ok ? 8 : e->d_ok ? 6 : c_ok ? 4 : (p_ok ? 1 : 0);
+    e->conv_variant = e->t_ok ? 9 : e->m_ok ? 8 : e->d_ok ? 6 : c_ok ? 4 : (p_ok ? 1 : 0);
   }
 
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)
@@ -1554,7 +1638,7 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) {
-    if (value < 0 || value > 8) return fail(FFN_ERR_ARG, "conv_variant must be 0..8");
+    if (value < 0 || value > 9) return fail(FFN_ERR_ARG, "conv_variant must be 0..9");
     if (value >= 4 && e->weights_set && !e->fp16_ok)
       return fail(FFN_ERR_ARG, "conv_variant %d: a weight is outside the fp16 range",
                   value);
@@ -1566,6 +1650,9 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
       return fail(FFN_ERR_ARG, "conv_variant 7 unsupported for this fov / depth");
     if (value == 8 && !e->m_ok)
       return fail(FFN_ERR_ARG, "conv_variant 8 unsupported for this fov / depth");
+    if (value == 9 && !e->t_ok)
+      return fail(FFN_ERR_ARG, "conv_variant 9 unsupported for this fov / depth "
+                               "(257 .. 512 chunks of 128 voxels)");
     if (value >= 6 && e->weights_set && !e->d_weights_ok)
       return fail(FFN_ERR_ARG, "conv_variant 6: a weight x 2^11 is outside the fp16 range");
     const Geom& g = e->g;
@@ -1594,6 +1681,13 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     // 96-voxel form (bit-identical), 2 = conv32m (another summation order)
     if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "batch_chunks 0..2");
     e->batch_chunks = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "tail_batched") == 0) {
+    // conv_variant 9: 1 = steps with >= 2 FoVs also split off the tail (in
+    // 96-voxel workgroups): every voxel then gets the same bits whatever the
+    // batch, at 5-10 % of the batched rate
+    e->tail_batched = value != 0;
     return FFN_OK;
   }
   if (std::strcmp(name, "debug_layer") == 0) {

@@ -2415,12 +2415,16 @@ __device__ __forceinline__ void split8_fp16(const f32x4& v0, const f32x4& v1,
 // 96-voxel chunks whose three slots fit in 80 KB, so that TWO workgroups share
 // a CU and one's MFMAs run under the other's staging / epilogue -- the same
 // arithmetic in the same order, bit-identical results (conv_variant 7).
-template <int KIND, bool ADD_SKIP, int KS, bool HEAD, int NT = 5, int R = 32 * KS,
-          int WPS = 1>
-__global__ __launch_bounds__(kDThreads, WPS) void conv32d_kernel(ConvDArgs a) {
+// (1, 144, 2) with KS = 5: a single 32-voxel tile, the form of conv32mt's tail.
+// The workgroup computes the 32 NT dense voxels from v0 of FoV `item`; gc = its
+// slot in head_count; aoff_tab = a.aoff or the table of another row count.
+template <int KIND, bool ADD_SKIP, int KS, bool HEAD, int NT, int R, int WPS>
+__device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
+                                             const int v0, const int gc,
+                                             const int* aoff_tab, const bool dbg_here) {
   typedef f16x8 frag_t;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  static_assert(NT == 5 || NT == 3, "tile loop is written for 5 or 3 tiles");
+  static_assert(NT == 5 || NT == 3 || NT == 1, "tile loop: 5, 3 or 1 tiles");
   static_assert(4 * KS * 64 >= 8 * R && R % 8 == 0, "KS pieces per wave cover a slot");
   constexpr int kChunkD = 32 * NT;  // dense voxels per workgroup
   constexpr int R16 = R * 16;    // bytes of one chunk plane of a segment in LDS
@@ -2430,18 +2434,13 @@ __global__ __launch_bounds__(kDThreads, WPS) void conv32d_kernel(ConvDArgs a) {
   const int tid = threadIdx.x;
   const long long dbg_c0 = a.dbg ? clock64() : 0;
   const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
-  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
-  if (gc >= a.total_slots) return;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int aoffs[7], btaps[7];
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
-    aoffs[j] = a.aoff[wave * 8 + j];
+    aoffs[j] = aoff_tab[wave * 8 + j];
     btaps[j] = a.btap[wave * 8 + j];
   }
-  const int item = (int)__umulhi((unsigned)gc, a.magic_nchunks);
-  const int chunk = gc - item * a.nchunks;
-  const int v0 = chunk * kChunkD;
   // dense FoV index -> padded position, by arithmetic: a table look-up would be
   // a memory operation of the compiler's in front of the DMAs (see above)
   auto padded = [&](int v) {
@@ -2592,14 +2591,20 @@ __global__ __launch_bounds__(kDThreads, WPS) void conv32d_kernel(ConvDArgs a) {
   {                                                                           \
     const int ao_ = aoffs[J];                                                 \
     const int an_ = aoffs[((J) + 1) % 7];                                     \
-    FFN_DTILE(0, XA, WCUR, loadX(1, ao_, XB), E0)                             \
-    FFN_DTILE(1, XB, WCUR, loadX(2, ao_, XA), E1)                             \
-    if constexpr (NT == 3) {                                                  \
-      FFN_DTILE(2, XA, WCUR, if (CONT) loadX(0, an_, XB), { E2; E3; E4; })    \
+    if constexpr (NT == 1) {                                                  \
+      (void)ao_;                                                              \
+      FFN_DTILE(0, XA, WCUR, if (CONT) loadX(0, an_, XB),                     \
+                { E0; E1; E2; E3; E4; })                                      \
     } else {                                                                  \
-      FFN_DTILE(2, XA, WCUR, loadX(3, ao_, XB), E2)                           \
-      FFN_DTILE(3, XB, WCUR, loadX(4, ao_, XA), E3)                           \
-      FFN_DTILE(4, XA, WCUR, if (CONT) loadX(0, an_, XB), E4)                 \
+      FFN_DTILE(0, XA, WCUR, loadX(1, ao_, XB), E0)                           \
+      FFN_DTILE(1, XB, WCUR, loadX(2, ao_, XA), E1)                           \
+      if constexpr (NT == 3) {                                                \
+        FFN_DTILE(2, XA, WCUR, if (CONT) loadX(0, an_, XB), { E2; E3; E4; })  \
+      } else {                                                                \
+        FFN_DTILE(2, XA, WCUR, loadX(3, ao_, XB), E2)                         \
+        FFN_DTILE(3, XB, WCUR, loadX(4, ao_, XA), E3)                         \
+        FFN_DTILE(4, XA, WCUR, if (CONT) loadX(0, an_, XB), E4)               \
+      }                                                                       \
     }                                                                         \
   }
   auto dma_range = [&](int seg, int k0, int k1) {
@@ -2793,7 +2798,7 @@ __global__ __launch_bounds__(kDThreads, WPS) void conv32d_kernel(ConvDArgs a) {
     if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *a.range_flag = a.range_tag;
   }
-  if (a.dbg && gc == 0 && (tid & 63) == 0) {
+  if (a.dbg && dbg_here && (tid & 63) == 0) {
     long long* d = a.dbg + wave * 6;
     d[0] = dbg_c0;
     d[1] = dbg_c1;
@@ -2802,6 +2807,17 @@ __global__ __launch_bounds__(kDThreads, WPS) void conv32d_kernel(ConvDArgs a) {
     d[4] = dbg_w0;
     d[5] = wall_clock64();
   }
+}
+
+template <int KIND, bool ADD_SKIP, int KS, bool HEAD, int NT = 5, int R = 32 * KS,
+          int WPS = 1>
+__global__ __launch_bounds__(kDThreads, WPS) void conv32d_kernel(ConvDArgs a) {
+  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
+  if (gc >= a.total_slots) return;
+  const int item = (int)__umulhi((unsigned)gc, a.magic_nchunks);
+  const int chunk = gc - item * a.nchunks;
+  conv32d_body<KIND, ADD_SKIP, KS, HEAD, NT, R, WPS>(a, item, chunk * (32 * NT), gc,
+                                                     a.aoff, gc == 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -2875,8 +2891,12 @@ __device__ __forceinline__ f32x4 hidden_load16f(const char* sbase, unsigned voff
   return d;
 }
 
+// The workgroup computes the 128 dense voxels from v0 of FoV `item`; gc = its
+// slot in head_count.
 template <int KIND, bool ADD_SKIP, bool HEAD>
-__global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
+__device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
+                                             const int v0, const int gc,
+                                             const bool dbg_here) {
   typedef f16x8 frag_t;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -2888,12 +2908,7 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
   const int tid = threadIdx.x;
   const long long dbg_c0 = a.dbg ? clock64() : 0;
   const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
-  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
-  if (gc >= a.total_slots) return;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int item = (int)__umulhi((unsigned)gc, a.magic_nchunks);
-  const int chunk = gc - item * a.nchunks;
-  const int v0 = chunk * kMChunk;
   auto padded = [&](int v) {
     v = v < a.V ? v : a.V - 1;
     const int z = (int)__umulhi((unsigned)v, a.magic_fyfx);
@@ -3179,7 +3194,7 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
     if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *a.range_flag = a.range_tag;
   }
-  if (a.dbg && gc == 0 && lane == 0) {
+  if (a.dbg && dbg_here && lane == 0) {
     long long* d = a.dbg + wave * 6;
     d[0] = dbg_c0;
     d[1] = dbg_c1;
@@ -3187,6 +3202,91 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
     d[3] = clock64();
     d[4] = dbg_w0;
     d[5] = wall_clock64();
+  }
+}
+
+template <int KIND, bool ADD_SKIP, bool HEAD>
+__global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
+  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
+  if (gc >= a.total_slots) return;
+  const int item = (int)__umulhi((unsigned)gc, a.magic_nchunks);
+  const int chunk = gc - item * a.nchunks;
+  conv32m_body<KIND, ADD_SKIP, HEAD>(a, item, chunk * kMChunk, gc, gc == 0);
+}
+
+// ---------------------------------------------------------------------------
+// conv32mt (conv_variant 9): conv32m with a K-split tail.
+//
+// 256 CUs host two conv32m workgroups each, and a CU that gets two takes the
+// matrix-pipe time of both: measured at batch 1, 7.5 us per layer for a FoV of
+// <= 256 chunks, 9.75 us for ANY FoV of 257 .. 400 chunks (profiles/
+// r02_chunks_vs_cus.txt) -- the 33^3 FoV's 281 chunks pay 30 % for the 25 CUs
+// that run two workgroups.  Here the first n_main <= 256 chunks (128 voxels)
+// stay conv32m workgroups, one per CU, and the voxels past them go to `tail`
+// workgroups of ONE 32-voxel tile whose 27 taps are split over the four waves
+// (conv32d's body with a single tile): a tail workgroup that shares a CU adds
+// 7 taps, not 27, to each SIMD's matrix work.
+// blockIdx -> XCD b & 7 gets mains_per_xcd main chunks FIRST (they take the
+// empty CUs), then tails_per_xcd tail chunks of the same region of the FoV.
+// The tail sums in conv32d's order (per-wave partial sums, then added), the
+// main part in conv32m's: each voxel's arithmetic is fixed by its position in
+// the FoV.  conv32d's sums do not depend on its tile count, so a step with
+// several FoVs -- where balance over the CUs is no issue but the cost per
+// voxel is -- runs the SAME tail voxels in 96-voxel workgroups (TNT = 3,
+// conv_variant 7's form) and gets the same bits as a single FoV does.
+// ---------------------------------------------------------------------------
+constexpr int kTRows = 144;   // TNT = 1: rows per dz segment of a tail workgroup
+constexpr int kTPieces = 5;   // its DMA pieces per wave and segment
+constexpr int kT3Rows = 208;  // TNT = 3 (= conv_variant 7's kERows / kEPieces)
+constexpr int kT3Pieces = 7;
+
+struct ConvTailMap {
+  int n;                      // FoVs
+  int n_main, n_tail;         // chunks per FoV: 128-voxel main, 32-voxel tail
+  int mains_per_xcd, tails_per_xcd;
+  int taoff[4 * 8];           // the tail's aoff table (its rows per segment)
+};
+
+template <int KIND, bool ADD_SKIP, bool HEAD, int TNT>
+__global__ __launch_bounds__(kDThreads, 2) void conv32mt_kernel(ConvDArgs a,
+                                                                ConvTailMap mp) {
+  const int xcd = blockIdx.x & 7;
+  const int idx = blockIdx.x >> 3;
+  int item, r;
+  bool main_wg;
+  if (TNT == 1) {
+    // one FoV at a time: its main chunks first (they take the empty CUs)
+    const int per_item = mp.mains_per_xcd + mp.tails_per_xcd;
+    item = idx / per_item;
+    r = idx - item * per_item;
+    main_wg = r < mp.mains_per_xcd;
+    if (!main_wg) r -= mp.mains_per_xcd;
+  } else {
+    // several FoVs: every tail workgroup first -- a K-split workgroup takes
+    // longer from start to end than a main one, and started last it would
+    // run on alone at the end of the launch
+    const int tails = mp.n * mp.tails_per_xcd;
+    main_wg = idx >= tails;
+    const int i2 = main_wg ? idx - tails : idx;
+    const int per = main_wg ? mp.mains_per_xcd : mp.tails_per_xcd;
+    item = i2 / per;
+    r = i2 - item * per;
+  }
+  if (item >= mp.n) return;
+  const int slots = mp.n_main + mp.n_tail;
+  if (main_wg) {
+    const int c = xcd * mp.mains_per_xcd + r;
+    if (c >= mp.n_main) return;
+    conv32m_body<KIND, ADD_SKIP, HEAD>(a, item, c * kMChunk, item * slots + c,
+                                       blockIdx.x == 0);
+  } else {
+    const int c = xcd * mp.tails_per_xcd + r;
+    if (c >= mp.n_tail) return;
+    constexpr int kPieces = TNT == 1 ? kTPieces : kT3Pieces;
+    constexpr int kRows = TNT == 1 ? kTRows : kT3Rows;
+    conv32d_body<KIND, ADD_SKIP, kPieces, HEAD, TNT, kRows, 2>(
+        a, item, mp.n_main * kMChunk + c * (32 * TNT), item * slots + mp.n_main + c,
+        mp.taoff, false);
   }
 }
 

@@ -35,6 +35,21 @@ def _close_all_engines():
       pass
 
 
+def pin_batched_arithmetic(engine):
+  """Called by the drivers that put several canvases into one engine call.
+
+  The default kernel choice (conv_variant 9) runs a step of ONE FoV as conv32mt
+  and a step of several as conv32m -- the same sums in another order for the
+  last voxels of the FoV, ~1e-6 in the logits.  In a batched run the number of
+  FoVs per call varies with timing, so a canvas would get either, step by
+  step; conv32m for every step keeps a batched run reproducible.  An explicit
+  choice made later (Runner(conv_variant=...)) still wins."""
+  if not isinstance(engine, HipEngine):
+    return  # a stand-in engine of the host-logic tests
+  if engine.max_batch > 1 and engine.get_option('conv_variant') == 9:
+    engine.set_option('conv_variant', 8)
+
+
 class HipEngine:
   """One GPU + one stream + the conv-stack weights (include/ffn_hip.h)."""
 

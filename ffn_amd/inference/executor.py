@@ -379,6 +379,7 @@ class HipBatchExecutor(ThreadingBatchExecutor):
   def _initialize_model(self):
     self.engine = hip_engine.HipEngine.from_model(
         self.model, max_batch=self.batch_size, device_id=self._device_id)
+    hip_engine.pin_batched_arithmetic(self.engine)
 
   def allocate_direct_id(self) -> int:
     with self.engine_lock:

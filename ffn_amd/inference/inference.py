@@ -38,6 +38,7 @@ from scipy.special import expit
 from scipy.special import logit
 
 from .. import _lib
+from .. import engine as hip_engine
 from ..training import model as ffn_model
 from . import executor
 from . import movement
@@ -1110,6 +1111,7 @@ class MultiCanvasDriver:
   def __init__(self, engine, batch_size=None, overlap=True,
                max_steps_per_canvas=None):
     self.engine = engine
+    hip_engine.pin_batched_arithmetic(engine)
     self.batch_size = batch_size or engine.max_batch
     self.overlap = overlap
     #: benchmarking / bounded runs: a canvas is dropped after this many steps

@@ -53,9 +53,10 @@ class Runner:
   DEVICE_U8 = True
 
   def __init__(self, device_id: int = 0, conv_variant: Optional[int] = None):
-    """conv_variant: None = the engine's default (conv32d; 2 = the exact-f32
-    kernel in the oracle's summation order, 8 = the M-split kernel for batched
-    drives: include/ffn_hip.h)."""
+    """conv_variant: None = the engine's default (9: conv32mt for steps of one
+    FoV; with batch_size > 1 the executor pins 8, conv32m, for every step); 2 =
+    the exact-f32 kernel in the oracle's summation order (include/ffn_hip.h,
+    DESIGN.md section 3)."""
     self.conv_variant = conv_variant
     self.counters = inference_utils.Counters()
     self.executor = None

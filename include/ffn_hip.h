@@ -252,7 +252,16 @@ int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
  * product carried as 6 exact bf16 x bf16 products on the bf16 MFMA (default
  * when the FoV allows), 4 = the same with fp16 (hi + 2^-11 * residual, 3
  * products, 22 mantissa bits: about the rounding noise of an f32 GEMM; operands
- * must stay inside the fp16 range, else FFN_ERR_RANGE).  Results are identical up to f32 summation order
+ * must stay inside the fp16 range, else FFN_ERR_RANGE), 5 = variant 4's
+ * products on 32x32x16 MFMAs with the 27 taps split over 4 waves, 6 = the same
+ * bits on producer-split fp16 planes staged by LDS-DMA (conv32d), 7 = 6 in
+ * 96-voxel chunks, 8 = conv32m (M split over the waves, weights through an
+ * LDS-DMA ring, two workgroups per CU), 9 (default where the FoV has 257 ..
+ * 512 chunks of 128 voxels, e.g. 33^3) = a step of ONE FoV runs conv32mt
+ * (conv32m for the first 256 chunks + 32-voxel K-split tail workgroups), a step
+ * of several runs conv32m; "tail_batched" 1 = conv32mt for every step (one
+ * arithmetic whatever the batch); "batch_chunks" (variant 6): the form batched
+ * steps take.  Results are identical up to f32 summation order
  * (variant 3: plus a truncation 100x below f32 rounding).  "fuse_head": 1x1x1
  * head inside the last conv launch.  "store_policy": 0 write-back, 1
  * write-through, 2 non-temporal conv stores.  "waves8" (variants 3 / 4): 0 =

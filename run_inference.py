@@ -39,9 +39,10 @@ def main(argv=None):
   ap.add_argument('--overlap', default='', help='x,y,z overlap of sub-boxes.')
   ap.add_argument('--batch_size', type=int, default=1)
   ap.add_argument('--conv_variant', type=int, default=None,
-                  help='kernel behind the 32->32 convs (default: conv32d; 2 = exact '
-                  'f32 in the oracle\'s summation order; 8 = M-split, for batched '
-                  'runs); see DESIGN.md section 3')
+                  help='kernel behind the 32->32 convs (default: 9 = conv32mt for '
+                  'single-FoV steps / conv32m for batched ones; 8 = conv32m; 2 = '
+                  'exact f32 in the oracle\'s summation order; 6 = conv32d, '
+                  'K-split); see DESIGN.md section 3')
   ap.add_argument('--assemble', default='',
                   help='With sharding: also assemble ONE global label volume '
                   '(RCCL all-reduce + union-find reconciliation of objects cut '

@@ -17,7 +17,7 @@ from tests.conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-DEFAULT_VARIANT = 8
+DEFAULT_VARIANT = 9
 DEFAULT_WAVES8 = 2  # what ffn_engine_create selects for the 33^3 FoV
 TOL = 1e-4
 
@@ -78,11 +78,24 @@ def test_predict_batch_and_ragged(engine, fib25_blob):
   want = ffn_oracle.forward(img, seed, fib25_blob, 12)
   got4 = engine.predict(seed, img)
   assert np.abs(got4 - want).max() <= TOL
-  # ragged batch (3 of 4 slots) and batch-1 give the same rows, bit for bit
+  # a ragged batch (3 of 4 slots) gives the same rows, bit for bit
   got3 = engine.predict(seed[:3], img[:3])
   assert np.array_equal(got3, got4[:3])
+  # the default kernel choice runs ONE FoV as conv32mt (K-split tail: the sums
+  # of the FoV's last voxels in another order), several as conv32m
+  assert engine.get_option('conv_variant') == 9
   got1 = engine.predict(seed[2:3], img[2:3])
-  assert np.array_equal(got1[0], got4[2])
+  assert np.abs(got1[0] - got4[2]).max() <= 2e-5
+  assert np.abs(got1 - want[2:3]).max() <= TOL
+  # one arithmetic whatever the batch: tail_batched (conv32mt for every step)
+  # or conv_variant 8 (conv32m for every step)
+  engine.set_option('tail_batched', 1)
+  assert np.array_equal(engine.predict(seed, img)[2], got1[0])
+  assert np.array_equal(engine.predict(seed[1:3], img[1:3])[1], got1[0])
+  engine.set_option('tail_batched', 0)
+  engine.set_option('conv_variant', 8)
+  assert np.array_equal(engine.predict(seed[2:3], img[2:3])[0], got4[2])
+  engine.set_option('conv_variant', DEFAULT_VARIANT)
 
 
 def test_predict_is_deterministic_and_variants_agree(engine):
@@ -92,16 +105,68 @@ def test_predict_is_deterministic_and_variants_agree(engine):
   b = engine.predict(seed, img)
   assert np.array_equal(a, b)
   by_variant = {}
-  for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+  for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
     engine.set_option('conv_variant', variant)
     c = engine.predict(seed, img)
     assert np.abs(a - c).max() <= 2e-5, variant
     by_variant[variant] = c
+  # variant 9 runs several FoVs as conv32m ...
+  assert np.array_equal(by_variant[9], by_variant[8])
+  # ... and ONE as conv32mt: conv32m's arithmetic for the first 256 chunks of 128
+  # voxels, conv32d's for the tail, in 32-voxel workgroups; with tail_batched a
+  # batch splits the same tail off in 96-voxel workgroups -- the same bits
+  engine.set_option('conv_variant', 9)
+  engine.set_option('tail_batched', 1)
+  both = engine.predict(seed, img)
+  engine.set_option('tail_batched', 0)
+  assert np.abs(a - both).max() <= 2e-5
+  assert not np.array_equal(both, by_variant[8])
+  for k in range(2):
+    one = engine.predict(seed[k:k + 1], img[k:k + 1])
+    assert np.array_equal(one[0], both[k])
   # conv32d = conv32k's arithmetic and summation order on producer-split planes,
   # whatever the chunk size
   assert np.array_equal(by_variant[5], by_variant[6])
   assert np.array_equal(by_variant[6], by_variant[7])
   engine.set_option('conv_variant', DEFAULT_VARIANT)
+
+
+@pytest.mark.parametrize('fov_xyz,deltas_xyz', [([25, 25, 25], [6, 6, 6]),
+                                                ([29, 21, 17], [7, 5, 4]),
+                                                ([49, 49, 25], [12, 12, 6]),
+                                                ([35, 33, 31], [8, 8, 7])])
+def test_other_fov_sizes_every_supported_variant(fov_xyz, deltas_xyz):
+  """Geometry generality: chunking, staging extents, magic divisions and the
+  per-FoV gating of each kernel (a variant that does not fit a FoV must refuse,
+  not miscompute) on FoVs other than 33^3 / 21x41x41; random weights, depth 3."""
+  from ffn_amd import _lib
+  from ffn_amd import engine as hip_engine
+  from ffn_amd.training.models import convstack_3d
+  from oracle import ffn_oracle
+  variables = ffn_oracle.random_weights(3, seed=21, stddev=0.07)
+  m = convstack_3d.ConvStack3DFFNModel(fov_size=fov_xyz, deltas=deltas_xyz,
+                                       depth=3)
+  m.set_variables(variables)
+  eng = hip_engine.HipEngine.from_model(m, max_batch=3)
+  zyx = fov_xyz[::-1]
+  rng = np.random.RandomState(9)
+  img = rng.normal(0, 1, [3] + zyx).astype(np.float32)
+  seed = rng.normal(0, 2, [3] + zyx).astype(np.float32)
+  want = ffn_oracle.forward(img, seed, ffn_oracle.weights_blob(variables, 3), 3)
+  ran = []
+  default = eng.get_option('conv_variant')
+  for variant in (default, 0, 2, 3, 4, 5, 6, 7, 8, 9):
+    try:
+      eng.set_option('conv_variant', variant)
+    except _lib.FFNHipError:
+      continue  # this kernel does not take this FoV
+    for n in (1, 3):
+      got = eng.predict(seed[:n], img[:n])
+      assert np.abs(got - want[:n]).max() <= TOL, (variant, n)
+    ran.append(variant)
+  print('fov %s: default %d, variants run %s' % (fov_xyz, default, ran))
+  assert 0 in ran and len(ran) >= 3
+  eng.close()
 
 
 def test_c5_model_full_depth(fib25_model):
@@ -833,7 +898,7 @@ def test_large_canvas_offsets_beyond_2gib(engine, fib25_blob):
   canvas.close()
 
 
-@pytest.mark.parametrize('fast', [8, 6, 4])
+@pytest.mark.parametrize('fast', [9, 8, 6, 4])
 def test_fp16_range_fallback(fib25_model, fib25_blob, fast):
   """conv_variants 4 / 6 / 8 keep operands in fp16: a value beyond 65504 must void
   the run (nothing pasted) and repeat it with the bf16x3 scheme -- silently for

@@ -65,7 +65,8 @@ def main():
             (b, v, med, t.min(), med / 23 / b * (23.0 / 25.0),
              b * flop / (med * 1e-6) / 1e12))
   eng.set_option('debug_clock', 1)
-  for v, nmfma in ((4, 13.5 * 27.0), (5, 210.0), (6, 210.0), (7, 126.0), (8, 162.0)):
+  for v, nmfma in ((4, 13.5 * 27.0), (5, 210.0), (6, 210.0), (7, 126.0), (8, 162.0),
+                   (9, 162.0)):
     if v not in args.variants:
       continue
     eng.set_option('conv_variant', v)
