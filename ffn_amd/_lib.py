@@ -127,6 +127,7 @@ SIGNATURES = {
                                     ctypes.POINTER(ctypes.c_int64), _I]),
     'ffn_engine_synchronize': (_I, [_P]),
     'ffn_engine_debug_clocks': (_I, [_P, _P]),
+    'ffn_engine_debug_workgroups': (_I, [_P, _P, _I]),
     'ffn_predict': (_I, [_P, _I, _P, _P, _P]),
     'ffn_forward_resident': (_I, [_P, _I, _I]),
     'ffn_canvas_create': (_I, [_P, _P, _I3, ctypes.POINTER(_P)]),
@@ -146,6 +147,7 @@ SIGNATURES = {
                                   ctypes.POINTER(StepResult)]),
     'ffn_canvas_segment_at': (_I, [_P, _I3, ctypes.POINTER(SegmentParams), _I,
                                    ctypes.POINTER(SegmentResult)]),
+    'ffn_canvas_segment_many': (_I, [_P, _I, _P, _P, _P, _P, _P, _P]),
     'ffn_canvas_segment_history': (_I, [_P, ctypes.c_size_t, ctypes.c_size_t,
                                         _P, _P,
                                         ctypes.POINTER(ctypes.c_size_t)]),

@@ -772,6 +772,7 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   std::memcpy(a.aoff, small ? e->esched_aoff : e->dsched_aoff, sizeof(a.aoff));
   std::memcpy(a.btap, e->dsched_btap, sizeof(a.btap));
   a.dbg = (e->dbg_clock && layer == e->dbg_layer) ? e->d_dbg : nullptr;
+  a.dbg_wgs = e->dbg_clock == 2 ? 1 : e->dbg_clock == 3 ? 2 : 0;
   a.head_w = e->weights + e->wl_off;
   a.seed_raw = e->seed_raw;
   a.logits = e->logits;
@@ -1050,7 +1051,7 @@ int grid_for(long total, int block = 256) {
 
 extern "C" {
 
-int ffn_abi_version(void) { return 5; }
+int ffn_abi_version(void) { return 6; }
 
 const char* ffn_last_error(void) { return g_error.c_str(); }
 
@@ -1300,8 +1301,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
           }
       }
     }
-    E_TRY(hipMalloc(&e->d_dbg, 24 * sizeof(long long)));
-    E_TRY(hipMemset(e->d_dbg, 0, 24 * sizeof(long long)));
+    E_TRY(hipMalloc(&e->d_dbg, (24 + 4 * kDbgMaxWgs) * sizeof(long long)));
+    E_TRY(hipMemset(e->d_dbg, 0, (24 + 4 * kDbgMaxWgs) * sizeof(long long)));
     E_TRY(hipMalloc(&e->pidx, pidx.size() * sizeof(int32_t)));
     E_TRY(hipMemcpy(e->pidx, pidx.data(), pidx.size() * sizeof(int32_t),
                     hipMemcpyHostToDevice));
@@ -1727,6 +1728,19 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   return FFN_OK;
 }
 
+int ffn_engine_debug_workgroups(ffn_engine* e, long long* out, int max_wgs) {
+  if (!e || !out) return fail(FFN_ERR_ARG, "null argument");
+  if (max_wgs < 0 || max_wgs > kDbgMaxWgs)
+    return fail(FFN_ERR_ARG, "max_wgs must be 0..%d", kDbgMaxWgs);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(out, e->d_dbg + 24, (size_t)4 * max_wgs * sizeof(long long),
+                    hipMemcpyDeviceToHost));
+  // the next run starts from zeros (a workgroup that did not run leaves them)
+  HIP_TRY(hipMemset(e->d_dbg + 24, 0, (size_t)4 * kDbgMaxWgs * sizeof(long long)));
+  return FFN_OK;
+}
+
 int ffn_engine_debug_clocks(ffn_engine* e, long long* out24) {
   if (!e || !out24) return fail(FFN_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(e->device));
@@ -2072,6 +2086,47 @@ int ffn_canvas_segment_at(ffn_canvas* c, const int32_t start[3],
   HipLoopDevice dev{c};
   ffn_host::SegmentLoop<HipLoopDevice> loop(dev, c->loop, *p);
   return loop.run(start, resume, out);
+}
+
+int ffn_canvas_segment_many(ffn_engine* e, int n, ffn_canvas* const* canvases,
+                            const int32_t (*starts)[3],
+                            const ffn_segment_params* params, const int32_t* resume,
+                            ffn_segment_result* results, int32_t* finished) {
+  if (!e || !canvases || !starts || !params || !resume || !results || !finished)
+    return fail(FFN_ERR_ARG, "null argument");
+  if (n < 1 || n > e->max_batch)
+    return fail(FFN_ERR_ARG, "batch %d outside [1, %d]", n, e->max_batch);
+  std::vector<HipLoopDevice> devs(n);
+  std::vector<ffn_host::SegmentState*> states(n);
+  for (int k = 0; k < n; ++k) {
+    ffn_canvas* c = canvases[k];
+    if (!c) return fail(FFN_ERR_ARG, "null canvas");
+    if (c->engine != e) return fail(FFN_ERR_ARG, "canvas %d is not of this engine", k);
+    for (int k2 = 0; k2 < k; ++k2)
+      if (canvases[k2] == c) return fail(FFN_ERR_ARG, "canvas appears twice");
+    const ffn_segment_params& p = params[k];
+    if (p.prefetch < 0 || p.prefetch > FFN_MAX_CANDIDATES)
+      return fail(FFN_ERR_ARG, "prefetch must be 0..%d", FFN_MAX_CANDIDATES);
+    if (p.shape_zyx[0] != c->cz || p.shape_zyx[1] != c->cy || p.shape_zyx[2] != c->cx)
+      return fail(FFN_ERR_ARG, "shape_zyx does not match canvas %d", k);
+    for (int a = 0; a < 3; ++a)
+      if (p.deltas_zyx[a] < 0 || p.margin_zyx[a] < 0)
+        return fail(FFN_ERR_ARG, "negative deltas / margin");
+    if (resume[k] && !c->loop.active)
+      return fail(FFN_ERR_STATE, "canvas %d: no segment to resume", k);
+    if (std::memcmp(&p.step, &params[0].step, sizeof(ffn_step_params)) != 0)
+      return fail(FFN_ERR_ARG, "canvas %d: step parameters differ from canvas 0's", k);
+    devs[k].c = c;
+    states[k] = &c->loop;
+  }
+  std::vector<ffn_canvas*> batch(n);
+  auto batch_step = [&](int nb, const int* idx, const ffn_step_request* reqs,
+                        const ffn_step_params& sp, ffn_step_result* res) {
+    for (int b = 0; b < nb; ++b) batch[b] = canvases[idx[b]];
+    return ffn_canvas_step(e, nb, batch.data(), reqs, &sp, res);
+  };
+  return ffn_host::segment_many(n, devs.data(), states.data(), starts, params, resume,
+                                results, finished, batch_step);
 }
 
 int ffn_canvas_segment_history(ffn_canvas* c, size_t first, size_t n,

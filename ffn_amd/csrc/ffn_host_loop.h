@@ -73,6 +73,9 @@ struct SegmentState {
   // history of the segment (keep_history): positions and deleted-voxel counts
   std::vector<int32_t> history;          // 3 per step
   std::vector<uint32_t> history_deleted;  // 1 per step
+  // segment_many: tallies since the segment's start, over all the calls it took
+  int64_t many_steps = 0, many_skip_threshold = 0, many_skip_invalid_pos = 0,
+          many_gate_rejects = 0;
 };
 
 template <class Dev>
@@ -89,7 +92,37 @@ class SegmentLoop {
 
   // Starts (resume = 0) or continues (resume = 1) the segment at `start`.
   int run(const int32_t start[3], int resume, ffn_segment_result* out) {
+    int rc = begin(start, resume, out);
+    if (rc) return rc;
+    for (;;) {
+      Pending pd;
+      bool ended = false;
+      rc = prepare(&pd, out, &ended);
+      if (rc || ended) break;
+      ffn_step_result res;
+      rc = dev_.step(pd.req, p_.step, &res);
+      if (rc) {  // nothing was pasted: the position stays pending
+        step_failed(pd);
+        break;
+      }
+      consume(pd, res);
+    }
+    finish(out);
+    return rc;
+  }
+
+  // ---- the same loop in phases, for a caller that batches the steps of several
+  // canvases into one engine call (ffn_canvas_segment_many) -----------------------
+  struct Pending {
+    Coord pos;
+    Coord cands[FFN_MAX_CANDIDATES];
+    int nc = 0;
+    ffn_step_request req;
+  };
+
+  int begin(const int32_t start[3], int resume, ffn_segment_result* out) {
     std::memset(out, 0, sizeof(*out));
+    steps_ = 0;
     if (!resume) {
       st_.queue.clear();
       st_.done.clear();
@@ -111,83 +144,100 @@ class SegmentLoop {
     } else if (!st_.active) {
       return FFN_ERR_STATE;
     }
-    int rc = FFN_OK;
-    int64_t steps = 0;
-    for (;;) {
-      if (p_.max_steps > 0 && steps >= p_.max_steps) {
-        out->budget_exhausted = 1;
-        break;
-      }
-      Coord pos;
-      if (st_.has_pending) {
-        pos = st_.pending;
-      } else {
-        bool found = false;
-        rc = next(&pos, &found, out);
-        if (rc) break;
-        if (!found) {
-          st_.active = false;
-          break;
-        }
-      }
-      // "seed got too weak" (inference.py:503-505)
-      if (!st_.start_logit_known) {
-        int32_t seg;
-        const int32_t sp[3] = {st_.start.z, st_.start.y, st_.start.x};
-        rc = dev_.read_point(sp, &st_.start_logit, &seg);
-        if (rc) {
-          st_.pending = pos;
-          st_.has_pending = true;
-          break;
-        }
-        st_.start_logit_known = true;
-      }
-      if (st_.start_logit < p_.step.move_threshold) {
-        out->seed_got_too_weak = 1;
-        st_.has_pending = false;
+    return FFN_OK;
+  }
+
+  // The next FoV step's request, or *ended (queue empty / seed too weak / step
+  // budget spent).  A device read that fails keeps the popped position pending.
+  int prepare(Pending* pd, ffn_segment_result* out, bool* ended) {
+    *ended = false;
+    if (p_.max_steps > 0 && steps_ >= p_.max_steps) {
+      out->budget_exhausted = 1;
+      *ended = true;
+      return FFN_OK;
+    }
+    Coord pos;
+    if (st_.has_pending) {
+      pos = st_.pending;
+    } else {
+      bool found = false;
+      const int rc = next(&pos, &found, out);
+      if (rc) return rc;
+      if (!found) {
         st_.active = false;
-        break;
+        *ended = true;
+        return FFN_OK;
       }
-      // ---- one FoV step --------------------------------------------------------
-      ffn_step_request req;
-      req.pos[0] = pos.z, req.pos[1] = pos.y, req.pos[2] = pos.x;
-      req.start_pos[0] = st_.start.z, req.start_pos[1] = st_.start.y,
-      req.start_pos[2] = st_.start.x;
-      Coord cands[FFN_MAX_CANDIDATES];
-      const int nc = peek(cands, p_.prefetch < FFN_MAX_CANDIDATES
-                                     ? p_.prefetch : FFN_MAX_CANDIDATES);
-      req.num_candidates = nc;
-      for (int k = 0; k < nc; ++k) {
-        req.candidates[k][0] = cands[k].z;
-        req.candidates[k][1] = cands[k].y;
-        req.candidates[k][2] = cands[k].x;
-      }
-      ffn_step_result res;
-      rc = dev_.step(req, p_.step, &res);
-      if (rc) {  // nothing was pasted: the position stays pending
+    }
+    // "seed got too weak" (inference.py:503-505)
+    if (!st_.start_logit_known) {
+      int32_t seg;
+      const int32_t sp[3] = {st_.start.z, st_.start.y, st_.start.x};
+      const int rc = dev_.read_point(sp, &st_.start_logit, &seg);
+      if (rc) {
         st_.pending = pos;
         st_.has_pending = true;
-        break;
+        return rc;
       }
-      st_.has_pending = false;
-      ++steps;
-      st_.cache.clear();
-      for (int k = 0; k < nc; ++k)
-        st_.cache.emplace(cands[k], std::make_pair(res.cand_seed[k], res.cand_seg[k]));
-      st_.start_logit = res.start_logit;
       st_.start_logit_known = true;
-      const int32_t pv[3] = {pos.z, pos.y, pos.x};
-      for (int a = 0; a < 3; ++a) {
-        if (pv[a] < st_.min_pos[a]) st_.min_pos[a] = pv[a];
-        if (pv[a] > st_.max_pos[a]) st_.max_pos[a] = pv[a];
-      }
-      if (p_.keep_history) {
-        st_.history.insert(st_.history.end(), pv, pv + 3);
-        st_.history_deleted.push_back(res.num_deleted);
-      }
-      update(res, pos);
     }
-    out->num_steps = steps;
+    if (st_.start_logit < p_.step.move_threshold) {
+      out->seed_got_too_weak = 1;
+      st_.has_pending = false;
+      st_.active = false;
+      *ended = true;
+      return FFN_OK;
+    }
+    // ---- one FoV step ----------------------------------------------------------
+    pd->pos = pos;
+    ffn_step_request& req = pd->req;
+    req.pos[0] = pos.z, req.pos[1] = pos.y, req.pos[2] = pos.x;
+    req.start_pos[0] = st_.start.z, req.start_pos[1] = st_.start.y,
+    req.start_pos[2] = st_.start.x;
+    pd->nc = peek(pd->cands, p_.prefetch < FFN_MAX_CANDIDATES
+                                 ? p_.prefetch : FFN_MAX_CANDIDATES);
+    req.num_candidates = pd->nc;
+    for (int k = 0; k < pd->nc; ++k) {
+      req.candidates[k][0] = pd->cands[k].z;
+      req.candidates[k][1] = pd->cands[k].y;
+      req.candidates[k][2] = pd->cands[k].x;
+    }
+    // until the step has been made the position counts as pending: a caller
+    // that returns between prepare and consume loses nothing
+    st_.pending = pos;
+    st_.has_pending = true;
+    return FFN_OK;
+  }
+
+  void step_failed(const Pending& pd) {
+    st_.pending = pd.pos;
+    st_.has_pending = true;
+  }
+
+  void consume(const Pending& pd, const ffn_step_result& res) {
+    const Coord& pos = pd.pos;
+    st_.has_pending = false;
+    ++steps_;
+    st_.cache.clear();
+    for (int k = 0; k < pd.nc; ++k)
+      st_.cache.emplace(pd.cands[k],
+                        std::make_pair(res.cand_seed[k], res.cand_seg[k]));
+    st_.start_logit = res.start_logit;
+    st_.start_logit_known = true;
+    const int32_t pv[3] = {pos.z, pos.y, pos.x};
+    for (int a = 0; a < 3; ++a) {
+      if (pv[a] < st_.min_pos[a]) st_.min_pos[a] = pv[a];
+      if (pv[a] > st_.max_pos[a]) st_.max_pos[a] = pv[a];
+    }
+    if (p_.keep_history) {
+      st_.history.insert(st_.history.end(), pv, pv + 3);
+      st_.history_deleted.push_back(res.num_deleted);
+    }
+    update(res, pos);
+  }
+
+  void finish(ffn_segment_result* out) const {
+    out->num_steps = steps_;
     out->start_logit = st_.start_logit;
     out->start_logit_known = st_.start_logit_known ? 1 : 0;
     out->active = st_.active ? 1 : 0;
@@ -196,7 +246,6 @@ class SegmentLoop {
       out->max_pos[a] = st_.max_pos[a];
     }
     out->queue_len = (int64_t)st_.queue.size();
-    return rc;
   }
 
  private:
@@ -351,6 +400,89 @@ class SegmentLoop {
   SegmentState& st_;
   const ffn_segment_params& p_;
   int32_t d_[3], dh_[3], dm_[3];
+  int64_t steps_ = 0;
 };
+
+// The segment loops of n canvases advanced TOGETHER (ffn_canvas_segment_many;
+// config C3: the reference's client threads + batching server thread,
+// executor.py:266-340, with the per-canvas queues in this library): every
+// round asks each running loop for its next FoV step and makes ONE batched
+// step for them.
+//   batch_step(nb, idx, reqs, step_params, results) -> rc steps canvases
+//   idx[0 .. nb) with reqs[0 .. nb).
+// Returns as soon as at least one loop has ended -- queue empty, seed too weak,
+// or its max_steps spent in this call -- so that the caller can finish that
+// segment and hand the canvas its next one; finished[k] says which.  The others
+// stay resumable (resume[k] = 1 on the next call, or later: a canvas may sit
+// out any number of calls).  out[k] always counts from the START of canvas k's
+// segment (all its calls), budget_exhausted aside.  Every canvas must use the
+// same step parameters (one engine call = one set); an error (e.g.
+// FFN_ERR_RANGE) leaves every prepared position pending: after the caller has
+// dealt with it the same call with resume = 1 everywhere repeats the step.
+template <class Dev, class BatchStep>
+int segment_many(int n, Dev* devs, SegmentState* const* states,
+                 const int32_t (*starts)[3], const ffn_segment_params* params,
+                 const int32_t* resume, ffn_segment_result* out, int32_t* finished,
+                 BatchStep&& batch_step) {
+  typedef SegmentLoop<Dev> Loop;
+  for (int k = 1; k < n; ++k)
+    if (std::memcmp(&params[k].step, &params[0].step, sizeof(ffn_step_params)) != 0)
+      return FFN_ERR_ARG;
+  std::vector<Loop> loops;
+  loops.reserve(n);
+  std::vector<char> running(n, 1);
+  std::vector<typename Loop::Pending> pend(n);
+  std::vector<int> idx(n);
+  std::vector<ffn_step_request> reqs(n);
+  std::vector<ffn_step_result> results(n);
+  int rc = FFN_OK;
+  for (int k = 0; k < n; ++k) {
+    finished[k] = 0;
+    loops.emplace_back(devs[k], *states[k], params[k]);
+    rc = loops[k].begin(starts[k], resume[k], &out[k]);
+    if (rc) return rc;
+    if (!resume[k])
+      states[k]->many_steps = states[k]->many_skip_threshold =
+          states[k]->many_skip_invalid_pos = states[k]->many_gate_rejects = 0;
+  }
+  bool any_ended = false;
+  while (!any_ended && rc == FFN_OK) {
+    int nb = 0;
+    for (int k = 0; k < n && rc == FFN_OK; ++k) {
+      if (!running[k]) continue;
+      bool ended = false;
+      rc = loops[k].prepare(&pend[k], &out[k], &ended);
+      if (rc) break;
+      if (ended) {
+        running[k] = 0;
+        finished[k] = 1;
+        any_ended = true;
+        continue;
+      }
+      idx[nb] = k;
+      reqs[nb] = pend[k].req;
+      ++nb;
+    }
+    if (rc || nb == 0) break;
+    // (the canvases that did prepare a step make it even when another loop has
+    // just ended: their positions are popped, the batch slot costs nothing)
+    rc = batch_step(nb, idx.data(), reqs.data(), params[0].step, results.data());
+    if (rc) break;  // nothing was pasted: every prepared position stays pending
+    for (int b = 0; b < nb; ++b) loops[idx[b]].consume(pend[idx[b]], results[b]);
+  }
+  for (int k = 0; k < n; ++k) {
+    loops[k].finish(&out[k]);
+    SegmentState& st = *states[k];
+    st.many_steps += out[k].num_steps;
+    st.many_skip_threshold += out[k].skip_threshold;
+    st.many_skip_invalid_pos += out[k].skip_invalid_pos;
+    st.many_gate_rejects += out[k].gate_rejects;
+    out[k].num_steps = st.many_steps;
+    out[k].skip_threshold = st.many_skip_threshold;
+    out[k].skip_invalid_pos = st.many_skip_invalid_pos;
+    out[k].gate_rejects = st.many_gate_rejects;
+  }
+  return rc;
+}
 
 }  // namespace ffn_host

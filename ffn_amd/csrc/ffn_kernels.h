@@ -2356,7 +2356,27 @@ struct ConvDArgs {
   float pad_value, move_thr;
   unsigned* range_flag;
   unsigned range_tag;
+  int dbg_wgs;           // debug_clock 2: every workgroup stamps dbg[24 + 4 blockIdx ..];
+                         // 3 (value 2 here): the clock stamps come from tail chunk 0
 };
+
+constexpr int kDbgMaxWgs = 4096;
+
+// debug_clock 2: when and where a workgroup ran -- [start, end] on the 100 MHz
+// wall clock, HW_ID (wave / SIMD / CU / SH / SE fields) and XCC_ID
+__device__ __forceinline__ void stamp_workgroup(const ConvDArgs& a, long long t0) {
+  if (a.dbg_wgs == 1 && a.dbg && threadIdx.x == 0 &&
+      blockIdx.x < (unsigned)kDbgMaxWgs) {
+    long long* d = a.dbg + 24 + 4 * (long)blockIdx.x;
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    d[0] = t0;
+    d[1] = wall_clock64();
+    d[2] = hw;
+    d[3] = xcc;
+  }
+}
 
 // one LDS-DMA wave instruction: 64 lanes x 16 B, global (sbase + voff) -> LDS
 // (lds_dst + 16 lane); invisible to the compiler's vmcnt bookkeeping
@@ -2959,18 +2979,23 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
   const int ppos = padded(v0 + jpos);
   const int xb = (ppos - p_lo) * 16 + lh * R16;
 
-  struct Frag { frag_t x[2][2]; frag_t w[2][2]; };  // [khalf][plane hi, res]
-  auto load_frags = [&](int s, Frag& f) {
+  // fragments [khalf][plane hi, res]: the weights of tap s are read one tap
+  // ahead (early in tap s - 1: the ring only has them then), the activations
+  // TWO taps ahead (three rotating buffers), so that no LDS latency and no
+  // straggling read sits between a tap's last MFMA and the next tap's first --
+  // with one wave per SIMD nothing else would cover it
+  struct XFrag { frag_t x[2][2]; };
+  struct WFrag { frag_t w[2][2]; };
+  auto load_x = [&](int s, int kh, XFrag& f) {  // 2 of the 4 activation reads of tap s
     const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
     const char* px = ldsb + xb + (kz & 1) * kMSeg + ((ky - 1) * a.XS + (kx - 1)) * 16;
+    f.x[kh][0] = *reinterpret_cast<const frag_t*>(px + (0 * 4 + kh * 2) * R16);
+    f.x[kh][1] = *reinterpret_cast<const frag_t*>(px + (1 * 4 + kh * 2) * R16);
+  };
+  auto load_w = [&](int s, int kh, WFrag& f) {  // 2 of the 4 weight reads of tap s
     const char* pw = ldsb + kMRing + (s % D) * 4096 + lane * 16;
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        f.x[kh][pl] = *reinterpret_cast<const frag_t*>(px + (pl * 4 + kh * 2) * R16);
-        f.w[kh][pl] = *reinterpret_cast<const frag_t*>(pw + (kh * 2 + pl) * 1024);
-      }
+    f.w[kh][0] = *reinterpret_cast<const frag_t*>(pw + (kh * 2 + 0) * 1024);
+    f.w[kh][1] = *reinterpret_cast<const frag_t*>(pw + (kh * 2 + 1) * 1024);
   };
   f32x16 acc, accC;
 #pragma unroll
@@ -2982,31 +3007,27 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
   f32x4 bias4[4], skip4[4], hw4[4];
   float seedv = 0.f, hbias = 0.f;
 
-  Frag F0, F1;
+  XFrag X0, X1, X2;
+  WFrag W0, W1;
   wait_vmcnt<kMPieces>();  // W0 .. W(D-2), dz = -1 landed
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   const long long dbg_c1 = a.dbg ? clock64() : 0;
   dma_w(D - 1);
-  load_frags(0, F0);
+  load_w(0, 0, W0);
+  load_w(0, 1, W0);
+  load_x(0, 0, X0);
+  load_x(0, 1, X0);
+  load_x(1, 0, X1);
+  load_x(1, 1, X1);
 
   // tap S: wait for W(S+1), barrier; then the 6 MFMAs of the current fragments
   // with everything else between them, in the shadow of the matrix pipe: the
-  // queueing of W(S+D-1) [, the dz = +1 DMAs, the epilogue operands] and the 8
-  // fragment reads of tap S+1
-  auto load_part = [&](int s, int part, Frag& f) {  // 2 of the 8 reads of tap s
-    const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
-    const char* px = ldsb + xb + (kz & 1) * kMSeg + ((ky - 1) * a.XS + (kx - 1)) * 16;
-    const char* pw = ldsb + kMRing + (s % D) * 4096 + lane * 16;
-    const int kh = part & 1;
-    if (part < 2) {
-      f.w[kh][0] = *reinterpret_cast<const frag_t*>(pw + (kh * 2 + 0) * 1024);
-      f.w[kh][1] = *reinterpret_cast<const frag_t*>(pw + (kh * 2 + 1) * 1024);
-    } else {
-      f.x[kh][0] = *reinterpret_cast<const frag_t*>(px + (0 * 4 + kh * 2) * R16);
-      f.x[kh][1] = *reinterpret_cast<const frag_t*>(px + (1 * 4 + kh * 2) * R16);
-    }
-  };
+  // queueing of W(S+D-1) [, the dz = +1 DMAs, the epilogue operands], the 4
+  // weight reads of tap S+1 (first: they must be back by its first MFMA) and
+  // the 4 activation reads of tap S+2 (nothing waits for them for a whole tap;
+  // no lgkmcnt(0) in front of the barrier: every read a ring / segment slot's
+  // next DMA could overtake was consumed by an MFMA a tap ago)
   auto dma_seg_part = [&](int k0, int k1) {  // pieces [k0, k1) of dz = +1 -> slot 0
 #pragma unroll
     for (int k = k0; k < k1; ++k) {
@@ -3015,33 +3036,35 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
                 lbase + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
     }
   };
-#define FFN_MGAP(S, PART, FNEXT)                                                \
+#define FFN_MGAP(S, PART, WNEXT, XNEXT)                                         \
   __builtin_amdgcn_sched_barrier(0);                                            \
-  if ((S) + 1 <= 26) load_part((S) + 1, PART, FNEXT);                           \
+  if ((PART) < 2 && (S) + 1 <= 26) load_w((S) + 1, PART, WNEXT);                \
+  if ((PART) >= 2 && (S) + 2 <= 26) load_x((S) + 2, (PART) - 2, XNEXT);         \
   if ((S) == 9) dma_seg_part(2 * (PART), 2 * (PART) + 2);                       \
   __builtin_amdgcn_sched_barrier(0);
-#define FFN_MTAP(S, FCUR, FNEXT)                                                \
+  // tap S: XCUR / WCUR hold its fragments; WNEXT takes tap S + 1's weights,
+  // XNEXT tap S + 2's activations
+#define FFN_MTAP(S, XCUR, WCUR, WNEXT, XNEXT)                                   \
   {                                                                             \
     if ((S) > 0) {                                                              \
       if constexpr (m_wait(S, D, NEPI) >= 0) wait_vmcnt<m_wait(S, D, NEPI)>();  \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
       __builtin_amdgcn_s_barrier();                                             \
       asm volatile("" ::: "memory");                                            \
     }                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                          \
-    accC = mma(FCUR.w[0][0], FCUR.x[0][1], accC);                               \
+    accC = mma(WCUR.w[0][0], XCUR.x[0][1], accC);                               \
     __builtin_amdgcn_sched_barrier(0);                                          \
     if ((S) > 0 && (S) + D - 1 <= 26) dma_w((S) + D - 1);                       \
     __builtin_amdgcn_sched_barrier(0);                                          \
-    acc = mma(FCUR.w[0][0], FCUR.x[0][0], acc);                                 \
-    FFN_MGAP(S, 0, FNEXT)                                                       \
-    accC = mma(FCUR.w[0][1], FCUR.x[0][0], accC);                               \
-    FFN_MGAP(S, 1, FNEXT)                                                       \
-    acc = mma(FCUR.w[1][0], FCUR.x[1][0], acc);                                 \
-    FFN_MGAP(S, 2, FNEXT)                                                       \
-    accC = mma(FCUR.w[1][0], FCUR.x[1][1], accC);                               \
-    FFN_MGAP(S, 3, FNEXT)                                                       \
-    accC = mma(FCUR.w[1][1], FCUR.x[1][0], accC);                               \
+    acc = mma(WCUR.w[0][0], XCUR.x[0][0], acc);                                 \
+    FFN_MGAP(S, 0, WNEXT, XNEXT)                                                \
+    accC = mma(WCUR.w[0][1], XCUR.x[0][0], accC);                               \
+    FFN_MGAP(S, 1, WNEXT, XNEXT)                                                \
+    acc = mma(WCUR.w[1][0], XCUR.x[1][0], acc);                                 \
+    FFN_MGAP(S, 2, WNEXT, XNEXT)                                                \
+    accC = mma(WCUR.w[1][0], XCUR.x[1][1], accC);                               \
+    FFN_MGAP(S, 3, WNEXT, XNEXT)                                                \
+    accC = mma(WCUR.w[1][1], XCUR.x[1][0], accC);                               \
     __builtin_amdgcn_sched_barrier(0);                                          \
     if ((S) == 27 - D) issue_epilogue_loads();                                  \
     __builtin_amdgcn_sched_barrier(0);                                          \
@@ -3075,33 +3098,33 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
                    : "memory");
     }
   };
-  FFN_MTAP(0, F0, F1)
-  FFN_MTAP(1, F1, F0)
-  FFN_MTAP(2, F0, F1)
-  FFN_MTAP(3, F1, F0)
-  FFN_MTAP(4, F0, F1)
-  FFN_MTAP(5, F1, F0)
-  FFN_MTAP(6, F0, F1)
-  FFN_MTAP(7, F1, F0)
-  FFN_MTAP(8, F0, F1)
-  FFN_MTAP(9, F1, F0)
-  FFN_MTAP(10, F0, F1)
-  FFN_MTAP(11, F1, F0)
-  FFN_MTAP(12, F0, F1)
-  FFN_MTAP(13, F1, F0)
-  FFN_MTAP(14, F0, F1)
-  FFN_MTAP(15, F1, F0)
-  FFN_MTAP(16, F0, F1)
-  FFN_MTAP(17, F1, F0)
-  FFN_MTAP(18, F0, F1)
-  FFN_MTAP(19, F1, F0)
-  FFN_MTAP(20, F0, F1)
-  FFN_MTAP(21, F1, F0)
-  FFN_MTAP(22, F0, F1)
-  FFN_MTAP(23, F1, F0)
-  FFN_MTAP(24, F0, F1)
-  FFN_MTAP(25, F1, F0)
-  FFN_MTAP(26, F0, F1)
+  FFN_MTAP(0, X0, W0, W1, X2)
+  FFN_MTAP(1, X1, W1, W0, X0)
+  FFN_MTAP(2, X2, W0, W1, X1)
+  FFN_MTAP(3, X0, W1, W0, X2)
+  FFN_MTAP(4, X1, W0, W1, X0)
+  FFN_MTAP(5, X2, W1, W0, X1)
+  FFN_MTAP(6, X0, W0, W1, X2)
+  FFN_MTAP(7, X1, W1, W0, X0)
+  FFN_MTAP(8, X2, W0, W1, X1)
+  FFN_MTAP(9, X0, W1, W0, X2)
+  FFN_MTAP(10, X1, W0, W1, X0)
+  FFN_MTAP(11, X2, W1, W0, X1)
+  FFN_MTAP(12, X0, W0, W1, X2)
+  FFN_MTAP(13, X1, W1, W0, X0)
+  FFN_MTAP(14, X2, W0, W1, X1)
+  FFN_MTAP(15, X0, W1, W0, X2)
+  FFN_MTAP(16, X1, W0, W1, X0)
+  FFN_MTAP(17, X2, W1, W0, X1)
+  FFN_MTAP(18, X0, W0, W1, X2)
+  FFN_MTAP(19, X1, W1, W0, X0)
+  FFN_MTAP(20, X2, W0, W1, X1)
+  FFN_MTAP(21, X0, W1, W0, X2)
+  FFN_MTAP(22, X1, W0, W1, X0)
+  FFN_MTAP(23, X2, W1, W0, X1)
+  FFN_MTAP(24, X0, W0, W1, X2)
+  FFN_MTAP(25, X1, W1, W0, X0)
+  FFN_MTAP(26, X2, W0, W1, X1)
 #undef FFN_MTAP
 #undef FFN_MGAP
   const long long dbg_c2 = a.dbg ? clock64() : 0;
@@ -3209,9 +3232,11 @@ template <int KIND, bool ADD_SKIP, bool HEAD>
 __global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
   const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
   if (gc >= a.total_slots) return;
+  const long long t0 = a.dbg_wgs ? wall_clock64() : 0;
   const int item = (int)__umulhi((unsigned)gc, a.magic_nchunks);
   const int chunk = gc - item * a.nchunks;
   conv32m_body<KIND, ADD_SKIP, HEAD>(a, item, chunk * kMChunk, gc, gc == 0);
+  stamp_workgroup(a, t0);
 }
 
 // ---------------------------------------------------------------------------
@@ -3273,21 +3298,27 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32mt_kernel(ConvDArgs a,
     r = i2 - item * per;
   }
   if (item >= mp.n) return;
+  const long long t0 = a.dbg_wgs ? wall_clock64() : 0;
   const int slots = mp.n_main + mp.n_tail;
   if (main_wg) {
     const int c = xcd * mp.mains_per_xcd + r;
     if (c >= mp.n_main) return;
     conv32m_body<KIND, ADD_SKIP, HEAD>(a, item, c * kMChunk, item * slots + c,
-                                       blockIdx.x == 0);
+                                       blockIdx.x == 0 && a.dbg_wgs != 2);
   } else {
     const int c = xcd * mp.tails_per_xcd + r;
     if (c >= mp.n_tail) return;
     constexpr int kPieces = TNT == 1 ? kTPieces : kT3Pieces;
     constexpr int kRows = TNT == 1 ? kTRows : kT3Rows;
+    // (everything queued up front, WPS = 2; the staged issue of WPS = 1 -- only
+    // W0, dz = -1, W1 in front of the first barrier -- was measured for the
+    // single-FoV tail: first barrier at 4.5 K instead of 5.2 K cycles, but the
+    // taps 6.9 K instead of 5.8 K: profiles/r02_wg_timeline.txt)
     conv32d_body<KIND, ADD_SKIP, kPieces, HEAD, TNT, kRows, 2>(
         a, item, mp.n_main * kMChunk + c * (32 * TNT), item * slots + mp.n_main + c,
-        mp.taoff, false);
+        mp.taoff, item == 0 && c == 0 && a.dbg_wgs == 2);
   }
+  stamp_workgroup(a, t0);
 }
 
 // ---------------------------------------------------------------------------

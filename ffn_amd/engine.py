@@ -138,6 +138,13 @@ class HipEngine:
     check(self._lib.ffn_engine_debug_clocks(self._h, out.ctypes.data))
     return out.reshape(4, 6)
 
+  def debug_workgroups(self, n: int = 4096):
+    """[n, 4]: wall clock (100 MHz) at entry / exit, HW_ID, XCC_ID per block of
+    the launch stamped under debug_clock 2 (ffn_engine_debug_workgroups)."""
+    out = np.zeros((n, 4), np.int64)
+    check(self._lib.ffn_engine_debug_workgroups(self._h, out.ctypes.data, n))
+    return out
+
   def synchronize(self):
     check(self._lib.ffn_engine_synchronize(self._h))
 
@@ -187,6 +194,43 @@ class HipEngine:
       rc = self._lib.ffn_canvas_step(self._h, n, self._canvas_arr, req,
                                      ctypes.byref(params), self._res_arr)
     check(rc)
+
+  def segment_many(self, canvases: Sequence['DeviceCanvasHandle'], starts,
+                   params: Sequence['_lib.SegmentParams'], resumes):
+    """ffn_canvas_segment_many: the segment loops of several canvases advanced
+    together inside the library, one batched step per round; returns once at
+    least one of them has ended.  -> (results, finished), one entry per canvas;
+    results count from the start of each canvas' segment.  A round voided by
+    the fp16 range check is repeated with the bf16x3 scheme and the call
+    resumed."""
+    n = len(canvases)
+    carr = (ctypes.c_void_p * n)(*[c._h for c in canvases])
+    sarr = (ctypes.c_int32 * 3 * n)()
+    parr = (_lib.SegmentParams * n)()
+    rarr = (ctypes.c_int32 * n)(*[int(bool(r)) for r in resumes])
+    for k in range(n):
+      for a in range(3):
+        sarr[k][a] = int(starts[k][a])
+      ctypes.pointer(parr[k])[0] = params[k]
+    res = (_lib.SegmentResult * n)()
+    fin = (ctypes.c_int32 * n)()
+    rc = self._lib.ffn_canvas_segment_many(self._h, n, carr, sarr, parr, rarr, res,
+                                           fin)
+    if rc == _lib.ERR_RANGE:
+      # the voided round changed nothing on the device and every prepared
+      # position stays pending: resume all of them on the bf16x3 scheme
+      self.range_fallbacks += 1
+      self.set_option('conv_variant', 3)
+      spent = [int(res[k].num_steps) for k in range(n)]
+      for k in range(n):
+        rarr[k] = 1
+        if parr[k].max_steps > 0:  # the budget is per call
+          parr[k].max_steps = max(parr[k].max_steps - spent[k], 1)
+      rc = self._lib.ffn_canvas_segment_many(self._h, n, carr, sarr, parr, rarr,
+                                             res, fin)
+    check(rc)
+    return ([_lib.SegmentResult.from_buffer_copy(res[k]) for k in range(n)],
+            [bool(fin[k]) for k in range(n)])
 
   def step_submit(self, canvases: Sequence['DeviceCanvasHandle'],
                   requests: Sequence[StepRequest], params: StepParams) -> int:

@@ -897,24 +897,31 @@ class DeviceCanvas(Canvas):
     sp.step = self._step_params
     return sp
 
-  def _segment_at_native(self, start_pos, max_steps=0, resume=False):
-    """Canvas.segment_at through `ffn_canvas_segment_at`; same state and
-    counters afterwards as the Python loop leaves."""
-    start_pos = tuple(int(v) for v in start_pos)
+  def _native_prelude(self, start_pos, resume=False):
+    """What Canvas.segment_at does before its loop; -> the loop's parameters, or
+    None if the loop has to stay in Python (a pre-filled policy queue)."""
     sp = self._segment_params()
     if not resume:
       if self.reset_seed_per_segment:
         self.init_seed(start_pos)
       self.reset_state(start_pos, reset_extents=self.reset_seed_per_segment)
       if self.movement_policy or self._min_pos is None:
-        # a pre-filled queue is the caller's business: Python loop
-        return self._drive(self._segment_at_gen_body(start_pos))
+        return None  # a pre-filled queue is the caller's business
       for a in range(3):
         sp.init_min_pos[a] = int(self._min_pos[a])
         sp.init_max_pos[a] = int(self._max_pos[a])
       cs = self._cached_start
       sp.initial_start_logit = (cs[1] if cs is not None and cs[0] == start_pos
                                 else float('nan'))
+    return sp
+
+  def _segment_at_native(self, start_pos, max_steps=0, resume=False):
+    """Canvas.segment_at through `ffn_canvas_segment_at`; same state and
+    counters afterwards as the Python loop leaves."""
+    start_pos = tuple(int(v) for v in start_pos)
+    sp = self._native_prelude(start_pos, resume)
+    if sp is None:
+      return self._drive(self._segment_at_gen_body(start_pos))
     sp.max_steps = int(max_steps)
     t0 = time.time()
     # a resumed leg belongs to the loop call that started the segment
@@ -922,7 +929,27 @@ class DeviceCanvas(Canvas):
                        increment=0 if resume else 1):
       self._invalidate_cache()
       res = self._call(self._handle.segment_at, start_pos, sp, resume)
+    return self._native_postlude(start_pos, res, time.time() - t0)
+
+  def _segment_at_native_many(self, start_pos):
+    """The same for a canvas advanced by `MultiCanvasDriver` in native mode: the
+    loop runs inside `ffn_canvas_segment_many` next to the other canvases'; the
+    driver sends back the result of the WHOLE segment."""
+    sp = self._native_prelude(start_pos)
+    if sp is None:
+      return (yield from self._segment_at_gen_body(start_pos))
+    sp.max_steps = 0
+    self._invalidate_cache()
+    t0 = time.time()
+    # a copy: the driver keeps it across calls, _segment_params() is reused
+    res = yield NativeSegment(start_pos, _lib.SegmentParams.from_buffer_copy(sp))
     dt = time.time() - t0
+    self.counters['segment_at-loop-calls'].Increment()
+    self.counters['segment_at-loop-time-ms'].IncrementBy(dt * MSEC_IN_SEC)
+    self._invalidate_cache()
+    return self._native_postlude(start_pos, res, dt)
+
+  def _native_postlude(self, start_pos, res, dt):
     n = int(res.num_steps)
     c = self.counters
     if n:
@@ -962,6 +989,10 @@ class DeviceCanvas(Canvas):
       # driven by blocking calls (segment_at / segment_all, not interleaved by
       # a MultiCanvasDriver): the whole loop runs inside the library
       return self._segment_at_native(start_pos)
+    if (not partial_segment_iters and
+        self.__dict__.get('_native_many', False) and self._native_loop_ok()):
+      # interleaved by a MultiCanvasDriver in native mode
+      return (yield from self._segment_at_native_many(start_pos))
     if not partial_segment_iters:
       if self.reset_seed_per_segment:
         self.init_seed(start_pos)
@@ -1091,6 +1122,20 @@ class DeviceCanvas(Canvas):
     self.seed[...] = np.asarray(seed, np.float32)
 
 
+class NativeSegment:
+  """What a DeviceCanvas yields instead of single FoV steps when its driver
+  runs whole segment loops in the library (`ffn_canvas_segment_many`): "run the
+  segment at `start_pos`"; the driver answers with that segment's
+  `SegmentResult` once the loop has ended."""
+
+  __slots__ = ('start_pos', 'params', 'started')
+
+  def __init__(self, start_pos, params):
+    self.start_pos = start_pos
+    self.params = params
+    self.started = False
+
+
 class MultiCanvasDriver:
   """Single-threaded scheduler advancing many DeviceCanvases: every round
   collects the pending FoV-step requests of up to `batch_size` canvases and
@@ -1109,11 +1154,21 @@ class MultiCanvasDriver:
   """
 
   def __init__(self, engine, batch_size=None, overlap=True,
-               max_steps_per_canvas=None):
+               max_steps_per_canvas=None, native=None):
+    """native: run whole segment loops inside the library
+    (`ffn_canvas_segment_many`: the per-canvas policy queues, validity tests and
+    the batching in C++, Python only between segments) instead of one Python
+    round trip per batched step.  Default: on when the engine has it
+    (FFN_AMD_NATIVE_MANY=0 in the environment turns it off); canvases that
+    cannot use the library's loop (custom policies, restrictors, hooks) are
+    stepped one by one next to it."""
     self.engine = engine
     hip_engine.pin_batched_arithmetic(engine)
     self.batch_size = batch_size or engine.max_batch
     self.overlap = overlap
+    if native is None:
+      native = os.environ.get('FFN_AMD_NATIVE_MANY', '1') != '0'
+    self.native = bool(native) and hasattr(engine, 'segment_many')
     #: benchmarking / bounded runs: a canvas is dropped after this many steps
     self.max_steps_per_canvas = max_steps_per_canvas
     self.calls = 0
@@ -1130,6 +1185,8 @@ class MultiCanvasDriver:
     place to save and close it -- and the next job is pulled.  A device canvas
     holds 12 B / voxel of HBM plus its host image, so a long job list must not
     be materialised up front."""
+    if self.native:
+      return self._run_native(jobs, window, on_done)
     jobs = iter(jobs)
     ready = collections.deque()  # [canvas, generator, pending request, steps]
     state = {'open': 0, 'exhausted': False}
@@ -1200,6 +1257,93 @@ class MultiCanvasDriver:
           finished(entry[0])
           continue
         ready.append(entry)
+      refill()
+
+
+  def _run_native(self, jobs, window, on_done):
+    """`run` with the segment loops in the library: every engine call advances
+    the current segments of up to `batch_size` canvases until one of them ends;
+    that canvas' generator then does its between-segment work (commit, next
+    seed) and yields its next segment."""
+    jobs = iter(jobs)
+    engine = self.engine
+    limit = self.max_steps_per_canvas
+    if window is None or window > self.batch_size:
+      # a canvas outside the engine call would only hold memory
+      window = self.batch_size
+    # [canvas, generator, pending request, steps of finished segments,
+    #  steps of the current segment reported so far]
+    live = []
+    state = {'exhausted': False}
+
+    def finished(entry):
+      live.remove(entry)
+      if on_done is not None:
+        on_done(entry[0])
+
+    def advance(entry, value):
+      """Feeds `value` to the canvas' generator; False once it is through."""
+      try:
+        entry[2] = entry[1].send(value) if value is not None else next(entry[1])
+        return True
+      except StopIteration:
+        finished(entry)
+        return False
+
+    def refill():
+      while not state['exhausted'] and len(live) < window:
+        try:
+          canvas, task = next(jobs)
+        except StopIteration:
+          state['exhausted'] = True
+          return
+        canvas._native_many = True
+        gen = (task if inspect.isgenerator(task) else
+               canvas._segment_all_gen(task))
+        entry = [canvas, gen, None, 0, 0]
+        live.append(entry)
+        advance(entry, None)
+
+    refill()
+    while live:
+      # canvases on the Python loop (no native segment pending): one blocking
+      # step each until they yield a native segment or finish
+      for entry in list(live):
+        while entry in live and not isinstance(entry[2], NativeSegment):
+          res = engine.step([entry[0]._handle], [entry[2]], entry[0]._step_params)
+          self.calls += 1
+          self.steps += 1
+          entry[3] += 1
+          if limit is not None and entry[3] >= limit:
+            entry[1].close()
+            finished(entry)
+            break
+          advance(entry, res[0])
+      if not live:
+        refill()
+        continue
+      key = bytes(live[0][2].params.step)
+      batch = [e for e in live if bytes(e[2].params.step) == key][:self.batch_size]
+      for e in batch:
+        e[2].params.max_steps = (max(limit - e[3] - e[4], 1)
+                                 if limit is not None else 0)
+      results, fin = engine.segment_many(
+          [e[0]._handle for e in batch], [e[2].start_pos for e in batch],
+          [e[2].params for e in batch], [e[2].started for e in batch])
+      self.calls += 1
+      for e, res, done in zip(batch, results, fin):
+        self.steps += int(res.num_steps) - e[4]
+        e[4] = int(res.num_steps)
+        e[2].started = True
+        if not done:
+          continue
+        e[3] += e[4]
+        e[4] = 0
+        if res.budget_exhausted or (limit is not None and e[3] >= limit):
+          e[1].close()
+          finished(e)
+          continue
+        advance(e, res)
       refill()
 
 

@@ -197,6 +197,25 @@ int ffn_canvas_step_wait(ffn_engine* engine, uint32_t ticket,
 int ffn_canvas_segment_at(ffn_canvas* canvas, const int32_t start_zyx[3],
                           const ffn_segment_params* params, int resume,
                           ffn_segment_result* result);
+/* Config C3 in the library (the reference's client threads + batching server
+ * thread, ffn/inference/executor.py:266-340, with the per-canvas policy queues
+ * here): the ffn_canvas_segment_at loops of n canvases of one engine advanced
+ * TOGETHER, one batched ffn_canvas_step per round over the loops still running.
+ * Returns as soon as at least one loop has ended (queue empty, seed too weak, or
+ * its max_steps spent in this call): finished[k] = 1 marks it, and the caller
+ * finishes that segment and gives the canvas its next one (resume[k] = 0); the
+ * others continue with resume[k] = 1, in the next call or a later one.
+ * results[k] counts from the START of canvas k's segment over all its calls
+ * (budget_exhausted aside).  n <= max_batch, canvases distinct, every
+ * params[k].step identical (one engine call = one set of step parameters).  On
+ * an error (e.g. FFN_ERR_RANGE) nothing of the failed round was pasted and
+ * every prepared position stays pending: deal with it, then call again with
+ * resume = 1 for every canvas. */
+int ffn_canvas_segment_many(ffn_engine* engine, int n, ffn_canvas* const* canvases,
+                            const int32_t (*starts_zyx)[3],
+                            const ffn_segment_params* params,
+                            const int32_t* resume, ffn_segment_result* results,
+                            int32_t* finished);
 /* keep_history: entries [first, first + n) of the current segment's history
  * (positions zyx, deleted-voxel counts); *total = entries recorded. */
 int ffn_canvas_segment_history(ffn_canvas* canvas, size_t first, size_t n,
@@ -275,6 +294,11 @@ int ffn_engine_get_option(ffn_engine* engine, const char* name, int* value);
  * first workgroup, per wave {shader clock at entry, at main-loop start, at
  * main-loop end, at exit, wall clock (100 MHz) at entry, at exit}. */
 int ffn_engine_debug_clocks(ffn_engine* engine, long long* out24);
+/* Debug: with "debug_clock" = 2 every workgroup of the conv32m / conv32mt launch
+ * of layer "debug_layer" also records {wall clock (100 MHz) at entry, at exit,
+ * HW_ID, XCC_ID}: out[4 b ..] for blockIdx b < max_wgs <= 4096 (zeros for a
+ * block that exited at once).  Clears the records. */
+int ffn_engine_debug_workgroups(ffn_engine* engine, long long* out, int max_wgs);
 /* Blocks until all work queued on the engine's stream has finished. */
 int ffn_engine_synchronize(ffn_engine* engine);
 

@@ -35,6 +35,38 @@ int shim_segment_at(void* state, shim_step_fn step_cb, shim_read_fn read_cb,
   return loop.run(start, resume, out);
 }
 
+// ffn_host::segment_many (what ffn_canvas_segment_many runs over HIP canvases)
+// over callbacks: ONE batched-step callback, point reads by canvas index.
+typedef int (*shim_batch_fn)(int, const int*, const ffn_step_request*,
+                             const ffn_step_params*, ffn_step_result*);
+typedef int (*shim_read_k_fn)(int, const int32_t*, float*, int32_t*);
+
+struct ShimManyDevice {
+  shim_read_k_fn read_cb;
+  int k;
+  int read_point(const int32_t pos[3], float* seed, int32_t* seg) {
+    return read_cb(k, pos, seed, seg);
+  }
+};
+
+int shim_segment_many(int n, void* const* states, shim_batch_fn batch_cb,
+                      shim_read_k_fn read_cb, const int32_t (*starts)[3],
+                      const ffn_segment_params* params, const int32_t* resume,
+                      ffn_segment_result* out, int32_t* finished) {
+  std::vector<ShimManyDevice> devs(n);
+  std::vector<ffn_host::SegmentState*> st(n);
+  for (int k = 0; k < n; ++k) {
+    devs[k] = ShimManyDevice{read_cb, k};
+    st[k] = static_cast<ffn_host::SegmentState*>(states[k]);
+  }
+  auto batch_step = [&](int nb, const int* idx, const ffn_step_request* reqs,
+                        const ffn_step_params& sp, ffn_step_result* res) {
+    return batch_cb(nb, idx, reqs, &sp, res);
+  };
+  return ffn_host::segment_many(n, devs.data(), st.data(), starts, params, resume, out,
+                                finished, batch_step);
+}
+
 size_t shim_history(void* state, int32_t* pos, uint32_t* deleted, size_t cap) {
   auto& st = *static_cast<ffn_host::SegmentState*>(state);
   const size_t n = st.history_deleted.size() < cap ? st.history_deleted.size() : cap;

@@ -20,6 +20,17 @@ _READ_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
                             ctypes.POINTER(ctypes.c_int32))
 
 
+_BATCH_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int,
+                             ctypes.POINTER(ctypes.c_int),
+                             ctypes.POINTER(_lib.StepRequest),
+                             ctypes.POINTER(_lib.StepParams),
+                             ctypes.POINTER(_lib.StepResult))
+_READ_K_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int,
+                              ctypes.POINTER(ctypes.c_int32),
+                              ctypes.POINTER(ctypes.c_float),
+                              ctypes.POINTER(ctypes.c_int32))
+
+
 def build_shim(out_dir):
   """Compiles the shim into `out_dir` and returns the loaded library."""
   out = os.path.join(str(out_dir), 'host_loop_shim.so')
@@ -33,6 +44,10 @@ def build_shim(out_dir):
       ctypes.c_void_p, _STEP_CB, _READ_CB, ctypes.POINTER(ctypes.c_int32),
       ctypes.POINTER(_lib.SegmentParams), ctypes.c_int,
       ctypes.POINTER(_lib.SegmentResult)]
+  lib.shim_segment_many.restype = ctypes.c_int
+  lib.shim_segment_many.argtypes = [
+      ctypes.c_int, ctypes.c_void_p, _BATCH_CB, _READ_K_CB, ctypes.c_void_p,
+      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
   lib.shim_history.restype = ctypes.c_size_t
   lib.shim_history.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
                                ctypes.c_void_p, ctypes.c_size_t]
@@ -105,3 +120,75 @@ class ShimClient(EmulatedDeviceClient):
   def create_canvas(self, image):
     ShimHandle.client = self
     return ShimHandle(image)
+
+
+class ShimEngine:
+  """What `MultiCanvasDriver` needs of a HipEngine, over emulated canvases:
+  `segment_many` through the C++ loop (ffn_host::segment_many), blocking `step`
+  for canvases on the Python loop."""
+
+  def __init__(self, client, max_batch):
+    self.client = client
+    self.max_batch = max_batch
+    self.many_calls = 0
+    self.batch_sizes = []
+    self.fail_round = None  # batched round at which the device reports ERR_RANGE once
+    self.rounds = 0
+    self.range_fallbacks = 0
+
+  def step(self, handles, requests, params):
+    return [self.client.step(h, r, params) for h, r in zip(handles, requests)]
+
+  def _segment_many_once(self, handles, sarr, parr, rarr, res, fin):
+    n = len(handles)
+
+    def batch_cb(nb, idx, reqs, par, out):
+      if self.fail_round is not None and self.rounds == self.fail_round:
+        self.fail_round = None
+        return _lib.ERR_RANGE
+      self.rounds += 1
+      self.batch_sizes.append(nb)
+      for b in range(nb):
+        h = handles[idx[b]]
+        h.steps_seen.append(tuple(reqs[b].pos))
+        r = self.client.step(h, reqs[b], par.contents)
+        ctypes.memmove(ctypes.addressof(out[b]), ctypes.addressof(r),
+                       ctypes.sizeof(r))
+      return 0
+
+    def read_cb(k, pos, seed, seg):
+      s, g = handles[k].read_point((pos[0], pos[1], pos[2]))
+      seed[0], seg[0] = s, g
+      return 0
+
+    states = (ctypes.c_void_p * n)(*[h._state for h in handles])
+    return ShimHandle.shim.shim_segment_many(
+        n, states, _BATCH_CB(batch_cb), _READ_K_CB(read_cb), sarr, parr, rarr, res,
+        fin)
+
+  def segment_many(self, handles, starts, params, resumes):
+    """Mirrors HipEngine.segment_many, ERR_RANGE handling included."""
+    n = len(handles)
+    assert n <= self.max_batch
+    self.many_calls += 1
+    sarr = (ctypes.c_int32 * 3 * n)()
+    parr = (_lib.SegmentParams * n)()
+    rarr = (ctypes.c_int32 * n)(*[int(bool(r)) for r in resumes])
+    for k in range(n):
+      for a in range(3):
+        sarr[k][a] = int(starts[k][a])
+      ctypes.pointer(parr[k])[0] = params[k]
+    res = (_lib.SegmentResult * n)()
+    fin = (ctypes.c_int32 * n)()
+    rc = self._segment_many_once(handles, sarr, parr, rarr, res, fin)
+    if rc == _lib.ERR_RANGE:
+      self.range_fallbacks += 1
+      spent = [int(res[k].num_steps) for k in range(n)]
+      for k in range(n):
+        rarr[k] = 1
+        if parr[k].max_steps > 0:
+          parr[k].max_steps = max(parr[k].max_steps - spent[k], 1)
+      rc = self._segment_many_once(handles, sarr, parr, rarr, res, fin)
+    assert rc == 0, rc
+    return ([_lib.SegmentResult.from_buffer_copy(res[k]) for k in range(n)],
+            [bool(fin[k]) for k in range(n)])

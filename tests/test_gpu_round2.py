@@ -465,3 +465,65 @@ def test_run_inference_main_sharded_assemble(tmp_path):
   assert len(ids) > 3 and ids[0] == 0
   assert np.mean(merged > 0) > 0.2
   assert os.path.exists(os.path.join(out_dir, 'counters.txt'))
+
+
+@pytest.mark.gpu
+def test_segment_many_in_the_library(fib25_model):
+  """ffn_canvas_segment_many (reference executor.py:266-340):
+  five device canvases of one engine under MultiCanvasDriver(native=True) --
+  whole segment loops in C++, one batched ffn_canvas_step per round, Python
+  only between segments -- against the per-step Python driver and the
+  reference-minted runs: same steps, same segmentation, same counters."""
+  import functools
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from ffn_amd.inference import seed as seed_lib
+  import bench
+  names = ['cells72', 'cells56', 'cells72', 'cells56', 'cells56']
+  gold = {n: np.load(os.path.join(GOLDEN, 'ref_canvas_%s.npz' % n))
+          for n in set(names)}
+  request = bench.make_request()
+  runs = {}
+  for native in (True, False):
+    counters = inference_utils.Counters()
+    exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
+                                    fib25_model.info, None, counters, 4)
+    assert exe.engine.get_option('conv_variant') == 8  # batched: pinned
+    canvases = []
+    for n in names:
+      sub = counters.get_sub_counters()
+      canvases.append(inference.DeviceCanvas(
+          fib25_model.info, exe.get_client(sub, direct=True),
+          synthetic.normalize(gold[n]['volume']), request.inference_options,
+          counters=sub, keep_history=True,
+          movement_policy_fn=movement.get_policy_fn(request, fib25_model.info)))
+    drv = inference.MultiCanvasDriver(exe.engine, batch_size=4, native=native)
+    assert drv.native == native
+    drv.run((c, functools.partial(seed_lib.PolicyFixed, coords=gold[n]['seeds']))
+            for c, n in zip(canvases, names))
+    out = []
+    for c, n in zip(canvases, names):
+      out.append(dict(
+          seg=np.array(np.asarray(c.segmentation)),
+          seed=np.array(c._handle.read_seed()),
+          counters={k: c.counters[k].value for k in (
+              'update_at-calls', 'skip_threshold', 'skip_invalid_pos',
+              'seed_got_too_weak', 'segment_at-loop-calls', 'voxels-segmented')},
+          rejects=c.gate_rejects))
+      assert np.array_equal(out[-1]['seg'], gold[n]['segmentation']), (native, n)
+      assert out[-1]['counters']['update_at-calls'] == len(gold[n]['steps'])
+      c.close()
+    runs[native] = (out, drv.calls, drv.steps)
+  total = sum(len(gold[n]['steps']) for n in names)
+  for a, b in zip(runs[True][0], runs[False][0]):
+    assert a['counters'] == b['counters'] and a['rejects'] == b['rejects']
+    assert np.array_equal(a['seg'], b['seg'])
+    assert np.array_equal(a['seed'], b['seed'], equal_nan=True)
+  assert runs[True][2] == runs[False][2] == total
+  # Python entered per segment, not per batched step
+  print('engine calls: native %d, per-step %d, for %d FoV steps' % (
+      runs[True][1], runs[False][1], total))
+  assert runs[True][1] < runs[False][1] / 3

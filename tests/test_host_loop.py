@@ -314,3 +314,74 @@ def test_timed_checkpoints_with_the_native_loop(shim, fib25_blob, tmp_path):
   assert b.restore_checkpoint(path) == 0
   b.segment_all(seed_policy=policy)
   assert np.array_equal(np.asarray(b.segmentation), g['segmentation'])
+
+
+def _many_canvases(shim, blob, names, **kwargs):
+  """Emulated canvases of ONE client + the engine that advances them together."""
+  from tests import native_shim
+  ShimHandle.shim = shim
+  r = _request()
+  info = _info()
+  client = ShimClient(inference_utils.Counters(), blob, 12, (33, 33, 33), (8, 8, 8))
+  gold = {n: np.load(os.path.join(GOLDEN, 'ref_canvas_%s.npz' % n))
+          for n in set(names)}
+  canvases = []
+  for n in names:
+    c = inference.make_canvas(info, client, synthetic.normalize(gold[n]['volume']),
+                              r.inference_options,
+                              counters=inference_utils.Counters(),
+                              movement_policy_fn=movement.get_policy_fn(r, info),
+                              **kwargs)
+    canvases.append(c)
+  return client, native_shim.ShimEngine(client, 4), canvases, gold
+
+
+@pytest.mark.parametrize('fail_round', [None, 37])
+def test_segment_many_reproduces_reference_runs(shim, fib25_blob, fail_round):
+  """ffn_host::segment_many (ffn_canvas_segment_many's loop) under the
+  MultiCanvasDriver: five canvases, at most four per engine call, whole segments
+  inside the C++ loop, Python only between segments.  Every canvas repeats the
+  reference's own run step for step whatever it shared its calls with -- also
+  when a batched round is voided once (FFN_ERR_RANGE) and the call resumed."""
+  import json
+  names = ['cells72', 'cells56', 'cells72', 'cells56', 'cells56']
+  client, engine, canvases, gold = _many_canvases(shim, fib25_blob, names)
+  engine.fail_round = fail_round
+  drv = inference.MultiCanvasDriver(engine, batch_size=4, native=True)
+  assert drv.native
+  done = []
+  drv.run(((c, functools.partial(seed_lib.PolicyFixed, coords=gold[n]['seeds']))
+           for c, n in zip(canvases, names)), on_done=done.append)
+  assert len(done) == len(names)
+  total = 0
+  for c, n in zip(canvases, names):
+    g = gold[n]
+    assert np.array_equal(np.array(c._handle.steps_seen).reshape(-1, 3), g['steps']), n
+    assert np.array_equal(np.asarray(c.segmentation), g['segmentation']), n
+    ref = json.loads(str(g['counters']))
+    for key in ('update_at-calls', 'voxels-segmented', 'skip_invalid_pos',
+                'skip_threshold', 'seed_got_too_weak', 'segment_at-loop-calls'):
+      if key in ref:
+        assert c.counters[key].value == ref[key], (n, key)
+    total += len(g['steps'])
+  assert drv.steps == total
+  # the steps really shared engine rounds, and Python was entered per SEGMENT
+  assert max(engine.batch_sizes) == 4 and engine.rounds < total
+  assert engine.many_calls < total / 3
+  assert engine.range_fallbacks == (0 if fail_round is None else 1)
+
+
+def test_segment_many_step_budget_per_canvas(shim, fib25_blob):
+  """max_steps_per_canvas under the native driver: every canvas is dropped after
+  exactly its budget, and what it did until then is the start of its full run."""
+  names = ['cells72', 'cells56', 'cells72']
+  client, engine, canvases, gold = _many_canvases(shim, fib25_blob, names)
+  drv = inference.MultiCanvasDriver(engine, batch_size=4, native=True,
+                                    max_steps_per_canvas=20)
+  drv.run((c, functools.partial(seed_lib.PolicyFixed, coords=gold[n]['seeds']))
+          for c, n in zip(canvases, names))
+  for c, n in zip(canvases, names):
+    want = gold[n]['steps'][:20]
+    got = np.array(c._handle.steps_seen).reshape(-1, 3)
+    assert np.array_equal(got, want), n
+  assert drv.steps == sum(min(20, len(gold[n]['steps'])) for n in names)
