@@ -385,3 +385,32 @@ def test_segment_many_step_budget_per_canvas(shim, fib25_blob):
     got = np.array(c._handle.steps_seen).reshape(-1, 3)
     assert np.array_equal(got, want), n
   assert drv.steps == sum(min(20, len(gold[n]['steps'])) for n in names)
+
+
+def test_segment_many_small_batches_and_argument_checks(shim, fib25_blob):
+  """Two canvases per engine call for four jobs (a finished canvas' slot goes to
+  the next job); canvases with different step parameters never share a call."""
+  names = ['cells56', 'cells72', 'cells56', 'cells72']
+  client, engine, canvases, gold = _many_canvases(shim, fib25_blob, names)
+  engine.max_batch = 2
+  drv = inference.MultiCanvasDriver(engine, batch_size=2, native=True)
+  drv.run((c, functools.partial(seed_lib.PolicyFixed, coords=gold[n]['seeds']))
+          for c, n in zip(canvases, names))
+  for c, n in zip(canvases, names):
+    assert np.array_equal(np.asarray(c.segmentation), gold[n]['segmentation']), n
+  assert max(engine.batch_sizes) == 2
+  # one engine call = one set of step parameters (FFN_ERR_ARG otherwise)
+  from tests import native_shim
+  client2, engine2, cs, _ = _many_canvases(shim, fib25_blob, ['cells56', 'cells56'])
+  sp = [c._segment_params() for c in cs]
+  a = _lib.SegmentParams.from_buffer_copy(sp[0])
+  b = _lib.SegmentParams.from_buffer_copy(sp[1])
+  b.step.move_threshold = a.step.move_threshold + 1.0
+  n = 2
+  sarr = (ctypes.c_int32 * 3 * n)()
+  parr = (_lib.SegmentParams * n)(a, b)
+  rarr = (ctypes.c_int32 * n)(0, 0)
+  res = (_lib.SegmentResult * n)()
+  fin = (ctypes.c_int32 * n)()
+  rc = engine2._segment_many_once([c._handle for c in cs], sarr, parr, rarr, res, fin)
+  assert rc == -1  # FFN_ERR_ARG
