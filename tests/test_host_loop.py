@@ -414,3 +414,40 @@ def test_segment_many_small_batches_and_argument_checks(shim, fib25_blob):
   fin = (ctypes.c_int32 * n)()
   rc = engine2._segment_many_once([c._handle for c in cs], sarr, parr, rarr, res, fin)
   assert rc == -1  # FFN_ERR_ARG
+
+
+def test_native_driver_steps_python_loop_canvases_next_to_native_ones(shim, fib25_blob):
+  """A canvas whose loop has to stay in Python (here: a MovementRestrictor with
+  masks) yields single FoV steps; the native driver makes them one by one and
+  runs the other canvases' segments in the library -- every canvas ends with
+  its reference-minted run."""
+  from tests import native_shim
+  from tests import test_masks
+  from ffn_amd.training import model as ffn_model
+  gm = np.load(test_masks.FIX)
+  names = ['cells56', 'cells72']
+  client, engine, canvases, gold = _many_canvases(shim, fib25_blob, names)
+  r = test_masks._options()
+  info = ffn_model.ModelInfo(np.array([8, 8, 8]), np.array([33, 33, 33]),
+                             np.array([33, 33, 33]), np.array([33, 33, 33]))
+  masked = inference.make_canvas(
+      info, client, synthetic.normalize(gm['run_volume']), r.inference_options,
+      counters=inference_utils.Counters(), restrictor=test_masks._restrictor(gm),
+      movement_policy_fn=movement.get_policy_fn(r, info))
+  assert not masked._native_loop_ok()
+  jobs = [(canvases[0], functools.partial(seed_lib.PolicyFixed,
+                                          coords=gold['cells56']['seeds'])),
+          (masked, functools.partial(seed_lib.PolicyFixed, coords=gm['run_seeds'])),
+          (canvases[1], functools.partial(seed_lib.PolicyFixed,
+                                          coords=gold['cells72']['seeds']))]
+  drv = inference.MultiCanvasDriver(engine, batch_size=4, native=True)
+  drv.run(jobs)
+  for c, n in zip(canvases, names):
+    assert np.array_equal(np.asarray(c.segmentation), gold[n]['segmentation']), n
+  assert np.array_equal(np.asarray(masked.segmentation), gm['run_segmentation'])
+  import json
+  ref = json.loads(str(gm['run_counters']))
+  for key in ('update_at-calls', 'skip_restriced_pos', 'voxels-segmented'):
+    assert masked.counters[key].value == ref[key], key
+  assert drv.steps == (len(gm['run_steps']) + len(gold['cells56']['steps']) +
+                       len(gold['cells72']['steps']))
