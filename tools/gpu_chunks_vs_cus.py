@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Batch-1 time of the conv stack against the number of conv32m chunks (128
 voxels each) of the FoV: 256 CUs host two workgroups each, so how much of a
-33^3 layer's time (281 chunks) is the 25 CUs that run two workgroups?
+33^3 layer's time (281 chunks) is the 25 CUs that run two workgroups?  (Variant
+9, conv32mt, where the FoV has 257 .. 512 chunks: the step it removes.)
 
   python tools/gpu_chunks_vs_cus.py
 """
@@ -39,7 +40,7 @@ def main():
     seed = rng.normal(0, 1, [1] + zyx).astype(np.float32)
     v = int(np.prod(fov))
     chunks = (v + 127) // 128
-    for variant in (8, 6):
+    for variant in (9, 8, 6):
       try:
         eng.set_option('conv_variant', variant)
       except Exception:  # pylint:disable=broad-except
