@@ -125,6 +125,16 @@ def make_request():
   return r
 
 
+def _engine_options(args):
+  """--engine-option name=value ... -> [(name, int)]: ffn_engine_set_option
+  switches applied to every engine of the run (A/B runs; recorded in the JSON)."""
+  out = []
+  for item in args.engine_option or []:
+    name, _, value = item.partition('=')
+    out.append((name, int(value)))
+  return out
+
+
 def load_model():
   from ffn_amd.training.models import convstack_3d
   model = convstack_3d.ConvStack3DFFNModel(
@@ -166,6 +176,8 @@ def run_gpu(args, rank, local_rank, world):
     eng.set_option('conv_variant', args.conv_variant)
   if args.sync_mode is not None:
     eng.set_option('sync_mode', args.sync_mode)
+  for name, value in _engine_options(args):
+    eng.set_option(name, value)
 
   shape = VOLUME_ZYX
   if args.workload == 'cells':
@@ -726,6 +738,9 @@ def main():
                   'anisotropic model of configs[4], random weights')
   ap.add_argument('--workload', choices=['cells', 'noise'], default='cells')
   ap.add_argument('--conv-variant', type=int, default=None)
+  ap.add_argument('--engine-option', action='append', default=[],
+                  metavar='NAME=VALUE', help='ffn_engine_set_option switch '
+                  '(e.g. use_graph=1); may be given several times')
   ap.add_argument('--profile-every', type=int, default=8)
   ap.add_argument('--sync-mode', type=int, default=None)
   ap.add_argument('--profile-mode', type=int, default=2,
@@ -850,6 +865,9 @@ def main():
           'host_loop': ('ffn_canvas_segment_at (segment loop inside the library)'
                         if args.host_loop == 'native' else
                         'Python, one ffn_canvas_step per FoV step'),
+          'engine_options': dict(_engine_options(args)),
+          'env': {k: os.environ[k] for k in ('HIP_FORCE_DEV_KERNARG',)
+                  if k in os.environ},
       },
       'voxels_segmented_per_s': round(
           res['voxels_run'] / max(res['seconds_run'], 1e-9), 1),

@@ -29,8 +29,9 @@ class FFNHipError(RuntimeError):
 
 
 class FFNRangeError(FFNHipError):
-  """FFN_ERR_RANGE: conv_variant 4 met an operand outside the fp16 range; the
-  step changed nothing and can be repeated with conv_variant 3."""
+  """FFN_ERR_RANGE: a split-product kernel (conv_variant >= 6) met an operand
+  outside the fp16 range; the step changed nothing and can be repeated with the
+  exact-f32 kernel (conv_variant -1)."""
 
 
 ERR_RANGE = -4
@@ -219,19 +220,33 @@ _lock = threading.Lock()
 
 
 def build(force: bool = False) -> str:
-  """Compiles csrc/*.hip for gfx950 into csrc/libffn_hip.so (in-tree)."""
-  srcs = [os.path.join(CSRC, name) for name in SOURCES]
-  deps = srcs + HEADERS + [os.path.join(CSRC, 'ffn_kernels.h'),
-                           os.path.join(CSRC, 'ffn_internal.h')]
-  if (not force and os.path.exists(LIB_PATH) and
-      all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
-    return LIB_PATH
+  """Compiles csrc/*.hip for gfx950 into csrc/libffn_hip.so (in-tree): one
+  object per source under csrc/build/ (stale ones only, in parallel), then the
+  link."""
+  headers = HEADERS + [os.path.join(CSRC, name) for name in
+                       ('ffn_kernels.h', 'ffn_internal.h', 'ffn_host_loop.h')]
   hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
   if not os.path.exists(hipcc):
     hipcc = 'hipcc'
-  cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared',
-         '-fPIC', '-o', LIB_PATH] + srcs
-  subprocess.check_call(cmd, cwd=CSRC)
+  objdir = os.path.join(CSRC, 'build')
+  os.makedirs(objdir, exist_ok=True)
+  jobs, objs = [], []
+  for name in SOURCES:
+    src = os.path.join(CSRC, name)
+    obj = os.path.join(objdir, os.path.splitext(name)[0] + '.o')
+    objs.append(obj)
+    if (force or not os.path.exists(obj) or
+        any(os.path.getmtime(obj) < os.path.getmtime(d) for d in [src] + headers)):
+      jobs.append((name, subprocess.Popen(
+          [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c',
+           src, '-o', obj], cwd=CSRC)))
+  failed = [name for name, p in jobs if p.wait() != 0]
+  if failed:
+    raise FFNHipError('hipcc failed for %s' % ', '.join(failed))
+  if (jobs or not os.path.exists(LIB_PATH) or
+      any(os.path.getmtime(LIB_PATH) < os.path.getmtime(o) for o in objs)):
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC',
+                           '-o', LIB_PATH] + objs, cwd=CSRC)
   return LIB_PATH
 
 

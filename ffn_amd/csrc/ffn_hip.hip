@@ -11,8 +11,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "ffn_internal.h"
@@ -76,31 +79,17 @@ struct ffn_engine {
   int32_t* pidx = nullptr;    // dense FoV index -> padded position (variant 2)
   int nchunks_c = 0, Rc = 0;
   int fuse_head = 1;      // 1x1x1 head fused into the last conv32c launch
-  int waves8 = 2;         // variants 3 / 4: 8-wave workgroups (conv32w8); 2 = with
-                          // the staging conversion interleaved into the taps
   int count_blocks = kHeadBlocks;  // entries per item in `count` for the last step
   int store_policy = 1;  // conv32c epilogue stores: sc1 write-through (-1.4 % per stack)
   long long* d_dbg = nullptr;  // debug clocks of conv32c WG 0 (24 values)
   int dbg_clock = 0;
   int dbg_layer = 3;      // the launch whose clocks are recorded (3 = a conv_a)
   size_t lds_bytes_c = 0;
-  size_t lds_bytes_x = 0;        // conv32x3: 2 slots x Rc rows x 224 B
-  uint16_t* wpack3 = nullptr;    // bf16 hi/mid/lo weight fragments, all layers
-  size_t wpack3_layer = 0;       // halves per layer
-  uint16_t* wpack2h = nullptr;   // fp16 hi / scaled-residual fragments (variant 4)
-  size_t wpack2h_layer = 0;
-  size_t lds_bytes_h = 0;        // conv32x3<SCHEME 2>: 2 slots x Rc rows x 160 B
-  // conv32k (variant 5): 160-voxel chunks, K split over the waves
+  // conv32d (variant 6): 160-voxel chunks, the 27 taps split over the waves,
+  // split-plane activations, LDS-DMA staging
   int nchunks_k = 0, Rc_k = 0;
-  size_t lds_bytes_k = 0;        // 3 slots x Rc_k rows x 144 B
-  uint16_t* wpackk = nullptr;    // fp16 hi / scaled-residual fragments, 32x32x16 order
-  size_t wpackk_layer = 0;
-  bool k_ok = false;             // geometry fits conv32k
-  int ksched_aoff[4 * kKMaxTaps] = {};
-  int ksched_btap[4 * kKMaxTaps] = {};
-  int ksched_ntaps[4] = {};
-  // conv32d (variant 6): conv32k's chunks / schedule, split-plane activations,
-  // LDS-DMA staging.  rawT / rawX / rawS: the three activation allocations
+  bool k_ok = false;             // the chunk + halo fits the LDS slots
+  // rawT / rawX / rawS: the three activation allocations
   float* rawT = nullptr;
   float* rawX = nullptr;
   float* rawS = nullptr;
@@ -130,13 +119,24 @@ struct ffn_engine {
   size_t lds_bytes_d = 0;        // 3 slots x 8 planes x Rc_k rows x 16 B
   int dsched_aoff[4 * 8] = {};
   int dsched_btap[4 * 8] = {};
-  unsigned* range_flag = nullptr;  // device word: tag of the last void run
-  unsigned range_tag = 0;        // tag of the run being queued
+  unsigned* range_flag = nullptr;  // device words: [0] tag of the last void eager run,
+                                   // [1], [2] the flags of captured runs (by parity)
+  unsigned range_tag = 0;        // tag of the last eager run
+  unsigned* cur_flag = nullptr;  // flag word / tag of the run being queued
+  unsigned cur_tag = 0;
+  unsigned* clear_flag = nullptr;  // captured runs: the word the NEXT run will use
+                                   // (faces_kernel zeroes it)
+  // option "use_graph": the 2*depth-1 conv launches of a step replayed from a
+  // captured hipGraph (one per batch size / thresholds / flag parity)
+  int use_graph = 0;
+  typedef std::tuple<int, unsigned, unsigned, int> GraphKey;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  long graph_runs = 0;
   bool fp16_ok = true;           // every weight inside the fp16 range
-  int conv_variant = 4;       // 0 conv32, 1 conv32p, 2 conv32c, 3 conv32x3 bf16x3, 4 fp16x2,
-                              // 5 fp16x2 on 32x32x16 with the taps split over the waves,
-                              // 6 the same on producer-split planes + LDS-DMA staging,
-                              // 7 = 6 with 96-voxel chunks, two workgroups per CU
+  int conv_variant = 0;       // 0 conv32 (any FoV), 2 conv32c (exact f32), 6 conv32d, 7 = 6
+                              // with 96-voxel chunks, 8 conv32m, 9 conv32mt (+ conv32m)
+  int exact_variant = 0;      // the f32 kernel a voided fp16 step is repeated with: 2
+                              // where conv32c takes the FoV, else 0
   float* h_io = nullptr;      // pinned staging of ffn_predict: seed, image, logits
   float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
   float* up_seed = nullptr;
@@ -245,37 +245,6 @@ int set_lds_attr(size_t bytes) {
   return FFN_OK;
 }
 
-template <bool RI, bool RO, bool SK, int ABL = 0>
-int set_lds_attr_p(size_t bytes) {
-  HIP_TRY(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv32p_kernel<RI, RO, SK, ABL>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return FFN_OK;
-}
-
-// f32 -> bf16 with round-to-nearest-even (what v_cvt_pk_bf16_f32 does on device)
-inline uint16_t to_bf16_rne(float x) {
-  uint32_t u;
-  std::memcpy(&u, &x, 4);
-  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);  // inf / nan
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-inline float from_bf16(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float x;
-  std::memcpy(&x, &u, 4);
-  return x;
-}
-// x == hi + mid + lo, each a bf16 (exact: 24 mantissa bits = 3 x 8)
-inline void split_bf16x3(float x, uint16_t part[3]) {
-  part[0] = to_bf16_rne(x);
-  const float r1 = x - from_bf16(part[0]);
-  part[1] = to_bf16_rne(r1);
-  const float r2 = r1 - from_bf16(part[1]);
-  part[2] = to_bf16_rne(r2);
-}
-
 // x ~= hi + 2^-11 * res with hi, res fp16 (what the device does when staging)
 inline void split_fp16x2(float x, uint16_t part[2]) {
   const float xh = std::fabs(x) < 6.103515625e-05f ? 0.0f : x;
@@ -283,43 +252,6 @@ inline void split_fp16x2(float x, uint16_t part[2]) {
   const _Float16 res = (_Float16)((x - (float)hi) * 2048.0f);
   std::memcpy(&part[0], &hi, 2);
   std::memcpy(&part[1], &res, 2);
-}
-
-template <bool RI, bool RO, bool SK, int SCHEME>
-int set_lds_attr_w8(size_t bytes) {
-  HIP_TRY(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv32w8_kernel<RI, RO, SK, 8, false, SCHEME>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  HIP_TRY(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv32w8_kernel<RI, RO, SK, 9, false, SCHEME>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  if (SK) {
-    HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv32w8_kernel<RI, RO, SK, 8, true, SCHEME>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv32w8_kernel<RI, RO, SK, 9, true, SCHEME>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  }
-  return FFN_OK;
-}
-
-template <bool RI, bool RO, bool SK>
-int set_lds_attr_k(size_t bytes) {
-#define FFN_K_ATTR(KSV, HEADV)                                                \
-  HIP_TRY(hipFuncSetAttribute(                                                \
-      reinterpret_cast<const void*>(&conv32k_kernel<RI, RO, SK, KSV, HEADV>), \
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes))
-  FFN_K_ATTR(8, false);
-  FFN_K_ATTR(9, false);
-  FFN_K_ATTR(10, false);
-  if (SK) {
-    FFN_K_ATTR(8, true);
-    FFN_K_ATTR(9, true);
-    FFN_K_ATTR(10, true);
-  }
-#undef FFN_K_ATTR
-  return FFN_OK;
 }
 
 int set_lds_attr_d(size_t bytes) {
@@ -382,44 +314,6 @@ int set_lds_attr_e(size_t bytes) {
   FFN_E_ATTR(1, false, true);
   FFN_E_ATTR(1, true, true);
 #undef FFN_E_ATTR
-  return FFN_OK;
-}
-
-template <bool RI, bool RO, bool SK>
-int set_lds_attr_h(size_t bytes) {
-  HIP_TRY(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 8, false, 2>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  HIP_TRY(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 9, false, 2>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  if (SK) {
-    HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 8, true, 2>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 9, true, 2>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  }
-  return FFN_OK;
-}
-
-template <bool RI, bool RO, bool SK>
-int set_lds_attr_x(size_t bytes) {
-  HIP_TRY(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 8>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  HIP_TRY(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 9>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  if (SK) {
-    HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 8, true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv32x3_kernel<RI, RO, SK, 9, true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  }
   return FFN_OK;
 }
 
@@ -491,58 +385,6 @@ int launch_conv32(ffn_engine* e, int n, const float* in, float* out,
   return FFN_OK;
 }
 
-template <bool RI, bool RO, bool SK>
-int launch_conv32p(ffn_engine* e, int n, const float* in, float* out,
-                   const float* skip, int layer) {
-  ConvPArgs a;
-  a.in = in;
-  a.out = out;
-  a.skip = skip;
-  a.wpack = e->weights + e->wpack_off[layer];
-  a.bias = e->weights + e->bias_off[layer];
-  a.validbits = e->validbits;
-  a.act_stride = e->g.act_stride;
-  a.XS = e->g.XS;
-  a.plane = e->g.plane;
-  a.R = e->g.R;
-  a.nchunks = e->g.nchunks;
-  a.total_slots = n * e->g.nchunks;
-  a.slots_per_xcd = (a.total_slots + 7) / 8;
-  const bool prof = e->prof_now;
-  if (prof) {
-    if (e->events_used + 2 > (int)e->events.size()) {
-      int rc = flush_events(e);
-      if (rc) return rc;
-    }
-    HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
-  }
-  const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
-  if (RI == false && RO == false && SK == true && e->ablate != 0) {
-    // debug ablations exist for the conv_b instantiation only
-    switch (e->ablate) {
-#define FFN_ABL_CASE(N)                                                     \
-  case N:                                                                   \
-    hipLaunchKernelGGL((conv32p_kernel<false, false, true, N>), grid, block, \
-                       e->lds_bytes, e->stream, a);                         \
-    break;
-      FFN_ABL_CASE(1)
-      FFN_ABL_CASE(2)
-      FFN_ABL_CASE(4)
-      FFN_ABL_CASE(5)
-      FFN_ABL_CASE(6)
-      FFN_ABL_CASE(7)
-#undef FFN_ABL_CASE
-      default:
-        return fail(FFN_ERR_ARG, "unsupported ablate mask %d", e->ablate);
-    }
-  } else {
-    hipLaunchKernelGGL((conv32p_kernel<RI, RO, SK>), grid, block, e->lds_bytes,
-                       e->stream, a);
-  }
-  if (prof) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
-  return FFN_OK;
-}
-
 struct HeadFusion {
   bool on = false;
   float pad_value = 0.f, move_thr = 0.f;
@@ -588,107 +430,9 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
     HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   }
   const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
-  a.range_flag = e->range_flag;
-  a.range_tag = e->range_tag;
-  if (e->conv_variant == 5) {
-    // taps split over 4 waves, 32x32x16 MFMA, 160-voxel chunks
-    ConvKArgs ka;
-    ka.c = a;
-    ka.c.wpack = reinterpret_cast<const float*>(e->wpackk +
-                                                (size_t)layer * e->wpackk_layer);
-    ka.c.Rc = e->Rc_k;
-    ka.c.nchunks = e->nchunks_k;
-    ka.c.total_slots = n * e->nchunks_k;
-    ka.c.slots_per_xcd = (ka.c.total_slots + 7) / 8;
-    std::memcpy(ka.aoff, e->ksched_aoff, sizeof(ka.aoff));
-    std::memcpy(ka.btap, e->ksched_btap, sizeof(ka.btap));
-    std::memcpy(ka.ntaps, e->ksched_ntaps, sizeof(ka.ntaps));
-    auto magic = [](int d) { return (unsigned)(((1ull << 32) + d - 1) / d); };
-    ka.magic_nchunks = magic(e->nchunks_k);
-    ka.magic_fyfx = magic(e->g.fy * e->g.fx);
-    ka.magic_fx = magic(e->g.fx);
-    ka.dbg_mode = e->dbg_clock == 2;
-    ka.ablate = e->ablate;
-    const dim3 gridk(8 * ka.c.slots_per_xcd), blockk(kKThreads);
-#define FFN_K_LAUNCH(KSV, HEADV)                                              \
-  hipLaunchKernelGGL((conv32k_kernel<RI, RO, SK, KSV, HEADV>), gridk, blockk, \
-                     e->lds_bytes_k, e->stream, ka)
-    const int ks = e->Rc_k / 32;
-    if (head.on) {
-      if constexpr (SK) {
-        if (ks == 8) FFN_K_LAUNCH(8, true);
-        else if (ks == 9) FFN_K_LAUNCH(9, true);
-        else FFN_K_LAUNCH(10, true);
-      }
-    } else {
-      if (ks == 8) FFN_K_LAUNCH(8, false);
-      else if (ks == 9) FFN_K_LAUNCH(9, false);
-      else FFN_K_LAUNCH(10, false);
-    }
-#undef FFN_K_LAUNCH
-  } else if (e->conv_variant >= 3 && e->waves8) {
-    // 8-wave workgroups: two waves per SIMD hide each other's operand loads
-    const dim3 block8(kW8Threads);
-    const bool h = e->conv_variant == 4;
-    a.wpack = h ? reinterpret_cast<const float*>(e->wpack2h +
-                                                 (size_t)layer * e->wpack2h_layer)
-                : reinterpret_cast<const float*>(e->wpack3 +
-                                                 (size_t)layer * e->wpack3_layer);
-    const size_t lb = h ? e->lds_bytes_h : e->lds_bytes_x;
-#define FFN_W8_LAUNCH(KSV, HEADV, SCH)                                        \
-  hipLaunchKernelGGL((conv32w8_kernel<RI, RO, SK, KSV, HEADV, SCH>), grid,    \
-                     block8, lb, e->stream, a)
-    const bool k8 = e->Rc == 256;
-    if (h && e->waves8 == 2) {  // staging conversion interleaved with the taps
-#define FFN_W8I_LAUNCH(KSV, HEADV)                                            \
-  hipLaunchKernelGGL((conv32w8_kernel<RI, RO, SK, KSV, HEADV, 2, true>), grid, \
-                     block8, lb, e->stream, a)
-      if (head.on) { if (k8) FFN_W8I_LAUNCH(8, true); else FFN_W8I_LAUNCH(9, true); }
-      else { if (k8) FFN_W8I_LAUNCH(8, false); else FFN_W8I_LAUNCH(9, false); }
-#undef FFN_W8I_LAUNCH
-    } else if (h) {
-      if (head.on) { if (k8) FFN_W8_LAUNCH(8, true, 2); else FFN_W8_LAUNCH(9, true, 2); }
-      else { if (k8) FFN_W8_LAUNCH(8, false, 2); else FFN_W8_LAUNCH(9, false, 2); }
-    } else {
-      if (head.on) { if (k8) FFN_W8_LAUNCH(8, true, 3); else FFN_W8_LAUNCH(9, true, 3); }
-      else { if (k8) FFN_W8_LAUNCH(8, false, 3); else FFN_W8_LAUNCH(9, false, 3); }
-    }
-#undef FFN_W8_LAUNCH
-  } else   if (e->conv_variant == 4) {
-    a.wpack = reinterpret_cast<const float*>(e->wpack2h +
-                                             (size_t)layer * e->wpack2h_layer);
-    if (head.on) {
-      if (e->Rc == 256)
-        hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 8, true, 2>), grid,
-                           block, e->lds_bytes_h, e->stream, a);
-      else
-        hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 9, true, 2>), grid,
-                           block, e->lds_bytes_h, e->stream, a);
-    } else if (e->Rc == 256) {
-      hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 8, false, 2>), grid, block,
-                         e->lds_bytes_h, e->stream, a);
-    } else {
-      hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 9, false, 2>), grid, block,
-                         e->lds_bytes_h, e->stream, a);
-    }
-  } else if (e->conv_variant == 3) {
-    a.wpack = reinterpret_cast<const float*>(e->wpack3 +
-                                             (size_t)layer * e->wpack3_layer);
-    if (head.on) {
-      if (e->Rc == 256)
-        hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 8, true>), grid, block,
-                           e->lds_bytes_x, e->stream, a);
-      else
-        hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 9, true>), grid, block,
-                           e->lds_bytes_x, e->stream, a);
-    } else if (e->Rc == 256) {
-      hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 8>), grid, block,
-                         e->lds_bytes_x, e->stream, a);
-    } else {
-      hipLaunchKernelGGL((conv32x3_kernel<RI, RO, SK, 9>), grid, block,
-                         e->lds_bytes_x, e->stream, a);
-    }
-  } else if (RI == false && RO == false && SK == true && e->ablate != 0 &&
+  a.range_flag = e->cur_flag;
+  a.range_tag = e->cur_tag;
+  if (RI == false && RO == false && SK == true && e->ablate != 0 &&
       e->Rc == 256) {
     switch (e->ablate) {  // issue-rate experiments (conv_b instantiation only)
       case 8:
@@ -779,8 +523,8 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   a.head_count = e->count;
   a.pad_value = head.pad_value;
   a.move_thr = head.move_thr;
-  a.range_flag = e->range_flag;
-  a.range_tag = e->range_tag;
+  a.range_flag = e->cur_flag;
+  a.range_tag = e->cur_tag;
   const bool prof = e->prof_now;
   if (prof) {
     if (e->events_used + 2 > (int)e->events.size()) {
@@ -859,25 +603,36 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
 int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
               float move_thr) {
   const Geom& g = e->g;
-  e->range_tag = e->range_tag + 1 ? e->range_tag + 1 : 1;  // never 0
   const bool sampled = (e->stack_calls % e->prof_every) == 0;
   e->stack_calls++;
   e->prof_now = e->prof_mode == 1 && sampled;
+  // a captured chain has its flag word and tag baked in: two words used in
+  // turn (the faces kernel of a run zeroes the word of the next one) and a
+  // constant tag; an eager run gets a fresh tag on word 0
+  const bool graph = e->use_graph && e->conv_variant >= 6 && !e->prof_now &&
+                     e->dbg_clock == 0 && e->depth >= 2;
+  if (graph) {
+    const int parity = (int)(e->graph_runs++ & 1);
+    e->cur_flag = e->range_flag + 1 + parity;
+    e->clear_flag = e->range_flag + 1 + (parity ^ 1);
+    e->cur_tag = 0xffffffffu;
+  } else {
+    e->range_tag = e->range_tag + 1 ? e->range_tag + 1 : 1;  // never 0
+    e->cur_flag = e->range_flag;
+    e->clear_flag = nullptr;
+    e->cur_tag = e->range_tag;
+  }
   const bool prof_chain = e->prof_mode == 2 && sampled;
   const float* W = e->weights;
   const int tz = (g.fz + kC0Z - 1) / kC0Z, ty = (g.fy + kC0Y - 1) / kC0Y,
             tx = (g.fx + kC0X - 1) / kC0X;
-  if (e->conv_variant == 0)  // plain VALU form, kept for A/B
-    hipLaunchKernelGGL(conv0a_kernel, dim3(tz * ty * tx, n), dim3(kC0Threads), 0,
-                       e->stream, si, pad_value, W + e->w0a_off, W + e->b0a_off,
-                       e->bufT, e->seed_raw, g, ty, tx);
-  else if (e->conv_variant >= 6) {
+  if (e->conv_variant >= 6) {
     Conv0SplitOut so;
     so.out_sp = reinterpret_cast<char*>(e->rawT) + (size_t)g.guard * 16;
     so.sp_plane_bytes = (g.act_stride / kFeatures) * 16;
     so.item_bytes = g.act_stride * (long)sizeof(float);
-    so.range_flag = e->range_flag;
-    so.range_tag = e->range_tag;
+    so.range_flag = e->cur_flag;
+    so.range_tag = e->cur_tag;
     hipLaunchKernelGGL(conv0a_mfma_kernel<true>, dim3(tz * ty * tx, n),
                        dim3(kC0Threads), 0, e->stream, si, pad_value,
                        W + e->w0a_off, W + e->b0a_off, e->bufT, e->seed_raw, g,
@@ -911,22 +666,54 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   // 5-10 % there) unless tail_batched asks for the single-FoV bits
   e->t_now = e->conv_variant == 9 && (n == 1 || e->tail_batched != 0);
   if (e->conv_variant >= 6) {
-    // T' -> (X, X') -> T' -> ... ; the head is always fused into the last conv_b
-    rc = launch_conv32d<1, false>(e, n, e->rawT, e->rawS, 0);
-    if (rc) return rc;
-    for (int i = 1; i < e->depth; ++i) {
-      rc = launch_conv32d<0, false>(e, n, e->rawS, e->rawT, 2 * i - 1);
-      if (rc) return rc;
-      HeadFusion hf;
-      hf.on = i == e->depth - 1;
-      hf.pad_value = pad_value;
-      hf.move_thr = move_thr;
-      rc = launch_conv32d<1, true>(e, n, e->rawT, e->rawS, 2 * i, hf);
-      if (rc) return rc;
-      head_fused = hf.on;
-    }
     if (e->depth == 1)
       return fail(FFN_ERR_ARG, "conv_variant 6 needs depth >= 2 (fused head)");
+    // T' -> (X, X') -> T' -> ... ; the head is always fused into the last conv_b
+    auto chain = [&]() -> int {
+      int r = launch_conv32d<1, false>(e, n, e->rawT, e->rawS, 0);
+      for (int i = 1; i < e->depth && !r; ++i) {
+        r = launch_conv32d<0, false>(e, n, e->rawS, e->rawT, 2 * i - 1);
+        if (r) break;
+        HeadFusion hf;
+        hf.on = i == e->depth - 1;
+        hf.pad_value = pad_value;
+        hf.move_thr = move_thr;
+        r = launch_conv32d<1, true>(e, n, e->rawT, e->rawS, 2 * i, hf);
+      }
+      return r;
+    };
+    if (graph) {
+      unsigned pb, tb;
+      std::memcpy(&pb, &pad_value, 4);
+      std::memcpy(&tb, &move_thr, 4);
+      const ffn_engine::GraphKey key(n, pb, tb, (int)(e->cur_flag - e->range_flag));
+      auto it = e->graphs.find(key);
+      if (it == e->graphs.end()) {
+        if (e->graphs.size() >= 64) {  // thresholds change per request, not per step
+          for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+          e->graphs.clear();
+        }
+        hipGraph_t gr = nullptr;
+        hipGraphExec_t ex = nullptr;
+        HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        rc = chain();
+        const hipError_t ce = hipStreamEndCapture(e->stream, &gr);
+        if (rc) {
+          if (gr) (void)hipGraphDestroy(gr);
+          return rc;
+        }
+        HIP_TRY(ce);
+        const hipError_t ie = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+        HIP_TRY(ie);
+        it = e->graphs.emplace(key, ex).first;
+      }
+      HIP_TRY(hipGraphLaunch(it->second, e->stream));
+    } else {
+      rc = chain();
+      if (rc) return rc;
+    }
+    head_fused = true;
     head_in = e->bufX;
   } else if (e->conv_variant == 0) {
     rc = launch_conv32<false, false, false>(e, n, e->bufT, e->bufX, nullptr, 0);
@@ -940,7 +727,9 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
       if (rc) return rc;
     }
     head_in = e->bufX;
-  } else if (e->conv_variant >= 2) {
+  } else {
+    // conv_variant 2: T is post-ReLU (conv0_a / conv_a apply it), X is the raw
+    // residual stream
     rc = launch_conv32c<false, false, false>(e, n, e->bufT, e->bufX, nullptr, 0);
     if (rc) return rc;
     for (int i = 1; i < e->depth; ++i) {
@@ -957,25 +746,12 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
       head_fused = hf.on;
     }
     head_in = e->bufX;
-  } else {
-    // T is post-ReLU (conv0_a / conv_a apply it); X is the raw residual stream
-    rc = launch_conv32p<false, false, false>(e, n, e->bufT, e->bufX, nullptr, 0);
-    if (rc) return rc;
-    for (int i = 1; i < e->depth; ++i) {
-      rc = launch_conv32p<true, true, false>(e, n, e->bufX, e->bufT, nullptr,
-                                             2 * i - 1);
-      if (rc) return rc;
-      rc = launch_conv32p<false, false, true>(e, n, e->bufT, e->bufX, e->bufX,
-                                              2 * i);
-      if (rc) return rc;
-    }
-    head_in = e->bufX;
   }
   if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   if (head_fused) {
     e->count_blocks = e->t_now ? e->n_main + (n == 1 ? e->n_tail : e->n_tail3)
                       : e->m_now ? e->nchunks_m : e->small_now ? e->nchunks_e
-                      : e->conv_variant >= 5 ? e->nchunks_k : e->nchunks_c;
+                      : e->conv_variant >= 6 ? e->nchunks_k : e->nchunks_c;
   } else {
     e->count_blocks = kHeadBlocks;
     hipLaunchKernelGGL(head_kernel, dim3(kHeadBlocks, n), dim3(256), 0, e->stream,
@@ -1051,7 +827,7 @@ int grid_for(long total, int block = 256) {
 
 extern "C" {
 
-int ffn_abi_version(void) { return 6; }
+int ffn_abi_version(void) { return 7; }
 
 const char* ffn_last_error(void) { return g_error.c_str(); }
 
@@ -1168,9 +944,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   // dense -> padded position table and LDS extent of the compact variant
   {
     e->nchunks_c = (g.V + kCChunk - 1) / kCChunk;
-    e->nchunks_k = (g.V + kKChunk - 1) / kKChunk;
+    e->nchunks_k = (g.V + kDChunk - 1) / kDChunk;
     std::vector<int32_t> pidx(std::max((size_t)e->nchunks_c * kCChunk,
-                                       (size_t)e->nchunks_k * kKChunk));
+                                       (size_t)e->nchunks_k * kDChunk));
     for (size_t v = 0; v < pidx.size(); ++v) {
       const int vv = (int)std::min<size_t>(v, (size_t)g.V - 1);
       const int x = vv % g.fx, y = (vv / g.fx) % g.fy, z = vv / (g.fx * g.fy);
@@ -1183,38 +959,21 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     e->Rc = ((span + 2 * (g.XS + 1)) + 31) / 32 * 32;
     if (e->Rc < 256) e->Rc = 256;  // the kernel stages 8 or 9 x 256 float4
     e->lds_bytes_c = (size_t)2 * e->Rc * kCLdsStride * sizeof(float);
-    e->lds_bytes_x = (size_t)2 * e->Rc * kXRowBytes;
-    e->lds_bytes_h = (size_t)2 * e->Rc * kHRowBytes;
     {
       int span_k = 0;
       for (int c = 0; c < e->nchunks_k; ++c)
-        span_k = std::max(span_k, pidx[(size_t)c * kKChunk + kKChunk - 1] -
-                                      pidx[(size_t)c * kKChunk] + 1);
+        span_k = std::max(span_k, pidx[(size_t)c * kDChunk + kDChunk - 1] -
+                                      pidx[(size_t)c * kDChunk] + 1);
       e->Rc_k = ((span_k + 2 * (g.XS + 1)) + 31) / 32 * 32;
       if (e->Rc_k < 256) e->Rc_k = 256;
       e->k_ok = e->Rc_k <= 320 && e->nchunks_k >= 2;  // (magic divisions: d >= 2)
-      e->lds_bytes_k = std::max((size_t)3 * e->Rc_k * kKRowB,
-                                (size_t)4 * kKChunk * kKRowB + 64);
-      // tap schedule of the four waves (see conv32k_kernel): two dz = -1 taps
+      // tap schedule of the four waves (see conv32d_body): two dz = -1 taps
       // each, then two taps of dz <= 0, then the rest; 7 / 7 / 7 / 6 taps
       static const int kSched[4][7] = {{0, 1, 8, 9, 16, 18, 19},
                                        {2, 3, 10, 11, 17, 20, 21},
                                        {4, 5, 12, 13, 22, 23, 24},
                                        {6, 7, 14, 15, 25, 26, -1}};
-      for (int w = 0; w < 4; ++w) {
-        int nt = 0;
-        for (int j = 0; j < 7; ++j) {
-          const int s = kSched[w][j];
-          if (s < 0) continue;
-          const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
-          e->ksched_aoff[w * kKMaxTaps + j] =
-              (kz * e->Rc_k + (ky - 1) * g.XS + (kx - 1)) * kKRowB;
-          e->ksched_btap[w * kKMaxTaps + j] = s;
-          ++nt;
-        }
-        e->ksched_ntaps[w] = nt;
-      }
-      // conv32d: the same schedule in the plane-major LDS image (8 planes x Rc_k
+      // in the plane-major LDS image (8 planes x Rc_k
       // rows x 16 B per segment); wave 3's seventh tap is the all-zero tap 27
       e->lds_bytes_d = std::max((size_t)3 * 128 * e->Rc_k,
                                 (size_t)4 * kDChunk * kDRowB + 64);
@@ -1306,13 +1065,13 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     E_TRY(hipMalloc(&e->pidx, pidx.size() * sizeof(int32_t)));
     E_TRY(hipMemcpy(e->pidx, pidx.data(), pidx.size() * sizeof(int32_t),
                     hipMemcpyHostToDevice));
-    // variants 1 / 2 need 7*256 <= R*8 <= 8*256 resp. Rc in {256, 288}
-    const bool p_ok = g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256;
+    // variant 2 needs Rc in {256, 288}
     const bool c_ok = e->Rc == 256 || e->Rc == 288;
-    if (e->lds_bytes_k > 160 * 1024) e->k_ok = false;
-    // default: conv32m where the geometry allows it (33^3: yes), else conv32d,
-    // else conv32w8, ...
-    e->conv_variant = e->t_ok ? 9 : e->m_ok ? 8 : e->d_ok ? 6 : c_ok ? 4 : (p_ok ? 1 : 0);
+    // default: conv32mt / conv32m where the geometry allows them (33^3: yes), else
+    // conv32d, else the exact-f32 kernels (conv32c, or conv32 for any FoV that
+    // fits the LDS at all)
+    e->exact_variant = c_ok ? 2 : 0;
+    e->conv_variant = e->t_ok ? 9 : e->m_ok ? 8 : e->d_ok ? 6 : e->exact_variant;
   }
 
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)
@@ -1333,20 +1092,12 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     off += kFeatures + 1;
     off = (off + 3) & ~(size_t)3;
     E_TRY(hipMalloc(&e->weights, off * sizeof(float)));
-    e->wpack3_layer = (size_t)27 * 2 * 3 * 64 * 8;
-    E_TRY(hipMalloc(&e->wpack3, e->wpack3_layer * (2 * depth - 1) *
-                                    sizeof(uint16_t)));
-    e->wpack2h_layer = (size_t)27 * 2 * 2 * 64 * 8;
-    E_TRY(hipMalloc(&e->wpack2h, e->wpack2h_layer * (2 * depth - 1) *
-                                     sizeof(uint16_t)));
-    e->wpackk_layer = (size_t)27 * 2 * 2 * 64 * 8;
     e->wpackd_layer = (size_t)kDTaps * 2 * 2 * 64 * 8;  // + the all-zero tap
     E_TRY(hipMalloc(&e->wpackd, e->wpackd_layer * (2 * depth - 1) *
                                     sizeof(uint16_t)));
-    E_TRY(hipMalloc(&e->wpackk, e->wpackk_layer * (2 * depth - 1) *
-                                    sizeof(uint16_t)));
-    E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
-    E_TRY(hipMemset(e->range_flag, 0, sizeof(unsigned)));
+    E_TRY(hipMalloc(&e->range_flag, 4 * sizeof(unsigned)));
+    E_TRY(hipMemset(e->range_flag, 0, 4 * sizeof(unsigned)));
+    e->cur_flag = e->range_flag;
   }
 
   e->events.resize(2 * 64);
@@ -1362,33 +1113,9 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (!rc) rc = set_lds_attr_c<false, false, true, 8>(e->lds_bytes_c);
     if (!rc) rc = set_lds_attr_c<false, false, true, 16>(e->lds_bytes_c);
     if (!rc) rc = set_lds_attr_c<false, false, true, 24>(e->lds_bytes_c);
-    if (!rc) rc = set_lds_attr_x<false, false, false>(e->lds_bytes_x);
-    if (!rc) rc = set_lds_attr_x<true, true, false>(e->lds_bytes_x);
-    if (!rc) rc = set_lds_attr_x<false, false, true>(e->lds_bytes_x);
-    if (!rc) rc = set_lds_attr_h<false, false, false>(e->lds_bytes_h);
-    if (!rc) rc = set_lds_attr_h<true, true, false>(e->lds_bytes_h);
-    if (!rc) rc = set_lds_attr_h<false, false, true>(e->lds_bytes_h);
-    if (!rc) rc = set_lds_attr_w8<false, false, false, 2>(e->lds_bytes_h);
-    if (!rc) rc = set_lds_attr_w8<true, true, false, 2>(e->lds_bytes_h);
-    if (!rc) rc = set_lds_attr_w8<false, false, true, 2>(e->lds_bytes_h);
-    if (!rc) rc = set_lds_attr_w8<false, false, false, 3>(e->lds_bytes_x);
-    if (!rc) rc = set_lds_attr_w8<true, true, false, 3>(e->lds_bytes_x);
-    if (!rc) rc = set_lds_attr_w8<false, false, true, 3>(e->lds_bytes_x);
-    if (!rc && e->k_ok) rc = set_lds_attr_k<false, false, false>(e->lds_bytes_k);
-    if (!rc && e->k_ok) rc = set_lds_attr_k<true, true, false>(e->lds_bytes_k);
-    if (!rc && e->k_ok) rc = set_lds_attr_k<false, false, true>(e->lds_bytes_k);
     if (!rc && e->d_ok) rc = set_lds_attr_d(e->lds_bytes_d);
     if (!rc && e->e_ok) rc = set_lds_attr_e(e->lds_bytes_e);
     if (!rc && e->m_ok) rc = set_lds_attr_m();
-    if (!rc) rc = set_lds_attr_p<false, false, false>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<true, true, false>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, false, true>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, false, true, 1>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, false, true, 2>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, false, true, 4>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, false, true, 5>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, false, true, 6>(e->lds_bytes);
-    if (!rc) rc = set_lds_attr_p<false, false, true, 7>(e->lds_bytes);
     if (rc) {
       ffn_engine_destroy(e);
       return rc;
@@ -1418,6 +1145,8 @@ void ffn_engine_destroy(ffn_engine* e) {
     c->engine = nullptr;
   }
   e->canvases.clear();
+  for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+  e->graphs.clear();
   for (auto& ev : e->events)
     if (ev) (void)hipEventDestroy(ev);
   (void)hipFree(e->act_base);
@@ -1426,9 +1155,6 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->seed_raw);
   (void)hipFree(e->logits);
   (void)hipFree(e->count);
-  (void)hipFree(e->wpack3);
-  (void)hipFree(e->wpack2h);
-  (void)hipFree(e->wpackk);
   (void)hipFree(e->wpackd);
   (void)hipFree(e->range_flag);
   (void)hipFree(e->valid);
@@ -1458,9 +1184,6 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   std::vector<float> host(e->wl_off + F + 1 + 3, 0.0f);
   const float* src = blob;
   // conv0_a: [27][2][32] + bias, used as stored
-  std::vector<uint16_t> host3(e->wpack3_layer * (2 * e->depth - 1));
-  std::vector<uint16_t> host2(e->wpack2h_layer * (2 * e->depth - 1));
-  std::vector<uint16_t> hostk(e->wpackk_layer * (2 * e->depth - 1));
   std::vector<uint16_t> hostd(e->wpackd_layer * (2 * e->depth - 1));  // zero tap 27
   bool d_weights_ok = true;
   bool weights_in_fp16_range = true;
@@ -1482,59 +1205,10 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
               wp[((((size_t)tap * 2 + nh) * 2 + h) * 64 + lane) * 4 + s] =
                   src[((size_t)tap * F + ci) * F + co];
             }
-    // bf16x3 form for conv32x3: W == hi + mid + lo exactly, fragments
-    //   wpack3[tap][nhalf][plane][lane = 16*g + j][c] = part(W[tap][8g + c][16*nhalf + j])
-    {
-      uint16_t* w3 = &host3[(size_t)l * e->wpack3_layer];
-      for (int tap = 0; tap < 27; ++tap)
-        for (int nh = 0; nh < 2; ++nh)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int c = 0; c < 8; ++c) {
-              const int gq = lane >> 4, j = lane & 15;
-              const float w = src[((size_t)tap * F + 8 * gq + c) * F + 16 * nh + j];
-              uint16_t part[3];
-              split_bf16x3(w, part);
-              for (int pl = 0; pl < 3; ++pl)
-                w3[((((size_t)tap * 2 + nh) * 3 + pl) * 64 + lane) * 8 + c] =
-                    part[pl];
-            }
-    }
-    // fp16 form for conv32x3<SCHEME 2>: W ~= hi + 2^-11 * res, planes hi, res
-    {
-      uint16_t* w2 = &host2[(size_t)l * e->wpack2h_layer];
-      for (int tap = 0; tap < 27; ++tap)
-        for (int nh = 0; nh < 2; ++nh)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int c = 0; c < 8; ++c) {
-              const int gq = lane >> 4, j = lane & 15;
-              const float w = src[((size_t)tap * F + 8 * gq + c) * F + 16 * nh + j];
-              if (!(std::fabs(w) <= 65504.0f)) weights_in_fp16_range = false;
-              uint16_t part[2];
-              split_fp16x2(w, part);
-              for (int pl = 0; pl < 2; ++pl)
-                w2[((((size_t)tap * 2 + nh) * 2 + pl) * 64 + lane) * 8 + c] =
-                    part[pl];
-            }
-    }
-    // conv32k: the same split as the 32x32x16 A operand (rows = cout)
-    //   wpackk[tap][khalf][plane][lane][c] = part(W[tap][16 khalf + 8 (lane >> 5) + c][lane & 31])
-    {
-      uint16_t* wk = &hostk[(size_t)l * e->wpackk_layer];
-      for (int tap = 0; tap < 27; ++tap)
-        for (int kh = 0; kh < 2; ++kh)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int c = 0; c < 8; ++c) {
-              const int ci = 16 * kh + 8 * (lane >> 5) + c, co = lane & 31;
-              const float w = src[((size_t)tap * F + ci) * F + co];
-              uint16_t part[2];
-              split_fp16x2(w, part);
-              for (int pl = 0; pl < 2; ++pl)
-                wk[((((size_t)tap * 2 + kh) * 2 + pl) * 64 + lane) * 8 + c] =
-                    part[pl];
-            }
-    }
-    // conv32d: the same A operand (+ an all-zero tap 27)
-    //   wpackd[tap][khalf][plane hi, res][lane][c]
+    // conv32d / conv32m: W ~= hi + 2^-11 res (both fp16) as the 32x32x16 A
+    // operand (rows = cout), + an all-zero tap 27
+    //   wpackd[tap][khalf][plane hi, res][lane][c] =
+    //       part(W[tap][16 khalf + 8 (lane >> 5) + c][lane & 31])
     {
       uint16_t* wd = &hostd[(size_t)l * e->wpackd_layer];
       for (int tap = 0; tap < 27; ++tap)
@@ -1543,6 +1217,7 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
             for (int c = 0; c < 8; ++c) {
               const int ci = 16 * kh + 8 * (lane >> 5) + c, co = lane & 31;
               const float w = src[((size_t)tap * F + ci) * F + co];
+              if (!(std::fabs(w) <= 65504.0f)) weights_in_fp16_range = false;
               uint16_t part[2];
               split_fp16x2(w, part);
               const size_t base = ((((size_t)tap * 2 + kh) * 2) * 64 + lane) * 8 + c;
@@ -1554,19 +1229,12 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
     std::memcpy(&host[e->bias_off[l]], src, sizeof(float) * F);
     src += F;
   }
-  HIP_TRY(hipMemcpy(e->wpack3, host3.data(), host3.size() * sizeof(uint16_t),
-                    hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(e->wpack2h, host2.data(), host2.size() * sizeof(uint16_t),
-                    hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(e->wpackk, hostk.data(), hostk.size() * sizeof(uint16_t),
-                    hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->wpackd, hostd.data(), hostd.size() * sizeof(uint16_t),
                     hipMemcpyHostToDevice));
   e->d_weights_ok = d_weights_ok;
   e->fp16_ok = weights_in_fp16_range;
-  if ((!e->fp16_ok && e->conv_variant >= 4) ||
-      (!e->d_weights_ok && e->conv_variant >= 6)) {
-    int rc = switch_variant(e, 3);
+  if ((!e->fp16_ok || !e->d_weights_ok) && e->conv_variant >= 6) {
+    int rc = switch_variant(e, e->exact_variant);
     if (rc) return rc;
   }
   std::memcpy(&host[e->wl_off], src, sizeof(float) * (F + 1));
@@ -1602,13 +1270,17 @@ int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
   HIP_TRY(hipMemcpyAsync(h_logits, e->logits, bytes, hipMemcpyDeviceToHost,
                          e->stream));
   unsigned flag = 0;
-  if (e->conv_variant >= 4)
-    HIP_TRY(hipMemcpyAsync(&flag, e->range_flag, sizeof(flag),
+  if (e->conv_variant >= 6)
+    HIP_TRY(hipMemcpyAsync(&flag, e->cur_flag, sizeof(flag),
                            hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  if (e->conv_variant >= 4 && flag == e->range_tag) {
-    // an operand left the fp16 range: this engine stays on the bf16x3 scheme
-    rc = switch_variant(e, 3);
+  if (e->conv_variant >= 6 && flag == e->cur_tag) {
+    // (a captured run's flag word is zeroed by the faces kernel of a canvas
+    // step; the stateless path has none)
+    if (e->cur_flag != e->range_flag)
+      HIP_TRY(hipMemsetAsync(e->cur_flag, 0, sizeof(unsigned), e->stream));
+    // an operand left the fp16 range: this engine stays on the exact-f32 kernel
+    rc = switch_variant(e, e->exact_variant);
     if (rc) return rc;
     rc = run_stack(e, n, si, std::nanf(""), INFINITY);
     if (rc) return rc;
@@ -1638,13 +1310,20 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
+  if (!e->graphs.empty()) {  // a captured chain has the kernel choice baked in
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+    e->graphs.clear();
+  }
   if (std::strcmp(name, "conv_variant") == 0) {
-    if (value < 0 || value > 9) return fail(FFN_ERR_ARG, "conv_variant must be 0..9");
-    if (value >= 4 && e->weights_set && !e->fp16_ok)
+    if (value == -1) value = e->exact_variant;  // "the exact-f32 kernel of this FoV"
+    if (value != 0 && value != 2 && !(value >= 6 && value <= 9))
+      return fail(FFN_ERR_ARG, "conv_variant must be 0, 2, 6, 7, 8 or 9 (1, 3, 4, 5 "
+                               "were removed in ABI 7)");
+    if (value >= 6 && e->weights_set && !e->fp16_ok)
       return fail(FFN_ERR_ARG, "conv_variant %d: a weight is outside the fp16 range",
                   value);
-    if (value == 5 && !e->k_ok)
-      return fail(FFN_ERR_ARG, "conv_variant 5 unsupported for this fov");
     if (value == 6 && !e->d_ok)
       return fail(FFN_ERR_ARG, "conv_variant 6 unsupported for this fov / depth");
     if (value == 7 && !e->e_ok)
@@ -1656,10 +1335,7 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
                                "(257 .. 512 chunks of 128 voxels)");
     if (value >= 6 && e->weights_set && !e->d_weights_ok)
       return fail(FFN_ERR_ARG, "conv_variant 6: a weight x 2^11 is outside the fp16 range");
-    const Geom& g = e->g;
-    if (value == 1 && !(g.R * 8 >= 7 * 256 && g.R * 8 <= 8 * 256))
-      return fail(FFN_ERR_ARG, "conv_variant 1 unsupported for this fov");
-    if (value >= 2 && value <= 4 && !(e->Rc == 256 || e->Rc == 288))
+    if (value == 2 && !(e->Rc == 256 || e->Rc == 288))
       return fail(FFN_ERR_ARG, "conv_variant %d unsupported for this fov", value);
     return switch_variant(e, value);
   }
@@ -1691,6 +1367,11 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->tail_batched = value != 0;
     return FFN_OK;
   }
+  if (std::strcmp(name, "use_graph") == 0) {
+    // 1 = the conv chain of a step is replayed from a captured hipGraph
+    e->use_graph = value != 0;
+    return FFN_OK;
+  }
   if (std::strcmp(name, "debug_layer") == 0) {
     e->dbg_layer = value;
     return FFN_OK;
@@ -1701,11 +1382,6 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   }
   if (std::strcmp(name, "fuse_head") == 0) {
     e->fuse_head = value != 0;
-    return FFN_OK;
-  }
-  if (std::strcmp(name, "waves8") == 0) {
-    if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "waves8 must be 0, 1 or 2");
-    e->waves8 = value;
     return FFN_OK;
   }
   if (std::strcmp(name, "store_policy") == 0) {
@@ -1720,7 +1396,8 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   if (!e || !name || !value) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) *value = e->conv_variant;
   else if (std::strcmp(name, "fuse_head") == 0) *value = e->fuse_head;
-  else if (std::strcmp(name, "waves8") == 0) *value = e->waves8;
+  else if (std::strcmp(name, "exact_variant") == 0) *value = e->exact_variant;
+  else if (std::strcmp(name, "use_graph") == 0) *value = e->use_graph;
   else if (std::strcmp(name, "store_policy") == 0) *value = e->store_policy;
   else if (std::strcmp(name, "sync_mode") == 0) *value = e->sync_mode;
   else if (std::strcmp(name, "profile_every") == 0) *value = e->prof_every;
@@ -1981,11 +1658,11 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, e->count_blocks,
                      params->move_threshold, params->disco_seed_threshold,
-                     params->deleted_threshold, e->range_flag, e->range_tag,
-                     h_results, h_seq, step_id);
+                     params->deleted_threshold, e->cur_flag, e->cur_tag,
+                     e->clear_flag, h_results, h_seq, step_id);
   hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, e->count_blocks,
-                     params->disco_seed_threshold, e->range_flag, e->range_tag);
+                     params->disco_seed_threshold, e->cur_flag, e->cur_tag);
   HIP_TRY(hipGetLastError());
   e->slot_n[slot] = n;
   e->slot_ticket[slot] = step_id;

@@ -75,89 +75,6 @@ struct StepItems {
 constexpr int kC0Z = 4, kC0Y = 8, kC0X = 8;  // conv0a output tile per block
 constexpr int kC0Threads = 512;               // 256 positions x 2 cout halves
 
-__global__ __launch_bounds__(kC0Threads) void conv0a_kernel(
-    StepItems si, float pad_value, const float* __restrict__ w /*[27][2][32]*/,
-    const float* __restrict__ bias, float* __restrict__ out,
-    float* __restrict__ seed_raw, Geom g, int tiles_y, int tiles_x) {
-  // input tile + 1-voxel halo, (image, seed) interleaved; weights for broadcast
-  constexpr int HZ = kC0Z + 2, HY = kC0Y + 2, HX = kC0X + 2;
-  __shared__ float2 tile[HZ * HY * HX];
-  __shared__ __attribute__((aligned(16))) float wl[27 * 2 * kFeatures];
-  const int item = blockIdx.y;
-  const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
-  int b = blockIdx.x;
-  const int tx = b % tiles_x;
-  b /= tiles_x;
-  const int ty = b % tiles_y;
-  const int tz = b / tiles_y;
-  const int oz = tz * kC0Z, oy = ty * kC0Y, ox = tx * kC0X;  // FoV coords
-  const int z0 = it.req.pos[0] - g.fz / 2;
-  const int y0 = it.req.pos[1] - g.fy / 2;
-  const int x0 = it.req.pos[2] - g.fx / 2;
-
-  for (int e = threadIdx.x; e < 27 * 2 * kFeatures / 4; e += kC0Threads)
-    reinterpret_cast<f32x4*>(wl)[e] = reinterpret_cast<const f32x4*>(w)[e];
-  for (int e = threadIdx.x; e < HZ * HY * HX; e += kC0Threads) {
-    const int hx = e % HX;
-    const int t = e / HX;
-    const int hy = t % HY;
-    const int hz = t / HY;
-    const int zz = oz + hz - 1, yy = oy + hy - 1, xx = ox + hx - 1;
-    float2 v = make_float2(0.0f, 0.0f);  // SAME zero padding outside the FoV
-    if (zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy && xx >= 0 && xx < g.fx) {
-      const size_t ci =
-          ((size_t)(z0 + zz) * it.cy + (y0 + yy)) * it.cx + (x0 + xx);
-      v.x = it.image ? it.image[ci] : it.image_lut[it.image_u8[ci]];
-      v.y = it.seed[ci];
-      if (hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y && hx >= 1 &&
-          hx <= kC0X)  // interior voxel: keep the raw seed (NaN preserved)
-        seed_raw[(size_t)item * g.V + ((size_t)zz * g.fy + yy) * g.fx + xx] = v.y;
-      if (v.y != v.y) v.y = pad_value;  // NaN -> pad (inference.py:406-407)
-    }
-    tile[e] = v;
-  }
-  __syncthreads();
-
-  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // couts
-  const int lp = threadIdx.x & 255;
-  const int lx = lp % kC0X;
-  const int ly = (lp / kC0X) % kC0Y;
-  const int lz = lp / (kC0X * kC0Y);
-  const int z = oz + lz, y = oy + ly, x = ox + lx;
-  if (z >= g.fz || y >= g.fy || x >= g.fx) return;
-
-  f32x4 acc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-    acc[c] = *reinterpret_cast<const f32x4*>(bias + half * 16 + c * 4);
-#pragma unroll
-  for (int tap = 0; tap < 27; ++tap) {
-    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-    const float2 a = tile[((lz + kz) * HY + (ly + ky)) * HX + (lx + kx)];
-    const f32x4* wt =
-        reinterpret_cast<const f32x4*>(wl + tap * 2 * kFeatures + half * 16);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x4 w0 = wt[c];                  // wave-uniform address: broadcast
-      const f32x4 w1 = wt[kFeatures / 4 + c];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[c][j] = __builtin_fmaf(a.x, w0[j], acc[c][j]);
-        acc[c][j] = __builtin_fmaf(a.y, w1[j], acc[c][j]);
-      }
-    }
-  }
-  const size_t p = (size_t)z * g.plane + (size_t)y * g.XS + x;
-  float* o = out + (size_t)item * g.act_stride + p * kFeatures + half * 16;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    f32x4 v;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[c][j], 0.0f);
-    *reinterpret_cast<f32x4*>(o + c * 4) = v;
-  }
-}
-
 // conv0_a on the matrix cores: same tile / halo staging as conv0a_kernel, then
 // an implicit GEMM with K = 27 taps x 2 channels = 54 (padded to 56 = 14
 // k-steps of v_mfma_f32_16x16x4_f32).  A block = 256 positions = 16 M-tiles;
@@ -457,242 +374,6 @@ __global__ __launch_bounds__(kConvThreads) void conv32_kernel(ConvArgs a) {
         if (ADD_SKIP) v += skp[(size_t)p * kFeatures + co];
         dst[(size_t)p * kFeatures + co] = v;
       }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// conv32p: the software-pipelined production variant of conv32.
-//
-// Same math and operand layout as conv32_kernel, plus:
-//  * staging has all 24 x 16-B loads per lane in flight at once (then the ReLU
-//    in front of conv_a on the registers, then the LDS writes) instead of 4-deep
-//    load -> max -> ds_write rounds;
-//  * explicit double-buffered A fragments (LDS -> VGPR one half-tap ahead) and a
-//    3-deep B ring (L2 -> VGPR two half-taps = 1280 MFMA-cycles ahead), pinned
-//    with sched_barrier so the 20 MFMAs of a half-tap never wait on the
-//    ds_read / global_load issued for the next one;
-//  * XCD-aware block -> chunk mapping: block b runs on XCD b % 8, so XCD k gets
-//    the contiguous chunk range [k*q, (k+1)*q): the 4.3x halo re-reads of
-//    neighbouring chunks hit the same 4 MiB L2 instead of crossing the fabric;
-//  * the padding-position mask comes from 5 scalar dwords per chunk.
-// ---------------------------------------------------------------------------
-struct ConvPArgs {
-  const float* in;       // pre-activated input, logical origin of item 0
-  float* out;            // RELU_OUT ? relu(conv) : conv (+ skip)
-  const float* skip;     // may alias out
-  const float* wpack;    // [27][2][2][64][4]
-  const float* bias;     // [32]
-  const uint32_t* validbits;  // [nchunks][5]
-  long act_stride;
-  int XS, plane, R, nchunks;
-  int total_slots, slots_per_xcd;
-};
-
-// Scheduling directive for one pipelined step: interleave the N MFMAs of the
-// step with the (independent) address VALU / SALU / ds_read / global_load
-// instructions that prefetch the NEXT step, one non-MFMA instruction in the
-// 32-cycle shadow of each MFMA, instead of issuing the whole prefetch block
-// in front of the MFMAs (measured with in-kernel clocks: 38 cycles per MFMA with
-// the block in front).
-#define FFN_INTERLEAVE(N)                                           \
-  _Pragma("unroll") for (int g_ = 0; g_ < (N); ++g_) {              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* MFMA */   \
-    __builtin_amdgcn_sched_group_barrier(0x1A6, 2, 0); /* other */  \
-  }
-
-#define FFN_MFMA20(AC, BC)                                                    \
-  _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                          \
-    _Pragma("unroll") for (int t_ = 0; t_ < kTilesPerWave; ++t_) acc[t_] =    \
-        __builtin_amdgcn_mfma_f32_16x16x4f32(AC[t_][s_], BC[s_], acc[t_], 0,  \
-                                             0, 0);                           \
-  }
-
-// ABL (debug ablation, 0 in production): 1 = no staging loads, 2 = no MFMA
-// loop, 4 = no epilogue memory traffic.
-template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int ABL = 0>
-__global__ __launch_bounds__(kConvThreads) void conv32p_kernel(ConvPArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
-  if (gc >= a.total_slots) return;
-  const int item = gc / a.nchunks;
-  const int chunk = gc - item * a.nchunks;
-  const int m0 = chunk * kChunk;
-  const float* src = a.in + (size_t)item * a.act_stride;
-  const int R = a.R;
-
-  // ---- stage chunk + halo: all loads first, then all LDS writes ----
-  // Host guarantees 7*256 <= R*8 <= 8*256 (31 <= XS <= 47): slots k < 7 need no
-  // bounds test, only the last one does.
-  {
-    const int nf4 = R * 8;
-    f32x4 v[3][8];
-#pragma unroll
-    for (int seg = 0; seg < 3; ++seg) {
-      const long p0 = (long)m0 - (a.XS + 1) + (long)(seg - 1) * a.plane;
-      const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
-#pragma unroll
-      for (int k = 0; k < 7; ++k)
-        v[seg][k] = (ABL & 1) ? f32x4{1.f, 2.f, 3.f, 4.f}
-                              : s4[tid + k * kConvThreads];
-      const int e7 = tid + 7 * kConvThreads;
-      v[seg][7] = (ABL & 1) ? f32x4{1.f, 2.f, 3.f, 4.f}
-                            : s4[e7 < nf4 ? e7 : tid];  // clamp: legal address
-    }
-    if (RELU_IN) {  // tf.nn.relu in front of conv_a (convstack_3d.py:44)
-#pragma unroll
-      for (int seg = 0; seg < 3; ++seg)
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            v[seg][k][c] = v[seg][k][c] > 0.0f ? v[seg][k][c] : 0.0f;
-    }
-#pragma unroll
-    for (int seg = 0; seg < 3; ++seg) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int e = tid + k * kConvThreads;
-        if (k < 7 || e < nf4) {
-          const int row = seg * R + (e >> 3);
-          const int q = e & 7;
-          *reinterpret_cast<f32x4*>(lds + row * 32 + ((q ^ (row & 7)) << 2)) =
-              v[seg][k];
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // Residual input of this thread's 5 output pieces, fetched now so that its
-  // latency hides under the MFMA loop (all chunk positions are inside the
-  // allocation; padding positions are simply never stored).
-  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + (tid & 7) * 4);
-  f32x4 skipv[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (ADD_SKIP && !(ABL & 4)) {
-    const f32x4* sp = reinterpret_cast<const f32x4*>(
-        a.skip + (size_t)item * a.act_stride +
-        ((size_t)m0 + (tid >> 3)) * kFeatures + (tid & 7) * 4);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) skipv[k] = sp[(size_t)k * 32 * (kFeatures / 4)];
-  }
-
-  // padding-position mask of this chunk: 5 scalar words, fetched up front
-  uint32_t vbw[5];
-  {
-    const uint32_t* vb = a.validbits + chunk * 5;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      vbw[k] = __builtin_amdgcn_readfirstlane(vb[k]);
-      asm volatile("" ::"s"(vbw[k]));
-    }
-  }
-
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nhalf = wave & 1;
-  const int tgrp = wave >> 1;
-  const int i = lane & 15;
-  const int grp = lane >> 4;
-
-  f32x4 acc[kTilesPerWave];
-#pragma unroll
-  for (int t = 0; t < kTilesPerWave; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int rbase = (a.XS + 1) + tgrp * kTilesPerWave * kTile + i;
-  const f32x4* wp =
-      reinterpret_cast<const f32x4*>(a.wpack) + nhalf * 128 + lane;
-
-  // half-tap ht = 2*tap + h: A = 5 x ds_read_b128, B = 1 x global_load_dwordx4
-  auto loadA = [&](int ht, f32x4(&dst)[kTilesPerWave]) {
-    const int tap = ht >> 1, h = ht & 1;
-    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-    const int row = rbase + kz * R + (ky - 1) * a.XS + (kx - 1);
-    const int ad = (row * 32 + ((grp ^ (row & 7)) << 2)) ^ (h << 4);
-#pragma unroll
-    for (int t = 0; t < kTilesPerWave; ++t)
-      dst[t] = *reinterpret_cast<const f32x4*>(lds + ad + t * (kTile * 32));
-  };
-  auto loadB = [&](int ht) -> f32x4 {
-    return wp[(ht >> 1) * 256 + (ht & 1) * 64];
-  };
-
-  f32x4 A0[kTilesPerWave], A1[kTilesPerWave];
-  f32x4 B0, B1, B2;
-  loadA(0, A0);
-  B0 = loadB(0);
-  B1 = loadB(1);
-
-#define FFN_STEP(K, ACUR, ANEXT, BCUR, BNEXT2)        \
-  if ((K) + 1 < 54) loadA((K) + 1, ANEXT);            \
-  if ((K) + 2 < 54) BNEXT2 = loadB((K) + 2);          \
-  FFN_MFMA20(ACUR, BCUR)                              \
-  FFN_INTERLEAVE(20)                                  \
-  __builtin_amdgcn_sched_barrier(0);
-
-#pragma unroll
-  for (int ht = 0; ht < ((ABL & 2) ? 0 : 54); ht += 6) {
-    FFN_STEP(ht + 0, A0, A1, B0, B2)
-    FFN_STEP(ht + 1, A1, A0, B1, B0)
-    FFN_STEP(ht + 2, A0, A1, B2, B1)
-    FFN_STEP(ht + 3, A1, A0, B0, B2)
-    FFN_STEP(ht + 4, A0, A1, B1, B0)
-    FFN_STEP(ht + 5, A1, A0, B2, B1)
-  }
-#undef FFN_STEP
-
-  if (ABL & 4) {
-#pragma unroll
-    for (int t = 0; t < kTilesPerWave; ++t) asm volatile("" ::"v"(acc[t]));
-#pragma unroll
-    for (int k = 0; k < 5; ++k) asm volatile("" ::"v"(skipv[k]));
-    return;
-  }
-  // ---- epilogue: transpose the accumulators through LDS so that every global
-  // access is a coalesced 16-byte piece of a 128-byte position row ----
-  // D[row = grp*4 + r][col = i] of tile t -> stage[pos = tile*16 + row][co]
-  __syncthreads();  // every wave is done reading the A tiles
-  {
-    const int co = nhalf * 16 + i;
-#pragma unroll
-    for (int t = 0; t < kTilesPerWave; ++t) {
-      const int prow = (tgrp * kTilesPerWave + t) * kTile + grp * 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lds[(prow + r) * 32 + co] = acc[t][r];
-    }
-  }
-  __syncthreads();
-  {
-    const int q = tid & 7;          // channel quad, constant per thread
-    const int prow0 = tid >> 3;     // 32 positions per sweep, 5 sweeps
-    // Branch-free stores through buffer descriptors: a padding position gets an
-    // out-of-range offset and the hardware drops the store (a per-position
-    // branch would make hipcc drain vmcnt(0) -- i.e. wait for the previous
-    // stores -- at every join).
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const unsigned nbytes = (unsigned)a.nchunks * kChunk * kFeatures * 4u;
-    float* obase = a.out + (size_t)item * a.act_stride;
-    const __amdgpu_buffer_rsrc_t rs_out =
-        __builtin_amdgcn_make_buffer_rsrc(obase, 0, nbytes, 0x00020000);
-    const unsigned off0 = ((unsigned)(m0 + prow0) * kFeatures + q * 4) * 4u;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const bool ok = (vbw[k] >> prow0) & 1u;
-      f32x4 v = *reinterpret_cast<const f32x4*>(lds + (prow0 + k * 32) * 32 +
-                                                q * 4);
-      v += b4;
-      if (RELU_OUT) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
-      }
-      if (ADD_SKIP) v += skipv[k];
-      const unsigned off = ok ? off0 + (unsigned)k * 32u * kFeatures * 4u
-                              : 0x80000000u;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                             rs_out, off, 0, 0);
     }
   }
 }
@@ -1100,1184 +781,11 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv32c_kernel(ConvCArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------
-// conv32x3: conv32c with the f32 contraction carried by the bf16 matrix cores.
-//
-// Every f32 operand is split EXACTLY into three bf16 parts, x = hi + mid + lo
-// (8 + 8 + 8 mantissa bits), activations while they are staged into LDS, weights
-// once on the host.  x * w is then the sum of nine bf16 x bf16 products, each of
-// which is exact in f32; the three smallest (mid*lo, lo*mid, lo*lo, below 2^-24
-// of the leading term) are dropped, the other six run as
-// v_mfma_f32_16x16x32_bf16 with f32 accumulation.  The truncation error is
-// 100x below the rounding error of an f32 GEMM (measured 2e-8 vs 2e-6 on this
-// model's layers), so the result is an f32 convolution in everything but the
-// summation order -- at 6 x 16 = 96 MFMA cycles per 16x16x32 block instead of
-// the 256 cycles eight v_mfma_f32_16x16x4_f32 need.
-//
-// Same chunks, tiles, wave roles, progressive staging, K-split middle tile,
-// epilogue and fused head as conv32c.  LDS row = 3 planes x 32 ch x 2 B = 192 B
-// at a 224-B stride (ds_read_b128 of the 16 rows of a tile conflict-free for
-// every tap); two segment slots = 2 x Rc x 224 B (112 KiB at Rc = 256), one
-// workgroup per CU.  A fragment = 3 x ds_read_b128 per (tile, tap) (lane group g
-// holds channels 8g..8g+7 of its row), B fragment = 3 x 16 B per (tap, cout
-// half), host-packed [tap][nhalf][plane][lane][8].
-// ---------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-constexpr int kXRowBytes = 224;  // SCHEME 3: 3 planes x 64 B + 32 B pad
-constexpr int kHRowBytes = 160;  // SCHEME 2: 2 planes x 64 B + 32 B pad
-template <int SCHEME> struct XFrag { typedef bf16x8 type; };
-template <> struct XFrag<2> { typedef f16x8 type; };
-
-template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int KS = 8, bool HEAD = false,
-          int SCHEME = 3>
-__global__ __launch_bounds__(kConvThreads, 1) void conv32x3_kernel(
-    ConvCArgs a) {
-  // SCHEME 3: bf16 hi/mid/lo planes, 6 products.  SCHEME 2: fp16 hi plane + the
-  // residual scaled by 2^11 (so that it stays a normal fp16), 3 products, the
-  // two cross products accumulate separately and join scaled by 2^-11.
-  constexpr int NP = SCHEME == 3 ? 3 : 2;
-  constexpr int kRowB = SCHEME == 3 ? kXRowBytes : kHRowBytes;
-  typedef typename XFrag<SCHEME>::type frag_t;
-  unsigned range_max = 0;  // SCHEME 2: max |operand| bit pattern seen by this thread
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  char* ldsb = reinterpret_cast<char*>(lds);
-  const int tid = threadIdx.x;
-  const long long dbg_c0 = a.dbg ? clock64() : 0;
-  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
-  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
-  if (gc >= a.total_slots) return;
-  const int item = gc / a.nchunks;
-  const int chunk = gc - item * a.nchunks;
-  const int v0 = chunk * kCChunk;
-  const int32_t* pidx = a.pidx + v0;
-  // padded position of the chunk's first voxel, by arithmetic (a table lookup
-  // here would put one more memory round trip in front of the staging loads)
-  int p_first;
-  {
-    int z = (int)((float)v0 / (float)a.fyfx);
-    z -= (z * a.fyfx > v0);
-    z += ((z + 1) * a.fyfx <= v0);
-    const int rem = v0 - z * a.fyfx;
-    int y = (int)((float)rem / (float)a.fx);
-    y -= (y * a.fx > rem);
-    y += ((y + 1) * a.fx <= rem);
-    p_first = __builtin_amdgcn_readfirstlane(z * a.plane + y * a.XS +
-                                             (rem - y * a.fx));
-  }
-  const int p_lo = p_first - (a.XS + 1);  // first staged row of the dz=0 segment
-  const float* src = a.in + (size_t)item * a.act_stride;
-  const int Rc = a.Rc;
-
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nhalf = wave & 1;
-  const int tgrp = wave >> 1;
-  const int i = lane & 15;
-  const int grp = lane >> 4;
-
-  // LDS float offset of this lane's position in each of its 5 tiles: tiles 0..3
-  // (tgrp 0) / 5..8 (tgrp 1), then the shared tile 4.  (Oldest loads of the
-  // kernel: the first A-fragment read needs them.)
-  int prow[5];
-#pragma unroll
-  for (int t = 0; t < 5; ++t) {
-    const int tile = t < 4 ? tgrp * 5 + t : 4;
-    prow[t] = (pidx[tile * kTile + i] - p_lo) * kRowB + grp * 16;  // bytes
-  }
-  // padded position of this thread's 5 epilogue pieces (also old loads: the
-  // residual prefetch below needs them without draining the staging loads)
-  // thread -> (position j = (tid >> 3) + 32 k, channel quad tid & 7), k = 0..4
-  const int q = tid & 7;
-  const int j0 = tid >> 3;
-  int pj[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int j = j0 + 32 * k;
-    pj[k] = pidx[(j < kCChunk && v0 + j < a.V) ? j : 0];
-  }
-  // weight fragments of taps 0 and 1: issued BEFORE the staging loads -- vmcnt
-  // retires in order, so a weight load queued behind the staging loads would
-  // make the first MFMA wait for all three dz segments.
-  // planes: 0 = hi, 1 = mid, 2 = lo bf16 part of every f32 (x == hi + mid + lo)
-  struct AFrag { frag_t p[3][5]; };
-  struct BFrag { frag_t p[3]; };
-  const frag_t* wp =
-      reinterpret_cast<const frag_t*>(a.wpack) + nhalf * NP * 64 + lane;
-  auto loadB = [&](int s, BFrag& dst) {
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl) dst.p[pl] = wp[s * 2 * NP * 64 + pl * 64];
-  };
-  BFrag B0, B1, B2;
-  loadB(0, B0);
-  loadB(1, B1);
-
-  // ---- staging: all 27 x 16-B loads of the three dz segments in flight at
-  // once; segment kz is written to LDS (and waited for) only right before the
-  // first tap that reads it, so dz = 0, +1 land behind the MFMAs of dz = -1.
-  // Only TWO segment slots exist in LDS (dz = +1 overwrites dz = -1 once every
-  // wave is past tap 8): 2 x 256 rows x 160 B = 80 KiB, so two workgroups fit
-  // on a CU and fill each other's MFMA issue bubbles / staging / epilogue.
-  f32x4 sv[3][KS];  // Rc * 8 == KS * 256 float4 per segment
-#pragma unroll
-  for (int seg = 0; seg < 3; ++seg) {
-    const long p0 = (long)p_lo + (long)(seg - 1) * a.plane;
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
-#pragma unroll
-    for (int k = 0; k < KS; ++k) sv[seg][k] = s4[tid + k * kConvThreads];
-  }
-  auto write_segment = [&](int seg) {
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      const int e = tid + k * kConvThreads;
-      {
-        f32x4 v = sv[seg][k];
-        if (RELU_IN) {  // tf.nn.relu in front of conv_a (convstack_3d.py:44)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
-        }
-        const int row = (seg & 1) * Rc + (e >> 3);  // slot 0: dz -1, +1; slot 1: dz 0
-        char* dstrow = ldsb + row * kRowB + (e & 7) * 8;
-        if constexpr (SCHEME == 3) {
-          // exact three-way split: v == hi + mid + lo, each part a bf16
-          const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-          const f32x4 r1 = v - __builtin_convertvector(hi, f32x4);
-          const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
-          const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
-          const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
-          *reinterpret_cast<bf16x4*>(dstrow) = hi;
-          *reinterpret_cast<bf16x4*>(dstrow + 64) = mid;
-          *reinterpret_cast<bf16x4*>(dstrow + 128) = lo;
-        } else {
-          // v ~= hi + 2^-11 * res, both fp16, 22 mantissa bits together.  A hi
-          // that would be subnormal is dropped (the residual carries it), and
-          // anything outside the fp16 range raises the range flag.
-          f32x4 vh = v;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            // |x| as an integer is monotonic (NaN sorts above inf): one running
-            // maximum per thread, compared with 65504 once in the epilogue
-            const unsigned mbits = __float_as_uint(v[c]) & 0x7fffffffu;
-            range_max = mbits > range_max ? mbits : range_max;
-            vh[c] = mbits < 0x38800000u ? 0.0f : v[c];  // |x| < 2^-14
-          }
-          const f16x4 hi = __builtin_convertvector(vh, f16x4);
-          const f32x4 r1 = (v - __builtin_convertvector(hi, f32x4)) * 2048.0f;
-          const f16x4 res = __builtin_convertvector(r1, f16x4);
-          *reinterpret_cast<f16x4*>(dstrow) = hi;
-          *reinterpret_cast<f16x4*>(dstrow + 64) = res;
-        }
-      }
-    }
-  };
-
-  write_segment(0);
-  __syncthreads();
-
-  // ---- main loop: one step = one tap (two half-taps of 4 k-steps) ----
-  //   A fragments (LDS -> VGPR, 10 x ds_read_b128) one tap ahead, ring of 2;
-  //   B fragments (L2 -> VGPR, 2 x 16 B)           two taps ahead, ring of 3.
-  // Tiles 0..3 of the wave run every tap; the shared tile 4 runs in tile group
-  // 0 on the first 5 / 4 / 5 taps of the dz = -1 / 0 / +1 segment (14 taps) and
-  // in tile group 1 on the other 13 -- balanced PER SEGMENT, because the
-  // segment barriers would otherwise serialise the imbalance (two
-  // accumulators, so its 8 MFMAs per tap do not form one dependent chain).
-  auto a_off = [&](int s) {  // LDS float offset of tap s (compile-time kz/ky/kx)
-    const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
-    return ((kz & 1) * Rc + (ky - 1) * a.XS + (kx - 1)) * kRowB;  // bytes
-  };
-  auto loadA_tile = [&](int t, int off, AFrag& dst) {
-    const char* p = ldsb + prow[t] + off;
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-      dst.p[pl][t] = *reinterpret_cast<const frag_t*>(p + pl * 64);
-  };
-  auto loadA = [&](int s, AFrag& dst) {
-    const int off = a_off(s);
-#pragma unroll
-    for (int t = 0; t < 5; ++t) loadA_tile(t, off, dst);
-  };
-  // SCHEME 2: accC / acc4b collect the cross products (weight 2^-11)
-  f32x4 acc[4], accC[4], acc4a, acc4b;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = accC[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  acc4a = acc4b = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mma = [](const frag_t& fa, const frag_t& fb, f32x4 c) {
-    if constexpr (SCHEME == 3)
-      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, c, 0, 0, 0);
-    else
-      return __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, c, 0, 0, 0);
-  };
-  AFrag A0, A1;
-  const long long dbg_c1 = a.dbg ? clock64() : 0;
-  loadA(0, A0);
-
-  // one group = the 4 own tiles x one (A plane, B plane) product of the split
-#define FFN_XGROUP(ACC, ACUR, BCUR, PA, PB)                                  \
-  _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) ACC[t_] =                 \
-      mma(ACUR.p[PA][t_], BCUR.p[PB], ACC[t_]);                              \
-  __builtin_amdgcn_sched_barrier(0);
-  // SCHEME 3: x * w = sum of the 6 products whose weight exceeds 2^-24 of hi*hi
-  // (smallest first): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi.  Every
-  // bf16 x bf16 product is exact in f32; the MFMA accumulates in f32.
-  // SCHEME 2: hi*hi into acc, res*hi + hi*res into accC.
-#define FFN_CTAP(S, ACUR, ANEXT, BCUR, BNEXT2, PF)                           \
-  {                                                                          \
-    const bool pa_ = (PF) && (S) + 1 < 27;                                   \
-    const int oa_ = a_off((S) + 1);                                          \
-    const bool t4_ = (tgrp == 0) == (((S) % 9) < (((S) / 9) == 1 ? 4 : 5)); \
-    if constexpr (SCHEME == 3) {                                             \
-      if (pa_) loadA_tile(0, oa_, ANEXT);                                    \
-      FFN_XGROUP(acc, ACUR, BCUR, 2, 0)                                      \
-      if (pa_) loadA_tile(1, oa_, ANEXT);                                    \
-      FFN_XGROUP(acc, ACUR, BCUR, 0, 2)                                      \
-      if (pa_) loadA_tile(2, oa_, ANEXT);                                    \
-      FFN_XGROUP(acc, ACUR, BCUR, 1, 1)                                      \
-      if (pa_) loadA_tile(3, oa_, ANEXT);                                    \
-      FFN_XGROUP(acc, ACUR, BCUR, 1, 0)                                      \
-      if (pa_) loadA_tile(4, oa_, ANEXT);                                    \
-      FFN_XGROUP(acc, ACUR, BCUR, 0, 1)                                      \
-      if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                              \
-      FFN_XGROUP(acc, ACUR, BCUR, 0, 0)                                      \
-      if (t4_) { /* the shared tile's taps of this tile group */            \
-        acc4a = mma(ACUR.p[2][4], BCUR.p[0], acc4a);                         \
-        acc4b = mma(ACUR.p[0][4], BCUR.p[2], acc4b);                         \
-        acc4a = mma(ACUR.p[1][4], BCUR.p[1], acc4a);                         \
-        acc4b = mma(ACUR.p[1][4], BCUR.p[0], acc4b);                         \
-        acc4a = mma(ACUR.p[0][4], BCUR.p[1], acc4a);                         \
-        acc4b = mma(ACUR.p[0][4], BCUR.p[0], acc4b);                         \
-        __builtin_amdgcn_sched_barrier(0);                                   \
-      }                                                                      \
-    } else {                                                                 \
-      if (pa_) { loadA_tile(0, oa_, ANEXT); loadA_tile(1, oa_, ANEXT); }     \
-      FFN_XGROUP(accC, ACUR, BCUR, 1, 0)                                     \
-      if (pa_) { loadA_tile(2, oa_, ANEXT); loadA_tile(3, oa_, ANEXT); }     \
-      FFN_XGROUP(accC, ACUR, BCUR, 0, 1)                                     \
-      if (pa_) loadA_tile(4, oa_, ANEXT);                                    \
-      if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                              \
-      FFN_XGROUP(acc, ACUR, BCUR, 0, 0)                                      \
-      if (t4_) {                                                             \
-        acc4b = mma(ACUR.p[1][4], BCUR.p[0], acc4b);                         \
-        acc4a = mma(ACUR.p[0][4], BCUR.p[0], acc4a);                         \
-        acc4b = mma(ACUR.p[0][4], BCUR.p[1], acc4b);                         \
-        __builtin_amdgcn_sched_barrier(0);                                   \
-      }                                                                      \
-    }                                                                        \
-  }
-  // A ring alternates every tap, B ring has period 3: the pattern repeats
-  // every 6 taps.  Taps 8 and 17 end a dz segment.
-  FFN_CTAP(0, A0, A1, B0, B2, true)
-  FFN_CTAP(1, A1, A0, B1, B0, true)
-  FFN_CTAP(2, A0, A1, B2, B1, true)
-  FFN_CTAP(3, A1, A0, B0, B2, true)
-  FFN_CTAP(4, A0, A1, B1, B0, true)
-  FFN_CTAP(5, A1, A0, B2, B1, true)
-  FFN_CTAP(6, A0, A1, B0, B2, true)
-  FFN_CTAP(7, A1, A0, B1, B0, true)
-  FFN_CTAP(8, A0, A1, B2, B1, false)
-  write_segment(1);
-  __syncthreads();
-  loadA(9, A1);
-  FFN_CTAP(9, A1, A0, B0, B2, true)
-  FFN_CTAP(10, A0, A1, B1, B0, true)
-  FFN_CTAP(11, A1, A0, B2, B1, true)
-  FFN_CTAP(12, A0, A1, B0, B2, true)
-  FFN_CTAP(13, A1, A0, B1, B0, true)
-  FFN_CTAP(14, A0, A1, B2, B1, true)
-  FFN_CTAP(15, A1, A0, B0, B2, true)
-  FFN_CTAP(16, A0, A1, B1, B0, true)
-  FFN_CTAP(17, A1, A0, B2, B1, false)
-  write_segment(2);
-  __syncthreads();
-  // ---- per-thread epilogue operands: residual input and bias, fetched once the
-  // staging registers of the last segment are free (9 taps of MFMAs cover them)
-  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
-  unsigned ooff[5];
-  f32x4 skipv[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int j = j0 + 32 * k;
-    const bool ok = j < kCChunk && v0 + j < a.V;
-    const int p = pj[k];
-    ooff[k] = ok ? ((unsigned)p * kFeatures + q * 4) * 4u : 0x80000000u;
-    skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (ADD_SKIP)
-      skipv[k] = *reinterpret_cast<const f32x4*>(
-          a.skip + (size_t)item * a.act_stride + (size_t)p * kFeatures + q * 4);
-  }
-  loadA(18, A0);
-  FFN_CTAP(18, A0, A1, B0, B2, true)
-  FFN_CTAP(19, A1, A0, B1, B0, true)
-  FFN_CTAP(20, A0, A1, B2, B1, true)
-  FFN_CTAP(21, A1, A0, B0, B2, true)
-  FFN_CTAP(22, A0, A1, B1, B0, true)
-  FFN_CTAP(23, A1, A0, B2, B1, true)
-  FFN_CTAP(24, A0, A1, B0, B2, true)
-  FFN_CTAP(25, A1, A0, B1, B0, true)
-  FFN_CTAP(26, A0, A1, B2, B1, true)
-#undef FFN_CTAP
-#undef FFN_XGROUP
-
-  const long long dbg_c2 = a.dbg ? clock64() : 0;
-  // ---- epilogue: accumulators -> LDS [position j][32 ch]; rows 144..159 hold
-  // tgrp 1's partial sums of the shared tile 4 ----
-  __syncthreads();
-  {
-    const int co = nhalf * 16 + i;
-    f32x4 acc4 = acc4a + acc4b;
-    if constexpr (SCHEME == 2) {
-      acc4 = acc4a + acc4b * 4.8828125e-4f;  // 2^-11
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] += accC[t] * 4.8828125e-4f;
-      // an operand left the fp16 range: the step is void, the host re-runs it
-      // with the bf16x3 scheme (ffn_step_result.range_error)
-      if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
-        *a.range_flag = a.range_tag;
-    }
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const int tile = t < 4 ? tgrp * 5 + t : 4;
-      const int jrow = (t == 4 && tgrp == 1) ? kCChunk + grp * 4
-                                             : tile * kTile + grp * 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        lds[(jrow + r) * 32 + co] = t < 4 ? acc[t][r] : acc4[r];
-    }
-  }
-  __syncthreads();
-  unsigned head_above = 0;
-  {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    float* obase = a.out + (size_t)item * a.act_stride;
-    const __amdgpu_buffer_rsrc_t rs_out =
-        __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.nbytes, 0x00020000);
-    f32x4 hw4 = {0.f, 0.f, 0.f, 0.f};
-    float hbias = 0.f;
-    if (HEAD) {
-      hw4 = *reinterpret_cast<const f32x4*>(a.head_w + q * 4);
-      hbias = a.head_w[kFeatures];
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int j = j0 + 32 * k;
-      const int jr = j < kCChunk ? j : 0;
-      f32x4 v = *reinterpret_cast<const f32x4*>(lds + jr * 32 + q * 4);
-      if (jr >= 4 * kTile && jr < 5 * kTile)  // shared tile: add the other half
-        v += *reinterpret_cast<const f32x4*>(
-            lds + (kCChunk + jr - 4 * kTile) * 32 + q * 4);
-      v += b4;
-      if (RELU_OUT) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
-      }
-      if (ADD_SKIP) v += skipv[k];
-      if (HEAD) {
-        // 8 lanes hold the 32 channels of position j: dot with the 1x1x1
-        // weights (same association as head_kernel), xor-shuffle reduce
-        float partial = fmaxf(v[0], 0.f) * hw4[0];
-        partial = __builtin_fmaf(fmaxf(v[1], 0.f), hw4[1], partial);
-        partial = __builtin_fmaf(fmaxf(v[2], 0.f), hw4[2], partial);
-        partial = __builtin_fmaf(fmaxf(v[3], 0.f), hw4[3], partial);
-        partial += __shfl_xor(partial, 1);
-        partial += __shfl_xor(partial, 2);
-        partial += __shfl_xor(partial, 4);
-        bool above = false;
-        if (q == 0 && ooff[k] != 0x80000000u) {
-          const size_t dv = (size_t)item * a.V + (v0 + j);
-          float s = a.seed_raw[dv];
-          if (s != s) s = a.pad_value;
-          const float lg = s + (partial + hbias);
-          a.logits[dv] = lg;
-          above = lg >= a.move_thr;
-        }
-        head_above += (unsigned)__popcll(__ballot(above));  // wave-uniform
-        continue;
-      }
-      // store_policy (A/B switch): 0 write-back, 1 write-through (sc1: no
-      // dirty L2 lines left for the kernel boundary to flush), 2 non-temporal
-      if (a.store_policy == 1)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                               rs_out, ooff[k], 0, 16);
-      else if (a.store_policy == 2)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                               rs_out, ooff[k], 0, 2);
-      else
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                               rs_out, ooff[k], 0, 0);
-    }
-  }
-  if (HEAD) {  // this chunk's count of logits >= move_thr (summed by faces / paste)
-    float* cnt = lds + 160 * 32;  // past the transposed accumulators
-    if ((tid & 63) == 0) cnt[tid >> 6] = __uint_as_float(head_above);
-    __syncthreads();
-    if (tid == 0)
-      a.head_count[gc] = __float_as_uint(cnt[0]) + __float_as_uint(cnt[1]) +
-                         __float_as_uint(cnt[2]) + __float_as_uint(cnt[3]);
-  }
-  if (a.dbg && gc == 0 && (tid & 63) == 0) {
-    long long* d = a.dbg + (tid >> 6) * 6;
-    d[0] = dbg_c0;
-    d[1] = dbg_c1;
-    d[2] = dbg_c2;
-    d[3] = clock64();
-    d[4] = dbg_w0;
-    d[5] = wall_clock64();
-  }
-}
-
-// ---------------------------------------------------------------------------
-// conv32w8: conv32x3 with 8 waves per workgroup (two per SIMD).
-//
-// With the contraction on the 16-bit matrix cores the main loop of conv32x3 is
-// no longer MFMA-bound: a wave spends about as long issuing its operand loads
-// (10 ds_read_b128 + 2 global 16-B loads per tap) as the MFMA pipe spends on its
-// 13.5 MFMAs.  Two waves per SIMD hide each other's issue: wave = (cout half,
-// tile quarter tq), tiles 2tq and 2tq+1 on every tap, the ninth tile on the taps
-// whose owner is tq (3/2/2/2 of each dz segment, rotating, so the quarters carry
-// 7/7/7/6 of its 27 taps).  No K split: only the ninth tile's four partial sums
-// meet in the LDS transpose of the epilogue.  Staging, splitting, tap order,
-// epilogue and fused head are those of conv32x3; each thread stages half as many
-// rows, so the kernel fits the 256 registers two waves per SIMD leave.
-// ---------------------------------------------------------------------------
-constexpr int kW8Threads = 512;
-
-template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int KS = 8, bool HEAD = false,
-          int SCHEME = 2, bool ILV = false>
-__global__ __launch_bounds__(kW8Threads, 2) void conv32w8_kernel(ConvCArgs a) {
-  constexpr int NP = SCHEME == 3 ? 3 : 2;
-  constexpr int kRowB = SCHEME == 3 ? kXRowBytes : kHRowBytes;
-  constexpr int KT = (KS * 256 + kW8Threads - 1) / kW8Threads;  // quads / thread / segment
-  constexpr bool kExact = KT * kW8Threads == KS * 256;
-  typedef typename XFrag<SCHEME>::type frag_t;
-  unsigned range_max = 0;  // SCHEME 2: max |operand| bit pattern seen by this thread
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  char* ldsb = reinterpret_cast<char*>(lds);
-  const int tid = threadIdx.x;
-  const long long dbg_c0 = a.dbg ? clock64() : 0;
-  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
-  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
-  if (gc >= a.total_slots) return;
-  const int item = gc / a.nchunks;
-  const int chunk = gc - item * a.nchunks;
-  const int v0 = chunk * kCChunk;
-  const int32_t* pidx = a.pidx + v0;
-  int p_first;
-  {
-    int z = (int)((float)v0 / (float)a.fyfx);
-    z -= (z * a.fyfx > v0);
-    z += ((z + 1) * a.fyfx <= v0);
-    const int rem = v0 - z * a.fyfx;
-    int y = (int)((float)rem / (float)a.fx);
-    y -= (y * a.fx > rem);
-    y += ((y + 1) * a.fx <= rem);
-    p_first = __builtin_amdgcn_readfirstlane(z * a.plane + y * a.XS +
-                                             (rem - y * a.fx));
-  }
-  const int p_lo = p_first - (a.XS + 1);  // first staged row of the dz=0 segment
-  const float* src = a.in + (size_t)item * a.act_stride;
-  const int Rc = a.Rc;
-  const int nquads = Rc * 8;
-
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nhalf = wave & 1;
-  const int tq = wave >> 1;
-  const int i = lane & 15;
-  const int grp = lane >> 4;
-
-  // LDS byte offset of this lane's row in its tiles: 2tq, 2tq+1 and the ninth
-  int prow[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int tile = t < 2 ? tq * 2 + t : 8;
-    prow[t] = (pidx[tile * kTile + i] - p_lo) * kRowB + grp * 16;
-  }
-  // epilogue pieces: thread -> (position j = (tid >> 3) + 64 k, quad tid & 7)
-  const int q = tid & 7;
-  const int j0 = tid >> 3;
-  int pj[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int j = j0 + 64 * k;
-    pj[k] = pidx[(j < kCChunk && v0 + j < a.V) ? j : 0];
-  }
-  struct AFrag { frag_t p[3][3]; };  // [plane][tile]
-  struct BFrag { frag_t p[3]; };
-  const frag_t* wp =
-      reinterpret_cast<const frag_t*>(a.wpack) + nhalf * NP * 64 + lane;
-  auto loadB = [&](int s, BFrag& dst) {
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl) dst.p[pl] = wp[s * 2 * NP * 64 + pl * 64];
-  };
-  BFrag B0, B1, B2;
-  loadB(0, B0);
-  loadB(1, B1);
-
-  // ---- staging (all loads of the three dz segments in flight, written to LDS
-  // segment by segment; two segment slots) ----
-  f32x4 sv[3][KT];
-#pragma unroll
-  for (int seg = 0; seg < 3; ++seg) {
-    const long p0 = (long)p_lo + (long)(seg - 1) * a.plane;
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const int e = tid + k * kW8Threads;
-      sv[seg][k] = s4[(kExact || e < nquads) ? e : tid];
-    }
-  }
-  auto write_piece = [&](int seg, int k) {
-    {
-      const int e = tid + k * kW8Threads;
-      if (kExact || e < nquads) {
-        f32x4 v = sv[seg][k];
-        if (RELU_IN) {  // tf.nn.relu in front of conv_a (convstack_3d.py:44)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
-        }
-        const int row = (seg & 1) * Rc + (e >> 3);  // slot 0: dz -1, +1; slot 1: dz 0
-        char* dstrow = ldsb + row * kRowB + (e & 7) * 8;
-        if constexpr (SCHEME == 3) {
-          const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-          const f32x4 r1 = v - __builtin_convertvector(hi, f32x4);
-          const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
-          const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
-          const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
-          *reinterpret_cast<bf16x4*>(dstrow) = hi;
-          *reinterpret_cast<bf16x4*>(dstrow + 64) = mid;
-          *reinterpret_cast<bf16x4*>(dstrow + 128) = lo;
-        } else {
-          f32x4 vh = v;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const unsigned mbits = __float_as_uint(v[c]) & 0x7fffffffu;
-            range_max = mbits > range_max ? mbits : range_max;
-            vh[c] = mbits < 0x38800000u ? 0.0f : v[c];  // |x| < 2^-14
-          }
-          const f16x4 hi = __builtin_convertvector(vh, f16x4);
-          const f32x4 r1 = (v - __builtin_convertvector(hi, f32x4)) * 2048.0f;
-          const f16x4 res = __builtin_convertvector(r1, f16x4);
-          *reinterpret_cast<f16x4*>(dstrow) = hi;
-          *reinterpret_cast<f16x4*>(dstrow + 64) = res;
-        }
-      }
-    }
-  };
-  auto write_segment = [&](int seg) {
-#pragma unroll
-    for (int k = 0; k < KT; ++k) write_piece(seg, k);
-  };
-  // ILV: the conversion + LDS writes of the NEXT dz segment are spread over the
-  // taps of the current one (one piece after the first product group of a tap),
-  // so their VALU work runs in the shadow of the MFMAs instead of between two
-  // barriers.  The slot they fill is not read by any wave during those taps.
-  auto ilv_piece = [&](int s) {
-    if constexpr (ILV) {
-      const int r = s % 9, seg = s / 9 + 1;
-      // pieces 0..KT-1 after taps 3, 4, 5, 6 (, 7) of the segment
-      if (seg < 3 && r >= 3 && r - 3 < KT) write_piece(seg, r - 3);
-    }
-  };
-  write_segment(0);
-  __syncthreads();
-
-  auto a_off = [&](int s) {  // LDS byte offset of tap s (compile-time kz/ky/kx)
-    const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
-    return ((kz & 1) * Rc + (ky - 1) * a.XS + (kx - 1)) * kRowB;
-  };
-  // owner (tile quarter) of the ninth tile on tap s
-  auto owner = [](int s) {
-    const int r = s % 9;
-    return ((r < 3 ? 0 : r < 5 ? 1 : r < 7 ? 2 : 3) + s / 9) & 3;
-  };
-  auto loadA_tile = [&](int t, int off, AFrag& dst) {
-    const char* p = ldsb + prow[t] + off;
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-      dst.p[pl][t] = *reinterpret_cast<const frag_t*>(p + pl * 64);
-  };
-  // acc[t]: products of weight 1; accC[t] (SCHEME 2): cross products, weight 2^-11
-  f32x4 acc[3], accC[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) acc[t] = accC[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mma = [](const frag_t& fa, const frag_t& fb, f32x4 c) {
-    if constexpr (SCHEME == 3)
-      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, c, 0, 0, 0);
-    else
-      return __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, c, 0, 0, 0);
-  };
-  AFrag A0, A1;
-  const long long dbg_c1 = a.dbg ? clock64() : 0;
-  {
-    const int off = a_off(0);
-    loadA_tile(0, off, A0);
-    loadA_tile(1, off, A0);
-    if (owner(0) == tq) loadA_tile(2, off, A0);
-  }
-
-  // one product of the split on the wave's tiles (NT = 2, or 3 on its own taps)
-#define FFN_W8PROD(ACC, ACUR, BCUR, PA, PB, OWN)                             \
-  ACC[0] = mma(ACUR.p[PA][0], BCUR.p[PB], ACC[0]);                           \
-  ACC[1] = mma(ACUR.p[PA][1], BCUR.p[PB], ACC[1]);                           \
-  if (OWN) ACC[2] = mma(ACUR.p[PA][2], BCUR.p[PB], ACC[2]);                  \
-  __builtin_amdgcn_sched_barrier(0);
-#define FFN_W8TAP(S, ACUR, ANEXT, BCUR, BNEXT2, PF)                          \
-  {                                                                          \
-    const bool pa_ = (PF) && (S) + 1 < 27;                                   \
-    const int oa_ = a_off((S) + 1);                                          \
-    const bool own_ = owner(S) == tq;                                        \
-    const bool ownn_ = pa_ && owner((S) + 1) == tq;                          \
-    if constexpr (SCHEME == 3) {                                             \
-      if (pa_) loadA_tile(0, oa_, ANEXT);                                    \
-      FFN_W8PROD(acc, ACUR, BCUR, 2, 0, own_)                                \
-      FFN_W8PROD(acc, ACUR, BCUR, 0, 2, own_)                                \
-      if (pa_) loadA_tile(1, oa_, ANEXT);                                    \
-      FFN_W8PROD(acc, ACUR, BCUR, 1, 1, own_)                                \
-      FFN_W8PROD(acc, ACUR, BCUR, 1, 0, own_)                                \
-      if (ownn_) loadA_tile(2, oa_, ANEXT);                                  \
-      FFN_W8PROD(acc, ACUR, BCUR, 0, 1, own_)                                \
-      if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                              \
-      FFN_W8PROD(acc, ACUR, BCUR, 0, 0, own_)                                \
-    } else {                                                                 \
-      if (pa_) loadA_tile(0, oa_, ANEXT);                                    \
-      FFN_W8PROD(accC, ACUR, BCUR, 1, 0, own_)                               \
-      if (pa_) loadA_tile(1, oa_, ANEXT);                                    \
-      ilv_piece(S);                                                          \
-      FFN_W8PROD(acc, ACUR, BCUR, 0, 0, own_)                                \
-      if (ownn_) loadA_tile(2, oa_, ANEXT);                                  \
-      if ((S) + 2 < 27) loadB((S) + 2, BNEXT2);                              \
-      FFN_W8PROD(accC, ACUR, BCUR, 0, 1, own_)                               \
-    }                                                                        \
-  }
-  FFN_W8TAP(0, A0, A1, B0, B2, true)
-  FFN_W8TAP(1, A1, A0, B1, B0, true)
-  FFN_W8TAP(2, A0, A1, B2, B1, true)
-  FFN_W8TAP(3, A1, A0, B0, B2, true)
-  FFN_W8TAP(4, A0, A1, B1, B0, true)
-  FFN_W8TAP(5, A1, A0, B2, B1, true)
-  FFN_W8TAP(6, A0, A1, B0, B2, true)
-  FFN_W8TAP(7, A1, A0, B1, B0, true)
-  FFN_W8TAP(8, A0, A1, B2, B1, false)
-  if constexpr (!ILV) write_segment(1);
-  __syncthreads();
-  {
-    const int off = a_off(9);
-    loadA_tile(0, off, A1);
-    loadA_tile(1, off, A1);
-    if (owner(9) == tq) loadA_tile(2, off, A1);
-  }
-  FFN_W8TAP(9, A1, A0, B0, B2, true)
-  FFN_W8TAP(10, A0, A1, B1, B0, true)
-  FFN_W8TAP(11, A1, A0, B2, B1, true)
-  FFN_W8TAP(12, A0, A1, B0, B2, true)
-  FFN_W8TAP(13, A1, A0, B1, B0, true)
-  FFN_W8TAP(14, A0, A1, B2, B1, true)
-  FFN_W8TAP(15, A1, A0, B0, B2, true)
-  FFN_W8TAP(16, A0, A1, B1, B0, true)
-  FFN_W8TAP(17, A1, A0, B2, B1, false)
-  if constexpr (!ILV) write_segment(2);
-  __syncthreads();
-  // residual input and bias of this thread's epilogue pieces
-  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
-  unsigned ooff[3];
-  f32x4 skipv[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int j = j0 + 64 * k;
-    const bool ok = j < kCChunk && v0 + j < a.V;
-    const int p = pj[k];
-    ooff[k] = ok ? ((unsigned)p * kFeatures + q * 4) * 4u : 0x80000000u;
-    skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (ADD_SKIP)
-      skipv[k] = *reinterpret_cast<const f32x4*>(
-          a.skip + (size_t)item * a.act_stride + (size_t)p * kFeatures + q * 4);
-  }
-  {
-    const int off = a_off(18);
-    loadA_tile(0, off, A0);
-    loadA_tile(1, off, A0);
-    if (owner(18) == tq) loadA_tile(2, off, A0);
-  }
-  FFN_W8TAP(18, A0, A1, B0, B2, true)
-  FFN_W8TAP(19, A1, A0, B1, B0, true)
-  FFN_W8TAP(20, A0, A1, B2, B1, true)
-  FFN_W8TAP(21, A1, A0, B0, B2, true)
-  FFN_W8TAP(22, A0, A1, B1, B0, true)
-  FFN_W8TAP(23, A1, A0, B2, B1, true)
-  FFN_W8TAP(24, A0, A1, B0, B2, true)
-  FFN_W8TAP(25, A1, A0, B1, B0, true)
-  FFN_W8TAP(26, A0, A1, B2, B1, true)
-#undef FFN_W8TAP
-#undef FFN_W8PROD
-
-  const long long dbg_c2 = a.dbg ? clock64() : 0;
-  // ---- epilogue: accumulators -> LDS [row][32 ch]; rows 0..127 tiles 0..7,
-  // rows 128 + 16 tq .. the four partial sums of the ninth tile ----
-  __syncthreads();
-  {
-    if constexpr (SCHEME == 2) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] += accC[t] * 4.8828125e-4f;  // 2^-11
-      // an operand left the fp16 range: the step is void, the host re-runs it
-      // with the bf16x3 scheme (ffn_step_result.range_error)
-      if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
-        *a.range_flag = a.range_tag;
-    }
-    const int co = nhalf * 16 + i;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int jrow = (t < 2 ? (tq * 2 + t) * kTile : 128 + tq * kTile) + grp * 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lds[(jrow + r) * 32 + co] = acc[t][r];
-    }
-  }
-  __syncthreads();
-  unsigned head_above = 0;
-  {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    float* obase = a.out + (size_t)item * a.act_stride;
-    const __amdgpu_buffer_rsrc_t rs_out =
-        __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.nbytes, 0x00020000);
-    f32x4 hw4 = {0.f, 0.f, 0.f, 0.f};
-    float hbias = 0.f;
-    if (HEAD) {
-      hw4 = *reinterpret_cast<const f32x4*>(a.head_w + q * 4);
-      hbias = a.head_w[kFeatures];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int j = j0 + 64 * k;
-      const int jr = j < kCChunk ? j : 0;
-      f32x4 v = *reinterpret_cast<const f32x4*>(lds + jr * 32 + q * 4);
-      if (jr >= 8 * kTile) {  // ninth tile: add the other three quarters' sums
-#pragma unroll
-        for (int o = 1; o < 4; ++o)
-          v += *reinterpret_cast<const f32x4*>(lds + (jr + o * kTile) * 32 + q * 4);
-      }
-      v += b4;
-      if (RELU_OUT) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
-      }
-      if (ADD_SKIP) v += skipv[k];
-      if (HEAD) {
-        float partial = fmaxf(v[0], 0.f) * hw4[0];
-        partial = __builtin_fmaf(fmaxf(v[1], 0.f), hw4[1], partial);
-        partial = __builtin_fmaf(fmaxf(v[2], 0.f), hw4[2], partial);
-        partial = __builtin_fmaf(fmaxf(v[3], 0.f), hw4[3], partial);
-        partial += __shfl_xor(partial, 1);
-        partial += __shfl_xor(partial, 2);
-        partial += __shfl_xor(partial, 4);
-        bool above = false;
-        if (q == 0 && ooff[k] != 0x80000000u) {
-          const size_t dv = (size_t)item * a.V + (v0 + j);
-          float s = a.seed_raw[dv];
-          if (s != s) s = a.pad_value;
-          const float lg = s + (partial + hbias);
-          a.logits[dv] = lg;
-          above = lg >= a.move_thr;
-        }
-        head_above += (unsigned)__popcll(__ballot(above));  // wave-uniform
-        continue;
-      }
-      if (a.store_policy == 1)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                               rs_out, ooff[k], 0, 16);
-      else if (a.store_policy == 2)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                               rs_out, ooff[k], 0, 2);
-      else
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                               rs_out, ooff[k], 0, 0);
-    }
-  }
-  if (HEAD) {  // this chunk's count of logits >= move_thr (summed by faces / paste)
-    float* cnt = lds + 192 * 32;  // past the transposed accumulators
-    if ((tid & 63) == 0) cnt[tid >> 6] = __uint_as_float(head_above);
-    __syncthreads();
-    if (tid == 0) {
-      unsigned total = 0;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) total += __float_as_uint(cnt[w]);
-      a.head_count[gc] = total;
-    }
-  }
-  if (a.dbg && gc == 0 && (tid & 63) == 0 && wave < 4) {
-    long long* d = a.dbg + wave * 6;
-    d[0] = dbg_c0;
-    d[1] = dbg_c1;
-    d[2] = dbg_c2;
-    d[3] = clock64();
-    d[4] = dbg_w0;
-    d[5] = wall_clock64();
-  }
-}
-
-// ---------------------------------------------------------------------------
-// conv32k: the split-product conv on v_mfma_f32_32x32x16_f16, K split over the
-// waves (conv_variant 5).
-//
-// What bounds conv32w8 is operand delivery, not the matrix pipe: every wave
-// needs the weight fragments of all 27 taps (8 waves x 54 KB through the CU's
-// L1 per launch) and a 16x16x32 MFMA consumes a KB of operands every 16 cycles.
-// Here
-//   * the MFMA is 32x32x16 (twice the MACs per operand byte);
-//   * a workgroup is 4 waves (one per SIMD) that split K, i.e. the 27 TAPS:
-//     wave w contracts its 7 (6) taps for ALL five 32-position tiles of the
-//     chunk, so each tap's weight fragment (4 KB) is fetched by exactly one
-//     wave -- 108 KB per workgroup instead of 432 KB -- and stays in registers
-//     for 30 MFMAs;
-//   * operand roles are swapped (A = weights [cout x cin], B = activations
-//     [cin x position]): a lane's accumulator registers are 4 consecutive
-//     channels of one position, so the four partial sums leave through LDS as
-//     ds_write_b128 / ds_read_b128 and are added in wave order (deterministic).
-// Chunk = 160 consecutive dense voxels (5 tiles of 32; 225 workgroups for the
-// 33^3 FoV, one per CU at batch 1).  The three dz segments are staged as in
-// conv32w8 (f32 -> fp16 hi + 2^-11-scaled residual, ReLU on the way in), but
-// into THREE LDS slots (3 x Rc x 144 B), so no slot is ever re-used and the two
-// in-loop barriers sit at wave-uniform tap counts instead of at segment ends:
-//   taps 0,1 of every wave: dz = -1 only       (dz = 0 is converted meanwhile)
-//   taps 2,3:               dz <= 0            (dz = +1 is converted meanwhile)
-//   taps 4..:               the rest
-// (host-made schedule in ConvKArgs: 7/7/7/6 taps per wave).
-// LDS row = hi plane 64 B | residual plane 64 B | 16 B pad = 144 B: the
-// ds_read_b128 of 32 consecutive rows is bank-conflict free (9 r mod 16).
-// Weight fragments: host-packed [tap][khalf][plane][lane][8] halves with
-//   lane l -> cout l & 31, cin 16 khalf + 8 (l >> 5) + c.
-// ---------------------------------------------------------------------------
-constexpr int kKChunk = 160;
-constexpr int kKTiles = 5;
-constexpr int kKTile = 32;
-constexpr int kKThreads = 256;
-constexpr int kKRowB = 144;
-constexpr int kKMaxTaps = 8;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvKArgs {
-  ConvCArgs c;
-  int aoff[4 * kKMaxTaps];  // [wave][j]: LDS byte offset of the wave's j-th tap
-  int btap[4 * kKMaxTaps];  // [wave][j]: its tap index (weight fragments)
-  int ntaps[4];
-  // ceil(2^32 / d) for d = nchunks, fy * fx, fx: exact quotients of the small
-  // dividends met here as one s_mul_hi_u32 (an integer or float division in
-  // front of the staging loads costs ~100 instructions per launch)
-  unsigned magic_nchunks, magic_fyfx, magic_fx;
-  int ablate;    // timing experiments only (results are wrong): 1 = no activation
-                 // fragment reads after the first, 2 = no staging conversion in
-                 // the loop, 4 = no weight loads after the first two taps
-  int dbg_mode;  // 0: {entry, loop start, loop end, exit}; 1: {entry, after the
-                 // first barrier, after the dz = 0 barrier, after the dz = +1
-                 // barrier} in clock slots 0..3
-};
-
-template <bool RELU_IN, bool RELU_OUT, bool ADD_SKIP, int KS = 9, bool HEAD = false>
-__global__ __launch_bounds__(kKThreads, 1) void conv32k_kernel(ConvKArgs ka) {
-  const ConvCArgs& a = ka.c;
-  typedef f16x8 frag_t;
-  unsigned range_max = 0;  // max |operand| bit pattern seen by this thread
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  char* ldsb = reinterpret_cast<char*>(lds);
-  const int tid = threadIdx.x;
-  const long long dbg_c0 = a.dbg ? clock64() : 0;
-  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
-  const int gc = (blockIdx.x & 7) * a.slots_per_xcd + (blockIdx.x >> 3);
-  if (gc >= a.total_slots) return;
-  // the wave's tap schedule first: scalar loads from the kernel arguments that
-  // the weight loads below depend on
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt = ka.ntaps[wave];
-  int aoffs[7], btaps[7];
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    aoffs[j] = ka.aoff[wave * kKMaxTaps + j];
-    btaps[j] = ka.btap[wave * kKMaxTaps + j];
-  }
-  const int item = (int)__umulhi((unsigned)gc, ka.magic_nchunks);
-  const int chunk = gc - item * a.nchunks;
-  const int v0 = chunk * kKChunk;
-  const int32_t* pidx = a.pidx + v0;
-  int p_first;
-  {
-    const int z = (int)__umulhi((unsigned)v0, ka.magic_fyfx);
-    const int rem = v0 - z * a.fyfx;
-    const int y = (int)__umulhi((unsigned)rem, ka.magic_fx);
-    p_first = z * a.plane + y * a.XS + (rem - y * a.fx);
-  }
-  const int p_lo = p_first - (a.XS + 1);  // first staged row of the dz = 0 segment
-  const float* src = a.in + (size_t)item * a.act_stride;
-  const int Rc = a.Rc;  // == 32 * KS
-
-  const int lane = tid & 63;
-  const int li = lane & 31;
-  const int lh = lane >> 5;
-
-  // LDS byte offset of this lane's position in each tile (+ its k-group)
-  int prow[kKTiles];
-#pragma unroll
-  for (int t = 0; t < kKTiles; ++t)
-    prow[t] = (pidx[t * kKTile + li] - p_lo) * kKRowB + lh * 16;
-  // epilogue pieces: thread -> (position j = (tid >> 3) + 32 k, quad tid & 7)
-  const int q = tid & 7;
-  const int j0 = tid >> 3;
-  int pj[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int j = j0 + 32 * k;
-    pj[k] = pidx[(v0 + j < a.V) ? j : 0];
-  }
-  struct XFragK { frag_t x[2][2]; };  // activations [khalf][plane]
-  struct WFragK { frag_t w[2][2]; };  // weights     [khalf][plane]
-  const frag_t* wp = reinterpret_cast<const frag_t*>(a.wpack) + lane;
-  auto loadW = [&](int s, WFragK& dst) {
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        dst.w[kh][pl] = wp[((s * 2 + kh) * 2 + pl) * 64];
-  };
-  // weights of the wave's first two taps BEFORE the staging loads (vmcnt
-  // retires in order)
-  WFragK W0, W1, W2;
-  loadW(btaps[0], W0);
-  loadW(btaps[1], W1);
-
-  // ---- staging: all loads of the three dz segments in flight at once ----
-  f32x4 sv[3][KS];
-#pragma unroll
-  for (int seg = 0; seg < 3; ++seg) {
-    const long p0 = (long)p_lo + (long)(seg - 1) * a.plane;
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + p0 * kFeatures);
-#pragma unroll
-    for (int k = 0; k < KS; ++k) sv[seg][k] = s4[tid + k * kKThreads];
-  }
-  auto write_piece = [&](int seg, int k) {
-    const int e = tid + k * kKThreads;
-    f32x4 v = sv[seg][k];
-    if (RELU_IN) {  // tf.nn.relu in front of conv_a (convstack_3d.py:44), as one
-                    // integer max on the bit pattern (negative floats are
-                    // negative ints; -0 -> +0)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int b = __float_as_int(v[c]);
-        v[c] = __int_as_float(b > 0 ? b : 0);
-      }
-    }
-    char* dstrow = ldsb + (seg * Rc + (e >> 3)) * kKRowB + (e & 7) * 8;
-    f32x4 vh = v;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const unsigned mbits = __float_as_uint(v[c]) & 0x7fffffffu;
-      range_max = mbits > range_max ? mbits : range_max;
-      vh[c] = mbits < 0x38800000u ? 0.0f : v[c];  // |x| < 2^-14
-    }
-    const f16x4 hi = __builtin_convertvector(vh, f16x4);
-    const f32x4 r1 = (v - __builtin_convertvector(hi, f32x4)) * 2048.0f;
-    const f16x4 res = __builtin_convertvector(r1, f16x4);
-    *reinterpret_cast<f16x4*>(dstrow) = hi;
-    *reinterpret_cast<f16x4*>(dstrow + 64) = res;
-  };
-#pragma unroll
-  for (int k = 0; k < KS; ++k) write_piece(0, k);
-  __syncthreads();
-  const long long dbg_b0 = a.dbg ? clock64() : 0;
-
-  auto loadX = [&](int t, int off, XFragK& dst) {
-    if (ka.ablate & 1) return;
-    const char* p = ldsb + prow[t] + off;
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        dst.x[kh][pl] = *reinterpret_cast<const frag_t*>(p + pl * 64 + kh * 32);
-  };
-  // acc: products of weight 1; accC: cross products, weight 2^-11
-  f32x16 acc[kKTiles], accC[kKTiles];
-#pragma unroll
-  for (int t = 0; t < kKTiles; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = accC[t][r] = 0.f;
-  auto mma = [](const frag_t& fw, const frag_t& fx, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fx, c, 0, 0, 0);
-  };
-  XFragK X0, X1;
-  if (ka.ablate & 1) {  // (timing experiment: the fragments must not be undefined)
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) X0.x[kh][pl][c] = X1.x[kh][pl][c] = (_Float16)0;
-  }
-  const long long dbg_c1 = a.dbg ? clock64() : 0;
-  loadX(0, aoffs[0], X0);
-
-  // one tile of one tap: prefetch the next activation fragments, 6 MFMAs,
-  // optionally one staging piece of the segment being converted
-#define FFN_KTILE(T, XCUR, WCUR, PREFETCH, PIECE)                             \
-  __builtin_amdgcn_sched_barrier(0); /* keep the prefetch AHEAD of the MFMAs */ \
-  PREFETCH;                                                                   \
-  __builtin_amdgcn_sched_barrier(0);                                          \
-  accC[T] = mma(WCUR.w[0][0], XCUR.x[0][1], accC[T]);                         \
-  acc[T] = mma(WCUR.w[0][0], XCUR.x[0][0], acc[T]);                           \
-  accC[T] = mma(WCUR.w[0][1], XCUR.x[0][0], accC[T]);                         \
-  acc[T] = mma(WCUR.w[1][0], XCUR.x[1][0], acc[T]);                           \
-  accC[T] = mma(WCUR.w[1][0], XCUR.x[1][1], accC[T]);                         \
-  PIECE;                                                                      \
-  accC[T] = mma(WCUR.w[1][1], XCUR.x[1][0], accC[T]);
-  // tap J of the wave (XA holds tile 0's fragments on entry); CONT: prefetch
-  // tile 0 of the next tap at the end (false in front of a barrier); SEG/PB:
-  // staging pieces PB .. PB + 4 of segment SEG ride on the five tiles
-#define FFN_KTAP(J, XA, XB, WCUR, WNEXT2, CONT, SEG, PB)                      \
-  if ((J) < 6 || nt == 7) { /* every wave has 6 or 7 taps */                  \
-    if ((J) + 2 < 7) {                                                        \
-      if (((J) + 2 < 6 || nt == 7) && !(abl & 4))                             \
-        loadW(btaps[((J) + 2) % 7], WNEXT2);                                  \
-    }                                                                         \
-    const int ao_ = aoffs[J];                                                 \
-    const int an_ = aoffs[((J) + 1) % 7];                                     \
-    FFN_KTILE(0, XA, WCUR, loadX(1, ao_, XB), ilv_piece(SEG, (PB) + 0))       \
-    FFN_KTILE(1, XB, WCUR, loadX(2, ao_, XA), ilv_piece(SEG, (PB) + 1))       \
-    FFN_KTILE(2, XA, WCUR, loadX(3, ao_, XB), ilv_piece(SEG, (PB) + 2))       \
-    FFN_KTILE(3, XB, WCUR, loadX(4, ao_, XA), ilv_piece(SEG, (PB) + 3))       \
-    FFN_KTILE(4, XA, WCUR,                                                    \
-              if ((CONT) && ((J) + 1 < 6 || nt == 7)) loadX(0, an_, XB),      \
-              ilv_piece(SEG, (PB) + 4))                                       \
-  }
-  const int abl = ka.ablate;
-  auto ilv_piece = [&](int seg, int k) {
-    if (seg > 0 && k < KS && !(abl & 2)) write_piece(seg, k);
-  };
-  // 5 tiles per tap: the fragment buffers swap roles from tap to tap
-  FFN_KTAP(0, X0, X1, W0, W2, true, 1, 0)
-  FFN_KTAP(1, X1, X0, W1, W0, false, 1, 5)
-  __syncthreads();  // dz = 0 landed
-  const long long dbg_b1 = a.dbg ? clock64() : 0;
-  loadX(0, aoffs[2], X0);
-  FFN_KTAP(2, X0, X1, W2, W1, true, 2, 0)
-  FFN_KTAP(3, X1, X0, W0, W2, false, 2, 5)
-  __syncthreads();  // dz = +1 landed
-  const long long dbg_b2 = a.dbg ? clock64() : 0;
-  // residual input and bias of this thread's epilogue pieces
-  const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
-  unsigned ooff[5];
-  f32x4 skipv[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int j = j0 + 32 * k;
-    const bool ok = v0 + j < a.V;
-    const int p = pj[k];
-    ooff[k] = ok ? ((unsigned)p * kFeatures + q * 4) * 4u : 0x80000000u;
-    skipv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (ADD_SKIP)
-      skipv[k] = *reinterpret_cast<const f32x4*>(
-          a.skip + (size_t)item * a.act_stride + (size_t)p * kFeatures + q * 4);
-  }
-  loadX(0, aoffs[4], X0);
-  FFN_KTAP(4, X0, X1, W1, W0, true, 0, 0)
-  FFN_KTAP(5, X1, X0, W2, W1, true, 0, 0)
-  FFN_KTAP(6, X0, X1, W0, W2, false, 0, 0)
-#undef FFN_KTAP
-#undef FFN_KTILE
-
-  const long long dbg_c2 = a.dbg ? clock64() : 0;
-  // ---- epilogue: the four waves' partial sums meet in LDS ----
-  // P[wave][position 0..159][32 ch] at a 144-B row stride (ds_write_b128 of 8
-  // consecutive positions conflict-free); accumulator register 4 g + i of a lane
-  // is channel 8 g + 4 (lane >> 5) + i of position lane & 31 of the tile.
-  __syncthreads();
-  {
-#pragma unroll
-    for (int t = 0; t < kKTiles; ++t) acc[t] += accC[t] * 4.8828125e-4f;  // 2^-11
-    if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
-      *a.range_flag = a.range_tag;
-    char* P = ldsb + wave * (kKChunk * kKRowB) + li * kKRowB + lh * 16;
-#pragma unroll
-    for (int t = 0; t < kKTiles; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(P + t * (kKTile * kKRowB) + g * 32) =
-            f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2],
-                  acc[t][4 * g + 3]};
-  }
-  __syncthreads();
-  unsigned head_above = 0;
-  {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    float* obase = a.out + (size_t)item * a.act_stride;
-    const __amdgpu_buffer_rsrc_t rs_out =
-        __builtin_amdgcn_make_buffer_rsrc(obase, 0, a.nbytes, 0x00020000);
-    f32x4 hw4 = {0.f, 0.f, 0.f, 0.f};
-    float hbias = 0.f;
-    if (HEAD) {
-      hw4 = *reinterpret_cast<const f32x4*>(a.head_w + q * 4);
-      hbias = a.head_w[kFeatures];
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int j = j0 + 32 * k;
-      const char* pp = ldsb + j * kKRowB + q * 16;
-      f32x4 v = *reinterpret_cast<const f32x4*>(pp);
-#pragma unroll
-      for (int w = 1; w < 4; ++w)
-        v += *reinterpret_cast<const f32x4*>(pp + w * (kKChunk * kKRowB));
-      v += b4;
-      if (RELU_OUT) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : 0.0f;
-      }
-      if (ADD_SKIP) v += skipv[k];
-      if (HEAD) {
-        float partial = fmaxf(v[0], 0.f) * hw4[0];
-        partial = __builtin_fmaf(fmaxf(v[1], 0.f), hw4[1], partial);
-        partial = __builtin_fmaf(fmaxf(v[2], 0.f), hw4[2], partial);
-        partial = __builtin_fmaf(fmaxf(v[3], 0.f), hw4[3], partial);
-        partial += __shfl_xor(partial, 1);
-        partial += __shfl_xor(partial, 2);
-        partial += __shfl_xor(partial, 4);
-        bool above = false;
-        if (q == 0 && ooff[k] != 0x80000000u) {
-          const size_t dv = (size_t)item * a.V + (v0 + j);
-          float s = a.seed_raw[dv];
-          if (s != s) s = a.pad_value;
-          const float lg = s + (partial + hbias);
-          a.logits[dv] = lg;
-          above = lg >= a.move_thr;
-        }
-        head_above += (unsigned)__popcll(__ballot(above));  // wave-uniform
-        continue;
-      }
-      if (a.store_policy == 1)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                               rs_out, ooff[k], 0, 16);
-      else if (a.store_policy == 2)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                               rs_out, ooff[k], 0, 2);
-      else
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v),
-                                               rs_out, ooff[k], 0, 0);
-    }
-  }
-  if (HEAD) {  // this chunk's count of logits >= move_thr (summed by faces / paste)
-    float* cnt = reinterpret_cast<float*>(ldsb + 4 * kKChunk * kKRowB);
-    if ((tid & 63) == 0) cnt[tid >> 6] = __uint_as_float(head_above);
-    __syncthreads();
-    if (tid == 0)
-      a.head_count[gc] = __float_as_uint(cnt[0]) + __float_as_uint(cnt[1]) +
-                         __float_as_uint(cnt[2]) + __float_as_uint(cnt[3]);
-  }
-  if (a.dbg && gc == 0 && (tid & 63) == 0) {
-    long long* d = a.dbg + wave * 6;
-    d[0] = dbg_c0;
-    d[1] = ka.dbg_mode ? dbg_b0 : dbg_c1;
-    d[2] = ka.dbg_mode ? dbg_b1 : dbg_c2;
-    d[3] = ka.dbg_mode ? dbg_b2 : clock64();
-    d[4] = dbg_w0;
-    d[5] = wall_clock64();
-  }
-}
-
 // ---------------------------------------------------------------------------
 // conv32d (conv_variant 6): conv32k with the operand split done ONCE by the
 // producer and the staging done by LDS-DMA.
@@ -3421,8 +1929,9 @@ __global__ __launch_bounds__(512) void faces_kernel(
     const float* __restrict__ in_seed,
     const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
     float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
-    unsigned range_tag, ffn_step_result* __restrict__ results,
-    unsigned* __restrict__ seq, unsigned step_id) {
+    unsigned range_tag, unsigned* __restrict__ clear_flag,
+    ffn_step_result* __restrict__ results, unsigned* __restrict__ seq,
+    unsigned step_id) {
   __shared__ unsigned s_cnt[8];
   __shared__ ffn_step_result s_res;
   const int item = blockIdx.x;
@@ -3548,6 +2057,9 @@ __global__ __launch_bounds__(512) void faces_kernel(
     if (lane == 0) {
       s_res.num_deleted = deleted;
       s_res.range_error = (*range_flag == range_tag) ? 1 : 0;
+      // captured conv chains (option use_graph) alternate between two flag
+      // words: the one the NEXT step's chain will raise is zeroed here
+      if (clear_flag && item == 0) *clear_flag = 0;
     }
   }
   __syncthreads();

@@ -43,11 +43,58 @@ def pin_batched_arithmetic(engine):
   last voxels of the FoV, ~1e-6 in the logits.  In a batched run the number of
   FoVs per call varies with timing, so a canvas would get either, step by
   step; conv32m for every step keeps a batched run reproducible.  An explicit
-  choice made later (Runner(conv_variant=...)) still wins."""
+  choice -- Runner(conv_variant=...), --conv_variant, engine.set_option(
+  'conv_variant', ...) -- wins whenever it was made: the drivers call this on
+  every run, and it leaves an engine alone whose kernel somebody chose."""
   if not isinstance(engine, HipEngine):
     return  # a stand-in engine of the host-logic tests
+  if engine.variant_is_explicit:
+    return
   if engine.max_batch > 1 and engine.get_option('conv_variant') == 9:
-    engine.set_option('conv_variant', 8)
+    engine.set_option('conv_variant', 8, explicit=False)
+
+
+def segment_many_with_retry(once, n, sarr, parr, rarr, before, fallback):
+  """One `ffn_canvas_segment_many` call plus the handling of a round voided by
+  the fp16 range check (FFN_ERR_RANGE), shared by HipEngine and the CPU shim of
+  the tests.  once(keys, starts, params, resumes, results, finished) -> rc makes
+  the call for the canvases `keys` (indices into the caller's list);
+  before[k] = steps canvas k's segment had made before this call (results count
+  from the start of the segment, budgets are per call).
+
+  The voided round changed nothing on the device and every prepared position
+  stays pending.  Loops that ENDED in this call before the voided round (queue
+  empty, seed too weak, budget spent) keep their result -- they are no longer
+  resumable, and asking the library to resume them is FFN_ERR_STATE.  The others
+  are resumed, after `fallback()` has switched kernels, with what is left of
+  their budgets."""
+  res = (_lib.SegmentResult * n)()
+  fin = (ctypes.c_int32 * n)()
+  rc = once(list(range(n)), sarr, parr, rarr, res, fin)
+  if rc != _lib.ERR_RANGE:
+    return rc, res, fin
+  fallback()
+  live = [k for k in range(n) if not fin[k]]
+  if not live:
+    return 0, res, fin
+  m = len(live)
+  sarr2 = (ctypes.c_int32 * 3 * m)()
+  parr2 = (_lib.SegmentParams * m)()
+  rarr2 = (ctypes.c_int32 * m)(*([1] * m))
+  res2 = (_lib.SegmentResult * m)()
+  fin2 = (ctypes.c_int32 * m)()
+  for j, k in enumerate(live):
+    for a in range(3):
+      sarr2[j][a] = sarr[k][a]
+    ctypes.pointer(parr2[j])[0] = parr[k]
+    if parr[k].max_steps > 0:
+      spent = int(res[k].num_steps) - before[k]
+      parr2[j].max_steps = max(parr[k].max_steps - spent, 1)
+  rc = once(live, sarr2, parr2, rarr2, res2, fin2)
+  for j, k in enumerate(live):
+    ctypes.pointer(res[k])[0] = res2[j]
+    fin[k] = fin2[j]
+  return rc, res, fin
 
 
 class HipEngine:
@@ -77,8 +124,12 @@ class HipEngine:
     self._slot_res_arr = [(StepResult * self.max_batch)() for _ in range(2)]
     self._submit_slot = 0
     self._ticket_slot = {}
-    #: steps repeated because conv_variant 4 met a value outside the fp16 range
+    #: steps repeated because a split-product kernel met a value outside the fp16 range
     self.range_fallbacks = 0
+    #: True once a caller has chosen the conv kernel (pin_batched_arithmetic
+    #: then keeps its hands off)
+    self.variant_is_explicit = False
+    self._default_variant = self.get_option('conv_variant')
     self._canvases = weakref.WeakSet()
     _LIVE_ENGINES.add(self)
 
@@ -120,8 +171,19 @@ class HipEngine:
                                           ctypes.byref(value)))
     return value.value
 
-  def set_option(self, name: str, value: int):
+  def set_option(self, name: str, value: int, explicit: bool = True):
+    """ffn_engine_set_option.  conv_variant: 0 / 2 (exact f32), 6 .. 9, or -1 =
+    this FoV's exact-f32 kernel; `explicit=False` is for the library's own
+    choices (the batched drivers' pin, the fp16-range fallback)."""
     check(self._lib.ffn_engine_set_option(self._h, name.encode(), int(value)))
+    if name == 'conv_variant' and explicit and int(value) != -1:
+      self.variant_is_explicit = True
+
+  def restore_default_variant(self):
+    """Back to the kernel choice the engine was created with, as if nobody had
+    chosen one."""
+    self.set_option('conv_variant', self._default_variant, explicit=False)
+    self.variant_is_explicit = False
 
   def set_profiling(self, mode: int):
     check(self._lib.ffn_engine_set_profiling(self._h, int(mode)))
@@ -183,14 +245,15 @@ class HipEngine:
     return self._res_arr
 
   def _blocking_step(self, n, req, params):
-    """ffn_canvas_step; a step voided by the fp16 range check (conv_variant 4)
-    changed nothing on the device: it is repeated with the bf16x3 scheme, which
-    has the full f32 exponent range, and the engine stays on that scheme."""
+    """ffn_canvas_step; a step voided by the fp16 range check (conv_variant >= 6)
+    changed nothing on the device: it is repeated with the exact-f32 kernel
+    (conv_variant -1 = the engine's `exact_variant`), which has the full f32
+    exponent range, and the engine stays on it."""
     rc = self._lib.ffn_canvas_step(self._h, n, self._canvas_arr, req,
                                    ctypes.byref(params), self._res_arr)
     if rc == _lib.ERR_RANGE:
       self.range_fallbacks += 1
-      self.set_option('conv_variant', 3)
+      self.set_option('conv_variant', -1, explicit=False)
       rc = self._lib.ffn_canvas_step(self._h, n, self._canvas_arr, req,
                                      ctypes.byref(params), self._res_arr)
     check(rc)
@@ -201,8 +264,8 @@ class HipEngine:
     together inside the library, one batched step per round; returns once at
     least one of them has ended.  -> (results, finished), one entry per canvas;
     results count from the start of each canvas' segment.  A round voided by
-    the fp16 range check is repeated with the bf16x3 scheme and the call
-    resumed."""
+    the fp16 range check is repeated with the exact-f32 kernel and the call
+    resumed for the canvases still running."""
     n = len(canvases)
     carr = (ctypes.c_void_p * n)(*[c._h for c in canvases])
     sarr = (ctypes.c_int32 * 3 * n)()
@@ -212,23 +275,21 @@ class HipEngine:
       for a in range(3):
         sarr[k][a] = int(starts[k][a])
       ctypes.pointer(parr[k])[0] = params[k]
-    res = (_lib.SegmentResult * n)()
-    fin = (ctypes.c_int32 * n)()
-    rc = self._lib.ffn_canvas_segment_many(self._h, n, carr, sarr, parr, rarr, res,
-                                           fin)
-    if rc == _lib.ERR_RANGE:
-      # the voided round changed nothing on the device and every prepared
-      # position stays pending: resume all of them on the bf16x3 scheme
+    def once(keys, sa, pa, ra, res, fin):
+      ca = (ctypes.c_void_p * len(keys))(*[canvases[k]._h for k in keys])
+      return self._lib.ffn_canvas_segment_many(self._h, len(keys), ca, sa, pa, ra,
+                                               res, fin)
+
+    def fallback():
       self.range_fallbacks += 1
-      self.set_option('conv_variant', 3)
-      spent = [int(res[k].num_steps) for k in range(n)]
-      for k in range(n):
-        rarr[k] = 1
-        if parr[k].max_steps > 0:  # the budget is per call
-          parr[k].max_steps = max(parr[k].max_steps - spent[k], 1)
-      rc = self._lib.ffn_canvas_segment_many(self._h, n, carr, sarr, parr, rarr,
-                                             res, fin)
+      self.set_option('conv_variant', -1, explicit=False)
+
+    before = [c._many_steps if rarr[k] else 0 for k, c in enumerate(canvases)]
+    rc, res, fin = segment_many_with_retry(once, n, sarr, parr, rarr, before,
+                                           fallback)
     check(rc)
+    for k, c in enumerate(canvases):
+      c._many_steps = int(res[k].num_steps)
     return ([_lib.SegmentResult.from_buffer_copy(res[k]) for k in range(n)],
             [bool(fin[k]) for k in range(n)])
 
@@ -258,10 +319,10 @@ class HipEngine:
     rc = self._lib.ffn_canvas_step_wait(self._h, ticket, res)
     if rc == _lib.ERR_RANGE:
       # voided by the fp16 range check: nothing was pasted.  Repeat this batch
-      # with the bf16x3 scheme (its descriptor arrays are still intact); a step
+      # with the exact-f32 kernel (its descriptor arrays are still intact); a step
       # of the other group that is already queued finishes first.
       self.range_fallbacks += 1
-      self.set_option('conv_variant', 3)
+      self.set_option('conv_variant', -1, explicit=False)
       again = ctypes.c_uint32(0)
       check(self._lib.ffn_canvas_step_submit(
           self._h, n, self._slot_canvas_arr[slot], self._slot_req_arr[slot],
@@ -306,6 +367,7 @@ class DeviceCanvasHandle:
     self._pt = (ctypes.c_int32 * 3)()
     self._pt_seed = ctypes.c_float()
     self._pt_seg = ctypes.c_int32()
+    self._many_steps = 0  # steps of the current segment reported by segment_many
     engine._canvases.add(self)
 
   def close(self):
@@ -333,8 +395,8 @@ class DeviceCanvasHandle:
   def segment_at(self, start_pos, params: '_lib.SegmentParams',
                  resume: bool = False) -> '_lib.SegmentResult':
     """ffn_canvas_segment_at: the whole FoV loop of a segment inside the
-    library.  A step voided by the fp16 range check is repeated with the bf16x3
-    scheme (as `HipEngine._blocking_step` does) and the loop resumed."""
+    library.  A step voided by the fp16 range check is repeated with the
+    exact-f32 kernel (as `HipEngine._blocking_step` does) and the loop resumed."""
     res = _lib.SegmentResult()
     rc = self._lib.ffn_canvas_segment_at(self._h, i3(start_pos),
                                          ctypes.byref(params), int(resume),
@@ -343,7 +405,7 @@ class DeviceCanvasHandle:
       # the voided step changed nothing on the device; the loop keeps the
       # position pending, so resuming repeats exactly that step
       self.engine.range_fallbacks += 1
-      self.engine.set_option('conv_variant', 3)
+      self.engine.set_option('conv_variant', -1, explicit=False)
       first = _lib.SegmentResult.from_buffer_copy(res)
       budget = params.max_steps
       if budget > 0:

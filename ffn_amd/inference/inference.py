@@ -1305,28 +1305,44 @@ class MultiCanvasDriver:
         advance(entry, None)
 
     refill()
+    #: steps a library call may make while canvases on the Python loop wait
+    mixed_call_steps = 8
     while live:
-      # canvases on the Python loop (no native segment pending): one blocking
-      # step each until they yield a native segment or finish
-      for entry in list(live):
-        while entry in live and not isinstance(entry[2], NativeSegment):
-          res = engine.step([entry[0]._handle], [entry[2]], entry[0]._step_params)
-          self.calls += 1
-          self.steps += 1
+      # canvases on the Python loop (restrictor masks, custom policies, hooks:
+      # no native segment pending) advance by ONE batched step per round, next
+      # to the library calls of the others -- never one canvas at a time
+      py = [e for e in live if not isinstance(e[2], NativeSegment)]
+      while py:
+        key = bytes(py[0][0]._step_params)
+        batch = [e for e in py if bytes(e[0]._step_params) == key]
+        batch = batch[:self.batch_size]
+        py = [e for e in py if e not in batch]
+        res = engine.step([e[0]._handle for e in batch], [e[2] for e in batch],
+                          batch[0][0]._step_params)
+        self.calls += 1
+        self.steps += len(batch)
+        # (copies: the result array is reused by the next engine call, and a
+        # generator may make one before it yields again)
+        res = [_lib.StepResult.from_buffer_copy(res[k]) for k in range(len(batch))]
+        for entry, r in zip(batch, res):
           entry[3] += 1
           if limit is not None and entry[3] >= limit:
             entry[1].close()
             finished(entry)
-            break
-          advance(entry, res[0])
-      if not live:
+            continue
+          advance(entry, r)
+      nat = [e for e in live if isinstance(e[2], NativeSegment)]
+      if not nat:
         refill()
         continue
-      key = bytes(live[0][2].params.step)
-      batch = [e for e in live if bytes(e[2].params.step) == key][:self.batch_size]
+      mixed = len(nat) < len(live)
+      key = bytes(nat[0][2].params.step)
+      batch = [e for e in nat if bytes(e[2].params.step) == key][:self.batch_size]
       for e in batch:
-        e[2].params.max_steps = (max(limit - e[3] - e[4], 1)
-                                 if limit is not None else 0)
+        left = limit - e[3] - e[4] if limit is not None else 0
+        if mixed:
+          left = min(left, mixed_call_steps) if limit is not None else mixed_call_steps
+        e[2].params.max_steps = max(left, 1) if (limit is not None or mixed) else 0
       results, fin = engine.segment_many(
           [e[0]._handle for e in batch], [e[2].start_pos for e in batch],
           [e[2].params for e in batch], [e[2].started for e in batch])
@@ -1337,9 +1353,15 @@ class MultiCanvasDriver:
         e[2].started = True
         if not done:
           continue
+        if res.budget_exhausted:
+          if limit is not None and e[3] + e[4] >= limit:
+            e[1].close()
+            finished(e)
+          # else: only this call's share was spent; the loop is resumed
+          continue
         e[3] += e[4]
         e[4] = 0
-        if res.budget_exhausted or (limit is not None and e[3] >= limit):
+        if limit is not None and e[3] >= limit:
           e[1].close()
           finished(e)
           continue

@@ -28,9 +28,9 @@ extern "C" {
 #define FFN_ERR_ARG (-1)     /* invalid argument / unsupported geometry      */
 #define FFN_ERR_HIP (-2)     /* HIP runtime failure (see ffn_last_error)     */
 #define FFN_ERR_STATE (-3)   /* call order violated (e.g. weights not set)   */
-#define FFN_ERR_RANGE (-4)   /* conv_variant 4 only: an operand left the fp16
+#define FFN_ERR_RANGE (-4)   /* conv_variant >= 6 only: an operand left the fp16
                                 range; the step changed nothing -- switch to
-                                conv_variant 3 and repeat it                    */
+                                conv_variant -1 (exact f32) and repeat it       */
 
 #define FFN_MAX_CANDIDATES 16
 
@@ -73,7 +73,7 @@ typedef struct ffn_step_result {
   int32_t cand_seg[FFN_MAX_CANDIDATES];   /* segmentation[candidate]           */
   uint32_t num_deleted;   /* history_deleted entry of this step (see
                              ffn_step_params.deleted_threshold), else 0        */
-  int32_t range_error;    /* conv_variant 4: 1 = an operand left the fp16 range,
+  int32_t range_error;    /* conv_variant >= 6: 1 = an operand left the fp16 range,
                              the step was NOT pasted (FFN_ERR_RANGE)           */
 } ffn_step_result;
 
@@ -265,30 +265,33 @@ int ffn_canvas_write_segmentation(ffn_canvas* canvas, const int32_t lo[3],
 int ffn_engine_set_profiling(ffn_engine* engine, int mode);
 int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
                            int64_t* conv_launches, int reset);
-/* Tuning / A-B switches.  "conv_variant": 0 = simple f32-MFMA conv, 1 =
- * software-pipelined f32-MFMA conv over padded positions, 2 = pipelined +
- * compact position space + K-split middle tile, 3 = variant 2 with every f32
- * product carried as 6 exact bf16 x bf16 products on the bf16 MFMA (default
- * when the FoV allows), 4 = the same with fp16 (hi + 2^-11 * residual, 3
- * products, 22 mantissa bits: about the rounding noise of an f32 GEMM; operands
- * must stay inside the fp16 range, else FFN_ERR_RANGE), 5 = variant 4's
- * products on 32x32x16 MFMAs with the 27 taps split over 4 waves, 6 = the same
- * bits on producer-split fp16 planes staged by LDS-DMA (conv32d), 7 = 6 in
- * 96-voxel chunks, 8 = conv32m (M split over the waves, weights through an
- * LDS-DMA ring, two workgroups per CU), 9 (default where the FoV has 257 ..
- * 512 chunks of 128 voxels, e.g. 33^3) = a step of ONE FoV runs conv32mt
- * (conv32m for the first 256 chunks + 32-voxel K-split tail workgroups), a step
- * of several runs conv32m; "tail_batched" 1 = conv32mt for every step (one
- * arithmetic whatever the batch); "batch_chunks" (variant 6): the form batched
- * steps take.  Results are identical up to f32 summation order
- * (variant 3: plus a truncation 100x below f32 rounding).  "fuse_head": 1x1x1
- * head inside the last conv launch.  "store_policy": 0 write-back, 1
- * write-through, 2 non-temporal conv stores.  "waves8" (variants 3 / 4): 0 =
- * 4-wave workgroups, 1 = 8-wave, 2 (default) = 8-wave with the staging of the
- * next depth segment interleaved into the taps (variant 4; bit-identical). */
+/* Kernel choice and tuning switches.  "conv_variant":
+ *   0 = simple exact-f32 MFMA conv over padded positions (takes any FoV that
+ *       fits the LDS at all),
+ *   2 = exact-f32 MFMA conv over compact chunks, pipelined, K-split middle tile
+ *       (bitwise the oracle's fmaf chain),
+ *   6 = conv32d: every f32 product carried as 3 fp16 products (hi + 2^-11 *
+ *       residual: 22 mantissa bits, about the rounding noise of an f32 GEMM) on
+ *       32x32x16 MFMAs, the 27 taps split over 4 waves, producer-split fp16
+ *       planes staged by LDS-DMA; operands must stay inside the fp16 range,
+ *       else FFN_ERR_RANGE,
+ *   7 = 6 in 96-voxel chunks (two workgroups per CU; the same bits),
+ *   8 = conv32m: the same products, M split over the waves, weights through an
+ *       LDS-DMA ring, two workgroups per CU,
+ *   9 (default where the FoV has 257 .. 512 chunks of 128 voxels, e.g. 33^3) =
+ *       a step of ONE FoV runs conv32mt (conv32m for the first 256 chunks +
+ *       32-voxel K-split tail workgroups), a step of several runs conv32m,
+ *  -1 = this FoV's exact-f32 kernel ("exact_variant": 2 where it fits, else 0).
+ * (1, 3, 4, 5 -- conv32p, the bf16x3 and the earlier fp16 kernels -- were removed
+ * in ABI 7; they are in the history up to commit af82310.)
+ * "tail_batched" 1 = conv32mt for every step (one arithmetic whatever the
+ * batch); "batch_chunks" (variant 6): the form batched steps take.  Results
+ * are identical up to f32 summation order.  "fuse_head" (variant 2): 1x1x1
+ * head inside the last conv launch.  "store_policy" (variant 2): 0 write-back,
+ * 1 write-through, 2 non-temporal conv stores. */
 int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
-/* Current value of an option ("conv_variant", "fuse_head", "store_policy",
- * "sync_mode", "profile_every", "waves8"). */
+/* Current value of an option ("conv_variant", "exact_variant", "fuse_head",
+ * "store_policy", "sync_mode", "profile_every"). */
 int ffn_engine_get_option(ffn_engine* engine, const char* name, int* value);
 /* Debug: with option "debug_clock" = 1 the compact conv kernel records, for its
  * first workgroup, per wave {shader clock at entry, at main-loop start, at

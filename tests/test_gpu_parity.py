@@ -18,7 +18,6 @@ from tests.conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 DEFAULT_VARIANT = 9
-DEFAULT_WAVES8 = 2  # what ffn_engine_create selects for the 33^3 FoV
 TOL = 1e-4
 
 
@@ -40,35 +39,31 @@ def _fov_inputs(rng, n=1):
   return img, seed
 
 
-@pytest.mark.parametrize('variant,fuse_head,waves8', [
-    (0, 1, 1), (1, 1, 1), (2, 1, 1), (2, 0, 1), (3, 1, 1), (3, 0, 1), (4, 1, 1),
-    (4, 0, 1), (3, 1, 0), (4, 1, 0), (4, 0, 0), (4, 1, 2), (4, 0, 2), (5, 1, 2), (5, 0, 2), (6, 1, 2), (7, 1, 2), (8, 1, 2)])
-def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head, waves8):
-  """conv_variant 0 simple f32 MFMA, 1 padded pipelined, 2 compact (exact f32
-  MFMA), 3 compact with bf16x3 split products, 4 with fp16 hi + scaled
-  residual, 5 the same products on 32x32x16 MFMAs with the taps split over the
-  waves (conv32k), 6 the same on producer-split planes staged by LDS-DMA
-  (conv32d), 7 = 6 with 96-voxel chunks for two workgroups per CU, 8 = the M-split
-  form with the weights in an LDS ring (conv32m); with the 1x1x1 head fused into
-  the last conv or as its own launch."""
+@pytest.mark.parametrize('variant,fuse_head,n', [
+    (0, 1, 1), (2, 1, 1), (2, 0, 1), (6, 1, 1), (7, 1, 1), (8, 1, 1), (9, 1, 1),
+    (9, 1, 2)])
+def test_predict_matches_oracle(engine, fib25_blob, variant, fuse_head, n):
+  """conv_variant 0 simple f32 MFMA (any FoV), 2 compact chunks (exact f32 MFMA,
+  the oracle's summation order), 6 the split-product conv on 32x32x16 MFMAs
+  with the taps split over the waves, producer-split planes staged by LDS-DMA
+  (conv32d), 7 = 6 with 96-voxel chunks for two workgroups per CU, 8 = the
+  M-split form with the weights in an LDS ring (conv32m), 9 (the default) =
+  conv32mt for a step of ONE FoV and conv32m for a step of several; variant 2
+  with the 1x1x1 head fused into the last conv or as its own launch."""
   from oracle import ffn_oracle
   engine.set_option('conv_variant', variant)
   engine.set_option('fuse_head', fuse_head)
-  # variants 3 / 4: 0 = 4-wave workgroups, 1 = 8-wave, 2 = 8-wave with the
-  # staging conversion interleaved into the taps (variant 4; the default)
-  engine.set_option('waves8', waves8)
   rng = np.random.RandomState(42)
-  img, seed = _fov_inputs(rng, 1)
+  img, seed = _fov_inputs(rng, n)
   got = engine.predict(seed, img)
   want = ffn_oracle.forward(img, seed, fib25_blob, 12)
   assert got.shape == want.shape
   err = np.abs(got - want).max()
-  print('variant %d fuse_head %d waves8 %d: max |err| %.3g' % (
-      variant, fuse_head, waves8, err))
+  print('variant %d fuse_head %d n %d: max |err| %.3g' % (
+      variant, fuse_head, n, err))
   assert err <= TOL
-  engine.set_option('conv_variant', DEFAULT_VARIANT)
+  engine.restore_default_variant()
   engine.set_option('fuse_head', 1)
-  engine.set_option('waves8', DEFAULT_WAVES8)
 
 
 def test_predict_batch_and_ragged(engine, fib25_blob):
@@ -95,7 +90,7 @@ def test_predict_batch_and_ragged(engine, fib25_blob):
   engine.set_option('tail_batched', 0)
   engine.set_option('conv_variant', 8)
   assert np.array_equal(engine.predict(seed[2:3], img[2:3])[0], got4[2])
-  engine.set_option('conv_variant', DEFAULT_VARIANT)
+  engine.restore_default_variant()
 
 
 def test_predict_is_deterministic_and_variants_agree(engine):
@@ -105,7 +100,7 @@ def test_predict_is_deterministic_and_variants_agree(engine):
   b = engine.predict(seed, img)
   assert np.array_equal(a, b)
   by_variant = {}
-  for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
+  for variant in (0, 2, 6, 7, 8, 9):
     engine.set_option('conv_variant', variant)
     c = engine.predict(seed, img)
     assert np.abs(a - c).max() <= 2e-5, variant
@@ -124,11 +119,9 @@ def test_predict_is_deterministic_and_variants_agree(engine):
   for k in range(2):
     one = engine.predict(seed[k:k + 1], img[k:k + 1])
     assert np.array_equal(one[0], both[k])
-  # conv32d = conv32k's arithmetic and summation order on producer-split planes,
-  # whatever the chunk size
-  assert np.array_equal(by_variant[5], by_variant[6])
+  # conv32d's arithmetic and summation order do not depend on the chunk size
   assert np.array_equal(by_variant[6], by_variant[7])
-  engine.set_option('conv_variant', DEFAULT_VARIANT)
+  engine.restore_default_variant()
 
 
 @pytest.mark.parametrize('fov_xyz,deltas_xyz', [([25, 25, 25], [6, 6, 6]),
@@ -155,7 +148,7 @@ def test_other_fov_sizes_every_supported_variant(fov_xyz, deltas_xyz):
   want = ffn_oracle.forward(img, seed, ffn_oracle.weights_blob(variables, 3), 3)
   ran = []
   default = eng.get_option('conv_variant')
-  for variant in (default, 0, 2, 3, 4, 5, 6, 7, 8, 9):
+  for variant in (default, 0, 2, 6, 7, 8, 9):
     try:
       eng.set_option('conv_variant', variant)
     except _lib.FFNHipError:
@@ -186,7 +179,7 @@ def test_c5_model_full_depth(fib25_model):
   seed = rng.normal(0, 2, (2, 21, 41, 41)).astype(np.float32)
   blob = ffn_oracle.weights_blob(variables, 18)
   want = ffn_oracle.forward(img, seed, blob, 18)
-  for variant in (2, 3, 4, 5, 6):
+  for variant in (2, 6, 7, eng.get_option('conv_variant')):
     eng.set_option('conv_variant', variant)
     got = eng.predict(seed, img)
     err = np.abs(got - want).max()
@@ -237,7 +230,7 @@ def test_anisotropic_fov(fib25_model):
   img = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
   seed = rng.normal(0, 1, (1, 21, 41, 41)).astype(np.float32)
   blob = ffn_oracle.weights_blob(variables, 2)
-  for variant in (0, 1, 2, 3, 4, 5, 6):
+  for variant in (0, 2, 6):
     eng.set_option('conv_variant', variant)
     got = eng.predict(seed, img)
     want = ffn_oracle.forward(img, seed, blob, 2)
@@ -898,10 +891,10 @@ def test_large_canvas_offsets_beyond_2gib(engine, fib25_blob):
   canvas.close()
 
 
-@pytest.mark.parametrize('fast', [9, 8, 6, 4])
+@pytest.mark.parametrize('fast', [9, 8, 6])
 def test_fp16_range_fallback(fib25_model, fib25_blob, fast):
-  """conv_variants 4 / 6 / 8 keep operands in fp16: a value beyond 65504 must void
-  the run (nothing pasted) and repeat it with the bf16x3 scheme -- silently for
+  """conv_variants 6 .. 9 keep operands in fp16: a value beyond 65504 must void
+  the run (nothing pasted) and repeat it with the exact-f32 kernel -- silently for
   ffn_predict, through FFN_ERR_RANGE + retry for canvas steps."""
   from ffn_amd import _lib
   from ffn_amd import engine as hip_engine
@@ -912,10 +905,10 @@ def test_fp16_range_fallback(fib25_model, fib25_blob, fast):
   rng = np.random.RandomState(12)
   img, seed = _fov_inputs(rng, 1)
   ok = eng.predict(seed, img)
-  assert eng.get_option('conv_variant') == fast  # ordinary data stays on fp16x2
+  assert eng.get_option('conv_variant') == fast  # ordinary data stays on fp16 pairs
   big = (img * 3e5).astype(np.float32)  # conv0_a outputs far beyond 65504
   got = eng.predict(seed, big)
-  assert eng.get_option('conv_variant') == 3
+  assert eng.get_option('conv_variant') == 2 == eng.get_option('exact_variant')
   want = ffn_oracle.forward(big, seed, fib25_blob, 12)
   assert np.isfinite(got).all()
   assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
@@ -944,7 +937,7 @@ def test_fp16_range_fallback(fib25_model, fib25_blob, fast):
   assert np.isnan(seed_now).sum() == seed_now.size - 1  # nothing was pasted
   eng.set_option('conv_variant', fast)
   r = eng.step1(canvas, req, params)  # Python handle: retries with bf16x3
-  assert eng.range_fallbacks == 1 and eng.get_option('conv_variant') == 3
+  assert eng.range_fallbacks == 1 and eng.get_option('conv_variant') == 2
   assert r.range_error == 0 and np.isfinite(r.start_logit)
   assert np.isfinite(canvas.read_seed((4, 4, 4), (37, 37, 37))).all()
   canvas.close()

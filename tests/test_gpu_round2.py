@@ -73,8 +73,7 @@ def _device_canvas(exe, model, image, **kwargs):
 # exact-f32 kernel (variant 2) sums in the oracle's order and reproduces the
 # first fixture; the split-product kernels (f32 accumulation of exact 16-term
 # products) reproduce the oneDNN / f64 run -- step for step, voxel for voxel.
-_FIXTURE_OF_VARIANT = {2: '', 4: '_onednn', 5: '_onednn', 6: '_f64', 8: '_f64',
-                       9: '_f64'}
+_FIXTURE_OF_VARIANT = {2: '', 6: '_f64', 8: '_f64', 9: '_f64'}
 RUN_TOL = 5e-3  # move scores ALONG a run (amplified noise); per step: TOL
 
 
@@ -119,7 +118,7 @@ def _check_against_fixture(canvas, g):
               int(k): v for k, v in origins.items()}
 
 
-@pytest.mark.parametrize('variant', [2, 4, 5, 6, 8, 9])
+@pytest.mark.parametrize('variant', [2, 6, 8, 9])
 def test_cells250_matches_reference_minted_run(hip_exe, fib25_model, variant):
   """configs[1] at full size: the 250^3 phantom bench.py runs, first row of its
   seed grid.  The fixtures were minted by the reference's own Canvas
@@ -219,7 +218,7 @@ def test_cells250_logit_tolerance_on_canvas_states(hip_exe, fib25_model):
     for k, img, seed in samples:
       eng.set_option('conv_variant', 2)
       ref = eng.predict(seed[None], img[None])[0]
-      for v in (3, 4, 5, 6, 8):
+      for v in (6, 8, 9):
         eng.set_option('conv_variant', v)
         err = float(np.abs(eng.predict(seed[None], img[None])[0] - ref).max())
         worst[v] = max(worst.get(v, 0.0), err)

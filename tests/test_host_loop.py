@@ -336,13 +336,15 @@ def _many_canvases(shim, blob, names, **kwargs):
   return client, native_shim.ShimEngine(client, 4), canvases, gold
 
 
-@pytest.mark.parametrize('fail_round', [None, 37])
+@pytest.mark.parametrize('fail_round', [None, 37, 'short'])
 def test_segment_many_reproduces_reference_runs(shim, fib25_blob, fail_round):
   """ffn_host::segment_many (ffn_canvas_segment_many's loop) under the
   MultiCanvasDriver: five canvases, at most four per engine call, whole segments
   inside the C++ loop, Python only between segments.  Every canvas repeats the
   reference's own run step for step whatever it shared its calls with -- also
-  when a batched round is voided once (FFN_ERR_RANGE) and the call resumed."""
+  when a batched round is voided once (FFN_ERR_RANGE) and the call resumed;
+  'short' voids the round in which a canvas' loop has just ENDED (that canvas
+  keeps its result and is not resumed: resuming it would be FFN_ERR_STATE)."""
   import json
   names = ['cells72', 'cells56', 'cells72', 'cells56', 'cells56']
   client, engine, canvases, gold = _many_canvases(shim, fib25_blob, names)

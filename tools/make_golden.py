@@ -333,7 +333,8 @@ def make_masks(blob, depth):
         {k: v for k, v in cdict.items() if k.startswith('skip')})
 
 
-def make_cells250(blob, depth, forward='oracle', variables=None):
+def make_cells250(blob, depth, forward='oracle', variables=None, num_seeds=14,
+                  threads=None, tag=''):
   """BASELINE configs[1] at its full size: the 250^3 cells phantom of bench.py
   (synthetic.cells_volume seed 1234), the first row of the bench's seed grid
   (14 seeds, 5 of which start a segment) -> 3,658 FoV steps through the
@@ -344,8 +345,11 @@ def make_cells250(blob, depth, forward='oracle', variables=None):
   shape = (250, 250, 250)
   vol = synthetic.cells_volume(shape, seed=1234)
   image = synthetic.normalize(vol)
-  seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))[:14]
-  ffn_oracle.set_threads(os.cpu_count() or 1)
+  seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))
+  if num_seeds > 0:  # 14 = the first row of the grid; 0 = the WHOLE volume
+    seeds = seeds[:num_seeds]
+  threads = threads or os.cpu_count() or 1
+  ffn_oracle.set_threads(threads)
   t0 = time.time()
   forward_fn, suffix = None, ''
   if forward != 'oracle':
@@ -354,9 +358,10 @@ def make_cells250(blob, depth, forward='oracle', variables=None):
     # TensorFlow's CPU path also uses), 'f64' = double precision throughout
     import functools
     forward_fn = functools.partial(ffn_oracle.forward_torch, variables=variables,
-                                   depth=depth, threads=os.cpu_count() or 1,
+                                   depth=depth, threads=threads,
                                    f64=forward == 'f64')
     suffix = '_' + forward
+  suffix += tag
   canvas, trace, counters = run_reference_canvas(image, blob, depth,
                                                  (33, 33, 33), (8, 8, 8), seeds,
                                                  forward_fn=forward_fn)
@@ -377,7 +382,8 @@ def make_cells250(blob, depth, forward='oracle', variables=None):
   np.savez_compressed(
       os.path.join(GOLD, 'ref_canvas_cells250%s.npz' % suffix),
       forward=forward, volume_sha256=hashlib.sha256(vol.tobytes()).hexdigest(), seeds=seeds,
-      segmentation=seg.astype(np.int8), steps=steps, n_moves=n_moves,
+      segmentation=seg.astype(np.int8 if seg.max() < 128 else np.int16),
+      steps=steps, n_moves=n_moves, num_seeds=len(seeds),
       move_scores=move_scores, move_coords=move_coords,
       origins=json.dumps(origins), counters=json.dumps(keep), depth=depth,
       # the seed array after the LAST segment, around its start (a 33^3 sample
@@ -396,6 +402,11 @@ def main():
                   help='cells250: the conv-stack implementation behind the '
                   "reference Canvas (default: the C oracle's sequential f32 "
                   'fmaf chain)')
+  ap.add_argument('--num-seeds', type=int, default=14,
+                  help='cells250: seeds of the grid to run (14 = first row, '
+                  '0 = all of them: the whole volume)')
+  ap.add_argument('--threads', type=int, default=0)
+  ap.add_argument('--tag', default='', help='cells250: file-name suffix')
   args = ap.parse_args()
   os.makedirs(GOLD, exist_ok=True)
   if args.only in ('', 'weights'):
@@ -414,7 +425,8 @@ def main():
     make_masks(ffn_oracle.weights_blob(v, 12), 12)
   if args.only == 'cells250':  # slow: only on request
     v = tf_checkpoint.load_checkpoint(CKPT)
-    make_cells250(ffn_oracle.weights_blob(v, 12), 12, args.forward, v)
+    make_cells250(ffn_oracle.weights_blob(v, 12), 12, args.forward, v,
+                  args.num_seeds, args.threads or None, args.tag)
 
 
 if __name__ == '__main__':
