@@ -11,11 +11,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
-#include <map>
 #include <string>
-#include <tuple>
 #include <vector>
 
 #include "ffn_internal.h"
@@ -119,19 +116,8 @@ struct ffn_engine {
   size_t lds_bytes_d = 0;        // 3 slots x 8 planes x Rc_k rows x 16 B
   int dsched_aoff[4 * 8] = {};
   int dsched_btap[4 * 8] = {};
-  unsigned* range_flag = nullptr;  // device words: [0] tag of the last void eager run,
-                                   // [1], [2] the flags of captured runs (by parity)
-  unsigned range_tag = 0;        // tag of the last eager run
-  unsigned* cur_flag = nullptr;  // flag word / tag of the run being queued
-  unsigned cur_tag = 0;
-  unsigned* clear_flag = nullptr;  // captured runs: the word the NEXT run will use
-                                   // (faces_kernel zeroes it)
-  // option "use_graph": the 2*depth-1 conv launches of a step replayed from a
-  // captured hipGraph (one per batch size / thresholds / flag parity)
-  int use_graph = 0;
-  typedef std::tuple<int, unsigned, unsigned, int> GraphKey;
-  std::map<GraphKey, hipGraphExec_t> graphs;
-  long graph_runs = 0;
+  unsigned* range_flag = nullptr;  // device word: tag of the last void run
+  unsigned range_tag = 0;        // tag of the run being queued
   bool fp16_ok = true;           // every weight inside the fp16 range
   int conv_variant = 0;       // 0 conv32 (any FoV), 2 conv32c (exact f32), 6 conv32d, 7 = 6
                               // with 96-voxel chunks, 8 conv32m, 9 conv32mt (+ conv32m)
@@ -430,8 +416,8 @@ int launch_conv32c(ffn_engine* e, int n, const float* in, float* out,
     HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   }
   const dim3 grid(8 * a.slots_per_xcd), block(kConvThreads);
-  a.range_flag = e->cur_flag;
-  a.range_tag = e->cur_tag;
+  a.range_flag = e->range_flag;
+  a.range_tag = e->range_tag;
   if (RI == false && RO == false && SK == true && e->ablate != 0 &&
       e->Rc == 256) {
     switch (e->ablate) {  // issue-rate experiments (conv_b instantiation only)
@@ -523,8 +509,8 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   a.head_count = e->count;
   a.pad_value = head.pad_value;
   a.move_thr = head.move_thr;
-  a.range_flag = e->cur_flag;
-  a.range_tag = e->cur_tag;
+  a.range_flag = e->range_flag;
+  a.range_tag = e->range_tag;
   const bool prof = e->prof_now;
   if (prof) {
     if (e->events_used + 2 > (int)e->events.size()) {
@@ -603,25 +589,10 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
 int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
               float move_thr) {
   const Geom& g = e->g;
+  e->range_tag = e->range_tag + 1 ? e->range_tag + 1 : 1;  // never 0
   const bool sampled = (e->stack_calls % e->prof_every) == 0;
   e->stack_calls++;
   e->prof_now = e->prof_mode == 1 && sampled;
-  // a captured chain has its flag word and tag baked in: two words used in
-  // turn (the faces kernel of a run zeroes the word of the next one) and a
-  // constant tag; an eager run gets a fresh tag on word 0
-  const bool graph = e->use_graph && e->conv_variant >= 6 && !e->prof_now &&
-                     e->dbg_clock == 0 && e->depth >= 2;
-  if (graph) {
-    const int parity = (int)(e->graph_runs++ & 1);
-    e->cur_flag = e->range_flag + 1 + parity;
-    e->clear_flag = e->range_flag + 1 + (parity ^ 1);
-    e->cur_tag = 0xffffffffu;
-  } else {
-    e->range_tag = e->range_tag + 1 ? e->range_tag + 1 : 1;  // never 0
-    e->cur_flag = e->range_flag;
-    e->clear_flag = nullptr;
-    e->cur_tag = e->range_tag;
-  }
   const bool prof_chain = e->prof_mode == 2 && sampled;
   const float* W = e->weights;
   const int tz = (g.fz + kC0Z - 1) / kC0Z, ty = (g.fy + kC0Y - 1) / kC0Y,
@@ -631,8 +602,8 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     so.out_sp = reinterpret_cast<char*>(e->rawT) + (size_t)g.guard * 16;
     so.sp_plane_bytes = (g.act_stride / kFeatures) * 16;
     so.item_bytes = g.act_stride * (long)sizeof(float);
-    so.range_flag = e->cur_flag;
-    so.range_tag = e->cur_tag;
+    so.range_flag = e->range_flag;
+    so.range_tag = e->range_tag;
     hipLaunchKernelGGL(conv0a_mfma_kernel<true>, dim3(tz * ty * tx, n),
                        dim3(kC0Threads), 0, e->stream, si, pad_value,
                        W + e->w0a_off, W + e->b0a_off, e->bufT, e->seed_raw, g,
@@ -682,37 +653,8 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
       }
       return r;
     };
-    if (graph) {
-      unsigned pb, tb;
-      std::memcpy(&pb, &pad_value, 4);
-      std::memcpy(&tb, &move_thr, 4);
-      const ffn_engine::GraphKey key(n, pb, tb, (int)(e->cur_flag - e->range_flag));
-      auto it = e->graphs.find(key);
-      if (it == e->graphs.end()) {
-        if (e->graphs.size() >= 64) {  // thresholds change per request, not per step
-          for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-          e->graphs.clear();
-        }
-        hipGraph_t gr = nullptr;
-        hipGraphExec_t ex = nullptr;
-        HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-        rc = chain();
-        const hipError_t ce = hipStreamEndCapture(e->stream, &gr);
-        if (rc) {
-          if (gr) (void)hipGraphDestroy(gr);
-          return rc;
-        }
-        HIP_TRY(ce);
-        const hipError_t ie = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(gr);
-        HIP_TRY(ie);
-        it = e->graphs.emplace(key, ex).first;
-      }
-      HIP_TRY(hipGraphLaunch(it->second, e->stream));
-    } else {
-      rc = chain();
-      if (rc) return rc;
-    }
+    rc = chain();
+    if (rc) return rc;
     head_fused = true;
     head_in = e->bufX;
   } else if (e->conv_variant == 0) {
@@ -1095,9 +1037,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     e->wpackd_layer = (size_t)kDTaps * 2 * 2 * 64 * 8;  // + the all-zero tap
     E_TRY(hipMalloc(&e->wpackd, e->wpackd_layer * (2 * depth - 1) *
                                     sizeof(uint16_t)));
-    E_TRY(hipMalloc(&e->range_flag, 4 * sizeof(unsigned)));
-    E_TRY(hipMemset(e->range_flag, 0, 4 * sizeof(unsigned)));
-    e->cur_flag = e->range_flag;
+    E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
+    E_TRY(hipMemset(e->range_flag, 0, sizeof(unsigned)));
   }
 
   e->events.resize(2 * 64);
@@ -1145,8 +1086,6 @@ void ffn_engine_destroy(ffn_engine* e) {
     c->engine = nullptr;
   }
   e->canvases.clear();
-  for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-  e->graphs.clear();
   for (auto& ev : e->events)
     if (ev) (void)hipEventDestroy(ev);
   (void)hipFree(e->act_base);
@@ -1271,14 +1210,10 @@ int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
                          e->stream));
   unsigned flag = 0;
   if (e->conv_variant >= 6)
-    HIP_TRY(hipMemcpyAsync(&flag, e->cur_flag, sizeof(flag),
+    HIP_TRY(hipMemcpyAsync(&flag, e->range_flag, sizeof(flag),
                            hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  if (e->conv_variant >= 6 && flag == e->cur_tag) {
-    // (a captured run's flag word is zeroed by the faces kernel of a canvas
-    // step; the stateless path has none)
-    if (e->cur_flag != e->range_flag)
-      HIP_TRY(hipMemsetAsync(e->cur_flag, 0, sizeof(unsigned), e->stream));
+  if (e->conv_variant >= 6 && flag == e->range_tag) {
     // an operand left the fp16 range: this engine stays on the exact-f32 kernel
     rc = switch_variant(e, e->exact_variant);
     if (rc) return rc;
@@ -1310,12 +1245,7 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
-  if (!e->graphs.empty()) {  // a captured chain has the kernel choice baked in
-    HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-    e->graphs.clear();
-  }
+
   if (std::strcmp(name, "conv_variant") == 0) {
     if (value == -1) value = e->exact_variant;  // "the exact-f32 kernel of this FoV"
     if (value != 0 && value != 2 && !(value >= 6 && value <= 9))
@@ -1367,11 +1297,6 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->tail_batched = value != 0;
     return FFN_OK;
   }
-  if (std::strcmp(name, "use_graph") == 0) {
-    // 1 = the conv chain of a step is replayed from a captured hipGraph
-    e->use_graph = value != 0;
-    return FFN_OK;
-  }
   if (std::strcmp(name, "debug_layer") == 0) {
     e->dbg_layer = value;
     return FFN_OK;
@@ -1397,7 +1322,6 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   if (std::strcmp(name, "conv_variant") == 0) *value = e->conv_variant;
   else if (std::strcmp(name, "fuse_head") == 0) *value = e->fuse_head;
   else if (std::strcmp(name, "exact_variant") == 0) *value = e->exact_variant;
-  else if (std::strcmp(name, "use_graph") == 0) *value = e->use_graph;
   else if (std::strcmp(name, "store_policy") == 0) *value = e->store_policy;
   else if (std::strcmp(name, "sync_mode") == 0) *value = e->sync_mode;
   else if (std::strcmp(name, "profile_every") == 0) *value = e->prof_every;
@@ -1658,11 +1582,11 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, e->count_blocks,
                      params->move_threshold, params->disco_seed_threshold,
-                     params->deleted_threshold, e->cur_flag, e->cur_tag,
-                     e->clear_flag, h_results, h_seq, step_id);
+                     params->deleted_threshold, e->range_flag, e->range_tag,
+                     h_results, h_seq, step_id);
   hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, e->count_blocks,
-                     params->disco_seed_threshold, e->cur_flag, e->cur_tag);
+                     params->disco_seed_threshold, e->range_flag, e->range_tag);
   HIP_TRY(hipGetLastError());
   e->slot_n[slot] = n;
   e->slot_ticket[slot] = step_id;

@@ -1929,9 +1929,8 @@ __global__ __launch_bounds__(512) void faces_kernel(
     const float* __restrict__ in_seed,
     const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
     float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
-    unsigned range_tag, unsigned* __restrict__ clear_flag,
-    ffn_step_result* __restrict__ results, unsigned* __restrict__ seq,
-    unsigned step_id) {
+    unsigned range_tag, ffn_step_result* __restrict__ results,
+    unsigned* __restrict__ seq, unsigned step_id) {
   __shared__ unsigned s_cnt[8];
   __shared__ ffn_step_result s_res;
   const int item = blockIdx.x;
@@ -2057,9 +2056,6 @@ __global__ __launch_bounds__(512) void faces_kernel(
     if (lane == 0) {
       s_res.num_deleted = deleted;
       s_res.range_error = (*range_flag == range_tag) ? 1 : 0;
-      // captured conv chains (option use_graph) alternate between two flag
-      // words: the one the NEXT step's chain will raise is zeroed here
-      if (clear_flag && item == 0) *clear_flag = 0;
     }
   }
   __syncthreads();

@@ -103,6 +103,54 @@ def assign_round_robin(boxes: Sequence[SubBox], rank: int,
   return [b for b in boxes if b.index % world == rank]
 
 
+class BoxDealer:
+  """Dynamic dealing of sub-boxes to the ranks of a job.
+
+  Segment cost is heavy-tailed (the reference's own sample: max 6,330 against a
+  median of 8 FoV steps per segment), so a static deal leaves ranks idle
+  while one finishes its expensive boxes.  Here the boxes are ordered by
+  estimated cost, largest first, and every rank takes the next one whenever
+  one of its canvas slots frees up -- an atomic fetch-and-add on a counter in
+  the job's `torch.distributed` store (the TCP store every process group
+  already has; ~0.1 ms per box, no collective, nothing on the data path).
+  With more boxes than ranks x slots the ranks finish within one box of each
+  other.  world == 1 (or no store): plain iteration in the same order.
+
+  Iterating yields the SubBox objects this rank was dealt; `taken` keeps them.
+  """
+
+  def __init__(self, boxes: Sequence[SubBox], rank: int = 0, world: int = 1,
+               store=None, key: str = 'ffn_amd/next_box', cost=None):
+    if cost is None:
+      cost = lambda b: int(np.prod(b.size))
+    # stable: equal costs keep the tiler's z-major order
+    self.order = sorted(boxes, key=lambda b: -cost(b))
+    self.rank, self.world = rank, world
+    self.taken: List[SubBox] = []
+    self._key = key
+    self._store = store
+    self._local = 0
+    if world > 1 and store is None:
+      import torch.distributed as dist  # pylint:disable=g-import-not-at-top
+      self._store = dist.distributed_c10d._get_default_store()
+
+  def _next_index(self) -> int:
+    if self.world > 1:
+      return int(self._store.add(self._key, 1)) - 1
+    self._local += 1
+    return self._local - 1
+
+  def __iter__(self):
+    return self
+
+  def __next__(self) -> SubBox:
+    k = self._next_index()
+    if k >= len(self.order):
+      raise StopIteration()
+    self.taken.append(self.order[k])
+    return self.order[k]
+
+
 class _HostAssembly:
   """Assembly on host arrays (numpy; collectives on CPU tensors / gloo): the
   device-free path, also the specification of `_DeviceAssembly`."""
@@ -143,6 +191,18 @@ class _HostAssembly:
         out[...] = t.cpu().numpy()
       else:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return out
+
+  def broadcast_cores(self, out, boxes, owner, rank):
+    """One broadcast per sub-box core from the rank that segmented it."""
+    import torch  # pylint:disable=g-import-not-at-top
+    import torch.distributed as dist  # pylint:disable=g-import-not-at-top
+    for b in boxes:
+      sel = tuple(slice(l, h) for l, h in zip(b.core_lo, b.core_hi))
+      t = torch.from_numpy(np.ascontiguousarray(out[sel]))
+      dist.broadcast(t, src=int(owner[b.index]))
+      if int(owner[b.index]) != rank:
+        out[sel] = t.numpy()
     return out
 
   def margin_pairs(self, box, seg, off, merged):
@@ -228,6 +288,19 @@ class _DeviceAssembly:
       self.torch.cuda.synchronize(self.device)
     return out
 
+  def broadcast_cores(self, out, boxes, owner, rank):
+    """One RCCL broadcast per sub-box core from the rank that segmented it
+    (through a contiguous staging tensor: a core is a strided box of `out`)."""
+    import torch.distributed as dist  # pylint:disable=g-import-not-at-top
+    for b in boxes:
+      sel = tuple(slice(l, h) for l, h in zip(b.core_lo, b.core_hi))
+      t = out[sel].contiguous()
+      dist.broadcast(t, src=int(owner[b.index]))
+      if int(owner[b.index]) != rank:
+        out[sel] = t
+    self.torch.cuda.synchronize(self.device)
+    return out
+
   def margin_pairs(self, box, seg, off, merged):
     self.torch.cuda.synchronize(self.device)
     lo = [c - b for c, b in zip(box.core_lo, box.corner)]
@@ -252,7 +325,8 @@ def _assembly_for(device, ops=None):
 
 
 def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
-                        device=None, assembly=None, keep_on_device=False):
+                        device=None, assembly=None, keep_on_device=False,
+                        num_boxes=None, collective='all_reduce'):
   """Assembles one global int32 label volume from per-rank sub-box results.
 
   Args:
@@ -270,6 +344,16 @@ def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
     assembly: an assembly object to use instead (tests)
     keep_on_device: return (assembled volume as the assembly holds it, offsets,
       the sub-box labels as the assembly holds them, the assembly) instead
+    num_boxes: total number of sub-boxes of the job.  Given, the id offsets
+      follow the sub-box INDEX (exclusive scan of the per-box id counts, one
+      all_reduce of num_boxes integers): the global ids then do not depend on
+      which rank segmented which box, i.e. on the timing of a dynamic deal.
+      None: offsets by (rank, position in local_results), the static scheme.
+    collective: 'all_reduce' = every rank writes its cores into a zero-filled
+      volume, one all_reduce(MAX) (what north_star names; 2 (N-1)/N volumes
+      over each ring link); 'broadcast' = one broadcast per sub-box core from
+      its owner (needs num_boxes; (N-1)/N volumes in total, and no zero-filled
+      buffer is reduced) -- for volumes of 1024^3 and more.
 
   Returns:
     (global int32 ndarray, list of per-sub-box id offsets of this rank)
@@ -279,30 +363,57 @@ def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
 
   asm = assembly if assembly is not None else _assembly_for(device)
   local_results = [(box, asm.labels(seg)) for box, seg in local_results]
-  # 1. global id space: offsets by exclusive scan over (rank, sub-box) order
+  coll_dev = device if asm.on_device else None
   local_max = [asm.max_id(seg) for _, seg in local_results]
-  my_total = int(sum(local_max))
-  if world > 1:
-    t = torch.tensor([my_total], dtype=torch.int64,
-                     device=device if asm.on_device else None)
-    gathered = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(gathered, t)
-    totals = [int(g.item()) for g in gathered]
+  owner = None
+  if num_boxes is not None:
+    # 1. global id space by sub-box index
+    counts = torch.zeros(2 * num_boxes, dtype=torch.int64, device=coll_dev)
+    for (box, _), m in zip(local_results, local_max):
+      counts[box.index] = m
+      counts[num_boxes + box.index] = rank + 1
+    if world > 1:
+      dist.all_reduce(counts, op=dist.ReduceOp.MAX)
+    counts = counts.cpu().numpy()
+    owner = counts[num_boxes:] - 1
+    starts = np.concatenate([[0], np.cumsum(counts[:num_boxes])])
+    total = int(starts[-1])
+    offsets = [int(starts[box.index]) for box, _ in local_results]
   else:
-    totals = [my_total]
-  base = int(sum(totals[:rank]))
-  offsets = []
-  for m in local_max:
-    offsets.append(base)
-    base += m
-  if sum(totals) >= 2**31:
+    # 1. global id space: offsets by exclusive scan over (rank, sub-box) order
+    my_total = int(sum(local_max))
+    if world > 1:
+      t = torch.tensor([my_total], dtype=torch.int64, device=coll_dev)
+      gathered = [torch.zeros_like(t) for _ in range(world)]
+      dist.all_gather(gathered, t)
+      totals = [int(g.item()) for g in gathered]
+    else:
+      totals = [my_total]
+    base = int(sum(totals[:rank]))
+    offsets = []
+    for m in local_max:
+      offsets.append(base)
+      base += m
+    total = int(sum(totals))
+  if total >= 2**31:
     raise OverflowError('global id space exceeds int32')
 
-  # 2. owned cores into a zero-filled volume, then union by all_reduce(MAX)
+  # 2. owned cores into a zero-filled volume, then the union over the ranks
   out = asm.zeros(shape_zyx)
   for (box, seg), off in zip(local_results, offsets):
     asm.place_core(out, box, seg, off)
-  out = asm.all_reduce_max(out, world)
+  if collective == 'broadcast' and world > 1:
+    if owner is None:
+      raise ValueError("collective='broadcast' needs num_boxes")
+    boxes = getattr(asm, 'job_boxes', None)
+    if boxes is None:
+      raise ValueError("collective='broadcast' needs assembly.job_boxes "
+                       '(every sub-box of the job, by index)')
+    out = asm.broadcast_cores(out, boxes, owner, rank)
+  elif collective not in ('all_reduce', 'broadcast'):
+    raise ValueError('unknown collective %r' % (collective,))
+  else:
+    out = asm.all_reduce_max(out, world)
   if keep_on_device:
     return out, offsets, local_results, asm
   return asm.to_host(out), offsets
@@ -412,7 +523,8 @@ def reconcile_segmentations(local_results, shape_zyx, rank: int, world: int,
                             device=None,
                             min_overlap_voxels: int = MIN_OVERLAP_VOXELS,
                             min_overlap_fraction: float = MIN_OVERLAP_FRACTION,
-                            ops=None, keep_on_device=False, assembly=None):
+                            ops=None, keep_on_device=False, assembly=None,
+                            num_boxes=None, collective='all_reduce'):
   """merge_segmentations + union-find reconciliation of objects that cross a
   cut between sub-boxes (doc/manual.md:119-127).
 
@@ -429,7 +541,7 @@ def reconcile_segmentations(local_results, shape_zyx, rank: int, world: int,
   asm = assembly if assembly is not None else _assembly_for(device, ops)
   merged, offsets, held, asm = merge_segmentations(
       local_results, shape_zyx, rank, world, device, assembly=asm,
-      keep_on_device=True)
+      keep_on_device=True, num_boxes=num_boxes, collective=collective)
   mine = []
   for (box, seg), off in zip(held, offsets):
     pa, pb, cnt = asm.margin_pairs(box, seg, off, merged)
@@ -458,15 +570,20 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
                    batch_size=None, reconcile: bool = True,
                    min_overlap_voxels: int = MIN_OVERLAP_VOXELS,
                    min_overlap_fraction: float = MIN_OVERLAP_FRACTION,
-                   save: bool = True):
+                   save: bool = True, deal: str = 'dynamic',
+                   collective: str = 'all_reduce', store=None):
   """Segments a whole bounding box on `world` GPUs (BASELINE configs C4 / C5).
 
   One process per GPU calls this with its rank.  The box is cut into
-  overlapping sub-boxes (`tile_volume`), dealt round-robin; each rank segments
-  its sub-boxes concurrently on its GPU (`Runner.run_many`: one batched engine
-  call per round) with no communication; then the ranks assemble one global
-  label volume (all-reduce over RCCL) and, if `reconcile`, merge objects cut by
-  sub-box borders (`reconcile_segmentations`).
+  overlapping sub-boxes (`tile_volume`; make them several times as many as
+  ranks x batch_size) that the ranks take one by one as their canvas slots
+  free up (`BoxDealer`, largest first; deal='static': round-robin); each rank
+  segments its sub-boxes concurrently on its GPU (`Runner.run_many`: one
+  batched engine call per round) with no communication; then the ranks
+  assemble one global label volume over RCCL (`merge_segmentations`; the ids
+  follow the sub-box index, so the result does not depend on the deal) and, if
+  `reconcile`, merge objects cut by sub-box borders
+  (`reconcile_segmentations`).
 
   Args:
     runner: a started `ffn_amd.inference.runner.Runner` (direct=True)
@@ -475,47 +592,64 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
     rank, world, device: torch.distributed coordinates (world == 1: no
       collective is issued)
     batch_size: sub-boxes advanced per engine call on one GPU
+    deal: 'dynamic' or 'static'
+    collective: 'all_reduce' or 'broadcast' (see merge_segmentations)
+    store: the job's torch.distributed store (default: the default group's)
 
   Returns:
     (global int32 label volume of shape size_zyx -- identical on every rank --,
-     dict with 'boxes', 'mine', 'offsets', 'edges', 'roots')
+     dict with 'boxes', 'mine', 'offsets', 'edges', 'roots', 'seconds')
   """
+  import time  # pylint:disable=g-import-not-at-top
   corner_zyx = tuple(int(c) for c in corner_zyx)
   size_zyx = tuple(int(s) for s in size_zyx)
   # full-size sub-boxes at the back edge: a clipped sliver narrower than the
   # FoV could not host a single seed
   boxes = tile_volume(size_zyx, sub_size_zyx, overlap_zyx, back_shift=True)
-  mine = assign_round_robin(boxes, rank, world)
-  results = [None] * len(mine)
+  if deal == 'dynamic':
+    dealer = BoxDealer(boxes, rank, world, store=store)
+  elif deal == 'static':
+    dealer = iter(assign_round_robin(boxes, rank, world))
+  else:
+    raise ValueError('unknown deal %r' % (deal,))
+  mine, results = [], []
   asm = _assembly_for(device)
+  asm.job_boxes = boxes
+
+  def subvolumes():
+    for b in dealer:
+      mine.append(b)
+      results.append(None)
+      yield tuple(c + o for c, o in zip(corner_zyx, b.corner)), b.size
 
   def collect(index, canvas):  # the canvas is closed right after this call
     # the -1 "excluded" markers (runner.py:452) are dropped; on a GPU the
     # labels go from the canvas into the assembly's own device array
     results[index] = (mine[index], asm.labels(canvas.segmentation))
 
-  runner.run_many(
-      [(tuple(c + o for c, o in zip(corner_zyx, b.corner)), b.size)
-       for b in mine], batch_size=batch_size, save=save, on_done=collect)
+  t0 = time.perf_counter()
+  runner.run_many(subvolumes(), batch_size=batch_size, save=save,
+                  on_done=collect)
+  t_seg = time.perf_counter() - t0
   for b, r in zip(mine, results):
     if r is None:
       raise RuntimeError('sub-box %r was skipped (output exists / masked); '
                          'assemble from the saved files instead' % (b,))
   info = {'boxes': boxes, 'mine': mine}
-  import time  # pylint:disable=g-import-not-at-top
   t0 = time.perf_counter()
   if reconcile:
     merged, offsets, edges, roots = reconcile_segmentations(
         results, size_zyx, rank, world, device, min_overlap_voxels,
-        min_overlap_fraction, keep_on_device=True, assembly=asm)
+        min_overlap_fraction, keep_on_device=True, assembly=asm,
+        num_boxes=len(boxes), collective=collective)
     info.update(offsets=offsets, edges=edges, roots=roots)
   else:
     merged, offsets, _, _ = merge_segmentations(
         results, size_zyx, rank, world, device, assembly=asm,
-        keep_on_device=True)
+        keep_on_device=True, num_boxes=len(boxes), collective=collective)
     info.update(offsets=offsets, edges=np.zeros((0, 3), np.int64), roots={})
   info['assemble_seconds'] = time.perf_counter() - t0
-  info['local_results'] = results
+  info['segment_seconds'] = t_seg  # this rank's own: waiting at the collective
+  info['local_results'] = results  # is in assemble_seconds
   info['merged_device'] = merged if asm.on_device else None
   return asm.to_host(merged), info
-

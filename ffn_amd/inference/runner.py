@@ -379,7 +379,10 @@ class Runner:
     a slot frees up, and saved and closed the moment it finishes.
 
     Args:
-      subvolumes: iterable of (corner_zyx, size_zyx)
+      subvolumes: iterable of (corner_zyx, size_zyx); consumed LAZILY, one
+        item whenever a canvas slot frees up -- a generator may decide what
+        comes next only then (`distributed.BoxDealer`: sub-boxes dealt to the
+        ranks of a job as they become free)
       batch_size: FoV steps per engine call (default: the engine's max batch)
       save: write each result like `run()` does (segmentation npz [+ prob])
       window: canvases open at once (default 2 x batch_size: two groups of
@@ -397,9 +400,7 @@ class Runner:
     if reset_counters:
       self.counters.reset()
     out_dir = self.request.segmentation_output_dir
-    subvolumes = [(tuple(int(c) for c in corner), tuple(int(s) for s in size))
-                  for corner, size in subvolumes]
-    canvases = [None] * len(subvolumes)
+    canvases = []
     meta = {}
     driver = inference.MultiCanvasDriver(self.executor.engine, batch_size)
     if window is None:
@@ -407,6 +408,9 @@ class Runner:
 
     def jobs():
       for index, (corner, size) in enumerate(subvolumes):
+        corner = tuple(int(c) for c in corner)
+        size = tuple(int(v) for v in size)
+        canvases.append(None)
         seg_path = storage.segmentation_path(out_dir, corner)
         if save and os.path.exists(seg_path):
           continue

@@ -86,17 +86,40 @@ class BaseSeedPolicy:
     return mask
 
 
+def _ensure_spacing(coords, spacing, p_norm):
+  """skimage._shared.coord.ensure_spacing: walking the peaks from the highest
+  down, a peak drops every other one closer than `spacing` (strictly; Minkowski
+  p-norm) to it."""
+  if len(coords) < 2 or spacing <= 0:
+    return coords
+  from scipy.spatial import cKDTree  # pylint:disable=g-import-not-at-top
+  near = cKDTree(coords).query_ball_point(coords, r=spacing, p=p_norm)
+  rejected = set()
+  for i, cand in enumerate(near):
+    if i in rejected:
+      continue
+    for j in cand:
+      if j == i:
+        continue
+      d = np.abs(coords[j] - coords[i]).astype(np.float64)
+      dist = d.max() if np.isinf(p_norm) else (d**p_norm).sum()**(1.0 / p_norm)
+      if dist < spacing:
+        rejected.add(j)
+  return np.delete(coords, sorted(rejected), axis=0)
+
+
 def peak_local_max(image, min_distance=1, threshold_abs=None, threshold_rel=None,
-                   footprint=None):
-  """skimage.feature.peak_local_max (0.18: exclude_border=True, p_norm=inf, no
-  labels, all peaks) -> [N, ndim] coordinates, highest peak first.
+                   footprint=None, p_norm=np.inf):
+  """skimage.feature.peak_local_max (0.18: exclude_border=True, no labels, all
+  peaks) -> [N, ndim] coordinates, highest peak first.
 
   A peak = a voxel equal to the maximum over the (2 min_distance + 1)^ndim box
   (or `footprint`; outside the image counts as 0) and above
   max(threshold_abs or image.min(), threshold_rel * image.max()); peaks within
-  min_distance of the border are dropped; of two peaks within min_distance
-  (Chebyshev) of each other the lower one is dropped (skimage's
-  `ensure_spacing`; only plateaus / ties can produce such a pair)."""
+  min_distance of the border are dropped; then `_ensure_spacing`.  Equal
+  intensities are ordered by numpy's unstable sort in skimage, i.e. not defined:
+  the order is exact for tie-free images (every caller below but the two
+  ImagePeaks policies adds the reference's tie-breaking noise)."""
   image = np.asarray(image)
   if image.size == 0:
     return np.zeros((0, image.ndim), np.intp)
@@ -113,37 +136,16 @@ def peak_local_max(image, min_distance=1, threshold_abs=None, threshold_rel=None
     if mask.all():  # a constant image has no peak
       mask[...] = False
     mask &= image > threshold
-  if min_distance > 0:  # exclude_border=True: the border width is min_distance
-    inner = np.zeros_like(mask)
-    inner[tuple(slice(min_distance, max(n - min_distance, min_distance))
-                for n in mask.shape)] = True
-    mask &= inner
+  for axis in range(mask.ndim if min_distance > 0 else 0):
+    # exclude_border=True: the border width is min_distance
+    edge = [slice(None)] * mask.ndim
+    edge[axis] = slice(None, min_distance)
+    mask[tuple(edge)] = False
+    edge[axis] = slice(-min_distance, None)
+    mask[tuple(edge)] = False
   coords = np.transpose(np.nonzero(mask))
-  order = np.argsort(-image[mask], kind='stable')
-  coords = coords[order]
-  if len(coords) > 1 and min_distance > 0:
-    # ensure_spacing: greedily keep the higher peak of any pair closer than
-    # min_distance in every axis
-    from scipy.spatial import cKDTree  # pylint:disable=g-import-not-at-top
-    tree = cKDTree(coords)
-    pairs = tree.query_pairs(r=min_distance, p=np.inf)
-    if pairs:
-      near = collections_defaultdict_list()
-      for i, j in pairs:
-        near[i].append(j)
-        near[j].append(i)
-      rejected = set()
-      for i in range(len(coords)):
-        if i in rejected:
-          continue
-        rejected.update(j for j in near.get(i, ()) if j > i)
-      coords = np.delete(coords, sorted(rejected), axis=0)
-  return coords
-
-
-def collections_defaultdict_list():
-  import collections  # pylint:disable=g-import-not-at-top
-  return collections.defaultdict(list)
+  coords = coords[np.argsort(-image[mask], kind='stable')]
+  return _ensure_spacing(coords, min_distance, p_norm)
 
 
 def _find_peaks(distances, **kwargs):
@@ -348,41 +350,12 @@ class PolicyImagePeaks2DDisk(BaseSeedPolicy):
     footprint = _disk(self._disk_radius).astype(bool)
     coords = []
     for z in range(img.shape[0]):
-      for y, x in peak_local_max_p2(img[z, ...], self._min_distance_2d,
-                                    self._threshold_rel, footprint):
+      for y, x in peak_local_max(img[z, ...],
+                                 min_distance=self._min_distance_2d,
+                                 threshold_rel=self._threshold_rel,
+                                 footprint=footprint, p_norm=2):
         coords.append((z, y, x))
     self.coords = np.array(coords).reshape(-1, 3)
-
-
-def peak_local_max_p2(image, min_distance, threshold_rel, footprint):
-  """peak_local_max(..., p_norm=2, exclude_border=True, footprint=...): the
-  pair-wise spacing test uses the Euclidean distance."""
-  image = np.asarray(image)
-  threshold = max(image.min(), threshold_rel * image.max())
-  mx = ndimage.maximum_filter(image, footprint=footprint, mode='constant')
-  mask = image == mx
-  if mask.all():
-    mask[...] = False
-  mask &= image > threshold
-  inner = np.zeros_like(mask)
-  inner[tuple(slice(min_distance, max(n - min_distance, min_distance))
-              for n in mask.shape)] = True
-  mask &= inner
-  coords = np.transpose(np.nonzero(mask))
-  coords = coords[np.argsort(-image[mask], kind='stable')]
-  if len(coords) > 1:
-    from scipy.spatial import cKDTree  # pylint:disable=g-import-not-at-top
-    pairs = cKDTree(coords).query_pairs(r=min_distance, p=2)
-    near = collections_defaultdict_list()
-    for i, j in pairs:
-      near[i].append(j)
-      near[j].append(i)
-    rejected = set()
-    for i in range(len(coords)):
-      if i not in rejected:
-        rejected.update(j for j in near.get(i, ()) if j > i)
-    coords = np.delete(coords, sorted(rejected), axis=0)
-  return coords
 
 
 class PolicyGrid3d(BaseSeedPolicy):

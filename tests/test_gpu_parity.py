@@ -179,7 +179,7 @@ def test_c5_model_full_depth(fib25_model):
   seed = rng.normal(0, 2, (2, 21, 41, 41)).astype(np.float32)
   blob = ffn_oracle.weights_blob(variables, 18)
   want = ffn_oracle.forward(img, seed, blob, 18)
-  for variant in (2, 6, 7, eng.get_option('conv_variant')):
+  for variant in sorted({2, 6, eng.get_option('conv_variant')}):
     eng.set_option('conv_variant', variant)
     got = eng.predict(seed, img)
     err = np.abs(got - want).max()

@@ -4,7 +4,7 @@ import numpy as np
 from scipy import ndimage
 
 
-def edt(data, anisotropy=(1, 1, 1), **kwargs):
+def edt(data, anisotropy=None, **kwargs):
   del kwargs
   return ndimage.distance_transform_edt(np.asarray(data) != 0,
                                         sampling=anisotropy)
