@@ -88,10 +88,10 @@ def model_variables():
   return v
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA
-# conv32x3 (default): every f32 product = 6 exact bf16 x bf16 products on the
-# bf16 MFMA, so the kernel's own ceiling in ALGORITHMIC (f32) flops is 1/6 of
-# the dense bf16 peak.
-BF16X3_PRODUCTS = 6
+# the split-product kernels (conv_variant >= 6): every f32 product = 3 fp16
+# products on the 16-bit MFMA, so their ceiling in ALGORITHMIC (f32) flops is
+# 1/3 of the dense 16-bit peak
+SPLIT_PRODUCTS = 3
 
 
 class _Done(Exception):
@@ -404,7 +404,16 @@ def run_sharded(args, rank, local_rank, world):
 
   n = args.sharded_volume
   shape = (n, n, n)
-  vol = synthetic.cells_volume(shape, seed=4321)  # the SAME volume on every rank
+  # ONE volume for the job: rank 0 builds it, the others map it (a per-rank
+  # build costs a nearest-centre query per voxel -- 10^9 at 1024^3 -- per rank)
+  t_setup0 = time.perf_counter()
+  shm = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
+  vol_path = os.path.join(shm, 'ffn_amd_bench_cells_%d_%s.npy' % (
+      n, os.environ.get('MASTER_PORT', str(os.getpid()))))
+  vol = synthetic.shared_volume(
+      lambda: synthetic.cells_volume(shape, seed=4321), vol_path, rank,
+      barrier if world > 1 else None)
+  t_volume = time.perf_counter() - t_setup0
   request = make_request()
   request.seed_policy = 'PolicyPeaks'
   out_dir = tempfile.mkdtemp(prefix='ffn_sharded_%d_' % rank)
@@ -414,38 +423,70 @@ def run_sharded(args, rank, local_rank, world):
   run = runner_lib.Runner(device_id=local_rank)
   run.start(request, batch_size=args.sharded_batch, direct=True,
             image_volume=vol)
+  eng = run.executor.engine
   if args.conv_variant is not None:
-    run.executor.engine.set_option('conv_variant', args.conv_variant)
-  conv_variant = run.executor.engine.get_option('conv_variant')
-  sub = (args.sharded_sub,) * 3
+    eng.set_option('conv_variant', args.conv_variant)
+  for name, value in _engine_options(args):
+    eng.set_option(name, value)
+  sub = tuple(args.sharded_sub_zyx) if args.sharded_sub_zyx else (
+      (args.sharded_sub,) * 3)
   ov = tuple(FOV)
   boxes = ffn_dist.tile_volume(shape, sub, ov, back_shift=True)
-  mine = ffn_dist.assign_round_robin(boxes, rank, world)
+  # sub-boxes are taken by the ranks as their canvas slots free up (the cost of
+  # a box is heavy-tailed); ids follow the box index, so the assembled volume
+  # does not depend on the deal
+  dealer = (ffn_dist.BoxDealer(boxes, rank, world) if args.sharded_deal == 'dynamic'
+            else iter(ffn_dist.assign_round_robin(boxes, rank, world)))
   asm = ffn_dist._assembly_for(device)
-  results = [None] * len(mine)
+  asm.job_boxes = boxes
+  mine, results = [], []
+
+  def subvolumes():
+    for b in dealer:
+      mine.append(b)
+      results.append(None)
+      yield b.corner, b.size
 
   def collect(index, canvas):
     results[index] = (mine[index], asm.labels(canvas.segmentation))
 
+  # kernel-only rate of the batched step (resident FoVs, no canvas): what the
+  # conv chain takes per FoV and launch at this batch -> the batched roofline
+  eng.forward_resident(args.sharded_batch, 3)
+  eng.synchronize()
+  tk = time.perf_counter()
+  kernel_reps = 20
+  eng.forward_resident(args.sharded_batch, kernel_reps)
+  eng.synchronize()
+  stack_us = (time.perf_counter() - tk) / kernel_reps * 1e6
+  t_setup = time.perf_counter() - t_setup0
+  eng.set_option('stat_reset', 0)
   barrier()
   t0 = time.perf_counter()
-  run.run_many([(b.corner, b.size) for b in mine],
-               batch_size=args.sharded_batch, save=False, on_done=collect)
+  run.run_many(subvolumes(), batch_size=args.sharded_batch, save=False,
+               on_done=collect, groups=args.sharded_groups,
+               max_steps_per_canvas=args.sharded_max_steps or None)
   torch.cuda.synchronize()
   t_seg_local = time.perf_counter() - t0
   barrier()
   t_seg = time.perf_counter() - t0
   steps = run.counters['update_at-calls'].value
   voxels = run.counters['voxels-segmented'].value
+  conv_variant = eng.get_option('conv_variant')  # after the run: what it used
+  step_calls = eng.get_option('stat_step_calls')
+  step_items = eng.get_option('stat_step_items')
+  step_hist = {k: eng.get_option('stat_hist_%d' % k)
+               for k in range(1, args.sharded_batch + 1)}
+  kw = dict(num_boxes=len(boxes), collective=args.sharded_collective)
   # timed assembly, in two parts (after one untimed pass: allocations, code
   # objects and the RCCL communicator are set up by the first call)
   merged, _, _, _ = ffn_dist.merge_segmentations(
-      results, shape, rank, world, device, assembly=asm, keep_on_device=True)
+      results, shape, rank, world, device, assembly=asm, keep_on_device=True, **kw)
   del merged
   barrier()
   tm = time.perf_counter()
   merged, offsets, held, _ = ffn_dist.merge_segmentations(
-      results, shape, rank, world, device, assembly=asm, keep_on_device=True)
+      results, shape, rank, world, device, assembly=asm, keep_on_device=True, **kw)
   barrier()
   merge_ms = (time.perf_counter() - tm) * 1e3
   plain_ids = int(torch.unique(merged).numel()) - 1
@@ -453,22 +494,32 @@ def run_sharded(args, rank, local_rank, world):
   barrier()
   tr = time.perf_counter()
   merged, offsets, edges, roots = ffn_dist.reconcile_segmentations(
-      results, shape, rank, world, device, keep_on_device=True, assembly=asm)
+      results, shape, rank, world, device, keep_on_device=True, assembly=asm, **kw)
   barrier()
   reconcile_total_ms = (time.perf_counter() - tr) * 1e3
   final_ids = int(torch.unique(merged).numel()) - 1
-  tot = torch.tensor([float(steps), float(voxels), t_seg_local],
-                     dtype=torch.float64, device=device)
+  tot = torch.tensor([float(steps), float(voxels), t_seg_local, t_seg_local,
+                      float(len(mine))], dtype=torch.float64, device=device)
+  per_rank = None
   if world > 1:
+    gathered = [torch.zeros_like(tot) for _ in range(world)]
+    dist.all_gather(gathered, tot)
+    per_rank = [[float(v) for v in g.tolist()] for g in gathered]
     part = tot.clone()
     dist.all_reduce(tot[:2], op=dist.ReduceOp.SUM)
-    dist.all_reduce(part[2:], op=dist.ReduceOp.MAX)
+    dist.all_reduce(part[2:3], op=dist.ReduceOp.MAX)
     tot[2] = part[2]
+  if rank == 0 and world > 1:
+    try:
+      os.remove(vol_path)
+    except OSError:
+      pass
   check = None
   if world == 1 and not args.no_cpu_baseline:
     # checker leg (untimed): the assembly against its numpy specification
     from oracle import labels_oracle
     host_results = [(b, seg.cpu().numpy()) for b, seg in held]
+    host_results.sort(key=lambda r: r[0].index)  # ids follow the box index
     want, want_edges, _ = labels_oracle.reconcile(
         host_results, shape, ffn_dist.MIN_OVERLAP_VOXELS,
         ffn_dist.MIN_OVERLAP_FRACTION)
@@ -483,7 +534,13 @@ def run_sharded(args, rank, local_rank, world):
     dist.destroy_process_group()
   if rank != 0:
     return
-  steps_all, voxels_all, t_seg_max = (float(v) for v in tot.tolist())
+  steps_all, voxels_all, t_seg_max = (float(v) for v in tot.tolist()[:3])
+  # batched roofline: algorithmic flops of the conv launches of one stack at this
+  # batch / the time of the whole resident stack (conv0_a included: it is
+  # 1 / (2 depth) of the launches), against the ceiling of the arithmetic used
+  fov_launch_us = stack_us / args.sharded_batch / (2 * DEPTH)
+  batched_tflops = CONV32_FLOPS / (fov_launch_us * 1e-6) / 1e12
+  batched_peak = PEAK_BF16_MFMA_TFLOPS / 3.0
   out = {
       'metric': 'FoV-steps/sec (one %d^3 volume sharded by sub-box over %d GPU(s))'
                 % (n, world),
@@ -499,16 +556,48 @@ def run_sharded(args, rank, local_rank, world):
       'dtype': 'f32 (split products on the fp16 MFMA)',
       'data': 'synthetic',
       'config': {
-          'workload': ('configs[3]-shaped: ONE synthetic cells %d^3 uint8 volume, '
-                       '%d overlapping sub-boxes of %d^3 (overlap = FoV) dealt '
-                       'round-robin, %d concurrent canvases per GPU, GPU '
-                       'PolicyPeaks seeds, FIB-25 weights; assembly on the devices'
-                       % (n, len(boxes), args.sharded_sub, args.sharded_batch)),
+          'workload': ('configs[2] / configs[3]-shaped: ONE synthetic cells %d^3 '
+                       'uint8 volume, %d overlapping sub-boxes of %s (overlap = '
+                       'FoV), %s deal, %d canvases open per GPU in %d group(s) '
+                       'of %d (= FoVs per engine call), GPU PolicyPeaks seeds, '
+                       'FIB-25 weights; assembly on the devices'
+                       % (n, len(boxes), 'x'.join(str(v) for v in sub),
+                          args.sharded_deal,
+                          args.sharded_batch * args.sharded_groups,
+                          args.sharded_groups, args.sharded_batch)),
           'volume': list(shape),
           'sub_boxes': len(boxes),
           'conv_variant': conv_variant,
+          'engine_options': dict(_engine_options(args)),
+          'max_steps_per_canvas': args.sharded_max_steps or None,
           'parallelism': 'sub-boxes sharded over ranks; collectives only in the '
                          'final assembly (RCCL)',
+      },
+      'setup_seconds': {'total': round(t_setup, 2), 'volume': round(t_volume, 2),
+                        'how': 'rank 0 builds the synthetic volume once, the '
+                               'other ranks map it (/dev/shm); untimed'},
+      'per_rank': None if per_rank is None else [
+          {'fov_steps': int(r[0]), 'busy_seconds': round(r[3], 3),
+           'sub_boxes': int(r[4])} for r in per_rank],
+      'engine_calls': {
+          'batched_steps': step_calls,
+          'mean_fovs_per_step': round(step_items / max(step_calls, 1), 2),
+          'steps_by_fovs': {str(k): v for k, v in step_hist.items() if v},
+          'note': 'rank 0; what separates the end-to-end rate from the kernel '
+                  'rate: steps with fewer FoVs than the batch (canvases between '
+                  'segments, the tail of the job) and host turn-around',
+      },
+      'batched_kernel': {
+          'batch': args.sharded_batch,
+          'us_per_stack': round(stack_us, 1),
+          'us_per_fov_launch': round(fov_launch_us, 3),
+          'achieved': round(batched_tflops, 1),
+          'peak': round(batched_peak, 1),
+          'unit': 'TFLOP/s',
+          'frac': round(batched_tflops / batched_peak, 4),
+          'timing': 'wall clock over %d resident stacks of %d FoVs (conv0_a + '
+                    '%d conv launches each), / batch / %d launches'
+                    % (kernel_reps, args.sharded_batch, 2 * DEPTH - 1, 2 * DEPTH),
       },
       'segmentation_seconds': round(t_seg, 3),
       'voxels_segmented_per_s': round(voxels_all / t_seg, 1),
@@ -581,7 +670,7 @@ def cpu_baseline(args):
       pass
     steps = n[0] - 1
     dt = time.perf_counter() - t0[0]
-    traces[id(forward_fn) if forward_fn is not None else 0] = list(oc.trace)
+    traces['torch_onednn' if forward_fn is not None else 'c_oracle'] = list(oc.trace)
     return steps / dt, steps, dt
 
   results = {}
@@ -596,7 +685,9 @@ def cpu_baseline(args):
   ffn_oracle.set_threads(best_thr)
   rate_c, steps_c, dt_c = run(None, args.cpu_seconds / 2, args.cpu_steps)
   results['c_oracle'] = (rate_c, steps_c, dt_c, best_thr)
-  oracle_trace = traces[0]  # (FoV position, queued moves) of the C oracle's run
+  # (FoV position, queued moves) of the C oracle's run; the oneDNN-forward
+  # run is kept too: the GPU replays both (gpu_parity_leg)
+  oracle_trace = {'c_oracle': traces['c_oracle']}
   try:
     import torch
     best_t, best_rate = None, 0.0
@@ -611,6 +702,7 @@ def cpu_baseline(args):
                            depth=DEPTH, threads=best_t)
     rate_t, steps_t, dt_t = run(fn, args.cpu_seconds / 2, args.cpu_steps)
     results['torch_onednn'] = (rate_t, steps_t, dt_t, best_t)
+    oracle_trace['torch_onednn'] = traces['torch_onednn']
   except ImportError:
     pass
   name = max(results, key=lambda k: results[k][0])
@@ -623,25 +715,29 @@ def cpu_baseline(args):
       'kind': 'port',
       'implementation': name,
       'all': {k: round(v[0], 3) for k, v in results.items()},
-      'sample': ('first %d FoV steps of the same %s %d^3 workload (same seeds, '
+      'sample': ('first %d FoV steps of the same %s %s workload (same seeds, '
                  'options, weights) through the oracle canvas loop with the %s '
                  'conv stack on %d threads, %.1f s'
-                 % (steps, args.workload, args.volume, name, thr, dt)),
+                 % (steps, args.workload, 'x'.join(str(v) for v in VOLUME_ZYX),
+                    name, thr, dt)),
   }
 
 
-def gpu_parity_leg(res, oracle_trace, tol=1e-4):
+def gpu_parity_leg(res, oracle_traces, tol=1e-4):
   """The first FoV steps of the bench workload once more on the GPU -- a fresh
   device canvas, same volume / seeds / options, default kernels -- compared
-  step for step with the oracle trajectory the cpu_baseline leg just produced:
-  FoV positions and queued move targets must be equal, move scores (the face
-  maxima of the pasted logits) within `tol`.  Untimed; rank 0 at N = 1 only."""
+  step for step with the trajectories the cpu_baseline leg just produced with
+  the oracle's canvas loop: one behind the C oracle's forward (sequential f32
+  sums), one behind the torch-CPU / oneDNN forward (the stand-in for the
+  reference's TF CPU path).  FoV positions and queued move targets must be
+  equal, move scores (the face maxima of the pasted logits) within `tol`.
+  Untimed; rank 0 at N = 1 only."""
   from ffn_amd.inference import inference
   from ffn_amd.inference import inference_utils
   from ffn_amd.inference import movement
   from ffn_amd.inference import seed as seed_lib
 
-  n_want = len(oracle_trace)
+  n_want = max((len(t) for t in oracle_traces.values()), default=0)
   if n_want == 0:
     return {'parity_steps_checked': 0, 'parity_ok': False}
   exe, model, request = res['exe'], res['model'], res['request']
@@ -677,27 +773,41 @@ def gpu_parity_leg(res, oracle_trace, tol=1e-4):
   except _Enough:
     pass
   canvas.close()
-  ok = len(got) >= n_want
-  max_err = 0.0
-  first_bad = None
-  for k in range(min(len(got), n_want)):
-    (gp, gm), (op, om) = got[k], oracle_trace[k]
-    same = (gp == tuple(int(v) for v in op) and len(gm) == len(om) and
-            all(tuple(int(v) for v in a[1]) == b[1] for a, b in zip(om, gm)))
-    if same and gm:
-      err = max(abs(a[0] - b[0]) for a, b in zip(om, gm))
-      max_err = max(max_err, err)
-      same = err <= tol
-    if not same:
-      ok = False
-      first_bad = k
-      break
-  return {'parity_steps_checked': min(len(got), n_want), 'parity_ok': bool(ok),
-          'parity_max_move_score_err': max_err, 'parity_tolerance': tol,
-          'parity_first_mismatch_step': first_bad,
+
+  def compare(trace):
+    n = len(trace)
+    ok = len(got) >= n
+    max_err = 0.0
+    first_bad = None
+    for k in range(min(len(got), n)):
+      (gp, gm), (op, om) = got[k], trace[k]
+      same = (gp == tuple(int(v) for v in op) and len(gm) == len(om) and
+              all(tuple(int(v) for v in a[1]) == b[1] for a, b in zip(om, gm)))
+      if same and gm:
+        err = max(abs(a[0] - b[0]) for a, b in zip(om, gm))
+        max_err = max(max_err, err)
+        same = err <= tol
+      if not same:
+        ok = False
+        first_bad = k
+        break
+    return {'steps_checked': min(len(got), n), 'ok': bool(ok),
+            'max_move_score_err': max_err, 'first_mismatch_step': first_bad}
+
+  legs = {name: compare(trace) for name, trace in oracle_traces.items()}
+  main = legs['c_oracle']
+  return {'parity_steps_checked': main['steps_checked'],
+          'parity_ok': bool(all(l['ok'] for l in legs.values())),
+          'parity_max_move_score_err': max(l['max_move_score_err']
+                                           for l in legs.values()),
+          'parity_tolerance': tol,
+          'parity_first_mismatch_step': main['first_mismatch_step'],
+          'parity_legs': legs,
           'parity_what': 'FoV position, queued move targets (equal) and move '
                          'scores (abs tol) of the first steps of this workload: '
-                         'default GPU path vs the CPU oracle canvas loop'}
+                         'default GPU path vs the CPU oracle canvas loop, once '
+                         'behind the C oracle forward and once behind the '
+                         'torch-CPU / oneDNN forward'}
 
 
 def _self_launch(args):
@@ -732,7 +842,20 @@ def main():
                   'one volume tiled into sub-boxes, timed assembly (configs[3])')
   ap.add_argument('--sharded-volume', type=int, default=320)
   ap.add_argument('--sharded-sub', type=int, default=176)
-  ap.add_argument('--sharded-batch', type=int, default=8)
+  ap.add_argument('--sharded-sub-zyx', type=int, nargs=3, default=None,
+                  help='sub-box size zyx (default: --sharded-sub cubed)')
+  ap.add_argument('--sharded-batch', type=int, default=8,
+                  help='FoVs per engine call (= canvases per group)')
+  ap.add_argument('--sharded-groups', type=int, default=2,
+                  help='canvas groups, each with its own host thread and engine '
+                  'calls (canvases open = groups x batch)')
+  ap.add_argument('--sharded-deal', choices=['dynamic', 'static'],
+                  default='dynamic')
+  ap.add_argument('--sharded-collective', choices=['all_reduce', 'broadcast'],
+                  default='all_reduce')
+  ap.add_argument('--sharded-max-steps', type=int, default=0,
+                  help='bound the run: a canvas is dropped after this many FoV '
+                  'steps (0 = segment everything)')
   ap.add_argument('--config', choices=['c1', 'c5'], default='c1',
                   help='c1: BASELINE configs[1] (the headline); c5: the depth-18 '
                   'anisotropic model of configs[4], random weights')
@@ -781,21 +904,18 @@ def main():
   try:
     with open(os.path.join(ROOT, 'profiles', 'conv32_pmc_traffic.json')) as f:
       tj = json.load(f)
-    if tj.get('conv_variant', 4) == res.get('conv_variant', 4):
+    if tj.get('conv_variant', 9) == res.get('conv_variant', 9):
       traffic = tj['traffic_bytes_per_launch']
       traffic_source = ('profiles/conv32_pmc_traffic.json: separate rocprofv3 '
                         '--pmc FETCH_SIZE / WRITE_SIZE passes of this command '
                         '(NOT measured in this run)')
   except (OSError, KeyError, ValueError):
     pass
-  variant = res.get('conv_variant', 4)
+  variant = res.get('conv_variant', 9)
   PEAK_F16_MFMA_TFLOPS = PEAK_BF16_MFMA_TFLOPS  # same dense rate on gfx950
-  if variant in (3, 4, 5, 6, 7, 8, 9):
-    products = BF16X3_PRODUCTS if variant == 3 else 3
-    mfma = {3: 'v_mfma_f32_16x16x32_bf16', 4: 'v_mfma_f32_16x16x32_f16',
-            5: 'v_mfma_f32_32x32x16_f16', 6: 'v_mfma_f32_32x32x16_f16',
-            7: 'v_mfma_f32_32x32x16_f16', 8: 'v_mfma_f32_32x32x16_f16',
-            9: 'v_mfma_f32_32x32x16_f16'}[variant]
+  if variant >= 6:
+    products = SPLIT_PRODUCTS
+    mfma = 'v_mfma_f32_32x32x16_f16'
     shape = ('conv32mt (3x3x3 32->32 implicit GEMM on producer-split fp16 planes '
              'staged by LDS-DMA: 256 conv32m workgroups of 128 voxels, one per '
              'CU -- one 32-position tile per wave for all 27 taps, weights '
@@ -808,23 +928,16 @@ def main():
              'workgroups per CU' if variant == 8 else
              'conv32d (3x3x3 32->32 implicit GEMM on producer-split fp16 planes '
              'staged by LDS-DMA, 4-wave workgroups, the 27 taps split over the '
-             'waves' if variant in (6, 7) else
-             'conv32k (3x3x3 32->32 implicit GEMM, 4-wave workgroups, the 27 taps '
-             'split over the waves' if variant == 5 else
-             'conv32w8 (3x3x3 32->32 implicit GEMM, 8-wave workgroups')
+             'waves')
     kernel_name = (
-        '%s; f32 operands split %s, %d products per f32 product on %s, f32 '
-        'accumulation)' %
-        (shape, 'exactly into 3 bf16 parts' if variant == 3 else
-         'into fp16 hi + 2^-11-scaled fp16 residual (22 mantissa bits)',
-         products, mfma))
+        '%s; f32 operands split into fp16 hi + 2^-11-scaled fp16 residual (22 '
+        'mantissa bits), %d products per f32 product on %s, f32 accumulation)' %
+        (shape, products, mfma))
     peak = PEAK_F16_MFMA_TFLOPS / products
     peak_basis = ('dense 16-bit MFMA peak %.0f TFLOP/s / %d products per '
                   'algorithmic f32 product' % (PEAK_F16_MFMA_TFLOPS, products))
     executed_ratio = products
-    dtype = ('f32 (bf16x3 split products on the bf16 MFMA, f32 accumulate)'
-             if variant == 3 else
-             'f32 (fp16 hi + scaled-residual split products on the fp16 MFMA, '
+    dtype = ('f32 (fp16 hi + scaled-residual split products on the fp16 MFMA, '
              'f32 accumulate)')
   else:
     kernel_name = ('conv32 (3x3x3 32->32 implicit GEMM, '

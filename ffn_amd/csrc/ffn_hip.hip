@@ -11,7 +11,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -62,9 +64,27 @@ namespace {
 }  // namespace
 
 struct ffn_engine {
+  // Entry points may be called from several host threads (the two canvas groups
+  // of MultiCanvasDriver, their between-segment work): each one holds this lock
+  // while it touches engine state or queues work on the stream -- except the
+  // wait for a step's completion flags, which is what the threads overlap.
+  std::recursive_mutex mu;
+  // The canvas utility calls (point / box reads and writes, commit counts) own
+  // the scratch buffers and WAIT for their result; they hold `util_mu` for all
+  // of it but `mu` only while they queue their work, and wait for their own
+  // event, not for the stream -- so another thread's next FoV step is queued
+  // (and runs) behind them instead of waiting for the host to wake up.
+  std::mutex util_mu;
+  hipEvent_t util_ev = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
-  Geom g{};
+  Geom g{};   // the FoV as the caller sees it (zyx): gather / paste / faces, I/O
+  Geom gp{};  // the FoV as the split-product kernels (conv_variant >= 6) lay it
+              // out: the same, or with its axes permuted (oa) so that the
+              // SHORTEST axis is the row direction -- rows of 21 instead of 41
+              // voxels put the anisotropic 21 x 41 x 41 FoV inside the row
+              // budget of conv32m / conv32mt
+  bool permuted = false;
   int depth = 0;
   int max_batch = 0;
   bool weights_set = false;
@@ -132,6 +152,7 @@ struct ffn_engine {
   uint8_t* valid = nullptr;
   float* weights = nullptr;  // one allocation; layout below
   size_t w0a_off = 0, b0a_off = 0, wl_off = 0;
+  size_t w0ap_off = 0;  // conv0_a weights with the taps in gp's axis order
   std::vector<size_t> wpack_off, bias_off;  // 2*depth-1 entries (conv0_b ..)
 
   StepItem* d_items = nullptr;
@@ -142,9 +163,14 @@ struct ffn_engine {
   // two result / descriptor slots: one step may be queued behind the running one
   int next_slot = 0;
   int slot_n[2] = {0, 0};
+  bool slot_waited[2] = {false, false};  // a thread is in ffn_canvas_step_wait for it
   unsigned slot_ticket[2] = {0, 0};
   std::vector<ffn_canvas*> slot_canvas[2];
   int sync_mode = 1;  // 0 = hipStreamSynchronize, 1 = poll h_seq (then sync)
+  // since the last set_option("stat_reset"): batched step calls, FoVs in them,
+  // and a histogram of FoVs per call (index min(n, 64))
+  long stat_calls = 0, stat_items = 0;
+  long stat_hist[65] = {};
 
   void* d_scratch = nullptr;
   void* h_scratch = nullptr;
@@ -190,6 +216,35 @@ struct ffn_canvas {
     }
   }
 };
+
+namespace {
+struct EngineLock {
+  std::unique_lock<std::recursive_mutex> lk;
+  explicit EngineLock(ffn_engine* e) {
+    if (e) lk = std::unique_lock<std::recursive_mutex>(e->mu);
+  }
+};
+// util_mu, then mu (the step path takes only mu: no lock-order inversion)
+struct UtilLock {
+  std::unique_lock<std::mutex> ul;
+  std::unique_lock<std::recursive_mutex> lk;
+  explicit UtilLock(ffn_engine* e) {
+    if (e) {
+      ul = std::unique_lock<std::mutex>(e->util_mu);
+      lk = std::unique_lock<std::recursive_mutex>(e->mu);
+    }
+  }
+  // everything queued so far has finished; `mu` is released while waiting
+  hipError_t wait(ffn_engine* e) {
+    hipError_t err = hipEventRecord(e->util_ev, e->stream);
+    if (err != hipSuccess) return err;
+    lk.unlock();
+    err = hipEventSynchronize(e->util_ev);
+    lk.lock();
+    return err;
+  }
+};
+}  // namespace
 
 int ffn_canvas_view(ffn_canvas* c, FfnCanvasView* out) {
   if (!c || !out) return ffn_set_error(FFN_ERR_ARG, "NULL canvas");
@@ -473,7 +528,7 @@ int switch_variant(ffn_engine* e, int value) {
 template <int KIND, bool SK>
 int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
                    int layer, const HeadFusion& head = HeadFusion()) {
-  const Geom& g = e->g;
+  const Geom& g = e->gp;
   const long positions = g.act_stride / kFeatures;
   ConvDArgs a;
   a.in_sp = reinterpret_cast<const char*>(raw_in) + (size_t)g.guard * 16;
@@ -498,6 +553,10 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   a.magic_nchunks = magic(nchunks);
   a.magic_fyfx = magic(g.fy * g.fx);
   a.magic_fx = magic(g.fx);
+  a.permuted = e->permuted;
+  a.ds0 = g.dstr[0];
+  a.ds1 = g.dstr[1];
+  a.ds2 = g.dstr[2];
   a.sp_bytes = (unsigned)((size_t)g.act_stride * sizeof(float) - (size_t)g.guard * 32);
   std::memcpy(a.aoff, small ? e->esched_aoff : e->dsched_aoff, sizeof(a.aoff));
   std::memcpy(a.btap, e->dsched_btap, sizeof(a.btap));
@@ -598,16 +657,19 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   const int tz = (g.fz + kC0Z - 1) / kC0Z, ty = (g.fy + kC0Y - 1) / kC0Y,
             tx = (g.fx + kC0X - 1) / kC0X;
   if (e->conv_variant >= 6) {
+    const Geom& q = e->gp;  // the split-product kernels' layout of the FoV
+    const int qz = (q.fz + kC0Z - 1) / kC0Z, qy = (q.fy + kC0Y - 1) / kC0Y,
+              qx = (q.fx + kC0X - 1) / kC0X;
     Conv0SplitOut so;
-    so.out_sp = reinterpret_cast<char*>(e->rawT) + (size_t)g.guard * 16;
-    so.sp_plane_bytes = (g.act_stride / kFeatures) * 16;
-    so.item_bytes = g.act_stride * (long)sizeof(float);
+    so.out_sp = reinterpret_cast<char*>(e->rawT) + (size_t)q.guard * 16;
+    so.sp_plane_bytes = (q.act_stride / kFeatures) * 16;
+    so.item_bytes = q.act_stride * (long)sizeof(float);
     so.range_flag = e->range_flag;
     so.range_tag = e->range_tag;
-    hipLaunchKernelGGL(conv0a_mfma_kernel<true>, dim3(tz * ty * tx, n),
+    hipLaunchKernelGGL(conv0a_mfma_kernel<true>, dim3(qz * qy * qx, n),
                        dim3(kC0Threads), 0, e->stream, si, pad_value,
-                       W + e->w0a_off, W + e->b0a_off, e->bufT, e->seed_raw, g,
-                       ty, tx, so);
+                       W + (e->permuted ? e->w0ap_off : e->w0a_off), W + e->b0a_off,
+                       e->bufT, e->seed_raw, q, qy, qx, so);
   } else
     hipLaunchKernelGGL(conv0a_mfma_kernel<false>, dim3(tz * ty * tx, n),
                        dim3(kC0Threads), 0, e->stream, si, pad_value,
@@ -817,8 +879,61 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   g.nchunks = (g.npos + kChunk - 1) / kChunk;
   g.V = g.fz * g.fy * g.fx;
   g.R = kChunk + 2 * (g.XS + 1);
-  const long positions = (long)g.guard + (long)g.nchunks * kChunk + g.guard + 320;
+  g.oa[0] = 0, g.oa[1] = 1, g.oa[2] = 2;
+  g.dstr[0] = g.fy * g.fx, g.dstr[1] = g.fx, g.dstr[2] = 1;
+  // the geometry with its axes permuted: internal axis a = original axis oa[a]
+  auto permute = [&](const int oa[3]) {
+    const int f[3] = {g.fz, g.fy, g.fx}, d[3] = {g.dz, g.dy, g.dx};
+    const int ds[3] = {g.fy * g.fx, g.fx, 1};
+    Geom q = g;
+    q.fz = f[oa[0]], q.fy = f[oa[1]], q.fx = f[oa[2]];
+    q.dz = d[oa[0]], q.dy = d[oa[1]], q.dx = d[oa[2]];
+    q.XS = q.fx + 1;
+    q.plane = (q.fy + 1) * q.XS;
+    q.npos = q.fz * q.plane;
+    q.guard = q.plane + q.XS + 1;
+    q.nchunks = (q.npos + kChunk - 1) / kChunk;
+    q.R = kChunk + 2 * (q.XS + 1);
+    for (int a = 0; a < 3; ++a) q.oa[a] = oa[a], q.dstr[a] = ds[oa[a]];
+    return q;
+  };
+  // largest padded span of `count` chunks of `chunk` dense voxels from `start`
+  auto chunk_span = [](const Geom& q, int start, int chunk, int count) {
+    auto pad = [&](int v) {
+      const int x = v % q.fx, y = (v / q.fx) % q.fy, z = v / (q.fx * q.fy);
+      return z * q.plane + y * q.XS + x;
+    };
+    int span = 0;
+    for (int c = 0; c < count; ++c) {
+      const int lo = start + c * chunk, hi = std::min(q.V, lo + chunk) - 1;
+      if (lo <= hi) span = std::max(span, pad(hi) - pad(lo) + 1);
+    }
+    return span;
+  };
+  auto m_fits = [&](const Geom& q) {  // conv32m's 128-voxel chunks in kMRows rows
+    return chunk_span(q, 0, kMChunk, (q.V + kMChunk - 1) / kMChunk) +
+               2 * (q.XS + 1) <= kMRows;
+  };
+  e->gp = g;
+  if (!m_fits(g)) {
+    // shortest axis last (= the row direction), the other two in their order
+    static const int kPerms[5][3] = {{0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1},
+                                     {2, 1, 0}};
+    int best = -1;
+    for (int k = 0; k < 5; ++k) {
+      const Geom q = permute(kPerms[k]);
+      if (m_fits(q) && (best < 0 || q.fx < permute(kPerms[best]).fx)) best = k;
+    }
+    if (best >= 0) {
+      e->gp = permute(kPerms[best]);
+      e->permuted = true;
+    }
+  }
+  const long positions = std::max(
+      (long)g.guard + (long)g.nchunks * kChunk + g.guard + 320,
+      (long)e->gp.guard + (long)e->gp.nchunks * kChunk + e->gp.guard + 320);
   g.act_stride = positions * kFeatures;
+  e->gp.act_stride = g.act_stride;
   e->lds_bytes = (size_t)3 * g.R * kFeatures * sizeof(float);
   if (e->lds_bytes > 160 * 1024) {
     delete e;
@@ -838,6 +953,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   } while (0)
 
   E_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  E_TRY(hipEventCreateWithFlags(&e->util_ev, hipEventDisableTiming));
   const size_t act_bytes = (size_t)3 * max_batch * g.act_stride * sizeof(float);
   E_TRY(hipMalloc(&e->act_base, act_bytes));
   E_TRY(hipMemset(e->act_base, 0, act_bytes));
@@ -902,11 +1018,10 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     if (e->Rc < 256) e->Rc = 256;  // the kernel stages 8 or 9 x 256 float4
     e->lds_bytes_c = (size_t)2 * e->Rc * kCLdsStride * sizeof(float);
     {
-      int span_k = 0;
-      for (int c = 0; c < e->nchunks_k; ++c)
-        span_k = std::max(span_k, pidx[(size_t)c * kDChunk + kDChunk - 1] -
-                                      pidx[(size_t)c * kDChunk] + 1);
-      e->Rc_k = ((span_k + 2 * (g.XS + 1)) + 31) / 32 * 32;
+      // everything from here on is the split-product family: laid out as gp
+      const Geom& q = e->gp;
+      const int span_k = chunk_span(q, 0, kDChunk, e->nchunks_k);
+      e->Rc_k = ((span_k + 2 * (q.XS + 1)) + 31) / 32 * 32;
       if (e->Rc_k < 256) e->Rc_k = 256;
       e->k_ok = e->Rc_k <= 320 && e->nchunks_k >= 2;  // (magic divisions: d >= 2)
       // tap schedule of the four waves (see conv32d_body): two dz = -1 taps
@@ -926,70 +1041,47 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
           if (dummy) s = kSched[w][j - 1];
           const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
           e->dsched_aoff[w * 8 + j] =
-              kz * 128 * e->Rc_k + ((ky - 1) * g.XS + (kx - 1)) * 16;
+              kz * 128 * e->Rc_k + ((ky - 1) * q.XS + (kx - 1)) * 16;
           e->dsched_btap[w * 8 + j] = dummy ? 27 : s;
         }
       e->d_ok = e->k_ok && e->lds_bytes_d <= 160 * 1024 && depth >= 2;
       // variant 7: 96-voxel chunks in kERows rows, three slots in 80 KB
       {
         const int ce = 32 * kETiles;
-        e->nchunks_e = (g.V + ce - 1) / ce;
-        int span_e = 0;
-        for (int c = 0; c < e->nchunks_e; ++c) {
-          const int v_lo = c * ce, v_hi = std::min(g.V, v_lo + ce) - 1;
-          auto pad = [&](int v) {
-            const int x = v % g.fx, y = (v / g.fx) % g.fy, z = v / (g.fx * g.fy);
-            return z * g.plane + y * g.XS + x;
-          };
-          span_e = std::max(span_e, pad(v_hi) - pad(v_lo) + 1);
-        }
+        e->nchunks_e = (q.V + ce - 1) / ce;
+        const int span_e = chunk_span(q, 0, ce, e->nchunks_e);
         e->lds_bytes_e = std::max((size_t)3 * 128 * kERows,
                                   (size_t)4 * ce * kDRowB + 64);
-        e->e_ok = e->d_ok && span_e + 2 * (g.XS + 1) <= kERows &&
+        e->e_ok = e->d_ok && span_e + 2 * (q.XS + 1) <= kERows &&
                   e->nchunks_e >= 2 && e->lds_bytes_e <= 80 * 1024;
         // variant 8: 128-voxel chunks in kMRows rows
-        e->nchunks_m = (g.V + kMChunk - 1) / kMChunk;
-        int span_m = 0;
-        auto padm = [&](int v) {
-          const int x = v % g.fx, y = (v / g.fx) % g.fy, z = v / (g.fx * g.fy);
-          return z * g.plane + y * g.XS + x;
-        };
-        for (int c = 0; c < e->nchunks_m; ++c) {
-          const int v_lo = c * kMChunk, v_hi = std::min(g.V, v_lo + kMChunk) - 1;
-          span_m = std::max(span_m, padm(v_hi) - padm(v_lo) + 1);
-        }
-        e->m_ok = e->d_ok && span_m + 2 * (g.XS + 1) <= kMRows && e->nchunks_m >= 2;
+        e->nchunks_m = (q.V + kMChunk - 1) / kMChunk;
+        const int span_m = chunk_span(q, 0, kMChunk, e->nchunks_m);
+        e->m_ok = e->d_ok && span_m + 2 * (q.XS + 1) <= kMRows && e->nchunks_m >= 2;
         // variant 9: the chunks past the 256th become 32-voxel tail workgroups,
         // as long as all of one FoV's workgroups find a slot at once (two per CU)
         if (e->m_ok && e->nchunks_m > 256) {
           e->n_main = 256;
-          e->n_tail = (g.V - 256 * kMChunk + 31) / 32;
-          e->n_tail3 = (g.V - 256 * kMChunk + 95) / 96;
-          int span_t = 0, span_t3 = 0;
-          for (int c = 0; c < e->n_tail; ++c) {
-            const int v_lo = 256 * kMChunk + c * 32, v_hi = std::min(g.V, v_lo + 32) - 1;
-            span_t = std::max(span_t, padm(v_hi) - padm(v_lo) + 1);
-          }
-          for (int c = 0; c < e->n_tail3; ++c) {
-            const int v_lo = 256 * kMChunk + c * 96, v_hi = std::min(g.V, v_lo + 96) - 1;
-            span_t3 = std::max(span_t3, padm(v_hi) - padm(v_lo) + 1);
-          }
+          e->n_tail = (q.V - 256 * kMChunk + 31) / 32;
+          e->n_tail3 = (q.V - 256 * kMChunk + 95) / 96;
+          const int span_t = chunk_span(q, 256 * kMChunk, 32, e->n_tail);
+          const int span_t3 = chunk_span(q, 256 * kMChunk, 96, e->n_tail3);
           static_assert((size_t)3 * 128 * kTRows <= kMLdsBytes &&
                             (size_t)4 * 32 * kDRowB + 64 <= kMLdsBytes &&
                             (size_t)3 * 128 * kT3Rows <= kMLdsBytes &&
                             (size_t)4 * 96 * kDRowB + 64 <= kMLdsBytes,
                         "a tail workgroup fits conv32m's LDS");
-          e->t_ok = span_t + 2 * (g.XS + 1) <= kTRows &&
-                    span_t3 + 2 * (g.XS + 1) <= kT3Rows && e->n_tail <= 256;
+          e->t_ok = span_t + 2 * (q.XS + 1) <= kTRows &&
+                    span_t3 + 2 * (q.XS + 1) <= kT3Rows && e->n_tail <= 256;
           for (int w = 0; w < 4; ++w)
             for (int j = 0; j < 7; ++j) {
               int s = kSched[w][j];
               if (s < 0) s = kSched[w][j - 1];
               const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
               e->tsched_aoff[w * 8 + j] =
-                  kz * 128 * kTRows + ((ky - 1) * g.XS + (kx - 1)) * 16;
+                  kz * 128 * kTRows + ((ky - 1) * q.XS + (kx - 1)) * 16;
               e->t3sched_aoff[w * 8 + j] =
-                  kz * 128 * kT3Rows + ((ky - 1) * g.XS + (kx - 1)) * 16;
+                  kz * 128 * kT3Rows + ((ky - 1) * q.XS + (kx - 1)) * 16;
             }
         }
         for (int w = 0; w < 4; ++w)
@@ -998,7 +1090,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
             if (s < 0) s = kSched[w][j - 1];
             const int kz = s / 9, ky = (s / 3) % 3, kx = s % 3;
             e->esched_aoff[w * 8 + j] =
-                kz * 128 * kERows + ((ky - 1) * g.XS + (kx - 1)) * 16;
+                kz * 128 * kERows + ((ky - 1) * q.XS + (kx - 1)) * 16;
           }
       }
     }
@@ -1024,6 +1116,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     off += 27 * 2 * kFeatures;
     e->b0a_off = off;
     off += kFeatures;
+    e->w0ap_off = off;
+    off += 27 * 2 * kFeatures;
     for (int l = 0; l < 2 * depth - 1; ++l) {
       e->wpack_off.push_back(off);
       off += 27 * kFeatures * kFeatures;
@@ -1086,6 +1180,7 @@ void ffn_engine_destroy(ffn_engine* e) {
     c->engine = nullptr;
   }
   e->canvases.clear();
+  if (e->util_ev) (void)hipEventDestroy(e->util_ev);
   for (auto& ev : e->events)
     if (ev) (void)hipEventDestroy(ev);
   (void)hipFree(e->act_base);
@@ -1113,6 +1208,7 @@ void ffn_engine_destroy(ffn_engine* e) {
 }
 
 int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
+  EngineLock lock_(e);
   if (!e || !blob) return fail(FFN_ERR_ARG, "null argument");
   const size_t want = ffn_engine_weight_count(e->depth, kFeatures);
   if (count != want)
@@ -1126,7 +1222,19 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   std::vector<uint16_t> hostd(e->wpackd_layer * (2 * e->depth - 1));  // zero tap 27
   bool d_weights_ok = true;
   bool weights_in_fp16_range = true;
+  // tap (kz', ky', kx') of the permuted layout = the original tap whose offset
+  // along axis oa[a] is k'[a]
+  int tap_of[27];
+  for (int t = 0; t < 27; ++t) {
+    const int kp[3] = {t / 9, (t / 3) % 3, t % 3};
+    int ko[3];
+    for (int a = 0; a < 3; ++a) ko[e->gp.oa[a]] = kp[a];
+    tap_of[t] = ko[0] * 9 + ko[1] * 3 + ko[2];
+  }
   std::memcpy(&host[e->w0a_off], src, sizeof(float) * 27 * 2 * F);
+  for (int t = 0; t < 27; ++t)
+    std::memcpy(&host[e->w0ap_off + (size_t)t * 2 * F], src + (size_t)tap_of[t] * 2 * F,
+                sizeof(float) * 2 * F);
   src += 27 * 2 * F;
   std::memcpy(&host[e->b0a_off], src, sizeof(float) * F);
   src += F;
@@ -1155,7 +1263,7 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
           for (int lane = 0; lane < 64; ++lane)
             for (int c = 0; c < 8; ++c) {
               const int ci = 16 * kh + 8 * (lane >> 5) + c, co = lane & 31;
-              const float w = src[((size_t)tap * F + ci) * F + co];
+              const float w = src[((size_t)tap_of[tap] * F + ci) * F + co];
               if (!(std::fabs(w) <= 65504.0f)) weights_in_fp16_range = false;
               uint16_t part[2];
               split_fp16x2(w, part);
@@ -1186,6 +1294,7 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
 
 int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
                 float* logits_out) {
+  EngineLock lock_(e);
   if (!e || !seed || !image || !logits_out) return fail(FFN_ERR_ARG, "null argument");
   if (n < 1 || n > e->max_batch)
     return fail(FFN_ERR_ARG, "batch %d outside [1, %d]", n, e->max_batch);
@@ -1228,6 +1337,7 @@ int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
 }
 
 int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
+  EngineLock lock_(e);
   if (!e) return fail(FFN_ERR_ARG, "null argument");
   if (n < 1 || n > e->max_batch)
     return fail(FFN_ERR_ARG, "batch %d outside [1, %d]", n, e->max_batch);
@@ -1244,6 +1354,7 @@ int ffn_forward_resident(ffn_engine* e, int n, int repeats) {
 }
 
 int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
+  EngineLock lock_(e);
   if (!e || !name) return fail(FFN_ERR_ARG, "null argument");
 
   if (std::strcmp(name, "conv_variant") == 0) {
@@ -1297,6 +1408,11 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->tail_batched = value != 0;
     return FFN_OK;
   }
+  if (std::strcmp(name, "stat_reset") == 0) {
+    e->stat_calls = e->stat_items = 0;
+    std::memset(e->stat_hist, 0, sizeof(e->stat_hist));
+    return FFN_OK;
+  }
   if (std::strcmp(name, "debug_layer") == 0) {
     e->dbg_layer = value;
     return FFN_OK;
@@ -1318,10 +1434,18 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
 }
 
 int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
+  EngineLock lock_(e);
   if (!e || !name || !value) return fail(FFN_ERR_ARG, "null argument");
   if (std::strcmp(name, "conv_variant") == 0) *value = e->conv_variant;
   else if (std::strcmp(name, "fuse_head") == 0) *value = e->fuse_head;
   else if (std::strcmp(name, "exact_variant") == 0) *value = e->exact_variant;
+  else if (std::strcmp(name, "stat_step_calls") == 0) *value = (int)e->stat_calls;
+  else if (std::strcmp(name, "stat_step_items") == 0) *value = (int)e->stat_items;
+  else if (std::strncmp(name, "stat_hist_", 10) == 0) {
+    const int k = std::atoi(name + 10);
+    if (k < 0 || k > 64) return fail(FFN_ERR_ARG, "stat_hist_<0..64>");
+    *value = (int)e->stat_hist[k];
+  }
   else if (std::strcmp(name, "store_policy") == 0) *value = e->store_policy;
   else if (std::strcmp(name, "sync_mode") == 0) *value = e->sync_mode;
   else if (std::strcmp(name, "profile_every") == 0) *value = e->prof_every;
@@ -1330,6 +1454,7 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
 }
 
 int ffn_engine_debug_workgroups(ffn_engine* e, long long* out, int max_wgs) {
+  EngineLock lock_(e);
   if (!e || !out) return fail(FFN_ERR_ARG, "null argument");
   if (max_wgs < 0 || max_wgs > kDbgMaxWgs)
     return fail(FFN_ERR_ARG, "max_wgs must be 0..%d", kDbgMaxWgs);
@@ -1343,6 +1468,7 @@ int ffn_engine_debug_workgroups(ffn_engine* e, long long* out, int max_wgs) {
 }
 
 int ffn_engine_debug_clocks(ffn_engine* e, long long* out24) {
+  EngineLock lock_(e);
   if (!e || !out24) return fail(FFN_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1351,6 +1477,7 @@ int ffn_engine_debug_clocks(ffn_engine* e, long long* out24) {
 }
 
 int ffn_engine_synchronize(ffn_engine* e) {
+  EngineLock lock_(e);
   if (!e) return fail(FFN_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1358,6 +1485,7 @@ int ffn_engine_synchronize(ffn_engine* e) {
 }
 
 int ffn_engine_set_profiling(ffn_engine* e, int mode) {
+  EngineLock lock_(e);
   if (!e) return fail(FFN_ERR_ARG, "null argument");
   if (mode < 0 || mode > 2) return fail(FFN_ERR_ARG, "mode must be 0, 1 or 2");
   HIP_TRY(hipSetDevice(e->device));
@@ -1370,6 +1498,7 @@ int ffn_engine_set_profiling(ffn_engine* e, int mode) {
 
 int ffn_engine_get_profile(ffn_engine* e, double* conv_ms_total,
                            int64_t* conv_launches, int reset) {
+  EngineLock lock_(e);
   if (!e) return fail(FFN_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(e->device));
   int rc = flush_events(e);
@@ -1391,6 +1520,7 @@ namespace {
 int canvas_create(ffn_engine* e, const float* image_f32, const uint8_t* image_u8,
                   float mean, float stddev, const int32_t shape_zyx[3],
                   ffn_canvas** out) {
+  EngineLock lock_(e);
   if (!e || (!image_f32 && !image_u8) || !shape_zyx || !out)
     return fail(FFN_ERR_ARG, "null argument");
   *out = nullptr;
@@ -1463,6 +1593,7 @@ int ffn_canvas_create_u8(ffn_engine* e, const uint8_t* image_u8,
 }
 
 void ffn_canvas_destroy(ffn_canvas* c) {
+  EngineLock lock_(c ? c->engine : nullptr);
   if (!c) return;
   if (c->engine) {
     ffn_engine* e = c->engine;
@@ -1480,6 +1611,7 @@ void ffn_canvas_destroy(ffn_canvas* c) {
 }
 
 int ffn_canvas_init_seed(ffn_canvas* c, const int32_t pos[3], float value) {
+  EngineLock lock_(c ? c->engine : nullptr);
   if (!c || !pos) return fail(FFN_ERR_ARG, "null argument");
   if (pos[0] < 0 || pos[0] >= c->cz || pos[1] < 0 || pos[1] >= c->cy ||
       pos[2] < 0 || pos[2] >= c->cx)
@@ -1517,12 +1649,15 @@ int ffn_canvas_init_seed(ffn_canvas* c, const int32_t pos[3], float value) {
 int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
                            const ffn_step_request* requests,
                            const ffn_step_params* params, uint32_t* ticket) {
+  EngineLock lock_(e);
   if (!e || !canvases || !requests || !params || !ticket)
     return fail(FFN_ERR_ARG, "null argument");
   if (n < 1 || n > e->max_batch)
     return fail(FFN_ERR_ARG, "batch %d outside [1, %d]", n, e->max_batch);
   if (!e->weights_set) return fail(FFN_ERR_STATE, "weights not set");
-  const int slot = e->next_slot;
+  // the slot after the last one used, else the other one (two host threads
+  // need not alternate)
+  const int slot = e->slot_n[e->next_slot] == 0 ? e->next_slot : e->next_slot ^ 1;
   if (e->slot_n[slot] != 0)
     return fail(FFN_ERR_STATE,
                 "two steps already in flight: call ffn_canvas_step_wait first");
@@ -1588,6 +1723,9 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
                      e->logits, e->seed_raw, e->count, e->count_blocks,
                      params->disco_seed_threshold, e->range_flag, e->range_tag);
   HIP_TRY(hipGetLastError());
+  e->stat_calls += 1;
+  e->stat_items += n;
+  e->stat_hist[n < 64 ? n : 64] += 1;
   e->slot_n[slot] = n;
   e->slot_ticket[slot] = step_id;
   e->slot_canvas[slot].assign(canvases, canvases + n);
@@ -1600,15 +1738,34 @@ int ffn_canvas_step_wait(ffn_engine* e, uint32_t ticket,
                          ffn_step_result* results) {
   if (!e || !results) return fail(FFN_ERR_ARG, "null argument");
   int slot = -1;
-  for (int s = 0; s < 2; ++s)
-    if (e->slot_n[s] != 0 && e->slot_ticket[s] == ticket) slot = s;
-  if (slot < 0) return fail(FFN_ERR_STATE, "no step with ticket %u in flight", ticket);
-  const int n = e->slot_n[slot];
+  int n = 0;
+  {
+    EngineLock lock_(e);
+    for (int s = 0; s < 2; ++s)
+      if (e->slot_n[s] != 0 && e->slot_ticket[s] == ticket && !e->slot_waited[s])
+        slot = s;
+    if (slot < 0)
+      return fail(FFN_ERR_STATE, "no step with ticket %u in flight", ticket);
+    n = e->slot_n[slot];
+    e->slot_waited[slot] = true;
+  }
   const unsigned step_id = ticket;
   ffn_step_result* h_results = e->h_results + (size_t)slot * e->max_batch;
   unsigned* h_seq = e->h_seq + (size_t)slot * e->max_batch;
-  e->slot_n[slot] = 0;  // the slot is free again whatever happens below
-  e->slot_canvas[slot].clear();
+  // The slot -- its descriptor, result and flag arrays -- stays taken until the
+  // results have been copied out (another thread may submit meanwhile); it is
+  // free again whatever happens below.  No lock while waiting: that wait is
+  // what two host threads overlap.
+  struct SlotRelease {
+    ffn_engine* e;
+    int slot;
+    ~SlotRelease() {
+      EngineLock lock_(e);
+      e->slot_n[slot] = 0;
+      e->slot_waited[slot] = false;
+      e->slot_canvas[slot].clear();
+    }
+  } release_{e, slot};
   HIP_TRY(hipSetDevice(e->device));
   if (e->sync_mode == 1) {
     // Poll the completion flags the faces kernel raises in pinned memory: lower
@@ -1639,8 +1796,8 @@ int ffn_canvas_step_wait(ffn_engine* e, uint32_t ticket,
   for (int k = 0; k < n; ++k)
     if (results[k].range_error)
       return fail(FFN_ERR_RANGE,
-                  "an activation left the fp16 range (conv_variant 4): the step "
-                  "changed nothing; set conv_variant 3 and repeat it");
+                  "an activation left the fp16 range (conv_variant >= 6): the "
+                  "step changed nothing; set conv_variant -1 and repeat it");
   return FFN_OK;
 }
 
@@ -1745,6 +1902,7 @@ int ffn_canvas_segment_history(ffn_canvas* c, size_t first, size_t n,
 
 int ffn_canvas_read_points(ffn_canvas* c, int n, const int32_t* pos,
                            float* seed_out, int32_t* seg_out) {
+  UtilLock lock_(c ? c->engine : nullptr);
   if (!c || !pos || !seed_out || !seg_out) return fail(FFN_ERR_ARG, "null argument");
   if (n < 1) return FFN_OK;
   ffn_engine* e = c->engine;
@@ -1765,7 +1923,7 @@ int ffn_canvas_read_points(ffn_canvas* c, int n, const int32_t* pos,
                      reinterpret_cast<const int32_t*>(ds), d_seed, d_seg);
   HIP_TRY(hipMemcpyAsync(hs + pbr, ds + pbr, 8 * (size_t)n, hipMemcpyDeviceToHost,
                          e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(lock_.wait(e));
   std::memcpy(seed_out, hs + pbr, 4 * (size_t)n);
   std::memcpy(seg_out, hs + pbr + 4 * (size_t)n, 4 * (size_t)n);
   return FFN_OK;
@@ -1773,6 +1931,7 @@ int ffn_canvas_read_points(ffn_canvas* c, int n, const int32_t* pos,
 
 int ffn_canvas_write_seg_points(ffn_canvas* c, int n, const int32_t* pos,
                                 const int32_t* values) {
+  UtilLock lock_(c ? c->engine : nullptr);
   if (!c || !pos || !values) return fail(FFN_ERR_ARG, "null argument");
   if (n < 1) return FFN_OK;
   for (int k = 0; k < n; ++k)
@@ -1796,12 +1955,13 @@ int ffn_canvas_write_seg_points(ffn_canvas* c, int n, const int32_t* pos,
                      e->stream, c->seg, c->cy, c->cx, n,
                      reinterpret_cast<const int32_t*>(ds),
                      reinterpret_cast<const int32_t*>(ds + pbr));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(lock_.wait(e));
   return FFN_OK;
 }
 
 int ffn_canvas_any_segmented(ffn_canvas* c, const int32_t lo[3],
                              const int32_t hi[3], int32_t* out) {
+  UtilLock lock_(c ? c->engine : nullptr);
   if (!c || !lo || !hi || !out) return fail(FFN_ERR_ARG, "null argument");
   // numpy slicing clips to the array bounds (inference.py:575-578)
   int32_t l[3], h[3];
@@ -1827,7 +1987,7 @@ int ffn_canvas_any_segmented(ffn_canvas* c, const int32_t lo[3],
                      static_cast<int32_t*>(e->d_scratch));
   HIP_TRY(hipMemcpyAsync(e->h_scratch, e->d_scratch, 4, hipMemcpyDeviceToHost,
                          e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(lock_.wait(e));
   *out = *static_cast<int32_t*>(e->h_scratch);
   return FFN_OK;
 }
@@ -1837,6 +1997,7 @@ int ffn_canvas_commit_count(ffn_canvas* c, const int32_t lo[3],
                             int32_t max_existing_id, ffn_commit_counts* counts,
                             int32_t max_overlaps, int32_t* overlap_ids,
                             int64_t* overlap_counts) {
+  UtilLock lock_(c ? c->engine : nullptr);
   if (!c || !lo || !hi || !counts) return fail(FFN_ERR_ARG, "null argument");
   int rc = check_box(c, lo, hi);
   if (rc) return rc;
@@ -1859,7 +2020,7 @@ int ffn_canvas_commit_count(ffn_canvas* c, const int32_t lo[3],
                        max_existing_id, d_counts, d_hist);
   HIP_TRY(hipMemcpyAsync(e->h_scratch, e->d_scratch, bytes, hipMemcpyDeviceToHost,
                          e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(lock_.wait(e));
   const auto* hc = static_cast<const unsigned long long*>(e->h_scratch);
   const auto* hh = reinterpret_cast<const unsigned*>(
       static_cast<const char*>(e->h_scratch) + 16);
@@ -1882,6 +2043,7 @@ int ffn_canvas_commit_count(ffn_canvas* c, const int32_t lo[3],
 int ffn_canvas_commit_assign(ffn_canvas* c, const int32_t lo[3],
                              const int32_t hi[3], float segment_threshold,
                              int32_t segment_id) {
+  EngineLock lock_(c ? c->engine : nullptr);
   if (!c || !lo || !hi) return fail(FFN_ERR_ARG, "null argument");
   int rc = check_box(c, lo, hi);
   if (rc) return rc;
@@ -1905,6 +2067,7 @@ namespace {
 template <typename T>
 int box_read(ffn_canvas* c, const T* vol, const int32_t lo[3], const int32_t hi[3],
              T* dst) {
+  UtilLock lock_(c ? c->engine : nullptr);
   if (!c || !lo || !hi || !dst) return fail(FFN_ERR_ARG, "null argument");
   int rc = check_box(c, lo, hi);
   if (rc) return rc;
@@ -1925,7 +2088,7 @@ int box_read(ffn_canvas* c, const T* vol, const int32_t lo[3], const int32_t hi[
                      e->stream, vol, b, total, static_cast<T*>(e->d_scratch));
   HIP_TRY(hipMemcpyAsync(e->h_scratch, e->d_scratch, sizeof(T) * total,
                          hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(lock_.wait(e));
   std::memcpy(dst, e->h_scratch, sizeof(T) * total);
   return FFN_OK;
 }
@@ -1933,6 +2096,7 @@ int box_read(ffn_canvas* c, const T* vol, const int32_t lo[3], const int32_t hi[
 template <typename T>
 int box_write(ffn_canvas* c, T* vol, const int32_t lo[3], const int32_t hi[3],
               const T* src) {
+  UtilLock lock_(c ? c->engine : nullptr);
   if (!c || !lo || !hi || !src) return fail(FFN_ERR_ARG, "null argument");
   int rc = check_box(c, lo, hi);
   if (rc) return rc;
@@ -1955,7 +2119,7 @@ int box_write(ffn_canvas* c, T* vol, const int32_t lo[3], const int32_t hi[3],
   hipLaunchKernelGGL((box_write_kernel<T>), dim3(grid_for(total)), dim3(256), 0,
                      e->stream, vol, b, total,
                      static_cast<const T*>(e->d_scratch));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(lock_.wait(e));
   return FFN_OK;
 }
 

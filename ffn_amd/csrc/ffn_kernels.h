@@ -40,6 +40,13 @@ struct Geom {
   int V;               // fz*fy*fx
   int R;               // LDS rows per dz segment = kChunk + 2*(XS+1)
   long act_stride;     // floats per FoV activation buffer
+  // The split-product kernels may lay the FoV out with its axes permuted (the
+  // shortest one as the row direction): axis a of THIS geometry is axis oa[a]
+  // (0 z, 1 y, 2 x) of the caller's FoV / of the canvas, and one step along it
+  // moves dstr[a] voxels in the caller's dense [z][y][x] order.  Identity:
+  // oa = {0, 1, 2}, dstr = {fy fx, fx, 1}.
+  int oa[3];
+  int dstr[3];
 };
 
 // Per-FoV step descriptor read by the gather / paste kernels.
@@ -75,8 +82,9 @@ struct StepItems {
 constexpr int kC0Z = 4, kC0Y = 8, kC0X = 8;  // conv0a output tile per block
 constexpr int kC0Threads = 512;               // 256 positions x 2 cout halves
 
-// conv0_a on the matrix cores: same tile / halo staging as conv0a_kernel, then
-// an implicit GEMM with K = 27 taps x 2 channels = 54 (padded to 56 = 14
+// conv0_a on the matrix cores: the 4 x 8 x 8 output tile + halo is staged once
+// in LDS (one canvas read per input voxel; gfx.oa / canvas strides map this
+// layout's axes onto the canvas'), then an implicit GEMM with K = 27 taps x 2 channels = 54 (padded to 56 = 14
 // k-steps of v_mfma_f32_16x16x4_f32).  A block = 256 positions = 16 M-tiles;
 // wave w owns M-tiles 2w, 2w+1 for both cout halves (56 MFMAs).  A operand: one
 // ds_read_b32 per k-step straight from the (image, seed) tile (lane group g
@@ -112,9 +120,12 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
   const int ty = b % tiles_y;
   const int tz = b / tiles_y;
   const int oz = tz * kC0Z, oy = ty * kC0Y, ox = tx * kC0X;  // FoV coords
-  const int z0 = it.req.pos[0] - g.fz / 2;
-  const int y0 = it.req.pos[1] - g.fy / 2;
-  const int x0 = it.req.pos[2] - g.fx / 2;
+  // canvas strides of this geometry's axes (axis a = canvas axis g.oa[a])
+  const long cstr[3] = {(long)it.cy * it.cx, (long)it.cx, 1};
+  const long sz = cstr[g.oa[0]], sy = cstr[g.oa[1]], sx = cstr[g.oa[2]];
+  const int z0 = it.req.pos[g.oa[0]] - g.fz / 2;
+  const int y0 = it.req.pos[g.oa[1]] - g.fy / 2;
+  const int x0 = it.req.pos[g.oa[2]] - g.fx / 2;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -139,14 +150,15 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
     const int zz = oz + hz - 1, yy = oy + hy - 1, xx = ox + hx - 1;
     float vi = 0.0f, vs = 0.0f;  // SAME zero padding outside the FoV
     if (zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy && xx >= 0 && xx < g.fx) {
-      const size_t ci =
-          ((size_t)(z0 + zz) * it.cy + (y0 + yy)) * it.cx + (x0 + xx);
+      const size_t ci = (size_t)((z0 + zz) * sz + (y0 + yy) * sy + (x0 + xx) * sx);
       // uint8 canvases: (x - mean) / stddev of runner.py:383-385 is a table look-up
       vi = it.image ? it.image[ci] : it.image_lut[it.image_u8[ci]];
       vs = it.seed[ci];
       if (hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y && hx >= 1 &&
-          hx <= kC0X)  // interior voxel: keep the raw seed (NaN preserved)
-        seed_raw[(size_t)item * g.V + ((size_t)zz * g.fy + yy) * g.fx + xx] = vs;
+          hx <= kC0X)  // interior voxel: keep the raw seed (NaN preserved), at
+                       // its place in the caller's dense [z][y][x] order
+        seed_raw[(size_t)item * g.V + (size_t)zz * g.dstr[0] + yy * g.dstr[1] +
+                 xx * g.dstr[2]] = vs;
       if (vs != vs) vs = pad_value;  // NaN -> pad (inference.py:406-407)
     }
     tile[2 * e] = vi;
@@ -379,12 +391,11 @@ __global__ __launch_bounds__(kConvThreads) void conv32_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// conv32c: "compact + K-split" variant of conv32p -- fewer MFMAs on the critical
-// path of a single field of view.
-//
-// conv32p walks the PADDED position space (6.2 % padding positions are computed
-// and dropped) in chunks of 160, which at batch 1 occupies 239 of 256 CUs with 5
-// tiles x 27 taps per wave = 1,080 MFMAs.  conv32c walks the DENSE FoV index v
+// conv32c (conv_variant 2): the exact-f32 conv, "compact + K-split" -- fewer
+// MFMAs on the critical path of a single field of view than conv32 above, which
+// walks the PADDED position space (6.2 % padding positions are computed and
+// dropped) in chunks of 160: 239 of 256 CUs at batch 1, 5 tiles x 27 taps per
+// wave = 1,080 MFMAs.  conv32c walks the DENSE FoV index v
 // (valid positions only; `pidx[v]` maps it to the padded position) in chunks of
 // 144 = 9 tiles -> 250 workgroups, and splits the middle tile's 27 taps between
 // the two tile groups: wave (nhalf, tgrp) owns 4 full tiles plus 14 (tgrp 0) or
@@ -426,7 +437,7 @@ struct ConvCArgs {
   unsigned* head_count;    // [n * nchunks] per-chunk count of logits >= move_thr
   float pad_value, move_thr;
   // fp16x2 scheme only: *range_flag = range_tag when an operand is outside the
-  // fp16 range (the step is then void and re-run with the bf16x3 scheme)
+  // fp16 range (the step is then void and re-run with the exact-f32 kernel)
   unsigned* range_flag;
   unsigned range_tag;
 };
@@ -787,14 +798,18 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------
-// conv32d (conv_variant 6): conv32k with the operand split done ONCE by the
-// producer and the staging done by LDS-DMA.
+// conv32d (conv_variant 6): the split-product conv -- every f32 product carried
+// as 3 fp16 products (x ~= hi + 2^-11 res) on v_mfma_f32_32x32x16_f16, f32
+// accumulation -- with the 27 taps split over the four waves (each tap's 4 KB
+// of weight fragments is fetched by ONE wave and serves all tiles), the operand
+// split done ONCE by the producer and the staging done by LDS-DMA.
 //
-// conv32w8 / conv32k stage f32 activations through registers and split every
-// value into fp16 hi + scaled residual on the way into LDS -- 5.3x redundantly
-// (three dz segments of 256-288 rows per 144-160 outputs) and with ~9 VALU
-// instructions per value in front of or between the MFMAs (conv32k: 3.3 K of
-// its 14.4 K loop cycles, profiles/r02_conv32k_ablations.txt).  Here
+// Its predecessors (conv32w8 / conv32k, removed in ABI 7; history up to commit
+// af82310) staged f32 activations through registers and split every value on
+// the way into LDS -- 5.3x redundantly (three dz segments of 256-288 rows per
+// 144-160 outputs) and with ~9 VALU instructions per value in front of or
+// between the MFMAs (3.3 K of conv32k's 14.4 K loop cycles,
+// profiles/r02_conv32k_ablations.txt).  Here
 //   * every layer WRITES its output already split: "split planes" in HBM,
 //       plane cp (0..3: hi of channels 8cp..8cp+7, 4..7: scaled residual of
 //       channels 8(cp-4)..) = [padded position] x 16 B, same zero guards / zero
@@ -815,8 +830,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //     destination usable;
 // Arithmetic, summation order, chunks (160 dense voxels), wave roles (the 27
 // taps split 7/7/7/6 over the four waves, + one all-zero tap so that every wave
-// runs the same straight-line code) and the fused head are conv32k's: the
-// logits are BIT-IDENTICAL to conv_variant 5.  (A single accumulator per tile
+// runs the same straight-line code): a wave's partial sums of its taps are added
+// across the waves in wave order, whatever the tile count.  (A single
+// accumulator per tile
 // with a 2^11-scaled weight plane was built and measured: one third less
 // accumulator read-out, but the cross terms then lose bits against the large
 // accumulator, and on the 250^3 fixture the run left the oneDNN / f64
@@ -853,6 +869,8 @@ struct ConvDArgs {
   long sp_plane_bytes;   // positions x 16: one chunk plane of the split layout
   int XS, plane, nchunks, V, fx, fyfx, total_slots, slots_per_xcd;
   unsigned magic_nchunks, magic_fyfx, magic_fx;
+  int permuted;          // the FoV is laid out with permuted axes (Geom::oa) ...
+  int ds0, ds1, ds2;     // ... one step along z' / y' / x' in the caller's dense order
   unsigned sp_bytes;     // bytes of a split / f32 buffer past position 0 (store range)
   int aoff[4 * 8];       // [wave][j]: LDS byte offset of the wave's j-th tap
   int btap[4 * 8];       // [wave][j]: its tap index (weight fragments)
@@ -869,6 +887,16 @@ struct ConvDArgs {
 };
 
 constexpr int kDbgMaxWgs = 4096;
+
+// dense index v of this layout -> index in the caller's dense [z][y][x] order
+// (logits, seed_raw); the identity unless the axes are permuted
+__device__ __forceinline__ int caller_index(const ConvDArgs& a, int v) {
+  if (!a.permuted) return v;
+  const int z = (int)__umulhi((unsigned)v, a.magic_fyfx);
+  const int rem = v - z * a.fyfx;
+  const int y = (int)__umulhi((unsigned)rem, a.magic_fx);
+  return z * a.ds0 + y * a.ds1 + (rem - y * a.fx) * a.ds2;
+}
 
 // debug_clock 2: when and where a workgroup ran -- [start, end] on the 100 MHz
 // wall clock, HW_ID (wave / SIMD / CU / SH / SE fields) and XCC_ID
@@ -1179,7 +1207,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
     seedv[k] = 0.f;
     if constexpr (HEAD) {
       if ((tid & 7) == 0 && eok[k])
-        seedv[k] = a.seed_raw[(size_t)item * a.V + (v0 + ej[k])];
+        seedv[k] = a.seed_raw[(size_t)item * a.V + caller_index(a, v0 + ej[k])];
     }
     if constexpr (HEAD) {
       biasv[k][0] = biasv[k][1] =
@@ -1256,7 +1284,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
       partial += __shfl_xor(partial, 4);
       bool above = false;
       if (q == 0 && eok[k]) {
-        const size_t dv = (size_t)item * a.V + (v0 + j);
+        const size_t dv = (size_t)item * a.V + caller_index(a, v0 + j);
         float s = seedv[k];
         if (s != s) s = a.pad_value;
         const float lg = s + (partial + hbias);
@@ -1322,7 +1350,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
                                              so, (int)(4 * a.sp_plane_bytes), 16);
     }
     // an operand of the next layer left the fp16 range: the step is void, the
-    // host re-runs it with the bf16x3 scheme (ffn_step_result.range_error)
+    // host re-runs it with the exact-f32 kernel (ffn_step_result.range_error)
     if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *a.range_flag = a.range_tag;
   }
@@ -1602,7 +1630,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
       const char* sp = reinterpret_cast<const char*>(a.seed_raw + (size_t)item * a.V);
       asm volatile("global_load_dword %0, %1, %2"
                    : "=v"(seedv)
-                   : "v"((unsigned)((ok ? v0 + jpos : 0) * 4)), "s"(sp)
+                   : "v"((unsigned)(caller_index(a, ok ? v0 + jpos : 0) * 4)), "s"(sp)
                    : "memory");
     }
   };
@@ -1666,7 +1694,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
     partial += __shfl_xor(partial, 32);  // the other 16 channels of the position
     bool above = false;
     if (lh == 0 && ok) {
-      const size_t dv = (size_t)item * a.V + (v0 + jpos);
+      const size_t dv = (size_t)item * a.V + caller_index(a, v0 + jpos);
       float sd = seedv;
       if (sd != sd) sd = a.pad_value;
       const float lg = sd + (partial + hbias);

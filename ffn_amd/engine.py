@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import atexit
 import ctypes
+import threading
 from typing import Sequence
 import weakref
 
@@ -124,6 +125,9 @@ class HipEngine:
     self._slot_res_arr = [(StepResult * self.max_batch)() for _ in range(2)]
     self._submit_slot = 0
     self._ticket_slot = {}
+    # `step` / `step1` share argument arrays: one caller at a time (the library
+    # itself is thread safe; `segment_many` brings its own arrays)
+    self._step_lock = threading.RLock()
     #: steps repeated because a split-product kernel met a value outside the fp16 range
     self.range_fallbacks = 0
     #: True once a caller has chosen the conv kernel (pin_batched_arithmetic
@@ -235,14 +239,14 @@ class HipEngine:
 
   def step(self, canvases: Sequence['DeviceCanvasHandle'],
            requests: Sequence[StepRequest], params: StepParams):
-    """One FoV step for each canvas; returns the internal StepResult array
-    (valid until the next call)."""
+    """One FoV step for each canvas; returns a list of StepResult copies."""
     n = len(canvases)
-    for k in range(n):
-      self._canvas_arr[k] = canvases[k]._h
-      ctypes.pointer(self._req_arr[k])[0] = requests[k]
-    self._blocking_step(n, self._req_arr, params)
-    return self._res_arr
+    with self._step_lock:
+      for k in range(n):
+        self._canvas_arr[k] = canvases[k]._h
+        ctypes.pointer(self._req_arr[k])[0] = requests[k]
+      self._blocking_step(n, self._req_arr, params)
+      return [StepResult.from_buffer_copy(self._res_arr[k]) for k in range(n)]
 
   def _blocking_step(self, n, req, params):
     """ffn_canvas_step; a step voided by the fp16 range check (conv_variant >= 6)
@@ -333,10 +337,11 @@ class HipEngine:
 
   def step1(self, canvas: 'DeviceCanvasHandle', request: StepRequest,
             params: StepParams) -> StepResult:
-    """Single-canvas fast path: no per-call copies of the request."""
-    self._canvas_arr[0] = canvas._h
-    self._blocking_step(1, ctypes.byref(request), params)
-    return self._res_arr[0]
+    """Single-canvas path: no per-call copy of the request."""
+    with self._step_lock:
+      self._canvas_arr[0] = canvas._h
+      self._blocking_step(1, ctypes.byref(request), params)
+      return StepResult.from_buffer_copy(self._res_arr[0])
 
 
 class DeviceCanvasHandle:

@@ -29,6 +29,7 @@ import ctypes
 import logging
 import os
 import struct
+import sys
 import threading
 import weakref
 import time
@@ -1154,8 +1155,17 @@ class MultiCanvasDriver:
   """
 
   def __init__(self, engine, batch_size=None, overlap=True,
-               max_steps_per_canvas=None, native=None):
-    """native: run whole segment loops inside the library
+               max_steps_per_canvas=None, native=None, groups=1):
+    """groups (native mode): 2 = the open canvases form two groups, each driven
+    by its own host thread and its own library calls, `batch_size` canvases per
+    call.  The library interleaves the two calls' steps on the engine's stream
+    (one step of each in flight), so while one thread does a canvas'
+    between-segment work in Python -- commit, seed policy, the next
+    `init_seed` -- the other group's steps keep the GPU busy; with one group
+    every ended segment idles it for that long.  What the reference's N client
+    threads give it (executor.py:266-340), with two threads.
+
+    native: run whole segment loops inside the library
     (`ffn_canvas_segment_many`: the per-canvas policy queues, validity tests and
     the batching in C++, Python only between segments) instead of one Python
     round trip per batched step.  Default: on when the engine has it
@@ -1169,6 +1179,7 @@ class MultiCanvasDriver:
     if native is None:
       native = os.environ.get('FFN_AMD_NATIVE_MANY', '1') != '0'
     self.native = bool(native) and hasattr(engine, 'segment_many')
+    self.groups = max(1, int(groups)) if self.native else 1
     #: benchmarking / bounded runs: a canvas is dropped after this many steps
     self.max_steps_per_canvas = max_steps_per_canvas
     self.calls = 0
@@ -1266,11 +1277,66 @@ class MultiCanvasDriver:
     that canvas' generator then does its between-segment work (commit, next
     seed) and yields its next segment."""
     jobs = iter(jobs)
-    engine = self.engine
-    limit = self.max_steps_per_canvas
     if window is None or window > self.batch_size:
       # a canvas outside the engine call would only hold memory
       window = self.batch_size
+    lock = threading.Lock()
+
+    def pull():
+      """Next (canvas, task) of the job list, or None."""
+      with lock:
+        try:
+          return next(jobs)
+        except StopIteration:
+          return None
+
+    def done(canvas):
+      if on_done is not None:
+        with lock:
+          on_done(canvas)
+
+    if self.groups == 1:
+      tally = [0, 0]
+      try:
+        self._run_native_group(pull, window, done, tally)
+      finally:
+        self.calls += tally[0]
+        self.steps += tally[1]
+      return
+    # one thread per group; the GIL is released inside the library calls, and a
+    # short switch interval hands it over promptly when one returns
+    errors = []
+    tallies = [[0, 0] for _ in range(self.groups)]
+
+    def work(k):
+      try:
+        self._run_native_group(pull, window, done, tallies[k])
+      except BaseException as e:  # pylint:disable=broad-except
+        errors.append(e)
+
+    interval = sys.getswitchinterval()
+    sys.setswitchinterval(min(interval, 2e-4))
+    threads = [threading.Thread(target=work, args=(k,), daemon=True,
+                                name='ffn-canvas-group-%d' % k)
+               for k in range(self.groups)]
+    try:
+      for t in threads:
+        t.start()
+      for t in threads:
+        t.join()
+    finally:
+      sys.setswitchinterval(interval)
+      for c, n in tallies:
+        self.calls += c
+        self.steps += n
+    if errors:
+      raise errors[0]
+
+  def _run_native_group(self, pull, window, on_done, tally):
+    """One group of at most `window` open canvases: the loop of `_run_native`.
+    tally = [engine calls, FoV steps] of this group."""
+    engine = self.engine
+    limit = self.max_steps_per_canvas
     # [canvas, generator, pending request, steps of finished segments,
     #  steps of the current segment reported so far]
     live = []
@@ -1278,8 +1344,7 @@ class MultiCanvasDriver:
 
     def finished(entry):
       live.remove(entry)
-      if on_done is not None:
-        on_done(entry[0])
+      on_done(entry[0])
 
     def advance(entry, value):
       """Feeds `value` to the canvas' generator; False once it is through."""
@@ -1292,11 +1357,11 @@ class MultiCanvasDriver:
 
     def refill():
       while not state['exhausted'] and len(live) < window:
-        try:
-          canvas, task = next(jobs)
-        except StopIteration:
+        job = pull()
+        if job is None:
           state['exhausted'] = True
           return
+        canvas, task = job
         canvas._native_many = True
         gen = (task if inspect.isgenerator(task) else
                canvas._segment_all_gen(task))
@@ -1319,11 +1384,8 @@ class MultiCanvasDriver:
         py = [e for e in py if e not in batch]
         res = engine.step([e[0]._handle for e in batch], [e[2] for e in batch],
                           batch[0][0]._step_params)
-        self.calls += 1
-        self.steps += len(batch)
-        # (copies: the result array is reused by the next engine call, and a
-        # generator may make one before it yields again)
-        res = [_lib.StepResult.from_buffer_copy(res[k]) for k in range(len(batch))]
+        tally[0] += 1
+        tally[1] += len(batch)
         for entry, r in zip(batch, res):
           entry[3] += 1
           if limit is not None and entry[3] >= limit:
@@ -1346,9 +1408,9 @@ class MultiCanvasDriver:
       results, fin = engine.segment_many(
           [e[0]._handle for e in batch], [e[2].start_pos for e in batch],
           [e[2].params for e in batch], [e[2].started for e in batch])
-      self.calls += 1
+      tally[0] += 1
       for e, res, done in zip(batch, results, fin):
-        self.steps += int(res.num_steps) - e[4]
+        tally[1] += int(res.num_steps) - e[4]
         e[4] = int(res.num_steps)
         e[2].started = True
         if not done:

@@ -363,7 +363,8 @@ class Runner:
     return canvas
 
   def run_many(self, subvolumes, batch_size=None, reset_counters=True,
-               save=True, window=None, on_done=None, keep_open=False):
+               save=True, window=None, on_done=None, keep_open=False, groups=1,
+               max_steps_per_canvas=None):
     """Segments several subvolumes CONCURRENTLY on this GPU (BASELINE config C3).
 
     The reference gets this from one thread per subvolume calling `run()` on a
@@ -390,6 +391,11 @@ class Runner:
       on_done: called as on_done(index, canvas) when subvolume `index` is
         finished and saved, before its canvas is closed
       keep_open: leave finished canvases open (the caller closes them)
+      max_steps_per_canvas: bounded runs (benchmarks): a canvas is dropped
+        after this many FoV steps
+      groups: 2 = two groups of `batch_size` canvases, each advanced by its own
+        host thread (`MultiCanvasDriver`): one group's steps run on the GPU
+        while the other's ended segments are committed and re-seeded
 
     Returns:
       list of canvases (None where the output already existed / all masked),
@@ -402,7 +408,9 @@ class Runner:
     out_dir = self.request.segmentation_output_dir
     canvases = []
     meta = {}
-    driver = inference.MultiCanvasDriver(self.executor.engine, batch_size)
+    driver = inference.MultiCanvasDriver(
+        self.executor.engine, batch_size, groups=groups,
+        max_steps_per_canvas=max_steps_per_canvas)
     if window is None:
       window = 2 * driver.batch_size
 

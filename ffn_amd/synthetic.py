@@ -36,7 +36,8 @@ def cells_volume(shape=(250, 250, 250), seed=1234, cells_per_96cube=12.0,
   for z in range(shape[0]):
     pts = np.concatenate(
         [np.full((plane.shape[0], 1), float(z)), plane], axis=1)
-    labels[z] = tree.query(pts)[1].reshape(shape[1], shape[2])
+    # (exact nearest neighbours: the worker count does not change the result)
+    labels[z] = tree.query(pts, workers=-1)[1].reshape(shape[1], shape[2])
   edge = np.zeros(shape, dtype=bool)
   for axis in range(3):
     d = np.diff(labels, axis=axis) != 0
@@ -53,6 +54,21 @@ def cells_volume(shape=(250, 250, 250), seed=1234, cells_per_96cube=12.0,
   if blur_sigma > 0:
     vol = ndimage.gaussian_filter(vol, blur_sigma)
   return np.clip(np.rint(vol), 0, 255).astype(np.uint8)
+
+
+def shared_volume(build, path, rank=0, barrier=None):
+  """One copy of a synthetic volume for all ranks of a node: rank 0 builds it
+  (`build()` -> ndarray) and saves it to `path` (a file in /dev/shm or TMPDIR),
+  `barrier()` orders the ranks, the others map it read-only."""
+  if barrier is None:  # a single rank: nothing to share
+    return build()
+  if rank == 0:
+    vol = build()
+    np.save(path, vol)
+    barrier()
+    return vol
+  barrier()
+  return np.load(path, mmap_mode='r')
 
 
 def normalize(volume_u8: np.ndarray, mean: float = 128.0,

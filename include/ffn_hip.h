@@ -291,7 +291,9 @@ int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
  * 1 write-through, 2 non-temporal conv stores. */
 int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
 /* Current value of an option ("conv_variant", "exact_variant", "fuse_head",
- * "store_policy", "sync_mode", "profile_every"). */
+ * "store_policy", "sync_mode", "profile_every"), or a statistic of the batched
+ * step calls since set_option("stat_reset", 0): "stat_step_calls",
+ * "stat_step_items" (FoVs in them), "stat_hist_<n>" (calls with n FoVs). */
 int ffn_engine_get_option(ffn_engine* engine, const char* name, int* value);
 /* Debug: with option "debug_clock" = 1 the compact conv kernel records, for its
  * first workgroup, per wave {shader clock at entry, at main-loop start, at

@@ -332,6 +332,8 @@ class OracleCanvas:
       return False
     return True
 
+  tie_tol = 1e-4  # the per-step float tolerance of the parity tests
+
   def _forward(self, img, seed):
     if self.forward_fn is not None:
       return self.forward_fn(img, seed)
@@ -352,6 +354,11 @@ class OracleCanvas:
       with np.errstate(invalid='ignore'):
         self.last_deleted = int(np.sum(
             (old_seed >= np.float32(logit(0.8))) & (logits < th_max)))
+        # voxels of that count a forward within `tie_tol` of this one may put
+        # on the other side of th_max (the count is exact up to these)
+        self.last_deleted_ties = int(np.sum(
+            (old_seed >= np.float32(logit(0.8))) &
+            (np.abs(logits - th_max) <= self.tie_tol)))
       if np.mean(logits >= self.move_threshold) > self.disco_seed_threshold:
         with np.errstate(invalid='ignore'):
           mask = (old_seed < th_max) & (logits > old_seed)

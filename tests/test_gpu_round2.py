@@ -526,3 +526,61 @@ def test_segment_many_in_the_library(fib25_model):
   print('engine calls: native %d, per-step %d, for %d FoV steps' % (
       runs[True][1], runs[False][1], total))
   assert runs[True][1] < runs[False][1] / 3
+
+
+@pytest.mark.gpu
+def test_two_canvas_groups_in_two_threads(fib25_model):
+  """BASELINE configs[2] shape: more canvases open than FoVs per engine call --
+  MultiCanvasDriver(groups=2): two host threads, each advancing its own group of
+  canvases through its own ffn_canvas_segment_many calls on ONE engine (the
+  library interleaves their steps: one of each in flight).  Every canvas equals
+  its standalone, reference-minted run -- whatever it shared its calls and the
+  GPU with -- and every job is done exactly once."""
+  import functools
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from ffn_amd.inference import seed as seed_lib
+  import bench
+  names = ['cells72', 'cells56', 'cells56', 'cells72', 'cells56', 'cells56',
+           'cells72', 'cells56', 'cells72']
+  gold = {n: np.load(os.path.join(GOLDEN, 'ref_canvas_%s.npz' % n))
+          for n in set(names)}
+  request = bench.make_request()
+  counters = inference_utils.Counters()
+  exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
+                                  fib25_model.info, None, counters, 3)
+  canvases = []
+
+  def jobs():
+    for n in names:  # created lazily, by whichever thread has a free slot
+      sub = counters.get_sub_counters()
+      c = inference.DeviceCanvas(
+          fib25_model.info, exe.get_client(sub, direct=True),
+          synthetic.normalize(gold[n]['volume']), request.inference_options,
+          counters=sub,
+          movement_policy_fn=movement.get_policy_fn(request, fib25_model.info))
+      canvases.append((c, n))
+      yield c, functools.partial(seed_lib.PolicyFixed, coords=gold[n]['seeds'])
+
+  results = {}
+
+  def on_done(c):
+    results[id(c)] = (np.array(np.asarray(c.segmentation)),
+                      c.counters['update_at-calls'].value)
+    c.close()
+
+  drv = inference.MultiCanvasDriver(exe.engine, batch_size=3, native=True,
+                                    groups=2)
+  drv.run(jobs(), on_done=on_done)
+  assert len(canvases) == len(names) == len(results)
+  total = 0
+  for c, n in canvases:
+    seg, calls = results[id(c)]
+    assert np.array_equal(seg, gold[n]['segmentation']), n
+    assert calls == len(gold[n]['steps']), n
+    total += calls
+  assert drv.steps == total
+  exe.engine.close()

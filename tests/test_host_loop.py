@@ -453,3 +453,33 @@ def test_native_driver_steps_python_loop_canvases_next_to_native_ones(shim, fib2
     assert masked.counters[key].value == ref[key], key
   assert drv.steps == (len(gm['run_steps']) + len(gold['cells56']['steps']) +
                        len(gold['cells72']['steps']))
+
+
+def test_segment_many_two_groups_in_two_threads(shim, fib25_blob):
+  """groups=2: the open canvases form two groups, each advanced by its own host
+  thread with its own library calls (on the GPU: one group's steps run while
+  the other's ended segments are committed and re-seeded).  Every canvas still
+  repeats its reference-minted run; every job is done exactly once."""
+  import json
+  names = ['cells72', 'cells56', 'cells56', 'cells72', 'cells56', 'cells56',
+           'cells72']
+  client, engine, canvases, gold = _many_canvases(shim, fib25_blob, names)
+  engine.max_batch = 2
+  drv = inference.MultiCanvasDriver(engine, batch_size=2, native=True, groups=2)
+  assert drv.groups == 2
+  done = []
+  drv.run(((c, functools.partial(seed_lib.PolicyFixed, coords=gold[n]['seeds']))
+           for c, n in zip(canvases, names)), on_done=done.append)
+  assert sorted(id(c) for c in done) == sorted(id(c) for c in canvases)
+  total = 0
+  for c, n in zip(canvases, names):
+    g = gold[n]
+    assert np.array_equal(np.array(c._handle.steps_seen).reshape(-1, 3), g['steps']), n
+    assert np.array_equal(np.asarray(c.segmentation), g['segmentation']), n
+    ref = json.loads(str(g['counters']))
+    for key in ('update_at-calls', 'voxels-segmented', 'segment_at-loop-calls'):
+      if key in ref:
+        assert c.counters[key].value == ref[key], (n, key)
+    total += len(g['steps'])
+  assert drv.steps == total
+  assert max(engine.batch_sizes) <= 2

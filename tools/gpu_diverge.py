@@ -22,7 +22,12 @@ from tests import test_gpu_round2 as t2  # noqa: E402  (canvas / request helpers
 
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument('--variants', type=int, nargs='+', default=[2, 4, 6])
+  ap.add_argument('--variants', type=int, nargs='+', default=[2, 9])
+  ap.add_argument('--fixture', default='',
+                  help="suffix of tests/golden/ref_canvas_cells250<suffix>.npz: '' "
+                  "(C oracle forward), '_onednn', '_f64', '_onednn_full' (the "
+                  'WHOLE volume: every seed of the grid, tools/make_golden.py '
+                  '--only cells250 --forward onednn --num-seeds 0 --tag _full)')
   args = ap.parse_args()
   from ffn_amd import synthetic
   from ffn_amd.inference import executor, inference_utils
@@ -34,7 +39,11 @@ def main():
   exe = executor.HipBatchExecutor(executor.ExecutorInterface(), model,
                                   model.info, None, inference_utils.Counters(),
                                   1, device_id=0)
-  g = np.load(os.path.join(ROOT, 'tests/golden/ref_canvas_cells250.npz'))
+  g = np.load(os.path.join(ROOT, 'tests/golden/ref_canvas_cells250%s.npz' %
+                           args.fixture))
+  print('fixture ref_canvas_cells250%s.npz: %d FoV steps, %d seeds, forward %s, '
+        'minted in %.0f s' % (args.fixture, len(g['steps']), len(g['seeds']),
+                              str(g['forward']), float(g['mint_wall_seconds'])))
   vol = synthetic.cells_volume((250, 250, 250), seed=1234)
   want_steps = [tuple(int(v) for v in p) for p in g['steps']]
   want_moves, off = [], 0
@@ -94,6 +103,26 @@ def main():
     inter = np.sum((seg > 0) & (want_seg > 0) & (seg == want_seg))
     union = np.sum((seg > 0) | (want_seg > 0))
     fg_inter = np.sum((seg > 0) & (want_seg > 0))
+    # id-agnostic: every reference object against the object of this run that
+    # covers most of it (two runs that part ways number their segments apart)
+    both = (seg > 0) & (want_seg > 0)
+    keys, cnt = np.unique(want_seg[both].astype(np.int64) * (1 << 32) +
+                          seg[both].astype(np.int64), return_counts=True)
+    size_w = np.bincount(want_seg[want_seg > 0].ravel())
+    size_g = np.bincount(seg[seg > 0].ravel())
+    best = {}
+    for kk, c in zip(keys, cnt):
+      w, gid = int(kk >> 32), int(kk & 0xffffffff)
+      iou = c / float(size_w[w] + size_g[gid] - c)
+      if iou > best.get(w, 0.0):
+        best[w] = iou
+    ref_ids = np.nonzero(size_w)[0]
+    matched = sum(best.get(int(w), 0.0) * size_w[w] for w in ref_ids) / max(
+        float(size_w.sum()), 1.0)
+    print('variant %d: objects %d (reference %d); size-weighted best-match IoU per '
+          'reference object %.6f; objects matched at IoU >= 0.999: %d' %
+          (variant, int(np.count_nonzero(size_g)), len(ref_ids), matched,
+           sum(1 for w in ref_ids if best.get(int(w), 0.0) >= 0.999)))
     print('variant %d: %d steps (reference %d); first position mismatch at step '
           '%s; first move-list mismatch at step %s; max move-score err before '
           'it %.3g; labelled IoU %.6f, foreground IoU %.6f, voxels %d vs %d' %
