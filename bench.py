@@ -579,6 +579,14 @@ def run_sharded(args, rank, local_rank, world):
       'per_rank': None if per_rank is None else [
           {'fov_steps': int(r[0]), 'busy_seconds': round(r[3], 3),
            'sub_boxes': int(r[4])} for r in per_rank],
+      'host_loop': {
+          'library_calls': run.last_driver.calls,
+          'seconds_inside_library_calls': round(run.last_driver.library_seconds, 3),
+          'segments_ended': run.last_driver.segments_ended,
+          'note': 'rank 0, summed over the group threads: the rest of '
+                  'groups x segmentation_seconds is Python between segments '
+                  '(commit, seed policy, next init_seed) and canvas set-up',
+      },
       'engine_calls': {
           'batched_steps': step_calls,
           'mean_fovs_per_step': round(step_items / max(step_calls, 1), 2),
@@ -810,6 +818,47 @@ def gpu_parity_leg(res, oracle_traces, tol=1e-4):
                          'torch-CPU / oneDNN forward'}
 
 
+def batched_leg(args):
+  """BASELINE configs[2] next to the headline, time-boxed: this script once more
+  with --mode sharded on a 512^3 volume -- 32 canvases open (two groups of 16
+  FoVs per engine call; --batched-max-steps > 0 drops every canvas after that
+  many FoV steps) -- in a process of its own (its engine holds 16 FoVs of activations;
+  the headline's holds one).  Reported: the kernel-only rate of the batched
+  conv stack with its roofline fraction, and the end-to-end FoV-steps/s of the
+  bounded run.  Never `value`."""
+  import subprocess
+  cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'sharded',
+         '--sharded-volume', '512', '--sharded-sub', '153', '--sharded-batch', '16',
+         '--sharded-groups', '2', '--sharded-max-steps',
+         str(args.batched_max_steps), '--no-cpu-baseline']
+  t0 = time.perf_counter()
+  try:
+    run = subprocess.run(cmd, capture_output=True, text=True,
+                         timeout=args.batched_timeout)
+    line = run.stdout.strip().splitlines()[-1]
+    d = json.loads(line)
+  except Exception as e:  # pylint:disable=broad-except
+    return {'error': repr(e), 'seconds': round(time.perf_counter() - t0, 1)}
+  return {
+      'what': ('bench.py --mode sharded on one 512^3 volume in %d sub-boxes, 32 '
+               'canvases open; %s' % (
+                   d['config']['sub_boxes'],
+                   'the whole volume' if not args.batched_max_steps else
+                   'bounded: a sub-box is dropped after %d FoV steps'
+                   % args.batched_max_steps)),
+      'workload': d['config']['workload'],
+      'value': d['value'],
+      'unit': d['unit'],
+      'steps': d['steps'],
+      'seconds': d['segmentation_seconds'],
+      'roofline': d['batched_kernel'],
+      'engine_calls': d['engine_calls'],
+      'host_loop': d['host_loop'],
+      'setup_seconds': d['setup_seconds'],
+      'wall_seconds_of_this_leg': round(time.perf_counter() - t0, 1),
+  }
+
+
 def _self_launch(args):
   """`python bench.py --gpus N` outside torch.distributed.run: become
   `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank
@@ -871,6 +920,11 @@ def main():
   ap.add_argument('--cpu-seconds', type=float, default=15.0)
   ap.add_argument('--cpu-steps', type=int, default=60)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-batched-leg', action='store_true',
+                  help='skip the time-boxed batched (configs[2]) leg of the '
+                  'default run')
+  ap.add_argument('--batched-max-steps', type=int, default=0)
+  ap.add_argument('--batched-timeout', type=float, default=420.0)
   ap.add_argument('--host-loop', choices=['native', 'python'], default='native',
                   help='native: ffn_canvas_segment_at runs each segment\'s FoV '
                   'loop inside the library; python: one ffn_canvas_step call '
@@ -1045,6 +1099,8 @@ def main():
     except Exception as e:  # pylint:disable=broad-except
       out.update({'parity_steps_checked': 0, 'parity_ok': False,
                   'parity_error': repr(e)})
+  if world == 1 and CONFIG == 'c1' and not args.no_batched_leg:
+    out['batched'] = batched_leg(args)
   print(json.dumps(out))
 
 

@@ -75,7 +75,17 @@ struct ffn_engine {
   // event, not for the stream -- so another thread's next FoV step is queued
   // (and runs) behind them instead of waiting for the host to wake up.
   std::mutex util_mu;
-  hipEvent_t util_ev = nullptr;
+  // They run on their OWN stream: a canvas between two segments is in no step,
+  // so what is committed / read / re-seeded on it must not queue behind the FoV
+  // steps other canvases have in flight (2 ms each at batch 16).  Ordering
+  // per canvas: the step side waits for the canvas' last utility event
+  // (ffn_canvas::ev_util) before its next step; the utility side starts after
+  // the canvas' last step has pasted -- batched steps paste BEFORE the faces
+  // kernel raises the completion flag the host waits for, a single-FoV step
+  // (faces first: the host's turn-around is on its critical path) makes the
+  // utility stream wait for an event recorded behind it.
+  hipStream_t ustream = nullptr;
+  hipEvent_t main_ev = nullptr;  // "everything queued on `stream` so far"
   int device = 0;
   hipStream_t stream = nullptr;
   Geom g{};   // the FoV as the caller sees it (zyx): gather / paste / faces, I/O
@@ -205,6 +215,9 @@ struct ffn_canvas {
   int dirty_lo[3] = {0, 0, 0};
   int dirty_hi[3] = {0, 0, 0};  // exclusive; lo >= hi: nothing dirty
   ffn_host::SegmentState loop;  // ffn_canvas_segment_at's queue / visited set
+  hipEvent_t ev_util = nullptr;  // behind the last utility operation on this canvas
+  bool util_pending = false;     // ... which the next step has to wait for
+  bool paste_after_flag = false; // the last step pasted AFTER raising its flag
 
   void mark_dirty(const int lo[3], const int hi[3]) {
     const int dims[3] = {cz, cy, cx};
@@ -234,22 +247,57 @@ struct UtilLock {
       lk = std::unique_lock<std::recursive_mutex>(e->mu);
     }
   }
-  // everything queued so far has finished; `mu` is released while waiting
-  hipError_t wait(ffn_engine* e) {
-    hipError_t err = hipEventRecord(e->util_ev, e->stream);
+  // Before the first utility operation of a call: the canvas' last step has
+  // pasted (see ffn_engine::ustream).
+  hipError_t begin(ffn_engine* e, ffn_canvas* c) {
+    if (!c->paste_after_flag) return hipSuccess;
+    hipError_t err = hipEventRecord(e->main_ev, e->stream);
+    if (err == hipSuccess) err = hipStreamWaitEvent(e->ustream, e->main_ev, 0);
+    if (err == hipSuccess) c->paste_after_flag = false;
+    return err;
+  }
+  // After the last one: mark the point the canvas' next step waits for ...
+  hipError_t end(ffn_engine* e, ffn_canvas* c) {
+    c->util_pending = true;
+    return hipEventRecord(c->ev_util, e->ustream);
+  }
+  // ... and, for calls that return data, wait for it (`mu` released meanwhile)
+  hipError_t wait(ffn_engine* e, ffn_canvas* c) {
+    hipError_t err = end(e, c);
     if (err != hipSuccess) return err;
     lk.unlock();
-    err = hipEventSynchronize(e->util_ev);
+    err = hipEventSynchronize(c->ev_util);
     lk.lock();
+    if (err == hipSuccess) c->util_pending = false;  // done: nothing to wait for
     return err;
   }
 };
+// host-side: nothing queued on canvas c is still running
+hipError_t canvas_quiesce(ffn_engine* e, ffn_canvas* c) {
+  hipError_t err = hipSuccess;
+  if (c->paste_after_flag) {
+    err = hipStreamSynchronize(e->stream);
+    if (err == hipSuccess) c->paste_after_flag = false;
+  }
+  if (err == hipSuccess && c->util_pending) {
+    err = hipEventSynchronize(c->ev_util);
+    if (err == hipSuccess) c->util_pending = false;
+  }
+  return err;
+}
 }  // namespace
 
 int ffn_canvas_view(ffn_canvas* c, FfnCanvasView* out) {
   if (!c || !out) return ffn_set_error(FFN_ERR_ARG, "NULL canvas");
   if (!c->engine)
     return ffn_set_error(FFN_ERR_STATE, "canvas outlived its engine");
+  {
+    // the caller (label / seed kernels on their own streams) reads the canvas
+    // once the engine's stream is idle: the utility stream has to be, too
+    EngineLock lock_(c->engine);
+    if (canvas_quiesce(c->engine, c) != hipSuccess)
+      return ffn_set_error(FFN_ERR_HIP, "canvas_quiesce failed");
+  }
   out->device_id = c->engine->device;
   out->engine_stream = c->engine->stream;
   out->image = c->image;
@@ -266,7 +314,7 @@ namespace {
 
 int ensure_scratch(ffn_engine* e, size_t bytes) {
   if (bytes <= e->scratch_bytes) return FFN_OK;
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipStreamSynchronize(e->ustream));  // (only utility calls use it)
   if (e->d_scratch) HIP_TRY(hipFree(e->d_scratch));
   if (e->h_scratch) HIP_TRY(hipHostFree(e->h_scratch));
   e->d_scratch = e->h_scratch = nullptr;
@@ -953,7 +1001,12 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   } while (0)
 
   E_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  E_TRY(hipEventCreateWithFlags(&e->util_ev, hipEventDisableTiming));
+  {
+    int lo = 0, hi = 0;  // (numerically lowest = highest priority)
+    E_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    E_TRY(hipStreamCreateWithPriority(&e->ustream, hipStreamNonBlocking, hi));
+  }
+  E_TRY(hipEventCreateWithFlags(&e->main_ev, hipEventDisableTiming));
   const size_t act_bytes = (size_t)3 * max_batch * g.act_stride * sizeof(float);
   E_TRY(hipMalloc(&e->act_base, act_bytes));
   E_TRY(hipMemset(e->act_base, 0, act_bytes));
@@ -1173,6 +1226,8 @@ void ffn_engine_destroy(ffn_engine* e) {
     (void)hipFree(c->image_lut);
     (void)hipFree(c->seed);
     (void)hipFree(c->seg);
+    if (c->ev_util) (void)hipEventDestroy(c->ev_util);
+    c->ev_util = nullptr;
     c->image = c->seed = nullptr;
     c->image_u8 = nullptr;
     c->image_lut = nullptr;
@@ -1180,7 +1235,9 @@ void ffn_engine_destroy(ffn_engine* e) {
     c->engine = nullptr;
   }
   e->canvases.clear();
-  if (e->util_ev) (void)hipEventDestroy(e->util_ev);
+  if (e->ustream) (void)hipStreamSynchronize(e->ustream);
+  if (e->main_ev) (void)hipEventDestroy(e->main_ev);
+  if (e->ustream) (void)hipStreamDestroy(e->ustream);
   for (auto& ev : e->events)
     if (ev) (void)hipEventDestroy(ev);
   (void)hipFree(e->act_base);
@@ -1571,6 +1628,14 @@ int canvas_create(ffn_engine* e, const float* image_f32, const uint8_t* image_u8
     ffn_canvas_destroy(c);
     return rc;
   }
+  {
+    const hipError_t ee = hipEventCreateWithFlags(&c->ev_util, hipEventDisableTiming);
+    if (ee != hipSuccess) {
+      int rc = fail(FFN_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(ee));
+      ffn_canvas_destroy(c);
+      return rc;
+    }
+  }
   e->canvases.push_back(c);
   *out = c;
   return FFN_OK;
@@ -1599,6 +1664,8 @@ void ffn_canvas_destroy(ffn_canvas* c) {
     ffn_engine* e = c->engine;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+    (void)hipStreamSynchronize(e->ustream);
+    if (c->ev_util) (void)hipEventDestroy(c->ev_util);
     e->canvases.erase(std::remove(e->canvases.begin(), e->canvases.end(), c),
                       e->canvases.end());
     (void)hipFree(c->image);
@@ -1611,7 +1678,7 @@ void ffn_canvas_destroy(ffn_canvas* c) {
 }
 
 int ffn_canvas_init_seed(ffn_canvas* c, const int32_t pos[3], float value) {
-  EngineLock lock_(c ? c->engine : nullptr);
+  UtilLock lock_(c ? c->engine : nullptr);
   if (!c || !pos) return fail(FFN_ERR_ARG, "null argument");
   if (pos[0] < 0 || pos[0] >= c->cz || pos[1] < 0 || pos[1] >= c->cy ||
       pos[2] < 0 || pos[2] >= c->cx)
@@ -1619,16 +1686,17 @@ int ffn_canvas_init_seed(ffn_canvas* c, const int32_t pos[3], float value) {
   ffn_engine* e = c->engine;
   if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(lock_.begin(e, c));
   if (c->dirty_lo[0] < c->dirty_hi[0]) {
     long total = 0;
     Box b = make_box(c, c->dirty_lo, c->dirty_hi, &total);
     if ((size_t)total * 2 >= c->nvox) {  // most of the volume: linear fill
-      hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, e->stream,
+      hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, e->ustream,
                          reinterpret_cast<uint32_t*>(c->seed), 0x7fc00000u,
                          c->nvox);
     } else if (total > 0) {
       hipLaunchKernelGGL((box_fill_kernel<uint32_t>), dim3(grid_for(total)),
-                         dim3(256), 0, e->stream,
+                         dim3(256), 0, e->ustream,
                          reinterpret_cast<uint32_t*>(c->seed), b, total,
                          0x7fc00000u);
     }
@@ -1640,9 +1708,10 @@ int ffn_canvas_init_seed(ffn_canvas* c, const int32_t pos[3], float value) {
     c->mark_dirty(lo, hi);
   }
   const size_t ci = ((size_t)pos[0] * c->cy + pos[1]) * c->cx + pos[2];
-  hipLaunchKernelGGL(set_seed_point_kernel, dim3(1), dim3(1), 0, e->stream,
+  hipLaunchKernelGGL(set_seed_point_kernel, dim3(1), dim3(1), 0, e->ustream,
                      c->seed, ci, value);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(lock_.end(e, c));
   return FFN_OK;
 }
 
@@ -1661,6 +1730,7 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   if (e->slot_n[slot] != 0)
     return fail(FFN_ERR_STATE,
                 "two steps already in flight: call ffn_canvas_step_wait first");
+  HIP_TRY(hipSetDevice(e->device));
   const Geom& g = e->g;
   StepItem* h_items = e->h_items + (size_t)slot * e->max_batch;
   StepItem* d_items = e->d_items + (size_t)slot * e->max_batch;
@@ -1692,6 +1762,12 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
                          r.pos[2] + half[2] + 1};
       const_cast<ffn_canvas*>(c)->mark_dirty(lo, hi);
     }
+    if (c->util_pending) {  // its last commit / re-seed, on the utility stream
+      HIP_TRY(hipStreamWaitEvent(e->stream, c->ev_util, 0));
+      const_cast<ffn_canvas*>(c)->util_pending = false;
+    }
+    // a single-FoV step raises its flag before it pastes (below)
+    const_cast<ffn_canvas*>(c)->paste_after_flag = n == 1;
     StepItem& it = h_items[k];
     it.image = c->image;
     it.image_u8 = c->image_u8;
@@ -1714,14 +1790,22 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   int rc = run_stack(e, n, si, params->pad_value, params->move_threshold);
   if (rc) return rc;
   const unsigned step_id = ++e->step_id ? e->step_id : ++e->step_id;  // never 0
+  // One FoV: faces first -- the host's turn-around is on the critical path and
+  // the paste runs under it.  Several: paste first, so that the completion flag
+  // the host waits for also says "pasted" and a canvas whose segment has ended
+  // can be committed on the utility stream at once (ffn_engine::ustream).
+  auto paste = [&]() {
+    hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
+                       e->logits, e->seed_raw, e->count, e->count_blocks,
+                       params->disco_seed_threshold, e->range_flag, e->range_tag);
+  };
+  if (n > 1) paste();
   hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
                      e->logits, e->seed_raw, e->count, e->count_blocks,
                      params->move_threshold, params->disco_seed_threshold,
                      params->deleted_threshold, e->range_flag, e->range_tag,
                      h_results, h_seq, step_id);
-  hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
-                     e->logits, e->seed_raw, e->count, e->count_blocks,
-                     params->disco_seed_threshold, e->range_flag, e->range_tag);
+  if (n == 1) paste();
   HIP_TRY(hipGetLastError());
   e->stat_calls += 1;
   e->stat_items += n;
@@ -1908,6 +1992,7 @@ int ffn_canvas_read_points(ffn_canvas* c, int n, const int32_t* pos,
   ffn_engine* e = c->engine;
   if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(lock_.begin(e, c));
   const size_t pb = sizeof(int32_t) * 3 * n;
   const size_t pbr = (pb + 15) & ~(size_t)15;
   int rc = ensure_scratch(e, pbr + 8 * (size_t)n);
@@ -1915,15 +2000,15 @@ int ffn_canvas_read_points(ffn_canvas* c, int n, const int32_t* pos,
   char* hs = static_cast<char*>(e->h_scratch);
   char* ds = static_cast<char*>(e->d_scratch);
   std::memcpy(hs, pos, pb);
-  HIP_TRY(hipMemcpyAsync(ds, hs, pb, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(ds, hs, pb, hipMemcpyHostToDevice, e->ustream));
   float* d_seed = reinterpret_cast<float*>(ds + pbr);
   int32_t* d_seg = reinterpret_cast<int32_t*>(ds + pbr + 4 * (size_t)n);
   hipLaunchKernelGGL(points_read_kernel, dim3((n + 63) / 64), dim3(64), 0,
-                     e->stream, c->seed, c->seg, c->cz, c->cy, c->cx, n,
+                     e->ustream, c->seed, c->seg, c->cz, c->cy, c->cx, n,
                      reinterpret_cast<const int32_t*>(ds), d_seed, d_seg);
   HIP_TRY(hipMemcpyAsync(hs + pbr, ds + pbr, 8 * (size_t)n, hipMemcpyDeviceToHost,
-                         e->stream));
-  HIP_TRY(lock_.wait(e));
+                         e->ustream));
+  HIP_TRY(lock_.wait(e, c));
   std::memcpy(seed_out, hs + pbr, 4 * (size_t)n);
   std::memcpy(seg_out, hs + pbr + 4 * (size_t)n, 4 * (size_t)n);
   return FFN_OK;
@@ -1941,6 +2026,15 @@ int ffn_canvas_write_seg_points(ffn_canvas* c, int n, const int32_t* pos,
   ffn_engine* e = c->engine;
   if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(lock_.begin(e, c));
+  if (n == 1) {  // (the -1 marker of a rejected seed: nothing to wait for)
+    const size_t ci = ((size_t)pos[0] * c->cy + pos[1]) * c->cx + pos[2];
+    hipLaunchKernelGGL(set_seg_point_kernel, dim3(1), dim3(1), 0, e->ustream, c->seg,
+                       ci, values[0]);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(lock_.end(e, c));
+    return FFN_OK;
+  }
   const size_t pb = sizeof(int32_t) * 3 * n;
   const size_t pbr = (pb + 15) & ~(size_t)15;
   int rc = ensure_scratch(e, pbr + 4 * (size_t)n);
@@ -1950,12 +2044,12 @@ int ffn_canvas_write_seg_points(ffn_canvas* c, int n, const int32_t* pos,
   std::memcpy(hs, pos, pb);
   std::memcpy(hs + pbr, values, 4 * (size_t)n);
   HIP_TRY(hipMemcpyAsync(ds, hs, pbr + 4 * (size_t)n, hipMemcpyHostToDevice,
-                         e->stream));
+                         e->ustream));
   hipLaunchKernelGGL(points_write_seg_kernel, dim3((n + 63) / 64), dim3(64), 0,
-                     e->stream, c->seg, c->cy, c->cx, n,
+                     e->ustream, c->seg, c->cy, c->cx, n,
                      reinterpret_cast<const int32_t*>(ds),
                      reinterpret_cast<const int32_t*>(ds + pbr));
-  HIP_TRY(lock_.wait(e));
+  HIP_TRY(lock_.wait(e, c));
   return FFN_OK;
 }
 
@@ -1977,17 +2071,18 @@ int ffn_canvas_any_segmented(ffn_canvas* c, const int32_t lo[3],
   ffn_engine* e = c->engine;
   if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(lock_.begin(e, c));
   int rc = ensure_scratch(e, 16);
   if (rc) return rc;
   long total;
   Box b = make_box(c, l, h, &total);
-  HIP_TRY(hipMemsetAsync(e->d_scratch, 0, 4, e->stream));
+  HIP_TRY(hipMemsetAsync(e->d_scratch, 0, 4, e->ustream));
   hipLaunchKernelGGL(any_segmented_kernel, dim3(grid_for(total)), dim3(256), 0,
-                     e->stream, c->seg, b, total,
+                     e->ustream, c->seg, b, total,
                      static_cast<int32_t*>(e->d_scratch));
   HIP_TRY(hipMemcpyAsync(e->h_scratch, e->d_scratch, 4, hipMemcpyDeviceToHost,
-                         e->stream));
-  HIP_TRY(lock_.wait(e));
+                         e->ustream));
+  HIP_TRY(lock_.wait(e, c));
   *out = *static_cast<int32_t*>(e->h_scratch);
   return FFN_OK;
 }
@@ -2005,22 +2100,23 @@ int ffn_canvas_commit_count(ffn_canvas* c, const int32_t lo[3],
   ffn_engine* e = c->engine;
   if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(lock_.begin(e, c));
   const size_t hist_n = (size_t)max_existing_id + 1;
   const size_t bytes = 16 + hist_n * sizeof(unsigned);
   rc = ensure_scratch(e, bytes);
   if (rc) return rc;
   long total;
   Box b = make_box(c, lo, hi, &total);
-  HIP_TRY(hipMemsetAsync(e->d_scratch, 0, bytes, e->stream));
+  HIP_TRY(hipMemsetAsync(e->d_scratch, 0, bytes, e->ustream));
   auto* d_counts = static_cast<unsigned long long*>(e->d_scratch);
   auto* d_hist = reinterpret_cast<unsigned*>(static_cast<char*>(e->d_scratch) + 16);
   if (total > 0)
     hipLaunchKernelGGL(commit_count_kernel, dim3(grid_for(total)), dim3(256), 0,
-                       e->stream, c->seed, c->seg, b, total, segment_threshold,
+                       e->ustream, c->seed, c->seg, b, total, segment_threshold,
                        max_existing_id, d_counts, d_hist);
   HIP_TRY(hipMemcpyAsync(e->h_scratch, e->d_scratch, bytes, hipMemcpyDeviceToHost,
-                         e->stream));
-  HIP_TRY(lock_.wait(e));
+                         e->ustream));
+  HIP_TRY(lock_.wait(e, c));
   const auto* hc = static_cast<const unsigned long long*>(e->h_scratch);
   const auto* hh = reinterpret_cast<const unsigned*>(
       static_cast<const char*>(e->h_scratch) + 16);
@@ -2043,20 +2139,22 @@ int ffn_canvas_commit_count(ffn_canvas* c, const int32_t lo[3],
 int ffn_canvas_commit_assign(ffn_canvas* c, const int32_t lo[3],
                              const int32_t hi[3], float segment_threshold,
                              int32_t segment_id) {
-  EngineLock lock_(c ? c->engine : nullptr);
+  UtilLock lock_(c ? c->engine : nullptr);
   if (!c || !lo || !hi) return fail(FFN_ERR_ARG, "null argument");
   int rc = check_box(c, lo, hi);
   if (rc) return rc;
   ffn_engine* e = c->engine;
   if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(lock_.begin(e, c));
   long total;
   Box b = make_box(c, lo, hi, &total);
   if (total > 0)
     hipLaunchKernelGGL(commit_assign_kernel, dim3(grid_for(total)), dim3(256), 0,
-                       e->stream, c->seed, c->seg, b, total, segment_threshold,
+                       e->ustream, c->seed, c->seg, b, total, segment_threshold,
                        segment_id);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(lock_.end(e, c));
   return FFN_OK;
 }
 
@@ -2077,18 +2175,19 @@ int box_read(ffn_canvas* c, const T* vol, const int32_t lo[3], const int32_t hi[
   long total;
   Box b = make_box(c, lo, hi, &total);
   if (total == 0) return FFN_OK;
-  if (total == (long)c->nvox) {  // whole volume: straight copy
-    HIP_TRY(hipStreamSynchronize(e->stream));
+  if (total == (long)c->nvox) {  // whole volume: straight (blocking) copy
+    HIP_TRY(canvas_quiesce(e, c));
     HIP_TRY(hipMemcpy(dst, vol, sizeof(T) * total, hipMemcpyDeviceToHost));
     return FFN_OK;
   }
+  HIP_TRY(lock_.begin(e, c));
   rc = ensure_scratch(e, sizeof(T) * total);
   if (rc) return rc;
   hipLaunchKernelGGL((box_read_kernel<T>), dim3(grid_for(total)), dim3(256), 0,
-                     e->stream, vol, b, total, static_cast<T*>(e->d_scratch));
+                     e->ustream, vol, b, total, static_cast<T*>(e->d_scratch));
   HIP_TRY(hipMemcpyAsync(e->h_scratch, e->d_scratch, sizeof(T) * total,
-                         hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(lock_.wait(e));
+                         hipMemcpyDeviceToHost, e->ustream));
+  HIP_TRY(lock_.wait(e, c));
   std::memcpy(dst, e->h_scratch, sizeof(T) * total);
   return FFN_OK;
 }
@@ -2106,20 +2205,21 @@ int box_write(ffn_canvas* c, T* vol, const int32_t lo[3], const int32_t hi[3],
   long total;
   Box b = make_box(c, lo, hi, &total);
   if (total == 0) return FFN_OK;
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  if (total == (long)c->nvox) {
+  if (total == (long)c->nvox) {  // whole volume: straight (blocking) copy
+    HIP_TRY(canvas_quiesce(e, c));
     HIP_TRY(hipMemcpy(vol, src, sizeof(T) * total, hipMemcpyHostToDevice));
     return FFN_OK;
   }
+  HIP_TRY(lock_.begin(e, c));
   rc = ensure_scratch(e, sizeof(T) * total);
   if (rc) return rc;
   std::memcpy(e->h_scratch, src, sizeof(T) * total);
   HIP_TRY(hipMemcpyAsync(e->d_scratch, e->h_scratch, sizeof(T) * total,
-                         hipMemcpyHostToDevice, e->stream));
+                         hipMemcpyHostToDevice, e->ustream));
   hipLaunchKernelGGL((box_write_kernel<T>), dim3(grid_for(total)), dim3(256), 0,
-                     e->stream, vol, b, total,
+                     e->ustream, vol, b, total,
                      static_cast<const T*>(e->d_scratch));
-  HIP_TRY(lock_.wait(e));
+  HIP_TRY(lock_.wait(e, c));
   return FFN_OK;
 }
 

@@ -2207,6 +2207,11 @@ __global__ void points_write_seg_kernel(int32_t* __restrict__ seg, int cy, int c
   seg[((size_t)pos[3 * k] * cy + pos[3 * k + 1]) * cx + pos[3 * k + 2]] = val[k];
 }
 
+__global__ void set_seg_point_kernel(int32_t* __restrict__ seg, size_t ci,
+                                     int32_t value) {
+  seg[ci] = value;
+}
+
 __global__ void set_seed_point_kernel(float* __restrict__ seed, size_t ci,
                                       float value) {
   seed[ci] = value;

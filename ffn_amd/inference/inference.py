@@ -741,11 +741,34 @@ class DeviceCanvas(Canvas):
     self._cache = {}
     self._cached_start = None
 
+  #: seeds whose (seed, segmentation) values one device call fetches ahead
+  SEED_PREFETCH = 256
+
   def _read_point(self, pos):
     pos = (int(pos[0]), int(pos[1]), int(pos[2]))
     hit = self._cache.get(pos)
     if hit is not None:
       return hit
+    # The seed loop tests one seed after the other (inference.py:573-581), and
+    # late in a subvolume it rejects hundreds in a row (already segmented): one
+    # device round trip each.  When `pos` is the seed the policy has just
+    # handed out, the values of the NEXT seeds ride along; every write to the
+    # canvas (a step, a commit) drops them again (`_invalidate_cache`), so
+    # what the loop sees is what a read at that moment returns.
+    policy = self.__dict__.get('seed_policy')
+    coords = getattr(policy, 'coords', None)
+    idx = getattr(policy, 'idx', 0)
+    if (coords is not None and 1 <= idx <= len(coords) and
+        self.SEED_PREFETCH > 1 and
+        (int(coords[idx - 1][0]), int(coords[idx - 1][1]),
+         int(coords[idx - 1][2])) == pos):
+      batch = np.ascontiguousarray(coords[idx - 1:idx - 1 + self.SEED_PREFETCH],
+                                   dtype=np.int32)
+      seeds, segs = self._call(self._handle.read_points, batch)
+      cache = self._cache
+      for c, sv, gv in zip(batch.tolist(), seeds.tolist(), segs.tolist()):
+        cache.setdefault((c[0], c[1], c[2]), (sv, gv))
+      return cache[pos]
     val = self._call(self._handle.read_point, pos)
     self._cache[pos] = val
     return val
@@ -1184,6 +1207,10 @@ class MultiCanvasDriver:
     self.max_steps_per_canvas = max_steps_per_canvas
     self.calls = 0
     self.steps = 0
+    #: native mode: seconds the group threads spent inside the library's
+    #: segment_many calls, and segments ended (= between-segment turns in Python)
+    self.library_seconds = 0.0
+    self.segments_ended = 0
 
   def run(self, jobs, window=None, on_done=None):
     """jobs: iterable of (DeviceCanvas, seed_policy_factory) -- a whole
@@ -1296,17 +1323,19 @@ class MultiCanvasDriver:
           on_done(canvas)
 
     if self.groups == 1:
-      tally = [0, 0]
+      tally = [0, 0, 0.0, 0]
       try:
         self._run_native_group(pull, window, done, tally)
       finally:
         self.calls += tally[0]
         self.steps += tally[1]
+        self.library_seconds += tally[2]
+        self.segments_ended += tally[3]
       return
     # one thread per group; the GIL is released inside the library calls, and a
     # short switch interval hands it over promptly when one returns
     errors = []
-    tallies = [[0, 0] for _ in range(self.groups)]
+    tallies = [[0, 0, 0.0, 0] for _ in range(self.groups)]
 
     def work(k):
       try:
@@ -1326,15 +1355,18 @@ class MultiCanvasDriver:
         t.join()
     finally:
       sys.setswitchinterval(interval)
-      for c, n in tallies:
+      for c, n, sec, ended in tallies:
         self.calls += c
         self.steps += n
+        self.library_seconds += sec
+        self.segments_ended += ended
     if errors:
       raise errors[0]
 
   def _run_native_group(self, pull, window, on_done, tally):
     """One group of at most `window` open canvases: the loop of `_run_native`.
-    tally = [engine calls, FoV steps] of this group."""
+    tally = [engine calls, FoV steps, seconds inside segment_many, segments
+    ended] of this group."""
     engine = self.engine
     limit = self.max_steps_per_canvas
     # [canvas, generator, pending request, steps of finished segments,
@@ -1405,9 +1437,12 @@ class MultiCanvasDriver:
         if mixed:
           left = min(left, mixed_call_steps) if limit is not None else mixed_call_steps
         e[2].params.max_steps = max(left, 1) if (limit is not None or mixed) else 0
+      t_call = time.perf_counter()
       results, fin = engine.segment_many(
           [e[0]._handle for e in batch], [e[2].start_pos for e in batch],
           [e[2].params for e in batch], [e[2].started for e in batch])
+      tally[2] += time.perf_counter() - t_call
+      tally[3] += sum(1 for d in fin if d)
       tally[0] += 1
       for e, res, done in zip(batch, results, fin):
         tally[1] += int(res.num_steps) - e[4]

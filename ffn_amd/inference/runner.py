@@ -452,4 +452,6 @@ class Runner:
         canvas.close()
 
     driver.run(jobs(), window=window, on_done=finished)
+    #: the driver of the last run_many (its call / step / time tallies)
+    self.last_driver = driver
     return canvases

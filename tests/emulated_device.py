@@ -36,6 +36,19 @@ class EmulatedHandle:
       return float('nan'), 0
     return float(self.seed[pos]), int(self.seg[pos])
 
+  def read_points(self, pos):
+    """ffn_canvas_read_points: (seed [n], segmentation [n]) of n positions in one
+    call (out-of-canvas: nan / 0)."""
+    pos = np.asarray(pos).reshape(-1, 3)
+    self.point_reads += 1
+    seeds = np.full(len(pos), np.nan, np.float32)
+    segs = np.zeros(len(pos), np.int32)
+    for k, p in enumerate(pos):
+      p = tuple(int(v) for v in p)
+      if all(0 <= v < s for v, s in zip(p, self.shape)):
+        seeds[k], segs[k] = self.seed[p], self.seg[p]
+    return seeds, segs
+
   def write_seg_points(self, pos, values):
     for p, v in zip(pos, values):
       self.seg[tuple(int(x) for x in p)] = v

@@ -28,7 +28,7 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--steps', type=int, default=1600)
   ap.add_argument('--every', type=int, default=100)
-  ap.add_argument('--variants', type=int, nargs='+', default=[3, 4, 6])
+  ap.add_argument('--variants', type=int, nargs='+', default=[6, 8, 9])
   ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out',
                                                 'r02_fov_samples.npz'))
   args = ap.parse_args()
