@@ -50,12 +50,14 @@ def configure(args):
   """--config c1 (default): BASELINE configs[1].  c5: the anisotropic hi-res
   model of configs[4] -- depth 18, FoV zyx (21, 41, 41), deltas (5, 10, 10),
   68.4 GFLOP per FoV step -- with random weights (no checkpoint of that shape
-  ships with the reference) on one (128, 384, 384) tile of its volume."""
+  ships with the reference) on one (64, 192, 192) tile of its volume."""
   global FOV, DELTAS, DEPTH, VOXELS, CONV32_FLOPS, STEP_FLOPS, CONFIG, VOLUME_ZYX
   CONFIG = args.config
   if args.config == 'c5':
     FOV, DELTAS, DEPTH = (21, 41, 41), (5, 10, 10), 18
-    VOLUME_ZYX = (128, 384, 384) if args.volume == 250 else (
+    # (small enough for the flood fill of the random-weights model to finish --
+    # and commit -- segments inside a default run)
+    VOLUME_ZYX = (64, 192, 192) if args.volume == 250 else (
         max(args.volume // 3, 64), args.volume, args.volume)
   else:
     VOLUME_ZYX = (args.volume,) * 3

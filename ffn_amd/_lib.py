@@ -223,8 +223,8 @@ def build(force: bool = False) -> str:
   """Compiles csrc/*.hip for gfx950 into csrc/libffn_hip.so (in-tree): one
   object per source under csrc/build/ (stale ones only, in parallel), then the
   link."""
-  headers = HEADERS + [os.path.join(CSRC, name) for name in
-                       ('ffn_kernels.h', 'ffn_internal.h', 'ffn_host_loop.h')]
+  headers = HEADERS + [os.path.join(CSRC, name) for name in sorted(os.listdir(CSRC))
+                       if name.endswith('.h')]
   hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
   if not os.path.exists(hipcc):
     hipcc = 'hipcc'
