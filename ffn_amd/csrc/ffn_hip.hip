@@ -132,12 +132,6 @@ struct ffn_engine {
   // K-split tail workgroups for the rest
   bool t_ok = false;
   bool t_now = false;
-  // conv32x (variant 9, one FoV): the FoV dealt evenly over the CUs, a shared
-  // fifth tile instead of tail workgroups
-  bool x_ok = false;
-  bool x_now = false;
-  int balanced = 1;      // option: 0 = a single FoV runs conv32mt instead
-  int x_chunk = 0, x_wgs = 0;
   int tail_batched = 0;  // option: steps with >= 2 FoVs take the tail form too
   int n_main = 0, n_tail = 0, n_tail3 = 0;  // tail workgroups of 32 / 96 voxels
   int tsched_aoff[4 * 8] = {};
@@ -381,28 +375,6 @@ int set_lds_attr_m() {
   FFN_M_ATTR(1, false, true);
   FFN_M_ATTR(1, true, true);
 #undef FFN_M_ATTR
-#define FFN_MT_ABL_ATTR(N)                                                        \
-  HIP_TRY(hipFuncSetAttribute(                                                    \
-      reinterpret_cast<const void*>(&conv32mt_kernel<0, false, false, 1, N>),     \
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMLdsBytes))
-  FFN_MT_ABL_ATTR(1);
-  FFN_MT_ABL_ATTR(2);
-  FFN_MT_ABL_ATTR(4);
-  FFN_MT_ABL_ATTR(8);
-  FFN_MT_ABL_ATTR(16);
-  FFN_MT_ABL_ATTR(12);
-  FFN_MT_ABL_ATTR(15);
-#undef FFN_MT_ABL_ATTR
-#define FFN_X_ATTR(KIND, SK, HEADV)                                               \
-  HIP_TRY(hipFuncSetAttribute(                                                    \
-      reinterpret_cast<const void*>(&conv32x_kernel<KIND, SK, HEADV>),            \
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLdsBytes))
-  FFN_X_ATTR(0, false, false);
-  FFN_X_ATTR(1, false, false);
-  FFN_X_ATTR(1, true, false);
-  FFN_X_ATTR(1, false, true);
-  FFN_X_ATTR(1, true, true);
-#undef FFN_X_ATTR
 #define FFN_MT_ATTR(KIND, SK, HEADV)                                              \
   HIP_TRY(hipFuncSetAttribute(                                                    \
       reinterpret_cast<const void*>(&conv32mt_kernel<KIND, SK, HEADV, 1>),        \
@@ -618,9 +590,7 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   a.plane = g.plane;
   const bool small = e->small_now;  // 96-voxel chunks, 2 workgroups / CU
   const bool msplit = e->m_now;     // conv32m: 128-voxel chunks, M split
-  const int nchunks = e->x_now ? e->x_wgs
-                      : msplit ? e->nchunks_m : small ? e->nchunks_e : e->nchunks_k;
-  a.xch = e->x_chunk;
+  const int nchunks = msplit ? e->nchunks_m : small ? e->nchunks_e : e->nchunks_k;
   a.nchunks = nchunks;
   a.V = g.V;
   a.fx = g.fx;
@@ -665,17 +635,7 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   hipLaunchKernelGGL(                                                            \
       (conv32d_kernel<KIND, SK, kEPieces, HEADV, kETiles, kERows, 2>), grid,     \
       block, e->lds_bytes_e, e->stream, a)
-  if (e->x_now) {
-    // one FoV, dealt evenly: x_wgs workgroups of x_chunk voxels, one per CU
-    if (head.on) {
-      if constexpr (KIND == 1)
-        hipLaunchKernelGGL((conv32x_kernel<KIND, SK, true>), grid, block, kXLdsBytes,
-                           e->stream, a);
-    } else {
-      hipLaunchKernelGGL((conv32x_kernel<KIND, SK, false>), grid, block, kXLdsBytes,
-                         e->stream, a);
-    }
-  } else if (e->t_now) {
+  if (e->t_now) {
     // one FoV: 32-voxel tail workgroups (balance over the CUs); several: the
     // same voxels in 96-voxel ones (cost per voxel) -- the same bits
     const bool one = n == 1;
@@ -687,31 +647,6 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
     mp.tails_per_xcd = (mp.n_tail + 7) / 8;
     std::memcpy(mp.taoff, one ? e->tsched_aoff : e->t3sched_aoff, sizeof(mp.taoff));
     const dim3 tgrid(8 * n * (mp.mains_per_xcd + mp.tails_per_xcd));
-    // debug: timing ablations of the main body (conv_a launches of a single FoV)
-    if (one && KIND == 0 && !head.on && e->ablate != 0) {
-      if constexpr (KIND == 0) {
-#define FFN_MT_ABL(N)                                                             \
-  case N:                                                                         \
-    hipLaunchKernelGGL((conv32mt_kernel<0, false, false, 1, N>), tgrid, block,    \
-                       kMLdsBytes, e->stream, a, mp);                             \
-    break;
-        switch (e->ablate) {
-          FFN_MT_ABL(1)
-          FFN_MT_ABL(2)
-          FFN_MT_ABL(4)
-          FFN_MT_ABL(8)
-          FFN_MT_ABL(16)
-          FFN_MT_ABL(12)
-          FFN_MT_ABL(15)
-          default:
-            return fail(FFN_ERR_ARG, "unsupported ablate mask %d for conv32mt",
-                        e->ablate);
-        }
-#undef FFN_MT_ABL
-      }
-      if (prof) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
-      return FFN_OK;
-    }
 #define FFN_MT_LAUNCH(HEADV)                                                      \
   if (one)                                                                        \
     hipLaunchKernelGGL((conv32mt_kernel<KIND, SK, HEADV, 1>), tgrid, block,       \
@@ -811,10 +746,6 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   // with several FoVs run plain conv32m (cost per voxel: the K-split tail costs
   // 5-10 % there) unless tail_batched asks for the single-FoV bits
   e->t_now = e->conv_variant == 9 && (n == 1 || e->tail_batched != 0);
-  // ... and, where the FoV allows it, the evenly dealt form for a single FoV
-  e->x_now = e->conv_variant == 9 && n == 1 && e->x_ok && e->balanced != 0 &&
-             e->tail_batched == 0;
-  if (e->x_now) e->t_now = false;
   if (e->conv_variant >= 6) {
     if (e->depth == 1)
       return fail(FFN_ERR_ARG, "conv_variant 6 needs depth >= 2 (fused head)");
@@ -870,8 +801,7 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   }
   if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   if (head_fused) {
-    e->count_blocks = e->x_now ? e->x_wgs
-                      : e->t_now ? e->n_main + (n == 1 ? e->n_tail : e->n_tail3)
+    e->count_blocks = e->t_now ? e->n_main + (n == 1 ? e->n_tail : e->n_tail3)
                       : e->m_now ? e->nchunks_m : e->small_now ? e->nchunks_e
                       : e->conv_variant >= 6 ? e->nchunks_k : e->nchunks_c;
   } else {
@@ -1207,18 +1137,6 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
                   kz * 128 * kT3Rows + ((ky - 1) * q.XS + (kx - 1)) * 16;
             }
         }
-        // conv32x: ceil(V / 256) voxels per workgroup, 129 .. 160 of them (four
-        // tiles + a partial fifth), in kXRows rows
-        if (e->m_ok && e->nchunks_m > 256) {
-          const int ch = (q.V + 255) / 256;
-          const int wgs = (q.V + ch - 1) / ch;
-          if (ch > 128 && ch <= 160 && wgs >= 2 &&
-              chunk_span(q, 0, ch, wgs) + 2 * (q.XS + 1) <= kXRows) {
-            e->x_ok = true;
-            e->x_chunk = ch;
-            e->x_wgs = wgs;
-          }
-        }
         for (int w = 0; w < 4; ++w)
           for (int j = 0; j < 7; ++j) {
             int s = kSched[w][j];
@@ -1540,13 +1458,6 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->batch_chunks = value;
     return FFN_OK;
   }
-  if (std::strcmp(name, "balanced") == 0) {
-    // conv_variant 9, a step of ONE FoV: 1 (default) = conv32x where the FoV
-    // allows it (every CU an equal share), 0 = conv32mt (256 conv32m workgroups
-    // + K-split tail workgroups)
-    e->balanced = value != 0;
-    return FFN_OK;
-  }
   if (std::strcmp(name, "tail_batched") == 0) {
     // conv_variant 9: 1 = steps with >= 2 FoVs also split off the tail (in
     // 96-voxel workgroups): every voxel then gets the same bits whatever the
@@ -1585,7 +1496,6 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   if (std::strcmp(name, "conv_variant") == 0) *value = e->conv_variant;
   else if (std::strcmp(name, "fuse_head") == 0) *value = e->fuse_head;
   else if (std::strcmp(name, "exact_variant") == 0) *value = e->exact_variant;
-  else if (std::strcmp(name, "balanced") == 0) *value = e->x_ok ? e->balanced : 0;
   else if (std::strcmp(name, "stat_step_calls") == 0) *value = (int)e->stat_calls;
   else if (std::strcmp(name, "stat_step_items") == 0) *value = (int)e->stat_items;
   else if (std::strncmp(name, "stat_hist_", 10) == 0) {

@@ -869,7 +869,6 @@ struct ConvDArgs {
   long sp_plane_bytes;   // positions x 16: one chunk plane of the split layout
   int XS, plane, nchunks, V, fx, fyfx, total_slots, slots_per_xcd;
   unsigned magic_nchunks, magic_fyfx, magic_fx;
-  int xch;               // conv32x: dense voxels per workgroup (129 .. 160)
   int permuted;          // the FoV is laid out with permuted axes (Geom::oa) ...
   int ds0, ds1, ds2;     // ... one step along z' / y' / x' in the caller's dense order
   unsigned sp_bytes;     // bytes of a split / f32 buffer past position 0 (store range)
@@ -1450,10 +1449,7 @@ __device__ __forceinline__ f32x4 hidden_load16f(const char* sbase, unsigned voff
 
 // The workgroup computes the 128 dense voxels from v0 of FoV `item`; gc = its
 // slot in head_count.
-// ABL (debug, timing only -- the results are garbage): 1 = no weight-ring DMA
-// inside the tap loop, 2 = no per-tap barrier, 4 = no activation fragment
-// reads in the loop, 8 = no weight fragment reads, 16 = no dz = +1 DMA.
-template <int KIND, bool ADD_SKIP, bool HEAD, int ABL = 0>
+template <int KIND, bool ADD_SKIP, bool HEAD>
 __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
                                              const int v0, const int gc,
                                              const bool dbg_here) {
@@ -1578,10 +1574,9 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
   };
 #define FFN_MGAP(S, PART, WNEXT, XNEXT)                                         \
   __builtin_amdgcn_sched_barrier(0);                                            \
-  if ((PART) < 2 && (S) + 1 <= 26 && !(ABL & 8)) load_w((S) + 1, PART, WNEXT);  \
-  if ((PART) >= 2 && (S) + 2 <= 26 && !(ABL & 4))                               \
-    load_x((S) + 2, (PART) - 2, XNEXT);                                         \
-  if ((S) == 9 && !(ABL & 16)) dma_seg_part(2 * (PART), 2 * (PART) + 2);        \
+  if ((PART) < 2 && (S) + 1 <= 26) load_w((S) + 1, PART, WNEXT);                \
+  if ((PART) >= 2 && (S) + 2 <= 26) load_x((S) + 2, (PART) - 2, XNEXT);         \
+  if ((S) == 9) dma_seg_part(2 * (PART), 2 * (PART) + 2);                       \
   __builtin_amdgcn_sched_barrier(0);
   // tap S: XCUR / WCUR hold its fragments; WNEXT takes tap S + 1's weights,
   // XNEXT tap S + 2's activations
@@ -1589,13 +1584,13 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
   {                                                                             \
     if ((S) > 0) {                                                              \
       if constexpr (m_wait(S, D, NEPI) >= 0) wait_vmcnt<m_wait(S, D, NEPI)>();  \
-      if (!(ABL & 2)) __builtin_amdgcn_s_barrier();                             \
+      __builtin_amdgcn_s_barrier();                                             \
       asm volatile("" ::: "memory");                                            \
     }                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                          \
     accC = mma(WCUR.w[0][0], XCUR.x[0][1], accC);                               \
     __builtin_amdgcn_sched_barrier(0);                                          \
-    if ((S) > 0 && (S) + D - 1 <= 26 && !(ABL & 1)) dma_w((S) + D - 1);         \
+    if ((S) > 0 && (S) + D - 1 <= 26) dma_w((S) + D - 1);                       \
     __builtin_amdgcn_sched_barrier(0);                                          \
     acc = mma(WCUR.w[0][0], XCUR.x[0][0], acc);                                 \
     FFN_MGAP(S, 0, WNEXT, XNEXT)                                                \
@@ -1813,7 +1808,7 @@ struct ConvTailMap {
   int taoff[4 * 8];           // the tail's aoff table (its rows per segment)
 };
 
-template <int KIND, bool ADD_SKIP, bool HEAD, int TNT, int ABL = 0>
+template <int KIND, bool ADD_SKIP, bool HEAD, int TNT>
 __global__ __launch_bounds__(kDThreads, 2) void conv32mt_kernel(ConvDArgs a,
                                                                 ConvTailMap mp) {
   const int xcd = blockIdx.x & 7;
@@ -1844,8 +1839,8 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32mt_kernel(ConvDArgs a,
   if (main_wg) {
     const int c = xcd * mp.mains_per_xcd + r;
     if (c >= mp.n_main) return;
-    conv32m_body<KIND, ADD_SKIP, HEAD, ABL>(a, item, c * kMChunk, item * slots + c,
-                                            blockIdx.x == 0 && a.dbg_wgs != 2);
+    conv32m_body<KIND, ADD_SKIP, HEAD>(a, item, c * kMChunk, item * slots + c,
+                                       blockIdx.x == 0 && a.dbg_wgs != 2);
   } else {
     const int c = xcd * mp.tails_per_xcd + r;
     if (c >= mp.n_tail) return;
@@ -1861,10 +1856,6 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32mt_kernel(ConvDArgs a,
   }
   stamp_workgroup(a, t0);
 }
-
-}  // namespace ffn
-#include "ffn_conv32x.h"
-namespace ffn {
 
 // ---------------------------------------------------------------------------
 // head: ReLU -> 1x1x1 conv 32->1 + bias; logits = seed + update

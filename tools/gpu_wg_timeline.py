@@ -75,27 +75,22 @@ def main():
   seed = rng.normal(0, 1, (1, 33, 33, 33)).astype(np.float32)
   eng.predict(seed, img)
   eng.set_option('debug_clock', 2)
-  for v, balanced in [(v, b) for v in args.variants
-                      for b in ((0, 1) if v == 9 else (0,))]:
+  for v in args.variants:
     eng.set_option('conv_variant', v)
-    eng.set_option('balanced', balanced)  # 1: conv32x, 0: conv32mt (variant 9)
     for layer in args.layers:
       eng.set_option('debug_layer', layer)
       for rep in range(2):
         eng.forward_resident(1, 3)
         rec = eng.debug_workgroups(512)
         if rep == 1:
-          tails = v == 9 and not balanced
-          describe(rec, 'variant %d%s layer %d' % (
-              v, ' (conv32x)' if v == 9 and balanced else '', layer),
-                   32 if tails else None, 13 if tails else None)
+          describe(rec, 'variant %d layer %d' % (v, layer),
+                   32 if v == 9 else None, 13 if v == 9 else None)
           ran = rec[:, 1] > 0
           end = (rec[ran, 1] - rec[ran, 0].min()) * 10.0 / 1e3
           hist, edges = np.histogram(end, bins=12)
           print('   end times (us): ' + '  '.join(
               '%.1f-%.1f:%d' % (edges[k], edges[k + 1], hist[k])
               for k in range(len(hist)) if hist[k]))
-  eng.set_option('balanced', 0)
   if 9 in args.variants:
     # the shader-clock stamps of ONE tail workgroup (debug_clock 3): entry ->
     # first barrier (W0 + dz = -1 landed) -> last tap -> exit
