@@ -958,13 +958,15 @@ def main():
   traffic = None
   traffic_source = None
   try:
-    with open(os.path.join(ROOT, 'profiles', 'conv32_pmc_traffic.json')) as f:
+    tname = ('conv32_pmc_traffic.json' if CONFIG == 'c1' else
+             'r03_conv32mt_c5_pmc_traffic.json')
+    with open(os.path.join(ROOT, 'profiles', tname)) as f:
       tj = json.load(f)
     if tj.get('conv_variant', 9) == res.get('conv_variant', 9):
       traffic = tj['traffic_bytes_per_launch']
-      traffic_source = ('profiles/conv32_pmc_traffic.json: separate rocprofv3 '
-                        '--pmc FETCH_SIZE / WRITE_SIZE passes of this command '
-                        '(NOT measured in this run)')
+      traffic_source = ('profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / '
+                        'WRITE_SIZE passes of this command (NOT measured in '
+                        'this run)' % tname)
   except (OSError, KeyError, ValueError):
     pass
   variant = res.get('conv_variant', 9)

@@ -14,7 +14,9 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libffn_hip.so')
+# (FFN_AMD_LIB: another build of the same sources, for A/B runs of compile-time
+# kernel switches)
+LIB_PATH = os.environ.get('FFN_AMD_LIB') or os.path.join(CSRC, 'libffn_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'ffn_hip.h')
 HEADERS = [HEADER,
            os.path.join(os.path.dirname(_HERE), 'include', 'ffn_labels.h'),

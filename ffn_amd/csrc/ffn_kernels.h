@@ -1420,15 +1420,23 @@ constexpr int kMLdsBytes = kMRing + kMRingTaps * 4096;  // 81,920: two per CU
 // that are NEWER than W(S+1).  D = ring depth: W0 .. W(D-2) are queued in front
 // of the segments, tap t queues W(t+D-1) [t = 9: then the dz = +1 DMAs; t =
 // 27 - D: then the NEPI epilogue operands].
+// (The dz = +1 segment is queued in ONE tap: spread over taps 9 .. 12 it leaves
+// batch 1 unchanged and costs batched steps 5 - 8 %, two workgroups per CU hide
+// a one-tap burst better than four taps with a DMA in them:
+// profiles/r03_ab_seg_dma_spread_not_kept.txt.)
 constexpr int m_wait(int S, int D, int NEPI) {
   if (S == 0) return kMPieces;      // dz = 0's DMAs are newer than dz = -1 / W1
   if (S + 1 > 26) return -1;
   if (S + 1 <= D - 2) return -1;    // queued in front of everything: landed
   const int tr = S + 2 - D;         // the tap that queued W(S+1)
   int n = 0;
-  for (int t = tr + 1; t <= S - 1; ++t) n += (t <= 27 - D) ? 1 : 0;
-  if (tr <= 9 && 9 <= S - 1) n += kMPieces;
-  if (tr <= 27 - D && 27 - D <= S - 1) n += NEPI;
+  for (int t = tr; t <= S - 1; ++t) {
+    // per tap t, in this order: the ring piece W(t+D-1), the dz = +1 pieces, the
+    // epilogue operands
+    if (t > tr && t <= 27 - D) n += 1;
+    if (t == 9) n += kMPieces;
+    if (t == 27 - D) n += NEPI;
+  }
   return n;
 }
 

@@ -588,14 +588,27 @@ class _DeviceArray:
   """
 
   def __init__(self, canvas: 'DeviceCanvas', which: str):
-    # a proxy, not a reference: canvas <-> array would be a cycle, and a cycle
-    # keeps a finished subvolume's HBM (12 B / voxel) alive until the cyclic
-    # collector happens to run
-    self._c = weakref.proxy(canvas)
+    # a weak reference, not a strong one: canvas <-> array would be a cycle, and
+    # a cycle keeps a finished subvolume's HBM (12 B / voxel) alive until the
+    # cyclic collector happens to run.  LIFETIME: the array is a VIEW of the
+    # canvas' device memory -- `np.asarray(canvas.segmentation)` (a host copy)
+    # is what outlives `canvas.close()` / the canvas itself; using the view
+    # afterwards raises `RuntimeError('canvas closed')`.
+    self._ref = weakref.ref(canvas)
     self._which = which
     self.shape = canvas.shape
     self.dtype = np.dtype(np.float32 if which == 'seed' else np.int32)
     self.ndim = 3
+
+  @property
+  def _c(self):
+    canvas = self._ref()
+    if canvas is None or canvas._handle is None:
+      raise RuntimeError(
+          'canvas closed: its device arrays are views of HBM that is gone; keep '
+          'np.asarray(canvas.%s) (a host copy) instead' % (
+              'seed' if self._which == 'seed' else 'segmentation'))
+    return canvas
 
   def canvas_handle(self):
     """The ffn_canvas* behind this array (device-side consumers: the assembly

@@ -235,6 +235,15 @@ def test_device_canvas_checkpoint_roundtrip(fib25_blob, tmp_path):
   assert np.array_equal(np.asarray(b.segmentation), g['segmentation'])
   assert np.array_equal(np.asarray(b.seed), g['seed_logits'], equal_nan=True)
   assert b._max_id == a._max_id and set(b.origins) == set(a.origins)
+  # the device arrays are VIEWS of the canvas' memory: a host copy outlives the
+  # canvas, the view says so instead of dangling
+  seg_view, host_copy = b.segmentation, np.asarray(b.segmentation)
+  b.close()
+  assert np.array_equal(host_copy, g['segmentation'])
+  with pytest.raises(RuntimeError, match='canvas closed'):
+    seg_view[0, 0, 0]
+  with pytest.raises(RuntimeError, match='canvas closed'):
+    np.asarray(seg_view)
 
 
 def test_mid_segment_checkpoint_resume_emulated_device(fib25_blob, tmp_path):

@@ -5,7 +5,7 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1; cd $GRAFT_REPO_ROOT
+  cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-batched-leg "$@" > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1; cd $GRAFT_REPO_ROOT
   tail -1 gpurun_out/pmc_$c.log | cut -c1-200
   f=$(find gpurun_out/pmc_$c -name "*counter_collection.csv" | head -1)
   python - "$f" $c <<'PY'

@@ -4,7 +4,7 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 c="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES"
-cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_LDS -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 10 --prewarm-seconds 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_LDS.log 2>&1; cd $GRAFT_REPO_ROOT
+cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_LDS -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 10 --prewarm-seconds 0 --no-cpu-baseline --no-batched-leg > $GRAFT_REPO_ROOT/gpurun_out/pmc_LDS.log 2>&1; cd $GRAFT_REPO_ROOT
 tail -1 gpurun_out/pmc_LDS.log | cut -c1-160
 f=$(find gpurun_out/pmc_LDS -name "*counter_collection.csv" | head -1)
 python - "$f" <<'PY'
