@@ -65,33 +65,49 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--variants', type=int, nargs='+', default=[8, 9])
   ap.add_argument('--layers', type=int, nargs='+', default=[3, 4])
+  ap.add_argument('--batch', type=int, default=1,
+                  help='FoVs per launch (<= 14: 4,096 workgroup stamps)')
   args = ap.parse_args()
+  B = args.batch
   model = convstack_3d.ConvStack3DFFNModel(fov_size=[33, 33, 33],
                                            deltas=[8, 8, 8], depth=12)
   model.load_checkpoint(os.path.join(ROOT, 'tests/golden/fib25_weights.npz'))
-  eng = hip_engine.HipEngine.from_model(model, max_batch=1)
+  eng = hip_engine.HipEngine.from_model(model, max_batch=B)
   rng = np.random.RandomState(0)
-  img = rng.normal(0, 1, (1, 33, 33, 33)).astype(np.float32)
-  seed = rng.normal(0, 1, (1, 33, 33, 33)).astype(np.float32)
+  img = rng.normal(0, 1, (B, 33, 33, 33)).astype(np.float32)
+  seed = rng.normal(0, 1, (B, 33, 33, 33)).astype(np.float32)
   eng.predict(seed, img)
+  if B > 1:
+    eng.set_option('batch_chunks', 0)
   eng.set_option('debug_clock', 2)
   for v in args.variants:
     eng.set_option('conv_variant', v)
     for layer in args.layers:
       eng.set_option('debug_layer', layer)
       for rep in range(2):
-        eng.forward_resident(1, 3)
-        rec = eng.debug_workgroups(512)
+        eng.forward_resident(B, 3)
+        rec = eng.debug_workgroups(512 if B == 1 else 4096)
         if rep == 1:
-          describe(rec, 'variant %d layer %d' % (v, layer),
-                   32 if v == 9 else None, 13 if v == 9 else None)
+          describe(rec, 'variant %d layer %d batch %d' % (v, layer, B),
+                   32 if v == 9 and B == 1 else None, 13 if v == 9 and B == 1 else None)
+          if B > 1:
+            # the in-kernel stamps of workgroup 0 (it shares its CU from the start)
+            eng.set_option('debug_clock', 1)
+            eng.forward_resident(B, 2)
+            c = eng.debug_clocks()
+            eng.set_option('debug_clock', 2)
+            for w in range(4):
+              print('   workgroup 0 wave %d: prologue %d  loop %d  epilogue %d  total %d '
+                    'cycles, wall %.2f us' % (w, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1],
+                                              c[w, 3] - c[w, 2], c[w, 3] - c[w, 0],
+                                              (c[w, 5] - c[w, 4]) / 100.0))
           ran = rec[:, 1] > 0
           end = (rec[ran, 1] - rec[ran, 0].min()) * 10.0 / 1e3
           hist, edges = np.histogram(end, bins=12)
           print('   end times (us): ' + '  '.join(
               '%.1f-%.1f:%d' % (edges[k], edges[k + 1], hist[k])
               for k in range(len(hist)) if hist[k]))
-  if 9 in args.variants:
+  if 9 in args.variants and B == 1:
     # the shader-clock stamps of ONE tail workgroup (debug_clock 3): entry ->
     # first barrier (W0 + dz = -1 landed) -> last tap -> exit
     eng.set_option('debug_clock', 3)
