@@ -342,6 +342,14 @@ def run_gpu(args, rank, local_rank, world):
       'conv_variant': (args.conv_variant if args.conv_variant is not None
                        else eng.get_option('conv_variant')),
       'prewarm_steps': state.get('prewarm_steps', 0),
+      'speculation': {
+          'conv0a_launched_ahead': eng.get_option('stat_spec_launched'),
+          'steps_that_used_one': eng.get_option('stat_spec_hits'),
+          'mismatches_repeated': eng.get_option('stat_spec_mismatch'),
+          'note': 'the whole run of this rank; single-FoV steps of the '
+                  'library segment loop queue the next conv0_a behind the paste '
+                  '(engine option speculate, DESIGN.md section 4)',
+      },
       'volume_passes_completed': state['volume_passes_completed'],
       'elapsed': elapsed,
       'elapsed_local': elapsed_local,
@@ -1062,6 +1070,7 @@ def main():
               'movement_policy-time-ms', 0) / max(res['counters'].get(
                   'movement_policy-calls', 1), 1), 1),
       },
+      'speculation': res['speculation'],
       'queue_stats': {k: res['counters'].get(k, 0) for k in (
           'update_at-calls', 'skip_threshold', 'skip_invalid_pos',
           'seed_got_too_weak', 'segment_at-loop-calls', 'gate_rejects')},

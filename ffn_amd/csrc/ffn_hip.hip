@@ -147,6 +147,22 @@ struct ffn_engine {
   int dsched_aoff[4 * 8] = {};
   int dsched_btap[4 * 8] = {};
   unsigned* range_flag = nullptr;  // device word: tag of the last void run
+  // Speculative conv0_a of a single-FoV step's successor (SpecArgs): the launch
+  // queued behind the last step's paste, and what a step must match to run on it
+  struct Spec {
+    bool valid = false;
+    const ffn_canvas* canvas = nullptr;
+    int n = 0;
+    int pos[kSpecMax][3] = {};
+    float pad_value = 0.f, move_thr = 0.f;
+    int variant = 0;
+  } spec;
+  int speculate = 1;        // option
+  int spec_force_mismatch = 0;  // debug option: fail the next N matches
+  long stat_spec_mismatch = 0;
+  int fuse_paste = 1;       // option: faces + paste of a single FoV as one launch
+  int* d_spec_choice = nullptr;
+  long stat_spec_launched = 0, stat_spec_hits = 0;
   unsigned range_tag = 0;        // tag of the run being queued
   bool fp16_ok = true;           // every weight inside the fp16 range
   int conv_variant = 0;       // 0 conv32 (any FoV), 2 conv32c (exact f32), 6 conv32d, 7 = 6
@@ -218,6 +234,10 @@ struct ffn_canvas {
   hipEvent_t ev_util = nullptr;  // behind the last utility operation on this canvas
   bool util_pending = false;     // ... which the next step has to wait for
   bool paste_after_flag = false; // the last step pasted AFTER raising its flag
+  // the segment loop's guess of the positions the step after the next one may
+  // be made at (consumed by the next single-FoV ffn_canvas_step_submit)
+  int hint_n = 0;
+  int hint_pos[kSpecMax][3] = {};
 
   void mark_dirty(const int lo[3], const int hi[3]) {
     const int dims[3] = {cz, cy, cx};
@@ -231,6 +251,14 @@ struct ffn_canvas {
 };
 
 namespace {
+inline unsigned next_tag(unsigned t) { return t + 1 ? t + 1 : 1; }  // never 0
+// A speculative conv0_a launch that no step will use: its range tag is spent.
+inline void drop_spec(ffn_engine* e) {
+  if (e->spec.valid) {
+    e->spec.valid = false;
+    e->range_tag = next_tag(e->range_tag);
+  }
+}
 struct EngineLock {
   std::unique_lock<std::recursive_mutex> lk;
   explicit EngineLock(ffn_engine* e) {
@@ -250,6 +278,7 @@ struct UtilLock {
   // Before the first utility operation of a call: the canvas' last step has
   // pasted (see ffn_engine::ustream).
   hipError_t begin(ffn_engine* e, ffn_canvas* c) {
+    drop_spec(e);  // the canvas may change under a speculative conv0_a
     if (!c->paste_after_flag) return hipSuccess;
     hipError_t err = hipEventRecord(e->main_ev, e->stream);
     if (err == hipSuccess) err = hipStreamWaitEvent(e->ustream, e->main_ev, 0);
@@ -274,6 +303,7 @@ struct UtilLock {
 };
 // host-side: nothing queued on canvas c is still running
 hipError_t canvas_quiesce(ffn_engine* e, ffn_canvas* c) {
+  drop_spec(e);  // the caller is about to read or change the canvas directly
   hipError_t err = hipSuccess;
   if (c->paste_after_flag) {
     err = hipStreamSynchronize(e->stream);
@@ -693,14 +723,10 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
 }
 
 // FoVs described by `si` -> logits (+ count of logits >= move_thr, + seed_raw)
-int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
-              float move_thr) {
+// conv0_a of a step whose range tag is `tag` (sp.n > 0: a speculative launch)
+void launch_conv0a(ffn_engine* e, int n, const StepItems& si, float pad_value,
+                   unsigned tag, const SpecArgs& sp) {
   const Geom& g = e->g;
-  e->range_tag = e->range_tag + 1 ? e->range_tag + 1 : 1;  // never 0
-  const bool sampled = (e->stack_calls % e->prof_every) == 0;
-  e->stack_calls++;
-  e->prof_now = e->prof_mode == 1 && sampled;
-  const bool prof_chain = e->prof_mode == 2 && sampled;
   const float* W = e->weights;
   const int tz = (g.fz + kC0Z - 1) / kC0Z, ty = (g.fy + kC0Y - 1) / kC0Y,
             tx = (g.fx + kC0X - 1) / kC0X;
@@ -713,16 +739,32 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     so.sp_plane_bytes = (q.act_stride / kFeatures) * 16;
     so.item_bytes = q.act_stride * (long)sizeof(float);
     so.range_flag = e->range_flag;
-    so.range_tag = e->range_tag;
+    so.range_tag = tag;
     hipLaunchKernelGGL(conv0a_mfma_kernel<true>, dim3(qz * qy * qx, n),
                        dim3(kC0Threads), 0, e->stream, si, pad_value,
                        W + (e->permuted ? e->w0ap_off : e->w0a_off), W + e->b0a_off,
-                       e->bufT, e->seed_raw, q, qy, qx, so);
+                       e->bufT, e->seed_raw, q, qy, qx, so, sp);
   } else
     hipLaunchKernelGGL(conv0a_mfma_kernel<false>, dim3(tz * ty * tx, n),
                        dim3(kC0Threads), 0, e->stream, si, pad_value,
                        W + e->w0a_off, W + e->b0a_off, e->bufT, e->seed_raw, g,
-                       ty, tx, Conv0SplitOut());
+                       ty, tx, Conv0SplitOut(), sp);
+}
+
+// conv0a_done: the step's conv0_a has been queued already (a speculative launch
+// that chose its position)
+int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
+              float move_thr, bool conv0a_done = false) {
+  const Geom& g = e->g;
+  const float* W = e->weights;
+  if (!conv0a_done) drop_spec(e);
+  e->spec.valid = false;
+  e->range_tag = next_tag(e->range_tag);
+  const bool sampled = (e->stack_calls % e->prof_every) == 0;
+  e->stack_calls++;
+  e->prof_now = e->prof_mode == 1 && sampled;
+  const bool prof_chain = e->prof_mode == 2 && sampled;
+  if (!conv0a_done) launch_conv0a(e, n, si, pad_value, e->range_tag, SpecArgs());
   int rc;
   const float* head_in;
   bool head_fused = false;
@@ -1186,6 +1228,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
                                     sizeof(uint16_t)));
     E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
     E_TRY(hipMemset(e->range_flag, 0, sizeof(unsigned)));
+    E_TRY(hipMalloc(&e->d_spec_choice, sizeof(int)));
+    E_TRY(hipMemset(e->d_spec_choice, 0xff, sizeof(int)));
   }
 
   e->events.resize(2 * 64);
@@ -1248,6 +1292,7 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->count);
   (void)hipFree(e->wpackd);
   (void)hipFree(e->range_flag);
+  (void)hipFree(e->d_spec_choice);
   (void)hipFree(e->valid);
   (void)hipFree(e->validbits);
   (void)hipFree(e->pidx);
@@ -1271,6 +1316,7 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   if (count != want)
     return fail(FFN_ERR_ARG, "weight blob has %zu floats, expected %zu", count,
                 want);
+  drop_spec(e);
   HIP_TRY(hipSetDevice(e->device));
   const int F = kFeatures;
   std::vector<float> host(e->wl_off + F + 1 + 3, 0.0f);
@@ -1465,7 +1511,23 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->tail_batched = value != 0;
     return FFN_OK;
   }
+  if (std::strcmp(name, "spec_force_mismatch") == 0) {
+    e->spec_force_mismatch = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "fuse_paste") == 0) {
+    e->fuse_paste = value != 0;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "speculate") == 0) {
+    // single-FoV steps of ffn_canvas_segment_at: queue the next step's conv0_a
+    // behind the paste, ahead of the host's turn-around (SpecArgs)
+    drop_spec(e);
+    e->speculate = value != 0;
+    return FFN_OK;
+  }
   if (std::strcmp(name, "stat_reset") == 0) {
+    e->stat_spec_launched = e->stat_spec_hits = e->stat_spec_mismatch = 0;
     e->stat_calls = e->stat_items = 0;
     std::memset(e->stat_hist, 0, sizeof(e->stat_hist));
     return FFN_OK;
@@ -1498,6 +1560,13 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "exact_variant") == 0) *value = e->exact_variant;
   else if (std::strcmp(name, "stat_step_calls") == 0) *value = (int)e->stat_calls;
   else if (std::strcmp(name, "stat_step_items") == 0) *value = (int)e->stat_items;
+  else if (std::strcmp(name, "speculate") == 0) *value = e->speculate;
+  else if (std::strcmp(name, "fuse_paste") == 0) *value = e->fuse_paste;
+  else if (std::strcmp(name, "stat_spec_launched") == 0)
+    *value = (int)e->stat_spec_launched;
+  else if (std::strcmp(name, "stat_spec_hits") == 0) *value = (int)e->stat_spec_hits;
+  else if (std::strcmp(name, "stat_spec_mismatch") == 0)
+    *value = (int)e->stat_spec_mismatch;
   else if (std::strncmp(name, "stat_hist_", 10) == 0) {
     const int k = std::atoi(name + 10);
     if (k < 0 || k > 64) return fail(FFN_ERR_ARG, "stat_hist_<0..64>");
@@ -1662,6 +1731,7 @@ void ffn_canvas_destroy(ffn_canvas* c) {
   if (!c) return;
   if (c->engine) {
     ffn_engine* e = c->engine;
+    drop_spec(e);
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     (void)hipStreamSynchronize(e->ustream);
@@ -1732,6 +1802,17 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
                 "two steps already in flight: call ffn_canvas_step_wait first");
   HIP_TRY(hipSetDevice(e->device));
   const Geom& g = e->g;
+  // the segment loop's hint belongs to THIS call (a single FoV) or to none
+  int hint_n = 0;
+  int hint_pos[kSpecMax][3];
+  for (int k = 0; k < n; ++k)
+    if (canvases[k]) {
+      if (n == 1) {
+        hint_n = canvases[k]->hint_n;
+        std::memcpy(hint_pos, canvases[k]->hint_pos, sizeof(hint_pos));
+      }
+      canvases[k]->hint_n = 0;
+    }
   StepItem* h_items = e->h_items + (size_t)slot * e->max_batch;
   StepItem* d_items = e->d_items + (size_t)slot * e->max_batch;
   ffn_step_result* h_results = e->h_results + (size_t)slot * e->max_batch;
@@ -1787,7 +1868,24 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   if (n > 1)
     HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(StepItem) * n,
                            hipMemcpyHostToDevice, e->stream));
-  int rc = run_stack(e, n, si, params->pad_value, params->move_threshold);
+  // the speculative conv0_a queued behind the last step, if this is the step it
+  // was made for (same canvas and parameters, a position on its list): the
+  // device took the first valid position of that list, and so did the caller
+  int spec_expected = -1;
+  if (e->spec.valid && n == 1 && e->spec.canvas == canvases[0] &&
+      e->spec.variant == e->conv_variant &&
+      std::memcmp(&e->spec.pad_value, &params->pad_value, sizeof(float)) == 0 &&
+      std::memcmp(&e->spec.move_thr, &params->move_threshold, sizeof(float)) == 0)
+    for (int j = 0; j < e->spec.n && spec_expected < 0; ++j)
+      if (std::memcmp(e->spec.pos[j], requests[0].pos, sizeof(int) * 3) == 0)
+        spec_expected = j;
+  if (spec_expected >= 0) e->stat_spec_hits += 1;
+  if (spec_expected >= 0 && e->spec_force_mismatch > 0) {  // test hook
+    e->spec_force_mismatch -= 1;
+    spec_expected = kSpecMax;  // an index the device cannot have chosen
+  }
+  int rc = run_stack(e, n, si, params->pad_value, params->move_threshold,
+                     spec_expected >= 0);
   if (rc) return rc;
   const unsigned step_id = ++e->step_id ? e->step_id : ++e->step_id;  // never 0
   // One FoV: faces first -- the host's turn-around is on the critical path and
@@ -1797,15 +1895,55 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   auto paste = [&]() {
     hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
                        e->logits, e->seed_raw, e->count, e->count_blocks,
-                       params->disco_seed_threshold, e->range_flag, e->range_tag);
+                       params->disco_seed_threshold, e->range_flag, e->range_tag,
+                       e->d_spec_choice, spec_expected);
   };
   if (n > 1) paste();
-  hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
-                     e->logits, e->seed_raw, e->count, e->count_blocks,
-                     params->move_threshold, params->disco_seed_threshold,
-                     params->deleted_threshold, e->range_flag, e->range_tag,
-                     h_results, h_seq, step_id);
-  if (n == 1) paste();
+  if (n == 1 && e->fuse_paste) {
+    hipLaunchKernelGGL(faces_paste_kernel, dim3(1 + 71), dim3(512), 0, e->stream, si,
+                       g, e->logits, e->seed_raw, e->count, e->count_blocks,
+                       params->move_threshold, params->disco_seed_threshold,
+                       params->deleted_threshold, e->range_flag, e->range_tag,
+                       h_results, h_seq, step_id, e->d_spec_choice, spec_expected);
+  } else {
+    hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
+                       e->logits, e->seed_raw, e->count, e->count_blocks,
+                       params->move_threshold, params->disco_seed_threshold,
+                       params->deleted_threshold, e->range_flag, e->range_tag,
+                       h_results, h_seq, step_id, e->d_spec_choice, spec_expected);
+    if (n == 1) paste();
+  }
+  // the next step's conv0_a, behind the paste and ahead of the host's turn-around
+  // (SpecArgs): for the positions the segment loop expects to pop next
+  if (n == 1) {
+    ffn_canvas* c = canvases[0];
+    SpecArgs sp;
+    sp.n = 0;
+    sp.move_thr = params->move_threshold;
+    sp.choice = e->d_spec_choice;
+    const int half[3] = {g.fz / 2, g.fy / 2, g.fx / 2};
+    const int dims[3] = {c->cz, c->cy, c->cx};
+    for (int j = 0; j < hint_n && e->speculate; ++j) {
+      bool inside = true;
+      for (int a = 0; a < 3; ++a)
+        if (hint_pos[j][a] - half[a] < 0 || hint_pos[j][a] + half[a] >= dims[a])
+          inside = false;
+      if (!inside) continue;
+      for (int a = 0; a < 3; ++a) sp.pos[sp.n][a] = hint_pos[j][a];
+      ++sp.n;
+    }
+    if (sp.n > 0) {
+      launch_conv0a(e, 1, si, params->pad_value, next_tag(e->range_tag), sp);
+      e->spec.valid = true;
+      e->spec.canvas = c;
+      e->spec.n = sp.n;
+      std::memcpy(e->spec.pos, sp.pos, sizeof(sp.pos));
+      e->spec.pad_value = params->pad_value;
+      e->spec.move_thr = params->move_threshold;
+      e->spec.variant = e->conv_variant;
+      e->stat_spec_launched += 1;
+    }
+  }
   HIP_TRY(hipGetLastError());
   e->stat_calls += 1;
   e->stat_items += n;
@@ -1818,8 +1956,23 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   return FFN_OK;
 }
 
+namespace {
+int step_wait_impl(ffn_engine* e, uint32_t ticket, ffn_step_result* results,
+                   bool* spec_mismatch);
+}
+
 int ffn_canvas_step_wait(ffn_engine* e, uint32_t ticket,
                          ffn_step_result* results) {
+  return step_wait_impl(e, ticket, results, nullptr);
+}
+
+namespace {
+// spec_mismatch: where to report a step that ran on a speculative conv0_a made
+// for another position (it pasted nothing; ffn_canvas_step repeats it) -- NULL:
+// such a step is an error
+int step_wait_impl(ffn_engine* e, uint32_t ticket, ffn_step_result* results,
+                   bool* spec_mismatch) {
+  if (spec_mismatch) *spec_mismatch = false;
   if (!e || !results) return fail(FFN_ERR_ARG, "null argument");
   int slot = -1;
   int n = 0;
@@ -1878,12 +2031,24 @@ int ffn_canvas_step_wait(ffn_engine* e, uint32_t ticket,
   }
   std::memcpy(results, h_results, sizeof(ffn_step_result) * n);
   for (int k = 0; k < n; ++k)
+    if (results[k].range_error == 2) {
+      if (spec_mismatch) {
+        *spec_mismatch = true;
+        return FFN_OK;
+      }
+      return fail(FFN_ERR_STATE,
+                  "the speculative conv0_a launch of step %u chose another position "
+                  "than the segment loop; the step changed nothing (speculate 0 "
+                  "turns the launches off)", step_id);
+    }
+  for (int k = 0; k < n; ++k)
     if (results[k].range_error)
       return fail(FFN_ERR_RANGE,
                   "an activation left the fp16 range (conv_variant >= 6): the "
                   "step changed nothing; set conv_variant -1 and repeat it");
   return FFN_OK;
 }
+}  // namespace
 
 int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
                     const ffn_step_request* requests,
@@ -1892,7 +2057,20 @@ int ffn_canvas_step(ffn_engine* e, int n, ffn_canvas* const* canvases,
   uint32_t ticket = 0;
   int rc = ffn_canvas_step_submit(e, n, canvases, requests, params, &ticket);
   if (rc) return rc;
-  return ffn_canvas_step_wait(e, ticket, results);
+  bool mismatch = false;
+  rc = step_wait_impl(e, ticket, results, &mismatch);
+  if (rc || !mismatch) return rc;
+  // The device's choice and the loop's differ (not expected: both apply
+  // Canvas.is_valid_pos to the same values).  Nothing was pasted: the step is
+  // made again, conv0_a included.
+  {
+    EngineLock lock_(e);
+    e->stat_spec_mismatch += 1;
+    drop_spec(e);
+  }
+  rc = ffn_canvas_step_submit(e, n, canvases, requests, params, &ticket);
+  if (rc) return rc;
+  return step_wait_impl(e, ticket, results, nullptr);
 }
 
 namespace {
@@ -1906,6 +2084,13 @@ struct HipLoopDevice {
   }
   int read_point(const int32_t pos[3], float* seed, int32_t* seg) {
     return ffn_canvas_read_points(c, 1, pos, seed, seg);
+  }
+  // the positions the loop expects to pop after the step it is about to make
+  void hint_next(int n, const int32_t (*pos)[3]) {
+    EngineLock lock_(c->engine);
+    c->hint_n = n < kSpecMax ? n : kSpecMax;
+    for (int j = 0; j < c->hint_n; ++j)
+      for (int a = 0; a < 3; ++a) c->hint_pos[j][a] = pos[j][a];
   }
 };
 }  // namespace

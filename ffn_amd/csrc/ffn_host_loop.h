@@ -78,6 +78,8 @@ struct SegmentState {
           many_gate_rejects = 0;
 };
 
+constexpr int kHintMax = 3;  // positions per Dev::hint_next call
+
 template <class Dev>
 class SegmentLoop {
  public:
@@ -99,6 +101,11 @@ class SegmentLoop {
       bool ended = false;
       rc = prepare(&pd, out, &ended);
       if (rc || ended) break;
+      // what the step AFTER this one will most likely be made at: the device may
+      // start on it before this step's result has come back (HipLoopDevice)
+      int32_t hint[kHintMax][3];
+      const int nh = guess_next(pd.pos, hint);
+      dev_.hint_next(nh, hint);
       ffn_step_result res;
       rc = dev_.step(pd.req, p_.step, &res);
       if (rc) {  // nothing was pasted: the position stays pending
@@ -326,6 +333,22 @@ class SegmentLoop {
       }
     }
     return FFN_OK;
+  }
+
+  // The first kHintMax queued positions that next() can still accept once the
+  // step at `cur` has been made: not visited (`cur` counts as visited by then),
+  // FoV inside the canvas.  Which of them is valid depends on the step's result;
+  // next() takes the first that is, moves queued by the step come after them.
+  int guess_next(const Coord& cur, int32_t (*out)[3]) const {
+    const Coord qc = quantize(cur);
+    int n = 0;
+    for (const auto& e : st_.queue) {
+      if (n >= kHintMax) break;
+      if (e.q == qc || st_.done.count(e.q) || !in_bounds(e.pos)) continue;
+      out[n][0] = e.pos.z, out[n][1] = e.pos.y, out[n][2] = e.pos.x;
+      ++n;
+    }
+    return n;
   }
 
   // first `limit` queued positions not yet visited (their post-step seed /

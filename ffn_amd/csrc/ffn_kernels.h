@@ -102,12 +102,29 @@ struct Conv0SplitOut {
 typedef _Float16 f16x8_c0 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_c0 __attribute__((ext_vector_type(4)));
 
+// Speculative launch (single-FoV steps of the library's segment loop): conv0_a of
+// the NEXT step is queued behind this step's paste, before the host has seen this
+// step's result, for the first of up to kSpecMax queued positions that passes
+// Canvas.is_valid_pos's device part (inference.py:325,341: NOT seed < move
+// threshold, segmentation <= 0; the bounds part is the host's, done before the
+// launch).  The host makes the same choice from the same values one turn-around
+// later (ffn_step_result.cand_seed / cand_seg) and then queues the rest of the
+// step behind this launch; `choice` (-1: none valid, nothing computed) lets the
+// step's faces kernel verify that both chose the same position.
+constexpr int kSpecMax = 3;
+struct SpecArgs {
+  int n;                 // 0: a normal launch at si's request position
+  int pos[kSpecMax][3];  // zyx
+  float move_thr;
+  int* choice;
+};
+
 template <bool SPLIT>
 __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
     StepItems si, float pad_value, const float* __restrict__ w /*[27][2][32]*/,
     const float* __restrict__ bias, float* __restrict__ out,
     float* __restrict__ seed_raw, Geom g, int tiles_y, int tiles_x,
-    Conv0SplitOut so) {
+    Conv0SplitOut so, SpecArgs sp) {
   constexpr int HZ = kC0Z + 2, HY = kC0Y + 2, HX = kC0X + 2;
   __shared__ float tile[HZ * HY * HX * 2];  // (image, seed) interleaved
   // SPLIT: the block's 256 x 32 outputs, transposed through LDS (36-float rows)
@@ -123,9 +140,35 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
   // canvas strides of this geometry's axes (axis a = canvas axis g.oa[a])
   const long cstr[3] = {(long)it.cy * it.cx, (long)it.cx, 1};
   const long sz = cstr[g.oa[0]], sy = cstr[g.oa[1]], sx = cstr[g.oa[2]];
-  const int z0 = it.req.pos[g.oa[0]] - g.fz / 2;
-  const int y0 = it.req.pos[g.oa[1]] - g.fy / 2;
-  const int x0 = it.req.pos[g.oa[2]] - g.fx / 2;
+  int pos[3] = {it.req.pos[0], it.req.pos[1], it.req.pos[2]};
+  if (sp.n > 0) {  // every block makes the same choice from the same two loads
+    int ch = -1;
+#pragma unroll
+    for (int k = kSpecMax - 1; k >= 0; --k) {
+      if (k < sp.n) {
+        const size_t ci =
+            ((size_t)sp.pos[k][0] * it.cy + sp.pos[k][1]) * it.cx + sp.pos[k][2];
+        const float sv = it.seed[ci];
+        const int gv = it.seg[ci];
+        if (!(sv < sp.move_thr) && gv <= 0) ch = k;
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sp.choice = ch;
+    if (ch < 0) return;
+#pragma unroll
+    for (int k = 0; k < kSpecMax; ++k)
+      if (k == ch) {
+        pos[0] = sp.pos[k][0];
+        pos[1] = sp.pos[k][1];
+        pos[2] = sp.pos[k][2];
+      }
+  }
+  const int pz = g.oa[0] == 0 ? pos[0] : g.oa[0] == 1 ? pos[1] : pos[2];
+  const int py = g.oa[1] == 0 ? pos[0] : g.oa[1] == 1 ? pos[1] : pos[2];
+  const int px = g.oa[2] == 0 ? pos[0] : g.oa[2] == 1 ? pos[1] : pos[2];
+  const int z0 = pz - g.fz / 2;
+  const int y0 = py - g.fy / 2;
+  const int x0 = px - g.fx / 2;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1960,16 +2003,16 @@ __device__ __forceinline__ unsigned sum_block_counts(
 // Values inside the FoV are recomputed from (logits, old seed) exactly as the
 // paste kernel will write them; values outside come from the canvas, which this
 // step does not modify there.
-__global__ __launch_bounds__(512) void faces_kernel(
-    StepItems si, Geom g, const float* __restrict__ logits,
-    const float* __restrict__ in_seed,
+__device__ __forceinline__ void faces_body(
+    const int item, const StepItems& si, const Geom& g,
+    const float* __restrict__ logits, const float* __restrict__ in_seed,
     const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
     float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
     unsigned range_tag, ffn_step_result* __restrict__ results,
-    unsigned* __restrict__ seq, unsigned step_id) {
+    unsigned* __restrict__ seq, unsigned step_id,
+    const int* __restrict__ spec_choice, int spec_expected) {
   __shared__ unsigned s_cnt[8];
   __shared__ ffn_step_result s_res;
-  const int item = blockIdx.x;
   const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
   const unsigned cnt = sum_block_counts(block_count, head_blocks, item, s_cnt);
   const bool disco = disco_on(cnt, g.V, disco_thr);
@@ -2091,7 +2134,11 @@ __global__ __launch_bounds__(512) void faces_kernel(
     }
     if (lane == 0) {
       s_res.num_deleted = deleted;
-      s_res.range_error = (*range_flag == range_tag) ? 1 : 0;
+      // (2: this step ran on a speculative conv0_a launch that chose another
+      // position than the host did: nothing is pasted, the library repeats it)
+      s_res.range_error = (*range_flag == range_tag) ? 1
+                          : (spec_expected >= 0 && *spec_choice != spec_expected) ? 2
+                                                                                  : 0;
     }
   }
   __syncthreads();
@@ -2109,16 +2156,31 @@ __global__ __launch_bounds__(512) void faces_kernel(
   }
 }
 
-// paste: disco bias + write-back into the canvas seed (inference.py:416-439).
-__global__ __launch_bounds__(512) void paste_kernel(
+__global__ __launch_bounds__(512) void faces_kernel(
     StepItems si, Geom g, const float* __restrict__ logits,
     const float* __restrict__ in_seed,
-    const unsigned* __restrict__ block_count, int head_blocks,
-    float disco_thr, const unsigned* __restrict__ range_flag,
-    unsigned range_tag) {
+    const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
+    float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
+    unsigned range_tag, ffn_step_result* __restrict__ results,
+    unsigned* __restrict__ seq, unsigned step_id,
+    const int* __restrict__ spec_choice, int spec_expected) {
+  faces_body(blockIdx.x, si, g, logits, in_seed, block_count, head_blocks, move_thr,
+             disco_thr, deleted_thr, range_flag, range_tag, results, seq, step_id,
+             spec_choice, spec_expected);
+}
+
+// paste: disco bias + write-back into the canvas seed (inference.py:416-439);
+// block bx of nbx of FoV `item`.
+__device__ __forceinline__ void paste_body(
+    const int item, const int bx, const int nbx, const StepItems& si, const Geom& g,
+    const float* __restrict__ logits, const float* __restrict__ in_seed,
+    const unsigned* __restrict__ block_count, int head_blocks, float disco_thr,
+    const unsigned* __restrict__ range_flag, unsigned range_tag,
+    const int* __restrict__ spec_choice, int spec_expected) {
   __shared__ unsigned s_cnt[8];
   if (*range_flag == range_tag) return;  // void step (fp16 range): no paste
-  const int item = blockIdx.y;
+  // ... or a step whose speculative conv0_a was made for another position
+  if (spec_expected >= 0 && *spec_choice != spec_expected) return;
   const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
   const unsigned cnt = sum_block_counts(block_count, head_blocks, item, s_cnt);
   const bool disco = disco_on(cnt, g.V, disco_thr);
@@ -2127,8 +2189,7 @@ __global__ __launch_bounds__(512) void paste_kernel(
   const int z0 = it.req.pos[0] - g.fz / 2;
   const int y0 = it.req.pos[1] - g.fy / 2;
   const int x0 = it.req.pos[2] - g.fx / 2;
-  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < g.V;
-       v += gridDim.x * blockDim.x) {
+  for (int v = bx * blockDim.x + threadIdx.x; v < g.V; v += nbx * blockDim.x) {
     const int x = v % g.fx;
     const int t = v / g.fx;
     const int y = t % g.fy;
@@ -2136,6 +2197,40 @@ __global__ __launch_bounds__(512) void paste_kernel(
     const size_t ci = ((size_t)(z0 + z) * it.cy + (y0 + y)) * it.cx + (x0 + x);
     it.seed[ci] = post_disco(lg[v], old[v], disco);
   }
+}
+
+__global__ __launch_bounds__(512) void paste_kernel(
+    StepItems si, Geom g, const float* __restrict__ logits,
+    const float* __restrict__ in_seed,
+    const unsigned* __restrict__ block_count, int head_blocks,
+    float disco_thr, const unsigned* __restrict__ range_flag,
+    unsigned range_tag, const int* __restrict__ spec_choice, int spec_expected) {
+  paste_body(blockIdx.y, blockIdx.x, gridDim.x, si, g, logits, in_seed, block_count,
+             head_blocks, disco_thr, range_flag, range_tag, spec_choice,
+             spec_expected);
+}
+
+// A single FoV's faces AND paste as one launch (engine option fuse_paste): block
+// 0 is the faces block -- it raises the host's flag as soon as ITS work is done,
+// as the separate launch does -- the others paste meanwhile.  Neither reads what
+// the other writes (faces recomputes the in-FoV values from the logits), and the
+// launch boundary between the two leaves the step's critical path.
+__global__ __launch_bounds__(512) void faces_paste_kernel(
+    StepItems si, Geom g, const float* __restrict__ logits,
+    const float* __restrict__ in_seed,
+    const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
+    float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
+    unsigned range_tag, ffn_step_result* __restrict__ results,
+    unsigned* __restrict__ seq, unsigned step_id,
+    const int* __restrict__ spec_choice, int spec_expected) {
+  if (blockIdx.x == 0)
+    faces_body(0, si, g, logits, in_seed, block_count, head_blocks, move_thr,
+               disco_thr, deleted_thr, range_flag, range_tag, results, seq, step_id,
+               spec_choice, spec_expected);
+  else
+    paste_body(0, blockIdx.x - 1, gridDim.x - 1, si, g, logits, in_seed, block_count,
+               head_blocks, disco_thr, range_flag, range_tag, spec_choice,
+               spec_expected);
 }
 
 // ---------------------------------------------------------------------------

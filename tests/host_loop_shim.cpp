@@ -11,9 +11,17 @@ typedef int (*shim_step_fn)(const ffn_step_request*, const ffn_step_params*,
                             ffn_step_result*);
 typedef int (*shim_read_fn)(const int32_t*, float*, int32_t*);
 
+// (optional) what the loop expects to pop after the step it is about to make
+typedef void (*shim_hint_fn)(int, const int32_t*);
+static shim_hint_fn g_hint_cb = nullptr;
+void shim_set_hint_cb(shim_hint_fn fn) { g_hint_cb = fn; }
+
 struct ShimDevice {
   shim_step_fn step_cb;
   shim_read_fn read_cb;
+  void hint_next(int n, const int32_t (*pos)[3]) {
+    if (g_hint_cb) g_hint_cb(n, &pos[0][0]);
+  }
   int step(const ffn_step_request& req, const ffn_step_params& params,
            ffn_step_result* res) {
     return step_cb(&req, &params, res);

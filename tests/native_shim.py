@@ -21,6 +21,9 @@ _READ_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
                             ctypes.POINTER(ctypes.c_int32))
 
 
+_HINT_CB = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.POINTER(ctypes.c_int32))
+
+
 _BATCH_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int,
                              ctypes.POINTER(ctypes.c_int),
                              ctypes.POINTER(_lib.StepRequest),
@@ -54,6 +57,7 @@ def build_shim(out_dir):
                                ctypes.c_void_p, ctypes.c_size_t]
   lib.shim_sizeof_params.restype = ctypes.c_size_t
   lib.shim_sizeof_result.restype = ctypes.c_size_t
+  lib.shim_set_hint_cb.argtypes = [_HINT_CB]
   return lib
 
 
@@ -65,6 +69,11 @@ class ShimHandle(EmulatedHandle):
   client = None
   fail_step = None  # step number at which the device reports FFN_ERR_RANGE once
   total_native_calls = 0  # over all handles
+  # the speculative conv0_a launch of the HIP device (ffn_hip.hip SpecArgs),
+  # emulated: [hints taken, steps made at a hinted position]; every such step
+  # asserts that the device's choice (first hinted position that is valid on the
+  # canvas as the previous step left it) is the position the loop then popped
+  spec_stats = [0, 0]
 
   def __init__(self, image):
     super().__init__(image)
@@ -76,13 +85,35 @@ class ShimHandle(EmulatedHandle):
     self.native_calls += 1
     ShimHandle.total_native_calls += 1
 
+    hint = []   # the loop's hint for the step being made
+    spec = {}   # 'list', 'choice': what the device queued behind the last step
+
+    def hint_cb(n, pos):
+      hint[:] = [(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]) for k in range(n)]
+
     def step_cb(req, par, res):
       if self.fail_step is not None and len(self.steps_seen) == self.fail_step:
         self.fail_step = None
         return _lib.ERR_RANGE
-      self.steps_seen.append(tuple(req.contents.pos))
+      pos = tuple(req.contents.pos)
+      if spec and pos in spec['list']:
+        assert spec['list'].index(pos) == spec['choice'], (pos, spec)
+        ShimHandle.spec_stats[1] += 1
+      spec.clear()
+      self.steps_seen.append(pos)
       out = self.client.step(self, req.contents, par.contents)
       ctypes.memmove(res, ctypes.addressof(out), ctypes.sizeof(out))
+      if hint:  # conv0_a's choice, on the canvas as this step left it
+        thr = par.contents.move_threshold
+        choice = -1
+        for k, q in enumerate(hint):
+          sv, gv = self.read_point(q)
+          if not (sv < thr) and gv <= 0:
+            choice = k
+            break
+        spec.update(list=list(hint), choice=choice)
+        ShimHandle.spec_stats[0] += 1
+        del hint[:]
       return 0
 
     def read_cb(pos, seed, seg):
@@ -92,6 +123,8 @@ class ShimHandle(EmulatedHandle):
 
     res = _lib.SegmentResult()
     start = (ctypes.c_int32 * 3)(*start_pos)
+    hint_fn = _HINT_CB(hint_cb)
+    self.shim.shim_set_hint_cb(hint_fn)
     rc = self.shim.shim_segment_at(self._state, _STEP_CB(step_cb),
                                    _READ_CB(read_cb), start,
                                    ctypes.byref(params), int(resume),
@@ -104,6 +137,7 @@ class ShimHandle(EmulatedHandle):
       for name in ('num_steps', 'skip_threshold', 'skip_invalid_pos',
                    'gate_rejects'):
         setattr(res, name, getattr(res, name) + getattr(first, name))
+    self.shim.shim_set_hint_cb(_HINT_CB())
     assert rc == 0, rc
     return res
 

@@ -626,3 +626,111 @@ def test_cells250_whole_volume_against_reference_minted_run(hip_exe, fib25_model
     canvas.close()
   finally:
     eng.set_option('conv_variant', 8)
+
+
+# ---------------------------------------------------------------------------
+# round 3: the next step's conv0_a queued behind the paste (engine option
+# `speculate`, ffn_hip.hip SpecArgs)
+# ---------------------------------------------------------------------------
+def test_speculative_conv0a_leaves_the_run_unchanged(hip_exe, fib25_model):
+  """ffn_canvas_segment_at with and without the speculative conv0_a launch: the
+  same reference-minted run (segmentation, counters, every FoV position), and
+  most steps do run on a launch made ahead of the host's turn-around.  A launch
+  that chose another position than the loop would fail the step
+  (ffn_step_result.range_error 2): none does."""
+  from ffn_amd import synthetic
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  eng = hip_exe.engine
+  steps = len(g['steps'])
+  stats = {}
+  try:
+    # (speculate, fuse_paste: faces + paste of a step as ONE launch)
+    # the last: five steps whose launch is declared a mismatch (test hook) --
+    # they paste nothing and are made again
+    for spec, fuse in ((1, 0), (0, 0), (1, 1), (0, 1), (1, 2)):
+      eng.set_option('speculate', spec)
+      eng.set_option('fuse_paste', fuse & 1)
+      eng.set_option('stat_reset', 0)
+      eng.set_option('spec_force_mismatch', 5 if fuse == 2 else 0)
+      canvas = _device_canvas(hip_exe, fib25_model,
+                              synthetic.normalize(g['volume']), keep_history=True)
+      assert canvas._native_loop_ok()
+      seen = []
+      inner = canvas._segment_at_native
+
+      def recording(start_pos, *a, _inner=inner, _c=canvas, **kw):
+        n = _inner(start_pos, *a, **kw)
+        seen.extend(tuple(int(v) for v in p) for p in _c.history[-n:] if n)
+        return n
+
+      canvas._segment_at_native = recording
+      canvas.segment_all(seed_policy=functools.partial(seed_lib_fixed(),
+                                                       coords=g['seeds']))
+      assert np.array_equal(np.asarray(canvas.segmentation), g['segmentation'])
+      assert canvas.counters['update_at-calls'].value == steps
+      if seen:
+        assert np.array_equal(np.array(seen), g['steps'])
+      stats[spec, fuse] = (eng.get_option('stat_spec_launched'),
+                           eng.get_option('stat_spec_hits'))
+      assert eng.get_option('stat_spec_mismatch') == (5 if fuse == 2 else 0)
+      canvas.close()
+  finally:
+    eng.set_option('speculate', 1)
+    eng.set_option('fuse_paste', 1)
+    eng.set_option('spec_force_mismatch', 0)
+  print('cells72, %d steps: conv0_a launched ahead %d times, used by %d steps'
+        % ((steps,) + stats[1, 0]))
+  assert stats[0, 0] == stats[0, 1] == (0, 0)
+  assert stats[1, 0] == stats[1, 1]
+  # (a repeated step carries no hint: the step after it runs without a launch)
+  assert stats[1, 2][0] == stats[1, 0][0]
+  assert stats[1, 0][1] - 5 <= stats[1, 2][1] <= stats[1, 0][1]
+  assert stats[1, 0][0] > steps // 2 and stats[1, 0][1] > 0.6 * stats[1, 0][0]
+
+
+def test_speculative_conv0a_permuted_layout():
+  """The same on BASELINE configs[4]'s FoV (zyx 21 x 41 x 41: the split-product
+  kernels lay it out with permuted axes): a flood through a
+  40 x 90 x 96 canvas (random weights, a move threshold below the pad value, so
+  every face queues a move), speculation on and off."""
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from ffn_amd.training.models import convstack_3d
+  from oracle import ffn_oracle
+  fov, deltas, depth = (21, 41, 41), (5, 10, 10), 3
+  m = convstack_3d.ConvStack3DFFNModel(fov_size=list(fov[::-1]),
+                                       deltas=list(deltas[::-1]), depth=depth)
+  m.set_variables(ffn_oracle.random_weights(depth, seed=8, stddev=0.06))
+  exe = executor.HipBatchExecutor(executor.ExecutorInterface(), m, m.info, None,
+                                  inference_utils.Counters(), 1, device_id=0)
+  eng = exe.engine
+  r = _request()
+  r.inference_options.move_threshold = 0.01
+  vol = synthetic.normalize(synthetic.cells_volume((40, 90, 96), seed=3))
+  out = {}
+  for spec in (1, 0):
+    eng.set_option('speculate', spec)
+    eng.set_option('stat_reset', 0)
+    counters = inference_utils.Counters()
+    canvas = inference.DeviceCanvas(
+        m.info, exe.get_client(counters, direct=True), vol, r.inference_options,
+        counters=counters, movement_policy_fn=movement.get_policy_fn(r, m.info),
+        keep_history=True)
+    assert canvas._native_loop_ok()
+    n = canvas.segment_at((20, 45, 48))
+    out[spec] = (n, [tuple(int(v) for v in p) for p in canvas.history],
+                 np.array(np.asarray(canvas.seed)),
+                 eng.get_option('stat_spec_launched'),
+                 eng.get_option('stat_spec_hits'))
+    canvas.close()
+  eng.close()
+  print('c5 FoV flood: %d steps, %d launched ahead, %d used' % (
+      out[1][0], out[1][3], out[1][4]))
+  assert out[1][0] == out[0][0] > 40
+  assert out[1][1] == out[0][1]
+  assert np.array_equal(out[1][2], out[0][2], equal_nan=True)
+  assert out[0][3:] == (0, 0)
+  assert out[1][4] > 0.5 * out[1][0]

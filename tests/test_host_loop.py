@@ -87,6 +87,26 @@ def test_native_loop_reproduces_reference_run(shim, fib25_blob, name):
       assert c.counters[key].value == ref[key], key
 
 
+def test_hinted_positions_are_what_the_loop_pops_next(shim, fib25_blob):
+  """The hint the loop gives the device before every step (SegmentLoop::
+  guess_next -> HipLoopDevice::hint_next: conv0_a of the next step is queued for
+  the first hinted position that is valid on the canvas once this step has
+  pasted): whenever the next step is made at a hinted position it is THAT one
+  (asserted step by step in tests/native_shim.py), and most steps are."""
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  ShimHandle.spec_stats[:] = [0, 0]
+  c = _canvas(shim, fib25_blob, synthetic.normalize(g['volume']), True)
+  c.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                              coords=g['seeds']))
+  assert np.array_equal(np.array(c._handle.steps_seen).reshape(-1, 3), g['steps'])
+  hinted, used = ShimHandle.spec_stats
+  steps = len(g['steps'])
+  print('%d steps, %d hints, %d steps made at a hinted position' % (
+      steps, hinted, used))
+  assert hinted > steps // 2
+  assert used > 0.6 * hinted
+
+
 def test_native_and_python_loops_leave_the_same_canvas_state(shim, fib25_blob):
   g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
   image = synthetic.normalize(g['volume'])
