@@ -74,7 +74,10 @@ typedef struct ffn_step_result {
   uint32_t num_deleted;   /* history_deleted entry of this step (see
                              ffn_step_params.deleted_threshold), else 0        */
   int32_t range_error;    /* conv_variant >= 6: 1 = an operand left the fp16 range,
-                             the step was NOT pasted (FFN_ERR_RANGE)           */
+                             the step was NOT pasted (FFN_ERR_RANGE); 2 = the
+                             step's conv0_a was a launch made ahead for another
+                             position (option "speculate"): NOT pasted either,
+                             ffn_canvas_step repeats such a step itself         */
 } ffn_step_result;
 
 /* Result of the per-segment commit reduction (inference.py:614-646). */
@@ -288,12 +291,22 @@ int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
  * batch); "batch_chunks" (variant 6): the form batched steps take.  Results
  * are identical up to f32 summation order.  "fuse_head" (variant 2): 1x1x1
  * head inside the last conv launch.  "store_policy" (variant 2): 0 write-back,
- * 1 write-through, 2 non-temporal conv stores. */
+ * 1 write-through, 2 non-temporal conv stores.
+ * "speculate" (default 1): single-FoV steps made by ffn_canvas_segment_at queue
+ * conv0_a of the NEXT step behind their paste, for the positions the segment
+ * loop expects to pop next (the kernel takes the first that passes
+ * Canvas.is_valid_pos on the pasted canvas; the host makes the same choice from
+ * the step result and then queues the rest of the step behind it; a step whose
+ * launch chose otherwise pastes nothing and is made again).  "fuse_paste"
+ * (default 1): faces and paste of a single-FoV step as one launch.  Neither
+ * changes any result. */
 int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
 /* Current value of an option ("conv_variant", "exact_variant", "fuse_head",
- * "store_policy", "sync_mode", "profile_every"), or a statistic of the batched
- * step calls since set_option("stat_reset", 0): "stat_step_calls",
- * "stat_step_items" (FoVs in them), "stat_hist_<n>" (calls with n FoVs). */
+ * "store_policy", "sync_mode", "profile_every", "speculate", "fuse_paste"), or
+ * a statistic of the step calls since set_option("stat_reset", 0):
+ * "stat_step_calls", "stat_step_items" (FoVs in them), "stat_hist_<n>" (calls
+ * with n FoVs), "stat_spec_launched" / "stat_spec_hits" / "stat_spec_mismatch"
+ * (conv0_a launches made ahead, steps that ran on one, steps repeated). */
 int ffn_engine_get_option(ffn_engine* engine, const char* name, int* value);
 /* Debug: with option "debug_clock" = 1 the compact conv kernel records, for its
  * first workgroup, per wave {shader clock at entry, at main-loop start, at
