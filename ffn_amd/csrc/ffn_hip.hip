@@ -1933,6 +1933,8 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
       ++sp.n;
     }
     if (sp.n > 0) {
+      for (int j = sp.n; j < kSpecMax; ++j)  // unused slots: readable positions
+        for (int a = 0; a < 3; ++a) sp.pos[j][a] = sp.pos[0][a];
       launch_conv0a(e, 1, si, params->pad_value, next_tag(e->range_tag), sp);
       e->spec.valid = true;
       e->spec.canvas = c;

@@ -79,6 +79,47 @@ struct StepItems {
   int use_inline;
 };
 
+// What the gather / faces / paste kernels read of a StepItem, in registers: with
+// `const StepItem& it = inline ? kernarg copy : items[item]` every field access
+// is a flat load behind a select (a dependent memory round trip each); here the
+// single-FoV path reads its fields straight from the kernel arguments.
+// (global address space spelled out: through generic pointers these would be
+// flat loads, which the compiler orders against every LDS access)
+#define FFN_GLOBAL __attribute__((address_space(1)))
+struct ItemView {
+  const FFN_GLOBAL float* image;
+  const FFN_GLOBAL uint8_t* image_u8;
+  const FFN_GLOBAL float* image_lut;
+  FFN_GLOBAL float* seed;
+  const FFN_GLOBAL int32_t* seg;
+  int cz, cy, cx;
+  int pos[3];
+  const ffn_step_request* req;  // start_pos / candidates (read per lane)
+};
+__device__ __forceinline__ ItemView item_view(const StepItems& si, int item) {
+  ItemView v;
+#define FFN_VIEW_FROM(S)                                                        \
+  v.image = (const FFN_GLOBAL float*)(S).image;                                  \
+  v.image_u8 = (const FFN_GLOBAL uint8_t*)(S).image_u8;                          \
+  v.image_lut = (const FFN_GLOBAL float*)(S).image_lut;                          \
+  v.seed = (FFN_GLOBAL float*)(S).seed;                                          \
+  v.seg = (const FFN_GLOBAL int32_t*)(S).seg;                                    \
+  v.cz = (S).cz, v.cy = (S).cy, v.cx = (S).cx;                                   \
+  v.pos[0] = (S).req.pos[0], v.pos[1] = (S).req.pos[1], v.pos[2] = (S).req.pos[2]; \
+  v.req = &(S).req;
+  // (the position is pinned on its side of the select, so that it is read from
+  // the kernel arguments there and not through the merged `req` pointer)
+  if (si.use_inline) {
+    FFN_VIEW_FROM(si.inline_item)
+    asm volatile("" : "+s"(v.pos[0]), "+s"(v.pos[1]), "+s"(v.pos[2]));
+  } else {
+    FFN_VIEW_FROM(si.items[item])
+    asm volatile("" : "+v"(v.pos[0]), "+v"(v.pos[1]), "+v"(v.pos[2]));
+  }
+#undef FFN_VIEW_FROM
+  return v;
+}
+
 constexpr int kC0Z = 4, kC0Y = 8, kC0X = 8;  // conv0a output tile per block
 constexpr int kC0Threads = 512;               // 256 positions x 2 cout halves
 
@@ -127,10 +168,11 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
     Conv0SplitOut so, SpecArgs sp) {
   constexpr int HZ = kC0Z + 2, HY = kC0Y + 2, HX = kC0X + 2;
   __shared__ float tile[HZ * HY * HX * 2];  // (image, seed) interleaved
+  __shared__ float s_lut[256];              // uint8 canvases: normalisation table
   // SPLIT: the block's 256 x 32 outputs, transposed through LDS (36-float rows)
   __shared__ __attribute__((aligned(16))) float otile[SPLIT ? 256 * 36 : 4];
   const int item = blockIdx.y;
-  const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
+  const ItemView it = item_view(si, item);
   int b = blockIdx.x;
   const int tx = b % tiles_x;
   b /= tiles_x;
@@ -140,19 +182,25 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
   // canvas strides of this geometry's axes (axis a = canvas axis g.oa[a])
   const long cstr[3] = {(long)it.cy * it.cx, (long)it.cx, 1};
   const long sz = cstr[g.oa[0]], sy = cstr[g.oa[1]], sx = cstr[g.oa[2]];
-  int pos[3] = {it.req.pos[0], it.req.pos[1], it.req.pos[2]};
-  if (sp.n > 0) {  // every block makes the same choice from the same two loads
+  int pos[3] = {it.pos[0], it.pos[1], it.pos[2]};
+  if (sp.n > 0) {  // every block makes the same choice from the same loads
+    // (all of them in flight at once)
+    float sv[kSpecMax];
+    int gv[kSpecMax];
+#pragma unroll
+    for (int k = 0; k < kSpecMax; ++k) {
+      const size_t ci =  // (the host fills unused slots with candidate 0)
+          ((size_t)sp.pos[k][0] * it.cy + sp.pos[k][1]) * it.cx + sp.pos[k][2];
+      sv[k] = it.seed[ci];
+      gv[k] = it.seg[ci];
+    }
+#pragma unroll
+    for (int k = 0; k < kSpecMax; ++k)  // (no short-circuit into dependent loads)
+      asm volatile("" : "+v"(sv[k]), "+v"(gv[k]));
     int ch = -1;
 #pragma unroll
-    for (int k = kSpecMax - 1; k >= 0; --k) {
-      if (k < sp.n) {
-        const size_t ci =
-            ((size_t)sp.pos[k][0] * it.cy + sp.pos[k][1]) * it.cx + sp.pos[k][2];
-        const float sv = it.seed[ci];
-        const int gv = it.seg[ci];
-        if (!(sv < sp.move_thr) && gv <= 0) ch = k;
-      }
-    }
+    for (int k = kSpecMax - 1; k >= 0; --k)
+      if (k < sp.n && !(sv[k] < sp.move_thr) && gv[k] <= 0) ch = k;
     if (blockIdx.x == 0 && threadIdx.x == 0) *sp.choice = ch;
     if (ch < 0) return;
 #pragma unroll
@@ -185,23 +233,61 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
   }
   const float bias0 = bias[i], bias1 = bias[16 + i];
 
-  for (int e = threadIdx.x; e < HZ * HY * HX; e += kC0Threads) {
-    const int hx = e % HX;
-    const int t = e / HX;
+  // Gather: every canvas load of the block is issued before any is waited for
+  // (<= kC0Per elements per thread), and a uint8 canvas' normalisation table
+  // ((x - mean) / stddev of runner.py:383-385 as a 256-entry look-up) goes
+  // through LDS -- one global round trip for the whole gather instead of one
+  // per pass and another per look-up.
+  constexpr int kC0Per = (HZ * HY * HX + kC0Threads - 1) / kC0Threads;
+  const bool u8 = it.image == nullptr;
+  float lut_v = 0.0f;  // in flight with the canvas loads below
+  if (u8 && threadIdx.x < 256) lut_v = it.image_lut[threadIdx.x];
+  float g_img[kC0Per] = {}, g_seed[kC0Per];
+  unsigned g_raw[kC0Per] = {};
+  size_t g_ci[kC0Per];
+  long g_out[kC0Per];  // seed_raw index of an interior voxel, else -1
+  bool g_in[kC0Per];
+#pragma unroll
+  for (int k = 0; k < kC0Per; ++k) {
+    const int e = threadIdx.x + k * kC0Threads;
+    const int ec = e < HZ * HY * HX ? e : 0;
+    const int hx = ec % HX;
+    const int t = ec / HX;
     const int hy = t % HY;
     const int hz = t / HY;
     const int zz = oz + hz - 1, yy = oy + hy - 1, xx = ox + hx - 1;
+    g_in[k] = e < HZ * HY * HX && zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy &&
+              xx >= 0 && xx < g.fx;
+    // (voxel 0 of the canvas stands in outside the FoV: loads without branches)
+    g_ci[k] = g_in[k] ? (size_t)((z0 + zz) * sz + (y0 + yy) * sy + (x0 + xx) * sx) : 0;
+    // interior voxel: keep the raw seed (NaN preserved), at its place in the
+    // caller's dense [z][y][x] order
+    g_out[k] = (g_in[k] && hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y &&
+                hx >= 1 && hx <= kC0X)
+                   ? (long)((size_t)item * g.V + (size_t)zz * g.dstr[0] +
+                            yy * g.dstr[1] + xx * g.dstr[2])
+                   : -1;
+  }
+  if (u8) {
+#pragma unroll
+    for (int k = 0; k < kC0Per; ++k) g_raw[k] = it.image_u8[g_ci[k]];
+  } else {
+#pragma unroll
+    for (int k = 0; k < kC0Per; ++k) g_img[k] = it.image[g_ci[k]];
+  }
+#pragma unroll
+  for (int k = 0; k < kC0Per; ++k) g_seed[k] = it.seed[g_ci[k]];
+  if (u8 && threadIdx.x < 256) s_lut[threadIdx.x] = lut_v;
+  __syncthreads();  // the table is in LDS
+#pragma unroll
+  for (int k = 0; k < kC0Per; ++k) {
+    const int e = threadIdx.x + k * kC0Threads;
+    if (e >= HZ * HY * HX) continue;
     float vi = 0.0f, vs = 0.0f;  // SAME zero padding outside the FoV
-    if (zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy && xx >= 0 && xx < g.fx) {
-      const size_t ci = (size_t)((z0 + zz) * sz + (y0 + yy) * sy + (x0 + xx) * sx);
-      // uint8 canvases: (x - mean) / stddev of runner.py:383-385 is a table look-up
-      vi = it.image ? it.image[ci] : it.image_lut[it.image_u8[ci]];
-      vs = it.seed[ci];
-      if (hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y && hx >= 1 &&
-          hx <= kC0X)  // interior voxel: keep the raw seed (NaN preserved), at
-                       // its place in the caller's dense [z][y][x] order
-        seed_raw[(size_t)item * g.V + (size_t)zz * g.dstr[0] + yy * g.dstr[1] +
-                 xx * g.dstr[2]] = vs;
+    if (g_in[k]) {
+      vi = u8 ? s_lut[g_raw[k]] : g_img[k];
+      vs = g_seed[k];
+      if (g_out[k] >= 0) seed_raw[g_out[k]] = vs;
       if (vs != vs) vs = pad_value;  // NaN -> pad (inference.py:406-407)
     }
     tile[2 * e] = vi;
@@ -2013,14 +2099,14 @@ __device__ __forceinline__ void faces_body(
     const int* __restrict__ spec_choice, int spec_expected) {
   __shared__ unsigned s_cnt[8];
   __shared__ ffn_step_result s_res;
-  const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
+  const ItemView it = item_view(si, item);
   const unsigned cnt = sum_block_counts(block_count, head_blocks, item, s_cnt);
   const bool disco = disco_on(cnt, g.V, disco_thr);
   const float* lg = logits + (size_t)item * g.V;
   const float* old = in_seed + (size_t)item * g.V;
-  const int z0 = it.req.pos[0] - g.fz / 2;
-  const int y0 = it.req.pos[1] - g.fy / 2;
-  const int x0 = it.req.pos[2] - g.fx / 2;
+  const int z0 = it.pos[0] - g.fz / 2;
+  const int y0 = it.pos[1] - g.fy / 2;
+  const int x0 = it.pos[2] - g.fx / 2;
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
 
@@ -2095,9 +2181,9 @@ __device__ __forceinline__ void faces_body(
       s_res.face_seg[wave] = sg;
     }
   } else if (wave == 6) {
-    const int n = it.req.num_candidates;
+    const int n = it.req->num_candidates;
     if (lane <= n && lane <= FFN_MAX_CANDIDATES) {
-      const int32_t* q = lane == 0 ? it.req.start_pos : it.req.candidates[lane - 1];
+      const int32_t* q = lane == 0 ? it.req->start_pos : it.req->candidates[lane - 1];
       const int z = q[0], y = q[1], x = q[2];
       float sv = __builtin_nanf("");
       int gv = 0;
@@ -2181,14 +2267,14 @@ __device__ __forceinline__ void paste_body(
   if (*range_flag == range_tag) return;  // void step (fp16 range): no paste
   // ... or a step whose speculative conv0_a was made for another position
   if (spec_expected >= 0 && *spec_choice != spec_expected) return;
-  const StepItem& it = si.use_inline ? si.inline_item : si.items[item];
+  const ItemView it = item_view(si, item);
   const unsigned cnt = sum_block_counts(block_count, head_blocks, item, s_cnt);
   const bool disco = disco_on(cnt, g.V, disco_thr);
   const float* lg = logits + (size_t)item * g.V;
   const float* old = in_seed + (size_t)item * g.V;
-  const int z0 = it.req.pos[0] - g.fz / 2;
-  const int y0 = it.req.pos[1] - g.fy / 2;
-  const int x0 = it.req.pos[2] - g.fx / 2;
+  const int z0 = it.pos[0] - g.fz / 2;
+  const int y0 = it.pos[1] - g.fy / 2;
+  const int x0 = it.pos[2] - g.fx / 2;
   for (int v = bx * blockDim.x + threadIdx.x; v < g.V; v += nbx * blockDim.x) {
     const int x = v % g.fx;
     const int t = v / g.fx;

@@ -635,9 +635,9 @@ def test_cells250_whole_volume_against_reference_minted_run(hip_exe, fib25_model
 def test_speculative_conv0a_leaves_the_run_unchanged(hip_exe, fib25_model):
   """ffn_canvas_segment_at with and without the speculative conv0_a launch: the
   same reference-minted run (segmentation, counters, every FoV position), and
-  most steps do run on a launch made ahead of the host's turn-around.  A launch
-  that chose another position than the loop would fail the step
-  (ffn_step_result.range_error 2): none does."""
+  most steps do run on a launch made ahead of the host's turn-around.  A step
+  whose launch chose another position than the loop pastes nothing and is made
+  again (ffn_step_result.range_error 2): none does unless provoked."""
   from ffn_amd import synthetic
   g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
   eng = hip_exe.engine
