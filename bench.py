@@ -61,6 +61,8 @@ def configure(args):
         max(args.volume // 3, 64), args.volume, args.volume)
   else:
     VOLUME_ZYX = (args.volume,) * 3
+  if args.volume_zyx:  # e.g. configs[4]'s stated canvas: 256 2048 2048
+    VOLUME_ZYX = tuple(args.volume_zyx)
   VOXELS = FOV[0] * FOV[1] * FOV[2]
   CONV32_FLOPS = 2.0 * 27 * 32 * 32 * VOXELS
   STEP_FLOPS = 2.0 * (2 * 27 * 32 + (2 * DEPTH - 1) * 27 * 32 * 32 + 32) * VOXELS
@@ -896,6 +898,8 @@ def main():
                   help='untimed spin-up (extra FoV steps) before the warmup '
                   'steps are counted')
   ap.add_argument('--volume', type=int, default=250)
+  ap.add_argument('--volume-zyx', type=int, nargs=3, default=None,
+                  help='canvas size zyx (overrides --volume)')
   ap.add_argument('--mode', choices=['stream', 'sharded'], default='stream',
                   help='stream: the headline (one seed stream per GPU); sharded: '
                   'one volume tiled into sub-boxes, timed assembly (configs[3])')
