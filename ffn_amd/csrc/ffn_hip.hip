@@ -238,6 +238,7 @@ struct ffn_canvas {
   // be made at (consumed by the next single-FoV ffn_canvas_step_submit)
   int hint_n = 0;
   int hint_pos[kSpecMax][3] = {};
+  bool hint_from_loop = false;  // the next step is the segment loop's own
 
   void mark_dirty(const int lo[3], const int hi[3]) {
     const int dims[3] = {cz, cy, cx};
@@ -1805,13 +1806,16 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   // the segment loop's hint belongs to THIS call (a single FoV) or to none
   int hint_n = 0;
   int hint_pos[kSpecMax][3];
+  bool from_loop = false;
   for (int k = 0; k < n; ++k)
     if (canvases[k]) {
       if (n == 1) {
         hint_n = canvases[k]->hint_n;
         std::memcpy(hint_pos, canvases[k]->hint_pos, sizeof(hint_pos));
+        from_loop = canvases[k]->hint_from_loop;
       }
       canvases[k]->hint_n = 0;
+      canvases[k]->hint_from_loop = false;
     }
   StepItem* h_items = e->h_items + (size_t)slot * e->max_batch;
   StepItem* d_items = e->d_items + (size_t)slot * e->max_batch;
@@ -1871,8 +1875,10 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   // the speculative conv0_a queued behind the last step, if this is the step it
   // was made for (same canvas and parameters, a position on its list): the
   // device took the first valid position of that list, and so did the caller
+  // (only the loop's own steps: it pops the FIRST valid position of its list; a
+  // caller stepping the canvas itself may pick any)
   int spec_expected = -1;
-  if (e->spec.valid && n == 1 && e->spec.canvas == canvases[0] &&
+  if (e->spec.valid && n == 1 && from_loop && e->spec.canvas == canvases[0] &&
       e->spec.variant == e->conv_variant &&
       std::memcmp(&e->spec.pad_value, &params->pad_value, sizeof(float)) == 0 &&
       std::memcmp(&e->spec.move_thr, &params->move_threshold, sizeof(float)) == 0)
@@ -2090,6 +2096,7 @@ struct HipLoopDevice {
   // the positions the loop expects to pop after the step it is about to make
   void hint_next(int n, const int32_t (*pos)[3]) {
     EngineLock lock_(c->engine);
+    c->hint_from_loop = true;
     c->hint_n = n < kSpecMax ? n : kSpecMax;
     for (int j = 0; j < c->hint_n; ++j)
       for (int a = 0; a < 3; ++a) c->hint_pos[j][a] = pos[j][a];
