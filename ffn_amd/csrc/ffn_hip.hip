@@ -183,8 +183,9 @@ struct ffn_engine {
 
   StepItem* d_items = nullptr;
   StepItem* h_items = nullptr;
-  ffn_step_result* h_results = nullptr;  // pinned; written by the paste kernel
-  unsigned* h_seq = nullptr;             // pinned per-item completion flags
+  // pinned, written by the faces block: kPubWords 8-byte words per item and slot,
+  // (step number << 32) | one 32-bit word of the item's ffn_step_result
+  unsigned long long* h_pub = nullptr;
   unsigned step_id = 0;
   // two result / descriptor slots: one step may be queued behind the running one
   int next_slot = 0;
@@ -192,7 +193,7 @@ struct ffn_engine {
   bool slot_waited[2] = {false, false};  // a thread is in ffn_canvas_step_wait for it
   unsigned slot_ticket[2] = {0, 0};
   std::vector<ffn_canvas*> slot_canvas[2];
-  int sync_mode = 1;  // 0 = hipStreamSynchronize, 1 = poll h_seq (then sync)
+  int sync_mode = 1;  // 0 = hipStreamSynchronize, 1 = poll h_pub (then sync)
   // since the last set_option("stat_reset"): batched step calls, FoVs in them,
   // and a histogram of FoVs per call (index min(n, 64))
   long stat_calls = 0, stat_items = 0;
@@ -1071,11 +1072,10 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   E_TRY(hipMalloc(&e->d_items, sizeof(StepItem) * 2 * max_batch));
   E_TRY(hipHostMalloc(&e->h_items, sizeof(StepItem) * 2 * max_batch,
                       hipHostMallocDefault));
-  E_TRY(hipHostMalloc(&e->h_results, sizeof(ffn_step_result) * 2 * max_batch,
+  E_TRY(hipHostMalloc(&e->h_pub,
+                      sizeof(unsigned long long) * kPubWords * 2 * max_batch,
                       hipHostMallocDefault));
-  E_TRY(hipHostMalloc(&e->h_seq, sizeof(unsigned) * 2 * max_batch,
-                      hipHostMallocDefault));
-  std::memset(e->h_seq, 0, sizeof(unsigned) * 2 * max_batch);
+  std::memset(e->h_pub, 0, sizeof(unsigned long long) * kPubWords * 2 * max_batch);
 
   // validity table of the padded-flat layout
   {
@@ -1303,8 +1303,7 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->d_scratch);
   if (e->h_io) (void)hipHostFree(e->h_io);
   if (e->h_items) (void)hipHostFree(e->h_items);
-  if (e->h_results) (void)hipHostFree(e->h_results);
-  if (e->h_seq) (void)hipHostFree(e->h_seq);
+  if (e->h_pub) (void)hipHostFree(e->h_pub);
   if (e->h_scratch) (void)hipHostFree(e->h_scratch);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1819,8 +1818,7 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     }
   StepItem* h_items = e->h_items + (size_t)slot * e->max_batch;
   StepItem* d_items = e->d_items + (size_t)slot * e->max_batch;
-  ffn_step_result* h_results = e->h_results + (size_t)slot * e->max_batch;
-  unsigned* h_seq = e->h_seq + (size_t)slot * e->max_batch;
+  unsigned long long* h_pub = e->h_pub + (size_t)slot * e->max_batch * kPubWords;
   const int other = slot ^ 1;
   for (int k = 0; k < n; ++k) {
     const ffn_canvas* c = canvases[k];
@@ -1910,13 +1908,13 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
                        g, e->logits, e->seed_raw, e->count, e->count_blocks,
                        params->move_threshold, params->disco_seed_threshold,
                        params->deleted_threshold, e->range_flag, e->range_tag,
-                       h_results, h_seq, step_id, e->d_spec_choice, spec_expected);
+                       h_pub, step_id, e->d_spec_choice, spec_expected);
   } else {
     hipLaunchKernelGGL(faces_kernel, dim3(n), dim3(512), 0, e->stream, si, g,
                        e->logits, e->seed_raw, e->count, e->count_blocks,
                        params->move_threshold, params->disco_seed_threshold,
                        params->deleted_threshold, e->range_flag, e->range_tag,
-                       h_results, h_seq, step_id, e->d_spec_choice, spec_expected);
+                       h_pub, step_id, e->d_spec_choice, spec_expected);
     if (n == 1) paste();
   }
   // the next step's conv0_a, behind the paste and ahead of the host's turn-around
@@ -1995,8 +1993,7 @@ int step_wait_impl(ffn_engine* e, uint32_t ticket, ffn_step_result* results,
     e->slot_waited[slot] = true;
   }
   const unsigned step_id = ticket;
-  ffn_step_result* h_results = e->h_results + (size_t)slot * e->max_batch;
-  unsigned* h_seq = e->h_seq + (size_t)slot * e->max_batch;
+  unsigned long long* h_pub = e->h_pub + (size_t)slot * e->max_batch * kPubWords;
   // The slot -- its descriptor, result and flag arrays -- stays taken until the
   // results have been copied out (another thread may submit meanwhile); it is
   // free again whatever happens below.  No lock while waiting: that wait is
@@ -2012,32 +2009,38 @@ int step_wait_impl(ffn_engine* e, uint32_t ticket, ffn_step_result* results,
     }
   } release_{e, slot};
   HIP_TRY(hipSetDevice(e->device));
+  // every published word of the n records carries this step's number
+  auto arrived = [&]() {
+    for (int k = 0; k < n * kPubWords; ++k)
+      if ((unsigned)(__atomic_load_n(&h_pub[k], __ATOMIC_ACQUIRE) >> 32) != step_id)
+        return false;
+    return true;
+  };
   if (e->sync_mode == 1) {
-    // Poll the completion flags the faces kernel raises in pinned memory: lower
-    // wake-up latency than a blocking stream synchronise.  Bounded spin, then
-    // fall back to the stream so that device faults still surface as errors.
-    volatile unsigned* seq = h_seq;
+    // Poll the records the faces blocks write into pinned memory: lower wake-up
+    // latency than a blocking stream synchronise.  Bounded spin, then fall back
+    // to the stream so that device faults still surface as errors.
     bool done = false;
     for (long spin = 0; spin < 200000000L && !done; ++spin) {
-      done = true;
-      for (int k = 0; k < n; ++k)
-        if (__atomic_load_n(&seq[k], __ATOMIC_ACQUIRE) != step_id) done = false;
+      done = arrived();
       if (!done && (spin & 0xfff) == 0xfff &&
           hipStreamQuery(e->stream) == hipSuccess) {
-        done = true;  // stream drained: flags must be set (or the kernel died)
+        done = true;  // stream drained: the records must be there (or the kernel died)
       }
     }
     if (!done) HIP_TRY(hipStreamSynchronize(e->stream));
-    for (int k = 0; k < n; ++k)
-      if (__atomic_load_n(&seq[k], __ATOMIC_ACQUIRE) != step_id) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        if (__atomic_load_n(&seq[k], __ATOMIC_ACQUIRE) != step_id)
-          return fail(FFN_ERR_HIP, "step %u did not complete", step_id);
-      }
   } else {
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
-  std::memcpy(results, h_results, sizeof(ffn_step_result) * n);
+  if (!arrived()) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!arrived()) return fail(FFN_ERR_HIP, "step %u did not complete", step_id);
+  }
+  {
+    uint32_t* out = reinterpret_cast<uint32_t*>(results);
+    for (int k = 0; k < n * kPubWords; ++k)
+      out[k] = (uint32_t)__atomic_load_n(&h_pub[k], __ATOMIC_RELAXED);
+  }
   for (int k = 0; k < n; ++k)
     if (results[k].range_error == 2) {
       if (spec_mismatch) {

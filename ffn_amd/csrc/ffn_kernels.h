@@ -2093,13 +2093,14 @@ __device__ __forceinline__ unsigned sum_block_counts(
 // Values inside the FoV are recomputed from (logits, old seed) exactly as the
 // paste kernel will write them; values outside come from the canvas, which this
 // step does not modify there.
+constexpr int kPubWords = (int)(sizeof(ffn_step_result) / 4);  // published words
+
 __device__ __forceinline__ void faces_body(
     const int item, const StepItems& si, const Geom& g,
     const float* __restrict__ logits, const float* __restrict__ in_seed,
     const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
     float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
-    unsigned range_tag, ffn_step_result* __restrict__ results,
-    unsigned* __restrict__ seq, unsigned step_id,
+    unsigned range_tag, unsigned long long* __restrict__ pub, unsigned step_id,
     const int* __restrict__ spec_choice, int spec_expected) {
   __shared__ unsigned s_cnt[8];
   __shared__ ffn_step_result s_res;
@@ -2232,17 +2233,18 @@ __device__ __forceinline__ void faces_body(
     }
   }
   __syncthreads();
-  // Publish from ONE wave: copy the record into pinned host memory, make it
-  // visible system-wide, then raise the item's sequence flag the host polls.
+  // Publish from ONE wave, in ONE trip over PCIe: every 32-bit word of the record
+  // goes to pinned host memory as an 8-byte word that carries the step number in
+  // its upper half (8-byte stores are atomic: a word is either the old step's or
+  // this one's), and the host waits until all kPubWords of them carry it.  No
+  // record -> system fence -> flag sequence (two more round trips inside the
+  // block the next launch waits for).
   if (wave == 0) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&s_res);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&results[item]);
-    for (int k = lane; k < (int)(sizeof(ffn_step_result) / 4); k += 64)
-      dst[k] = src[k];
-    __threadfence_system();
-    if (lane == 0)
-      __hip_atomic_store(&seq[item], step_id, __ATOMIC_RELEASE,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned long long* dst = pub + (size_t)item * kPubWords;
+    for (int k = lane; k < kPubWords; k += 64)
+      __hip_atomic_store(&dst[k], ((unsigned long long)step_id << 32) | src[k],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -2251,11 +2253,10 @@ __global__ __launch_bounds__(512) void faces_kernel(
     const float* __restrict__ in_seed,
     const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
     float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
-    unsigned range_tag, ffn_step_result* __restrict__ results,
-    unsigned* __restrict__ seq, unsigned step_id,
+    unsigned range_tag, unsigned long long* __restrict__ pub, unsigned step_id,
     const int* __restrict__ spec_choice, int spec_expected) {
   faces_body(blockIdx.x, si, g, logits, in_seed, block_count, head_blocks, move_thr,
-             disco_thr, deleted_thr, range_flag, range_tag, results, seq, step_id,
+             disco_thr, deleted_thr, range_flag, range_tag, pub, step_id,
              spec_choice, spec_expected);
 }
 
@@ -2310,12 +2311,11 @@ __global__ __launch_bounds__(512) void faces_paste_kernel(
     const float* __restrict__ in_seed,
     const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
     float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
-    unsigned range_tag, ffn_step_result* __restrict__ results,
-    unsigned* __restrict__ seq, unsigned step_id,
+    unsigned range_tag, unsigned long long* __restrict__ pub, unsigned step_id,
     const int* __restrict__ spec_choice, int spec_expected) {
   if (blockIdx.x == 0)
     faces_body(0, si, g, logits, in_seed, block_count, head_blocks, move_thr,
-               disco_thr, deleted_thr, range_flag, range_tag, results, seq, step_id,
+               disco_thr, deleted_thr, range_flag, range_tag, pub, step_id,
                spec_choice, spec_expected);
   else
     paste_body(0, blockIdx.x - 1, gridDim.x - 1, si, g, logits, in_seed, block_count,
