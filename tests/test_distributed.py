@@ -207,3 +207,45 @@ def test_dynamic_dealing_world4_skewed_costs(tmp_path):
       [(b, _deal_labels(b)) for b in boxes], _DEAL_SHAPE, 0, 1,
       num_boxes=len(boxes))
   assert np.array_equal(want, single)
+
+
+def _shared_volume_worker(rank, world, port, tmpdir):
+  import torch.distributed as dist
+  from ffn_amd import synthetic
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  builds = []
+
+  def build():
+    builds.append(rank)
+    return synthetic.cells_volume((24, 32, 40), seed=77)
+
+  vol = synthetic.shared_volume(build, os.path.join(tmpdir, 'vol.npy'), rank,
+                                dist.barrier)
+  np.save(os.path.join(tmpdir, 'got_%d.npy' % rank), np.asarray(vol))
+  np.save(os.path.join(tmpdir, 'builds_%d.npy' % rank), np.array(builds))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_shared_volume_is_built_once_world2(tmp_path):
+  """bench.py --mode sharded under torch.distributed.run: rank 0 builds the
+  synthetic volume, every other rank maps the same bytes (no per-rank build:
+  10^9 nearest-centre queries per rank at BASELINE configs[3]'s 1024^3)."""
+  import torch.multiprocessing as mp
+  from ffn_amd import synthetic
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  mp.spawn(_shared_volume_worker, args=(2, port, str(tmp_path)), nprocs=2,
+           join=True)
+  want = synthetic.cells_volume((24, 32, 40), seed=77)
+  for r in range(2):
+    assert np.array_equal(np.load(tmp_path / ('got_%d.npy' % r)), want)
+  assert np.load(tmp_path / 'builds_0.npy').tolist() == [0]
+  assert np.load(tmp_path / 'builds_1.npy').tolist() == []
+  # a single rank needs no file and no barrier
+  assert np.array_equal(synthetic.shared_volume(
+      lambda: want, str(tmp_path / 'unused.npy')), want)
+  assert not (tmp_path / 'unused.npy').exists()
