@@ -27,6 +27,13 @@ import os
 import sys
 import time
 
+# Kernel arguments in device memory (read by the HIP runtime when it starts):
+# the command processor then fetches them from HBM instead of over PCIe -- on a
+# quiet, well-placed host it changes nothing measurable
+# (profiles/r03_ab_hipgraph_conv_chain.txt), on a badly placed one every launch
+# of the 25-launch dependent chain pays for the fetch (ffn_amd/hostenv.py).
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -151,6 +158,7 @@ def load_model():
 def run_gpu(args, rank, local_rank, world):
   import torch
   import torch.distributed as dist
+  from ffn_amd import hostenv
   from ffn_amd import synthetic
   from ffn_amd.inference import executor
   from ffn_amd.inference import inference
@@ -161,6 +169,9 @@ def run_gpu(args, rank, local_rank, world):
   if not torch.cuda.is_available():
     raise RuntimeError('bench.py needs an MI355X: no CPU fallback exists')
   torch.cuda.set_device(local_rank)
+  # this rank's threads -> the CPUs of its GPU's NUMA node (before the engine,
+  # its stream and the runtime's queue / kernel-argument pools exist)
+  host_binding = hostenv.bind_to_gpu_node(local_rank)
   if world > 1:
     dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
@@ -344,6 +355,7 @@ def run_gpu(args, rank, local_rank, world):
       'conv_variant': (args.conv_variant if args.conv_variant is not None
                        else eng.get_option('conv_variant')),
       'prewarm_steps': state.get('prewarm_steps', 0),
+      'host_binding': host_binding,
       'speculation': {
           'conv0a_launched_ahead': eng.get_option('stat_spec_launched'),
           'steps_that_used_one': eng.get_option('stat_spec_hits'),
@@ -426,6 +438,9 @@ def run_sharded(args, rank, local_rank, world):
       lambda: synthetic.cells_volume(shape, seed=4321), vol_path, rank,
       barrier if world > 1 else None)
   t_volume = time.perf_counter() - t_setup0
+  # (after the volume: its nearest-centre queries use every CPU the job has)
+  from ffn_amd import hostenv
+  host_binding = hostenv.bind_to_gpu_node(local_rank)
   request = make_request()
   request.seed_policy = 'PolicyPeaks'
   out_dir = tempfile.mkdtemp(prefix='ffn_sharded_%d_' % rank)
@@ -599,6 +614,7 @@ def run_sharded(args, rank, local_rank, world):
                   'groups x segmentation_seconds is Python between segments '
                   '(commit, seed policy, next init_seed) and canvas set-up',
       },
+      'host_binding': host_binding,
       'engine_calls': {
           'batched_steps': step_calls,
           'mean_fovs_per_step': round(step_items / max(step_calls, 1), 2),
@@ -1075,6 +1091,7 @@ def main():
                   'movement_policy-calls', 1), 1), 1),
       },
       'speculation': res['speculation'],
+      'host_binding': res['host_binding'],
       'queue_stats': {k: res['counters'].get(k, 0) for k in (
           'update_at-calls', 'skip_threshold', 'skip_invalid_pos',
           'seed_got_too_weak', 'segment_at-loop-calls', 'gate_rejects')},
