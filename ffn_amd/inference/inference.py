@@ -1321,10 +1321,13 @@ class MultiCanvasDriver:
       # a canvas outside the engine call would only hold memory
       window = self.batch_size
     lock = threading.Lock()
+    errors = []  # of the group threads: a failed group ends the deal for all
 
     def pull():
       """Next (canvas, task) of the job list, or None."""
       with lock:
+        if errors:
+          return None
         try:
           return next(jobs)
         except StopIteration:
@@ -1347,7 +1350,6 @@ class MultiCanvasDriver:
       return
     # one thread per group; the GIL is released inside the library calls, and a
     # short switch interval hands it over promptly when one returns
-    errors = []
     tallies = [[0, 0, 0.0, 0] for _ in range(self.groups)]
 
     def work(k):
