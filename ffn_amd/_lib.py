@@ -131,6 +131,7 @@ SIGNATURES = {
     'ffn_engine_synchronize': (_I, [_P]),
     'ffn_engine_debug_clocks': (_I, [_P, _P]),
     'ffn_engine_debug_workgroups': (_I, [_P, _P, _I]),
+    'ffn_engine_debug_flow_trace': (_I, [_P, _P, _I]),
     'ffn_predict': (_I, [_P, _I, _P, _P, _P]),
     'ffn_forward_resident': (_I, [_P, _I, _I]),
     'ffn_canvas_create': (_I, [_P, _P, _I3, ctypes.POINTER(_P)]),

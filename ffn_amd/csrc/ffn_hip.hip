@@ -133,6 +133,18 @@ struct ffn_engine {
   bool t_ok = false;
   bool t_now = false;
   int tail_batched = 0;  // option: steps with >= 2 FoVs take the tail form too
+  // FLOW (ffn_kernels.h "flagged launches"): 0 off; 1 conv32mt's launches with
+  // the flagged hand-off compiled in (still one dependent launch per conv: the
+  // words are always there already -- isolates the cost of the sc1 reads and
+  // the poll); 2 the resident stack, conv32ps: ONE launch for the 2 depth - 1 convs
+  // of a single-FoV step
+  int flow = 0;
+  unsigned* flow_flags = nullptr;  // one word per 32-voxel tile of the FoV
+  unsigned* flow_err = nullptr;    // polls that gave up, ever
+  unsigned flow_epoch = 0;         // sequence number of the last conv queued
+  int flow_debug = 0;              // debug option: ConvDArgs::flow_dbg
+  long long* flow_trace = nullptr; // debug_clock 4: ConvDArgs::flow_trace
+  int flow_trace_slots = 0;
   int n_main = 0, n_tail = 0, n_tail3 = 0;  // tail workgroups of 32 / 96 voxels
   int tsched_aoff[4 * 8] = {};
   int t3sched_aoff[4 * 8] = {};
@@ -420,6 +432,18 @@ int set_lds_attr_m() {
   FFN_MT_ATTR(1, false, true);
   FFN_MT_ATTR(1, true, true);
 #undef FFN_MT_ATTR
+#define FFN_MTF_ATTR(KIND, SK, HEADV)                                             \
+  HIP_TRY(hipFuncSetAttribute(                                                    \
+      reinterpret_cast<const void*>(&conv32mt_kernel<KIND, SK, HEADV, 1, true>),  \
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMLdsBytes))
+  FFN_MTF_ATTR(0, false, false);
+  FFN_MTF_ATTR(1, false, false);
+  FFN_MTF_ATTR(1, true, false);
+  FFN_MTF_ATTR(1, true, true);
+#undef FFN_MTF_ATTR
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32ps_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kMLdsBytes));
   return FFN_OK;
 }
 
@@ -605,17 +629,15 @@ int switch_variant(ffn_engine* e, int value) {
 
 // conv32d launch: KIND 0 conv_a (T' = split(relu(conv(X') + b))), KIND 1 conv_b
 // (X = conv(T') + b [+ X]; X' = split(relu(X))), or the fused head
-template <int KIND, bool SK>
-int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
-                   int layer, const HeadFusion& head = HeadFusion()) {
+void conv32d_args(ffn_engine* e, int n, const float* raw_in, float* raw_out, int layer,
+                  const HeadFusion& head, ConvDArgs& a) {
   const Geom& g = e->gp;
   const long positions = g.act_stride / kFeatures;
-  ConvDArgs a;
-  a.in_sp = reinterpret_cast<const char*>(raw_in) + (size_t)g.guard * 16;
-  a.out_sp = reinterpret_cast<char*>(raw_out) + (size_t)g.guard * 16;
+  a.L.in_sp = reinterpret_cast<const char*>(raw_in) + (size_t)g.guard * 16;
+  a.L.out_sp = reinterpret_cast<char*>(raw_out) + (size_t)g.guard * 16;
   a.x_f32 = e->rawX + (size_t)g.guard * 4;
-  a.wpack = reinterpret_cast<const char*>(e->wpackd + (size_t)layer * e->wpackd_layer);
-  a.bias = e->weights + e->bias_off[layer];
+  a.L.wpack = reinterpret_cast<const char*>(e->wpackd + (size_t)layer * e->wpackd_layer);
+  a.L.bias = e->weights + e->bias_off[layer];
   a.item_bytes = g.act_stride * (long)sizeof(float);
   a.sp_plane_bytes = positions * 16;
   a.XS = g.XS;
@@ -640,7 +662,7 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   a.sp_bytes = (unsigned)((size_t)g.act_stride * sizeof(float) - (size_t)g.guard * 32);
   std::memcpy(a.aoff, small ? e->esched_aoff : e->dsched_aoff, sizeof(a.aoff));
   std::memcpy(a.btap, e->dsched_btap, sizeof(a.btap));
-  a.dbg = (e->dbg_clock && layer == e->dbg_layer) ? e->d_dbg : nullptr;
+  a.L.dbg = (e->dbg_clock && layer == e->dbg_layer) ? e->d_dbg : nullptr;
   a.dbg_wgs = e->dbg_clock == 2 ? 1 : e->dbg_clock == 3 ? 2 : 0;
   a.head_w = e->weights + e->wl_off;
   a.seed_raw = e->seed_raw;
@@ -650,6 +672,33 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
   a.move_thr = head.move_thr;
   a.range_flag = e->range_flag;
   a.range_tag = e->range_tag;
+  a.flow_flags = e->flow_flags;
+  a.flow_err = e->flow_err;
+  a.flow_halo = g.fy * g.fx + g.fx + 1;
+  a.flow_dbg = e->flow_debug;
+  a.flow_trace = e->dbg_clock == 4 ? e->flow_trace : nullptr;
+  a.L.layer = layer;
+  a.L.flow_wait_on = 0;
+  a.L.flow_wait = a.L.flow_set = 0;
+}
+
+void tail_map(const ffn_engine* e, int n, ConvTailMap& mp) {
+  const bool one = n == 1;
+  mp.n = n;
+  mp.n_main = e->n_main;
+  mp.n_tail = one ? e->n_tail : e->n_tail3;
+  mp.mains_per_xcd = (mp.n_main + 7) / 8;
+  mp.tails_per_xcd = (mp.n_tail + 7) / 8;
+  std::memcpy(mp.taoff, one ? e->tsched_aoff : e->t3sched_aoff, sizeof(mp.taoff));
+}
+
+template <int KIND, bool SK>
+int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
+                   int layer, const HeadFusion& head = HeadFusion()) {
+  ConvDArgs a;
+  conv32d_args(e, n, raw_in, raw_out, layer, head, a);
+  const bool small = e->small_now;
+  const bool msplit = e->m_now;
   const bool prof = e->prof_now;
   if (prof) {
     if (e->events_used + 2 > (int)e->events.size()) {
@@ -672,15 +721,20 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
     // same voxels in 96-voxel ones (cost per voxel) -- the same bits
     const bool one = n == 1;
     ConvTailMap mp;
-    mp.n = n;
-    mp.n_main = e->n_main;
-    mp.n_tail = one ? e->n_tail : e->n_tail3;
-    mp.mains_per_xcd = (mp.n_main + 7) / 8;
-    mp.tails_per_xcd = (mp.n_tail + 7) / 8;
-    std::memcpy(mp.taoff, one ? e->tsched_aoff : e->t3sched_aoff, sizeof(mp.taoff));
+    tail_map(e, n, mp);
     const dim3 tgrid(8 * n * (mp.mains_per_xcd + mp.tails_per_xcd));
+    const bool flow1 = one && e->flow == 1;
+    if (flow1) {
+      a.L.flow_wait_on = layer > 0;
+      a.L.flow_wait = e->flow_epoch;
+      a.L.flow_set = ++e->flow_epoch;
+    }
 #define FFN_MT_LAUNCH(HEADV)                                                      \
-  if (one)                                                                        \
+  if (flow1) {                                                                    \
+    if constexpr (KIND == 0 || SK || !HEADV)                                      \
+      hipLaunchKernelGGL((conv32mt_kernel<KIND, SK, HEADV, 1, true>), tgrid,      \
+                         block, kMLdsBytes, e->stream, a, mp);                    \
+  } else if (one)                                                                 \
     hipLaunchKernelGGL((conv32mt_kernel<KIND, SK, HEADV, 1>), tgrid, block,       \
                        kMLdsBytes, e->stream, a, mp);                             \
   else                                                                            \
@@ -753,6 +807,48 @@ void launch_conv0a(ffn_engine* e, int n, const StepItems& si, float pad_value,
                        ty, tx, Conv0SplitOut(), sp);
 }
 
+// The 2 depth - 1 convs of ONE FoV as a single resident launch (conv32ps,
+// ffn_kernels.h): conv32mt's workgroups keep their voxels through the stack and
+// hand rows to each other through the tile words instead of kernel boundaries.
+int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr) {
+  HeadFusion hf;
+  hf.on = true;
+  hf.pad_value = pad_value;
+  hf.move_thr = move_thr;
+  ConvDArgs a;
+  conv32d_args(e, 1, e->rawT, e->rawS, 0, hf, a);
+  a.L.dbg = e->dbg_clock ? e->d_dbg : nullptr;
+  ConvTailMap mp;
+  tail_map(e, 1, mp);
+  const Geom& g = e->gp;
+  ConvStackTab tb;
+  tb.nlayers = 2 * e->depth - 1;
+  tb.dbg_layer = e->dbg_layer;
+  tb.sp_t = reinterpret_cast<const char*>(e->rawT) + (size_t)g.guard * 16;
+  tb.sp_s = reinterpret_cast<char*>(e->rawS) + (size_t)g.guard * 16;
+  tb.wpack0 = reinterpret_cast<const char*>(e->wpackd);
+  tb.wpack_stride = (long)(e->wpackd_layer * sizeof(uint16_t));
+  tb.bias0 = e->weights + e->bias_off[0];
+  tb.bias_stride = e->depth > 1 ? (long)(e->bias_off[1] - e->bias_off[0]) : 0;
+  tb.epoch0 = e->flow_epoch;
+  e->flow_epoch += (unsigned)tb.nlayers;
+  const dim3 grid(8 * (mp.mains_per_xcd + mp.tails_per_xcd)), block(kDThreads);
+  // (debug: flow_debug >> 4 = convs per launch, 0 = the whole stack in one)
+  const int per = (e->flow_debug >> 4) > 0 ? (e->flow_debug >> 4) : tb.nlayers;
+  for (int l0 = 0; l0 < tb.nlayers; l0 += per) {
+    tb.l_begin = l0;
+    tb.l_end = std::min(l0 + per, tb.nlayers);
+    if (e->flow_debug & 8) {
+      const bool odd = l0 & 1;
+      conv32d_args(e, 1, odd ? e->rawS : e->rawT, odd ? e->rawT : e->rawS, l0, hf, a);
+      a.L.dbg = nullptr;
+      a.L.flow_set = tb.epoch0 + l0 + 1;
+    }
+    hipLaunchKernelGGL(conv32ps_kernel, grid, block, kMLdsBytes, e->stream, a, mp, tb);
+  }
+  return FFN_OK;
+}
+
 // conv0a_done: the step's conv0_a has been queued already (a speculative launch
 // that chose its position)
 int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
@@ -795,6 +891,8 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
       return fail(FFN_ERR_ARG, "conv_variant 6 needs depth >= 2 (fused head)");
     // T' -> (X, X') -> T' -> ... ; the head is always fused into the last conv_b
     auto chain = [&]() -> int {
+      if (e->t_now && n == 1 && e->flow == 2)
+        return launch_conv32ps(e, pad_value, move_thr);
       int r = launch_conv32d<1, false>(e, n, e->rawT, e->rawS, 0);
       for (int i = 1; i < e->depth && !r; ++i) {
         r = launch_conv32d<0, false>(e, n, e->rawS, e->rawT, 2 * i - 1);
@@ -923,7 +1021,7 @@ int grid_for(long total, int block = 256) {
 
 extern "C" {
 
-int ffn_abi_version(void) { return 7; }
+int ffn_abi_version(void) { return 8; }
 
 const char* ffn_last_error(void) { return g_error.c_str(); }
 
@@ -1229,6 +1327,19 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
                                     sizeof(uint16_t)));
     E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
     E_TRY(hipMemset(e->range_flag, 0, sizeof(unsigned)));
+    {
+      const size_t words = (size_t)(e->gp.V + 31) / 32 + 64;
+      E_TRY(hipMalloc(&e->flow_flags, words * sizeof(unsigned)));
+      E_TRY(hipMemset(e->flow_flags, 0, words * sizeof(unsigned)));
+      E_TRY(hipMalloc(&e->flow_err, sizeof(unsigned)));
+      E_TRY(hipMemset(e->flow_err, 0, sizeof(unsigned)));
+      if (e->t_ok) {
+        e->flow_trace_slots = e->n_main + e->n_tail;
+        const size_t bytes = (size_t)e->flow_trace_slots * kFlowTraceLayers * 8 * sizeof(long long);
+        E_TRY(hipMalloc(&e->flow_trace, bytes));
+        E_TRY(hipMemset(e->flow_trace, 0, bytes));
+      }
+    }
     E_TRY(hipMalloc(&e->d_spec_choice, sizeof(int)));
     E_TRY(hipMemset(e->d_spec_choice, 0xff, sizeof(int)));
   }
@@ -1293,6 +1404,9 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->count);
   (void)hipFree(e->wpackd);
   (void)hipFree(e->range_flag);
+  (void)hipFree(e->flow_flags);
+  (void)hipFree(e->flow_err);
+  (void)hipFree(e->flow_trace);
   (void)hipFree(e->d_spec_choice);
   (void)hipFree(e->valid);
   (void)hipFree(e->validbits);
@@ -1511,6 +1625,22 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->tail_batched = value != 0;
     return FFN_OK;
   }
+  if (std::strcmp(name, "flow_debug") == 0) {
+    e->flow_debug = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "flow") == 0) {
+    // single-FoV steps of conv_variant 9: 0 one dependent launch per conv; 1 the
+    // same launches with the flagged hand-off compiled in; 2 the resident stack
+    // (conv32ps: one launch for all convs).  Same bits in every mode.
+    if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "flow: 0, 1 or 2");
+    if (value && !e->t_ok)
+      return fail(FFN_ERR_ARG, "flow needs conv32mt's geometry (conv_variant 9)");
+    if (value && e->depth < 2) return fail(FFN_ERR_ARG, "flow needs depth >= 2");
+    drop_spec(e);
+    e->flow = value;
+    return FFN_OK;
+  }
   if (std::strcmp(name, "spec_force_mismatch") == 0) {
     e->spec_force_mismatch = value;
     return FFN_OK;
@@ -1567,6 +1697,14 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "stat_spec_hits") == 0) *value = (int)e->stat_spec_hits;
   else if (std::strcmp(name, "stat_spec_mismatch") == 0)
     *value = (int)e->stat_spec_mismatch;
+  else if (std::strcmp(name, "flow") == 0) *value = e->flow;
+  else if (std::strcmp(name, "stat_flow_timeouts") == 0) {
+    unsigned v = 0;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(&v, e->flow_err, sizeof(v), hipMemcpyDeviceToHost));
+    *value = (int)v;
+  }
   else if (std::strncmp(name, "stat_hist_", 10) == 0) {
     const int k = std::atoi(name + 10);
     if (k < 0 || k > 64) return fail(FFN_ERR_ARG, "stat_hist_<0..64>");
@@ -1576,6 +1714,20 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "sync_mode") == 0) *value = e->sync_mode;
   else if (std::strcmp(name, "profile_every") == 0) *value = e->prof_every;
   else return fail(FFN_ERR_ARG, "unknown option '%s'", name);
+  return FFN_OK;
+}
+
+int ffn_engine_debug_flow_trace(ffn_engine* e, long long* out, int max_slots) {
+  EngineLock lock_(e);
+  if (!e || !out) return fail(FFN_ERR_ARG, "null argument");
+  if (!e->flow_trace) return fail(FFN_ERR_ARG, "no flow trace on this engine (conv_variant 9)");
+  if (max_slots < 0 || max_slots > e->flow_trace_slots)
+    return fail(FFN_ERR_ARG, "max_slots must be 0..%d", e->flow_trace_slots);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const size_t row = (size_t)kFlowTraceLayers * 8 * sizeof(long long);
+  HIP_TRY(hipMemcpy(out, e->flow_trace, row * max_slots, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(e->flow_trace, 0, row * e->flow_trace_slots));
   return FFN_OK;
 }
 

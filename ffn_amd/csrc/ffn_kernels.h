@@ -988,12 +988,23 @@ constexpr int kDRowB = 144;   // epilogue: row stride of the partial sums in LDS
 constexpr int kDTaps = 28;    // 27 + the all-zero tap
 constexpr int kDTapBytes = 2 * 2 * 1024;  // weight fragments of one tap (hi, res)
 
-struct ConvDArgs {
+// what changes from one conv of the stack to the next (a launch's own in
+// ConvDArgs::L; the resident stack, conv32ps_kernel, derives one per layer)
+struct ConvLayer {
   const char* in_sp;     // split planes read (position 0 of plane 0, item 0)
   char* out_sp;          // split planes written (T' or X')
-  float* x_f32;          // residual stream, f32 planes [8][position][4] (position 0 of plane 0)
   const char* wpack;     // [28][khalf][plane hi, res][64 lanes][8] fp16 (tap 27 = zeros)
   const float* bias;
+  long long* dbg;        // debug_clock: this conv's stamps are recorded
+  unsigned flow_wait;    // FLOW: inputs are complete once their tiles' words reach this ...
+  unsigned flow_set;     // ... and this conv publishes that
+  int flow_wait_on;      // 0: behind a kernel boundary, nothing to wait for
+  int layer;             // index of the conv in the stack (flow_trace rows)
+};
+
+struct ConvDArgs {
+  ConvLayer L;
+  float* x_f32;          // residual stream, f32 planes [8][position][4] (position 0 of plane 0)
   long item_bytes;       // bytes per item of an activation buffer (split or f32)
   long sp_plane_bytes;   // positions x 16: one chunk plane of the split layout
   int XS, plane, nchunks, V, fx, fyfx, total_slots, slots_per_xcd;
@@ -1003,7 +1014,6 @@ struct ConvDArgs {
   unsigned sp_bytes;     // bytes of a split / f32 buffer past position 0 (store range)
   int aoff[4 * 8];       // [wave][j]: LDS byte offset of the wave's j-th tap
   int btap[4 * 8];       // [wave][j]: its tap index (weight fragments)
-  long long* dbg;
   const float* head_w;
   const float* seed_raw;
   float* logits;
@@ -1013,6 +1023,17 @@ struct ConvDArgs {
   unsigned range_tag;
   int dbg_wgs;           // debug_clock 2: every workgroup stamps dbg[24 + 4 blockIdx ..];
                          // 3 (value 2 here): the clock stamps come from tail chunk 0
+  // FLOW kernels (section "flagged launches" below): one word per 32-voxel tile
+  // of the FoV = sequence number of the last conv launch whose outputs for that
+  // tile are complete in memory
+  unsigned* flow_flags;
+  unsigned* flow_err;    // number of polls that gave up (the step is void then)
+  int flow_halo;         // dense voxels a 3x3x3 neighbourhood reaches back / ahead
+  long long* flow_trace; // debug_clock 4: [workgroup slot][kFlowTraceLayers][8] wall-clock
+                         // stamps of every FLOW body (entry, poll done, first barrier,
+                         // loop end, stores drained, published), else NULL
+  int flow_dbg;          // debug bits: 1 wait for EVERY tile of the FoV; 2 buffer_inv sc1
+                         // behind the poll; 4 buffer_wbl2 sc1 in front of the publish
 };
 
 constexpr int kDbgMaxWgs = 4096;
@@ -1029,10 +1050,10 @@ __device__ __forceinline__ int caller_index(const ConvDArgs& a, int v) {
 
 // debug_clock 2: when and where a workgroup ran -- [start, end] on the 100 MHz
 // wall clock, HW_ID (wave / SIMD / CU / SH / SE fields) and XCC_ID
-__device__ __forceinline__ void stamp_workgroup(const ConvDArgs& a, long long t0) {
-  if (a.dbg_wgs == 1 && a.dbg && threadIdx.x == 0 &&
+__device__ __forceinline__ void stamp_workgroup(const ConvDArgs& a, const ConvLayer& L, long long t0) {
+  if (a.dbg_wgs == 1 && L.dbg && threadIdx.x == 0 &&
       blockIdx.x < (unsigned)kDbgMaxWgs) {
-    long long* d = a.dbg + 24 + 4 * (long)blockIdx.x;
+    long long* d = L.dbg + 24 + 4 * (long)blockIdx.x;
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1043,25 +1064,135 @@ __device__ __forceinline__ void stamp_workgroup(const ConvDArgs& a, long long t0
   }
 }
 
+// ---------------------------------------------------------------------------
+// Flagged launches (FLOW): the conv chain of a single
+// FoV without its kernel boundaries.
+//
+// A dependent launch costs 1.7 us of boundary + 0.3 of start-up + ~1 us of
+// first bytes through an L2 the boundary invalidated -- a third of an 8.75-us
+// layer -- because the AQL barrier bit holds the next launch back until the
+// LAST workgroup of this one has ended and the caches are flushed.  A FLOW
+// launch is queued with the barrier bit cleared (hipExtAnyOrderLaunch): its
+// workgroups are dispatched as soon as CU slots are free, stage their weight
+// taps (no dependency), and then wait -- not for a boundary but for the 32-voxel
+// tiles of the previous layer their own rows come from (+- fy fx + fx + 1 dense
+// voxels: 75 words for a 128-voxel chunk of the 33^3 FoV), one word per tile:
+// the sequence number of the last conv launch whose outputs for that tile are
+// complete.  Placement-independent (G16): every activation store of the
+// split-product kernels is an sc1 write-through store already, every storing
+// wave drains (vmcnt(0)) before one lane publishes the tile words with sc1
+// stores; the consumer polls with relaxed agent-scope loads from ONE wave and
+// reads the rows with sc1 loads (LDS-DMA and the residual stream alike).
+// Write-after-read is covered by the same words: a tile is overwritten two
+// launches later by a workgroup that first waited for every reader of it.
+// The arithmetic of a FLOW kernel is its plain kernel's, instruction for
+// instruction: same bits.  Every spin is bounded; a poll that gives up voids
+// the step through the range flag (the host repeats it without FLOW).
+// ---------------------------------------------------------------------------
+constexpr unsigned kFlowSpinMax = 1u << 15;
+constexpr int kFlowTraceLayers = 64;
+
+// ONE wave: until every tile that holds inputs of dense voxels [v_first, v_last]
+// has been published by launch L.flow_wait (or a later one)
+__device__ __forceinline__ void flow_wait_tiles(const ConvDArgs& a, const ConvLayer& L,
+                                                int v_first,
+                                                int v_last, int lane) {
+  typedef FFN_GLOBAL unsigned gu32;
+  int lo = v_first - a.flow_halo;
+  lo = (lo < 0 ? 0 : lo) >> 5;
+  int hi = v_last + a.flow_halo;
+  hi = (hi > a.V - 1 ? a.V - 1 : hi) >> 5;
+  if (a.flow_dbg & 1) {
+    lo = 0;
+    hi = (a.V - 1) >> 5;
+  }
+  gu32* flags = (gu32*)a.flow_flags;
+  unsigned spins = 0;
+  for (int base = lo; base <= hi; base += 64) {
+    const int t = base + lane <= hi ? base + lane : hi;
+    for (;;) {
+      const unsigned x =
+          __hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all((int)(x - L.flow_wait) >= 0)) break;
+      if (++spins > kFlowSpinMax) {
+        if (lane == 0) {
+          atomicAdd(a.flow_err, 1u);
+          *a.range_flag = a.range_tag;
+        }
+        return;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+}
+
+// every wave of the workgroup, behind its last activation store: drain, meet,
+// then lanes 0 .. ntiles-1 publish the workgroup's tiles (first dense voxel v0)
+__device__ __forceinline__ long long flow_publish(const ConvDArgs& a, const ConvLayer& L,
+                                                  int v0, int ntiles, int tid) {
+  typedef FFN_GLOBAL unsigned gu32;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (a.flow_dbg & 4) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+  const long long t_drained = a.flow_trace ? wall_clock64() : 0;
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const int t = (v0 >> 5) + tid;
+  if (tid < ntiles && t * 32 < a.V)
+    __hip_atomic_store((gu32*)a.flow_flags + t, L.flow_set, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  return t_drained;
+}
+
+// debug_clock 4: the stamps of one FLOW body, written when it is over (a store
+// among the hand-counted loads would shift their vmcnt)
+__device__ __forceinline__ void flow_trace_row(const ConvDArgs& a, const ConvLayer& L,
+                                               int gc, const long long (&t)[6]) {
+  if (a.flow_trace && threadIdx.x == 0 && L.layer < kFlowTraceLayers) {
+    long long* d = a.flow_trace + ((long)gc * kFlowTraceLayers + L.layer) * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = t[i];
+  }
+}
+
 // one LDS-DMA wave instruction: 64 lanes x 16 B, global (sbase + voff) -> LDS
 // (lds_dst + 16 lane); invisible to the compiler's vmcnt bookkeeping
+// SC1: an agent-scope load (bypasses this CU's L1, coherent with the sc1
+// write-through stores of workgroups on other XCDs): what a FLOW kernel reads
+// another RUNNING launch's outputs with.
+// NOP: the resident stack spills SGPRs to VGPR lanes, and a base restored by
+// v_readlane right in front of this statement is a VALU-written SGPR read by a
+// VMEM instruction: 5 wait states the compiler does not insert for inline asm
+// (symptom: a wrong chunk in ~0.2 % of the workgroup-layers).  The plain
+// kernels' bases come from scalar loads and need none.
+template <bool SC1 = false, bool NOP = false>
 __device__ __forceinline__ void lds_dma16(const char* sbase, unsigned voff,
                                           unsigned lds_dst) {
-  asm volatile(
-      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-      :
-      : "v"(voff), "s"(sbase), "s"(lds_dst)
-      : "memory");
+#define FFN_DMA16(PRE, POST)                                                    \
+  asm volatile(PRE "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" POST \
+               :                                                                \
+               : "v"(voff), "s"(sbase), "s"(lds_dst)                            \
+               : "memory")
+  if constexpr (SC1 && NOP) FFN_DMA16("s_nop 2\n\t", " sc1");
+  else if constexpr (SC1) FFN_DMA16("", " sc1");
+  else if constexpr (NOP) FFN_DMA16("s_nop 2\n\t", "");
+  else FFN_DMA16("", "");
+#undef FFN_DMA16
 }
 
 // a 16-B load the compiler does not count either (waited for by hand)
-template <int OFF>
+template <int OFF, bool NOP = false>
 __device__ __forceinline__ f16x8 hidden_load16(const char* sbase, unsigned voff) {
   f16x8 d;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
-               : "=v"(d)
-               : "v"(voff), "s"(sbase), "n"(OFF)
-               : "memory");
+  if constexpr (NOP)  // (see lds_dma16: a base fresh from v_readlane)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3"
+                 : "=v"(d)
+                 : "v"(voff), "s"(sbase), "n"(OFF)
+                 : "memory");
+  else
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                 : "=v"(d)
+                 : "v"(voff), "s"(sbase), "n"(OFF)
+                 : "memory");
   return d;
 }
 
@@ -1103,13 +1234,16 @@ __device__ __forceinline__ void split8_fp16(const f32x4& v0, const f32x4& v1,
 // (1, 144, 2) with KS = 5: a single 32-voxel tile, the form of conv32mt's tail.
 // The workgroup computes the 32 NT dense voxels from v0 of FoV `item`; gc = its
 // slot in head_count; aoff_tab = a.aoff or the table of another row count.
-template <int KIND, bool ADD_SKIP, int KS, bool HEAD, int NT, int R, int WPS>
-__device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
+template <int KIND, bool ADD_SKIP, int KS, bool HEAD, int NT, int R, int WPS,
+          bool FLOW = false>
+__device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const ConvLayer& L,
+                                             const int item,
                                              const int v0, const int gc,
                                              const int* aoff_tab, const bool dbg_here) {
   typedef f16x8 frag_t;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   static_assert(NT == 5 || NT == 3 || NT == 1, "tile loop: 5, 3 or 1 tiles");
+  static_assert(!FLOW || WPS > 1, "FLOW: the everything-up-front issue order");
   static_assert(4 * KS * 64 >= 8 * R && R % 8 == 0, "KS pieces per wave cover a slot");
   constexpr int kChunkD = 32 * NT;  // dense voxels per workgroup
   constexpr int R16 = R * 16;    // bytes of one chunk plane of a segment in LDS
@@ -1117,8 +1251,10 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x;
-  const long long dbg_c0 = a.dbg ? clock64() : 0;
-  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
+  const long long dbg_c0 = L.dbg ? clock64() : 0;
+  const long long dbg_w0 = L.dbg ? wall_clock64() : 0;
+  long long ft[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (FLOW) ft[0] = a.flow_trace ? wall_clock64() : 0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int aoffs[7], btaps[7];
 #pragma unroll
@@ -1146,19 +1282,19 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
   struct WFragD { frag_t w[2][2]; };  // weights     [khalf][plane hi, res]
   WFragD W0, W1, W2, W3, W4;
   auto hiddenW = [&](int s, WFragD& dst) {
-    const char* b0 = a.wpack + (long)s * kDTapBytes;
+    const char* b0 = L.wpack + (long)s * kDTapBytes;
     const unsigned vo = (unsigned)lane * 16;
-    dst.w[0][0] = hidden_load16<0>(b0, vo);
-    dst.w[0][1] = hidden_load16<1024>(b0, vo);
-    dst.w[1][0] = hidden_load16<2048>(b0, vo);
-    dst.w[1][1] = hidden_load16<3072>(b0, vo);
+    dst.w[0][0] = hidden_load16<0, FLOW>(b0, vo);
+    dst.w[0][1] = hidden_load16<1024, FLOW>(b0, vo);
+    dst.w[1][0] = hidden_load16<2048, FLOW>(b0, vo);
+    dst.w[1][1] = hidden_load16<3072, FLOW>(b0, vo);
   };
   auto pinW = [&](WFragD& w) {  // "the data is here": consumers stay below
     asm volatile(""
                  : "+v"(w.w[0][0]), "+v"(w.w[0][1]), "+v"(w.w[1][0]),
                    "+v"(w.w[1][1]));
   };
-  const frag_t* wp = reinterpret_cast<const frag_t*>(a.wpack) + lane;
+  const frag_t* wp = reinterpret_cast<const frag_t*>(L.wpack) + lane;
   auto loadW = [&](int s, WFragD& dst) {
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -1171,7 +1307,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
   // first two weight taps in front of the first barrier ----
   const unsigned lbase =
       (unsigned)(size_t)(__attribute__((address_space(3))) char*)ldsb;
-  const char* g0 = a.in_sp + (long)item * a.item_bytes + (long)p_lo * 16;
+  const char* g0 = L.in_sp + (long)item * a.item_bytes + (long)p_lo * 16;
   unsigned voff[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
@@ -1184,23 +1320,43 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
   }
   auto dma_piece = [&](int seg, int k) {
     const int u0 = 64 * (wave + 4 * k);  // wave-uniform; wraps with the units
-    lds_dma16(g0 + (long)(seg - 1) * a.plane * 16, voff[k],
-              lbase + seg * SEG + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
+    lds_dma16<FLOW, FLOW>(g0 + (long)(seg - 1) * a.plane * 16, voff[k],
+                    lbase + seg * SEG + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
   };
   // WPS == 2: a neighbour workgroup's MFMAs cover this one's issue time, so
   // EVERYTHING is queued up front and the later barriers never wait for a DMA
   constexpr bool kEarly = WPS > 1;
-  hiddenW(btaps[0], W0);
-#pragma unroll
-  for (int k = 0; k < KS; ++k) dma_piece(0, k);
-  hiddenW(btaps[1], W1);
-  if constexpr (kEarly) {
-#pragma unroll
-    for (int k = 0; k < KS; ++k) dma_piece(1, k);
+  if constexpr (FLOW) {
+    // the weights depend on nothing: queued first; the rows of the previous
+    // launch only once their tiles are published
+    hiddenW(btaps[0], W0);
+    hiddenW(btaps[1], W1);
     hiddenW(btaps[2], W2);
     hiddenW(btaps[3], W3);
+    if (L.flow_wait_on) {
+      if (wave == 0) flow_wait_tiles(a, L, v0, v0 + kChunkD - 1, lane);
+      ft[1] = a.flow_trace ? wall_clock64() : 0;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (a.flow_dbg & 2) asm volatile("buffer_inv sc1" ::: "memory");
+    }
 #pragma unroll
-    for (int k = 0; k < KS; ++k) dma_piece(2, k);
+    for (int seg = 0; seg < 3; ++seg)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) dma_piece(seg, k);
+  } else {
+    hiddenW(btaps[0], W0);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) dma_piece(0, k);
+    hiddenW(btaps[1], W1);
+    if constexpr (kEarly) {
+#pragma unroll
+      for (int k = 0; k < KS; ++k) dma_piece(1, k);
+      hiddenW(btaps[2], W2);
+      hiddenW(btaps[3], W3);
+#pragma unroll
+      for (int k = 0; k < KS; ++k) dma_piece(2, k);
+    }
   }
   // LDS byte offset of this lane's (position, k-group) in each tile
   int xb[NT];
@@ -1249,12 +1405,16 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
   };
   XFragD X0, X1;
 
-  // W0, dz = -1 landed (newer: W1 [, dz = 0, W2, W3, dz = +1])
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEarly ? 2 * KS + 12 : 4) : "memory");
+  // W0, dz = -1 landed (newer: W1 [, dz = 0, W2, W3, dz = +1]; FLOW: dz = 0, dz = +1.
+  // Its later waits keep the plain order's counts: at least as many operations
+  // are newer than what they wait for, the weights landed before the poll)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FLOW ? 2 * KS : kEarly ? 2 * KS + 12 : 4)
+               : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   pinW(W0);
-  const long long dbg_c1 = a.dbg ? clock64() : 0;
+  const long long dbg_c1 = L.dbg ? clock64() : 0;
+  if constexpr (FLOW) ft[2] = a.flow_trace ? wall_clock64() : 0;
   loadX(0, aoffs[0], X0);
 
   // EXTRA: memory instructions riding on the tile (issued behind its prefetch)
@@ -1340,14 +1500,27 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
     }
     if constexpr (HEAD) {
       biasv[k][0] = biasv[k][1] =
-          *reinterpret_cast<const f32x4*>(a.bias + (tid & 7) * 4);
+          *reinterpret_cast<const f32x4*>(L.bias + (tid & 7) * 4);
     } else {
-      biasv[k][0] = *reinterpret_cast<const f32x4*>(a.bias + ec[k] * 8);
-      biasv[k][1] = *reinterpret_cast<const f32x4*>(a.bias + ec[k] * 8 + 4);
+      biasv[k][0] = *reinterpret_cast<const f32x4*>(L.bias + ec[k] * 8);
+      biasv[k][1] = *reinterpret_cast<const f32x4*>(L.bias + ec[k] * 8 + 4);
     }
     if (ADD_SKIP) {
       const float* xs = a.x_f32 + (long)item * (a.item_bytes >> 2);
-      if constexpr (HEAD) {
+      if constexpr (FLOW) {
+        // the residual stream was written by another launch that may still be
+        // running elsewhere: agent-scope loads (the compiler counts these)
+        const __amdgpu_buffer_rsrc_t rs_skip = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xs), 0, a.sp_bytes, 0x00020000);
+        const unsigned o = (unsigned)((HEAD ? ec[k] : 2 * ec[k]) * (int)a.sp_plane_bytes +
+                                      ep[k] * 16);
+        skipv[k][0] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_skip, o, 0, 16));
+        if constexpr (!HEAD)
+          skipv[k][1] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                         rs_skip, o, (int)a.sp_plane_bytes, 16));
+      } else if constexpr (HEAD) {
         const int q = ec[k];
         skipv[k][0] = *reinterpret_cast<const f32x4*>(
             xs + (long)q * (a.sp_plane_bytes >> 2) + (long)ep[k] * 4);
@@ -1365,7 +1538,8 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
 #undef FFN_DTAP
 #undef FFN_DTILE
 
-  const long long dbg_c2 = a.dbg ? clock64() : 0;
+  const long long dbg_c2 = L.dbg ? clock64() : 0;
+  if constexpr (FLOW) ft[3] = a.flow_trace ? wall_clock64() : 0;
   // ---- epilogue: the four waves' partial sums meet in LDS ----
   // P[wave][position 0..159][32 ch] at a 144-B row stride; accumulator register
   // 4 g + i of a lane is channel 8 g + 4 (lane >> 5) + i of position lane & 31.
@@ -1430,7 +1604,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
                          __float_as_uint(cnt[2]) + __float_as_uint(cnt[3]);
   } else {
     const __amdgpu_buffer_rsrc_t rs_sp = __builtin_amdgcn_make_buffer_rsrc(
-        a.out_sp + (long)item * a.item_bytes, 0, a.sp_bytes, 0x00020000);
+        L.out_sp + (long)item * a.item_bytes, 0, a.sp_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(a.x_f32) + (long)item * a.item_bytes, 0, a.sp_bytes,
         0x00020000);
@@ -1482,9 +1656,14 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const int item,
     // host re-runs it with the exact-f32 kernel (ffn_step_result.range_error)
     if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *a.range_flag = a.range_tag;
+    if constexpr (FLOW) ft[4] = flow_publish(a, L, v0, NT, tid);
   }
-  if (a.dbg && dbg_here && (tid & 63) == 0) {
-    long long* d = a.dbg + wave * 6;
+  if constexpr (FLOW) {
+    ft[5] = a.flow_trace ? wall_clock64() : 0;
+    flow_trace_row(a, L, gc, ft);
+  }
+  if (L.dbg && dbg_here && (tid & 63) == 0) {
+    long long* d = L.dbg + wave * 6;
     d[0] = dbg_c0;
     d[1] = dbg_c1;
     d[2] = dbg_c2;
@@ -1501,7 +1680,7 @@ __global__ __launch_bounds__(kDThreads, WPS) void conv32d_kernel(ConvDArgs a) {
   if (gc >= a.total_slots) return;
   const int item = (int)__umulhi((unsigned)gc, a.magic_nchunks);
   const int chunk = gc - item * a.nchunks;
-  conv32d_body<KIND, ADD_SKIP, KS, HEAD, NT, R, WPS>(a, item, chunk * (32 * NT), gc,
+  conv32d_body<KIND, ADD_SKIP, KS, HEAD, NT, R, WPS>(a, a.L, item, chunk * (32 * NT), gc,
                                                      a.aoff, gc == 0);
 }
 
@@ -1574,20 +1753,27 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int OFF>
+template <int OFF, bool SC1 = false, bool NOP = false>
 __device__ __forceinline__ f32x4 hidden_load16f(const char* sbase, unsigned voff) {
   f32x4 d;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
-               : "=v"(d)
-               : "v"(voff), "s"(sbase), "n"(OFF)
-               : "memory");
+#define FFN_HL16(PRE, POST)                                                  \
+  asm volatile(PRE "global_load_dwordx4 %0, %1, %2 offset:%3" POST           \
+               : "=v"(d)                                                     \
+               : "v"(voff), "s"(sbase), "n"(OFF)                             \
+               : "memory")
+  if constexpr (SC1 && NOP) FFN_HL16("s_nop 4\n\t", " sc1");
+  else if constexpr (SC1) FFN_HL16("", " sc1");
+  else if constexpr (NOP) FFN_HL16("s_nop 4\n\t", "");
+  else FFN_HL16("", "");
+#undef FFN_HL16
   return d;
 }
 
 // The workgroup computes the 128 dense voxels from v0 of FoV `item`; gc = its
 // slot in head_count.
-template <int KIND, bool ADD_SKIP, bool HEAD>
-__device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
+template <int KIND, bool ADD_SKIP, bool HEAD, bool FLOW = false>
+__device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer& L,
+                                             const int item,
                                              const int v0, const int gc,
                                              const bool dbg_here) {
   typedef f16x8 frag_t;
@@ -1599,8 +1785,10 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x;
-  const long long dbg_c0 = a.dbg ? clock64() : 0;
-  const long long dbg_w0 = a.dbg ? wall_clock64() : 0;
+  const long long dbg_c0 = L.dbg ? clock64() : 0;
+  const long long dbg_w0 = L.dbg ? wall_clock64() : 0;
+  long long ft[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (FLOW) ft[0] = a.flow_trace ? wall_clock64() : 0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   auto padded = [&](int v) {
     v = v < a.V ? v : a.V - 1;
@@ -1620,13 +1808,14 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
   // ---- weight ring: tap s -> slot s % D, this wave copies piece `wave` ----
   constexpr int D = kMRingTaps;
   auto dma_w = [&](int s) {
-    lds_dma16(a.wpack + (long)s * kDTapBytes + wave * 1024, (unsigned)lane * 16,
-              lbase + kMRing + (s % D) * 4096 + wave * 1024);
+    lds_dma16<false, FLOW>(L.wpack + (long)s * kDTapBytes + wave * 1024,
+                           (unsigned)lane * 16,
+                           lbase + kMRing + (s % D) * 4096 + wave * 1024);
   };
 #pragma unroll
   for (int s = 0; s < D - 1; ++s) dma_w(s);
   // ---- activations: dz = -1 -> slot 0, dz = 0 -> slot 1 (dz = +1 later -> slot 0)
-  const char* g0 = a.in_sp + (long)item * a.item_bytes + (long)p_lo * 16;
+  const char* g0 = L.in_sp + (long)item * a.item_bytes + (long)p_lo * 16;
   unsigned voff[kMPieces];
 #pragma unroll
   for (int k = 0; k < kMPieces; ++k) {
@@ -1639,10 +1828,20 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
 #pragma unroll
     for (int k = 0; k < kMPieces; ++k) {
       const int u0 = 64 * (wave + 4 * k);
-      lds_dma16(g0 + (long)(seg - 1) * a.plane * 16, voff[k],
-                lbase + (seg & 1) * kMSeg + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
+      lds_dma16<FLOW, FLOW>(g0 + (long)(seg - 1) * a.plane * 16, voff[k],
+                      lbase + (seg & 1) * kMSeg + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
     }
   };
+  if constexpr (FLOW) {
+    // W0 .. W3 are on their way; the rows only once their tiles are published
+    if (L.flow_wait_on) {
+      if (wave == 0) flow_wait_tiles(a, L, v0, v0 + kMChunk - 1, lane);
+      ft[1] = a.flow_trace ? wall_clock64() : 0;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (a.flow_dbg & 2) asm volatile("buffer_inv sc1" ::: "memory");
+    }
+  }
   dma_seg(0);
   dma_seg(1);
 
@@ -1685,7 +1884,8 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
   wait_vmcnt<kMPieces>();  // W0 .. W(D-2), dz = -1 landed
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  const long long dbg_c1 = a.dbg ? clock64() : 0;
+  const long long dbg_c1 = L.dbg ? clock64() : 0;
+  if constexpr (FLOW) ft[2] = a.flow_trace ? wall_clock64() : 0;
   dma_w(D - 1);
   load_w(0, 0, W0);
   load_w(0, 1, W0);
@@ -1705,8 +1905,8 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
 #pragma unroll
     for (int k = k0; k < k1; ++k) {
       const int u0 = 64 * (wave + 4 * k);
-      lds_dma16(g0 + (long)a.plane * 16, voff[k],
-                lbase + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
+      lds_dma16<FLOW, FLOW>(g0 + (long)a.plane * 16, voff[k],
+                      lbase + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
     }
   };
 #define FFN_MGAP(S, PART, WNEXT, XNEXT)                                         \
@@ -1744,31 +1944,38 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
   }
   auto issue_epilogue_loads = [&]() {
     const unsigned vb = (unsigned)lh * 16;  // channels 8 g + 4 lh .. + 3
-    const char* bp = reinterpret_cast<const char*>(a.bias);
-    bias4[0] = hidden_load16f<0>(bp, vb);
-    bias4[1] = hidden_load16f<32>(bp, vb);
-    bias4[2] = hidden_load16f<64>(bp, vb);
-    bias4[3] = hidden_load16f<96>(bp, vb);
+    const char* bp = reinterpret_cast<const char*>(L.bias);
+    bias4[0] = hidden_load16f<0, false, FLOW>(bp, vb);
+    bias4[1] = hidden_load16f<32, false, FLOW>(bp, vb);
+    bias4[2] = hidden_load16f<64, false, FLOW>(bp, vb);
+    bias4[3] = hidden_load16f<96, false, FLOW>(bp, vb);
     if constexpr (ADD_SKIP) {
       // f32 plane 2 g + lh, 16 B per position
       const char* xs = reinterpret_cast<const char*>(a.x_f32) + (long)item * a.item_bytes;
       const unsigned vs = (unsigned)(lh * (int)a.sp_plane_bytes + ppos * 16);
-      skip4[0] = hidden_load16f<0>(xs, vs);
-      skip4[1] = hidden_load16f<0>(xs + 2 * a.sp_plane_bytes, vs);
-      skip4[2] = hidden_load16f<0>(xs + 4 * a.sp_plane_bytes, vs);
-      skip4[3] = hidden_load16f<0>(xs + 6 * a.sp_plane_bytes, vs);
+      skip4[0] = hidden_load16f<0, FLOW, FLOW>(xs, vs);
+      skip4[1] = hidden_load16f<0, FLOW, FLOW>(xs + 2 * a.sp_plane_bytes, vs);
+      skip4[2] = hidden_load16f<0, FLOW, FLOW>(xs + 4 * a.sp_plane_bytes, vs);
+      skip4[3] = hidden_load16f<0, FLOW, FLOW>(xs + 6 * a.sp_plane_bytes, vs);
     }
     if constexpr (HEAD) {
       const char* hp = reinterpret_cast<const char*>(a.head_w);
-      hw4[0] = hidden_load16f<0>(hp, vb);
-      hw4[1] = hidden_load16f<32>(hp, vb);
-      hw4[2] = hidden_load16f<64>(hp, vb);
-      hw4[3] = hidden_load16f<96>(hp, vb);
+      hw4[0] = hidden_load16f<0, false, FLOW>(hp, vb);
+      hw4[1] = hidden_load16f<32, false, FLOW>(hp, vb);
+      hw4[2] = hidden_load16f<64, false, FLOW>(hp, vb);
+      hw4[3] = hidden_load16f<96, false, FLOW>(hp, vb);
       const char* sp = reinterpret_cast<const char*>(a.seed_raw + (size_t)item * a.V);
-      asm volatile("global_load_dword %0, %1, %2"
-                   : "=v"(seedv)
-                   : "v"((unsigned)(caller_index(a, ok ? v0 + jpos : 0) * 4)), "s"(sp)
-                   : "memory");
+      const unsigned so = (unsigned)(caller_index(a, ok ? v0 + jpos : 0) * 4);
+      if constexpr (FLOW)  // (lds_dma16: NOP)
+        asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2"
+                     : "=v"(seedv)
+                     : "v"(so), "s"(sp)
+                     : "memory");
+      else
+        asm volatile("global_load_dword %0, %1, %2"
+                     : "=v"(seedv)
+                     : "v"(so), "s"(sp)
+                     : "memory");
     }
   };
   FFN_MTAP(0, X0, W0, W1, X2)
@@ -1800,7 +2007,8 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
   FFN_MTAP(26, X2, W0, W1, X1)
 #undef FFN_MTAP
 #undef FFN_MGAP
-  const long long dbg_c2 = a.dbg ? clock64() : 0;
+  const long long dbg_c2 = L.dbg ? clock64() : 0;
+  if constexpr (FLOW) ft[3] = a.flow_trace ? wall_clock64() : 0;
 
   // ---- epilogue: straight from the accumulators (lane = position jpos,
   // register 4 g + i = channel 8 g + 4 lh + i) ----
@@ -1851,7 +2059,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
                          __float_as_uint(cnt[2]) + __float_as_uint(cnt[3]);
   } else {
     const __amdgpu_buffer_rsrc_t rs_sp = __builtin_amdgcn_make_buffer_rsrc(
-        a.out_sp + (long)item * a.item_bytes, 0, a.sp_bytes, 0x00020000);
+        L.out_sp + (long)item * a.item_bytes, 0, a.sp_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(a.x_f32) + (long)item * a.item_bytes, 0, a.sp_bytes,
         0x00020000);
@@ -1889,9 +2097,14 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const int item,
     }
     if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *a.range_flag = a.range_tag;
+    if constexpr (FLOW) ft[4] = flow_publish(a, L, v0, kMChunk / 32, tid);
   }
-  if (a.dbg && dbg_here && lane == 0) {
-    long long* d = a.dbg + wave * 6;
+  if constexpr (FLOW) {
+    ft[5] = a.flow_trace ? wall_clock64() : 0;
+    flow_trace_row(a, L, gc, ft);
+  }
+  if (L.dbg && dbg_here && lane == 0) {
+    long long* d = L.dbg + wave * 6;
     d[0] = dbg_c0;
     d[1] = dbg_c1;
     d[2] = dbg_c2;
@@ -1908,8 +2121,8 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32m_kernel(ConvDArgs a) {
   const long long t0 = a.dbg_wgs ? wall_clock64() : 0;
   const int item = (int)__umulhi((unsigned)gc, a.magic_nchunks);
   const int chunk = gc - item * a.nchunks;
-  conv32m_body<KIND, ADD_SKIP, HEAD>(a, item, chunk * kMChunk, gc, gc == 0);
-  stamp_workgroup(a, t0);
+  conv32m_body<KIND, ADD_SKIP, HEAD>(a, a.L, item, chunk * kMChunk, gc, gc == 0);
+  stamp_workgroup(a, a.L, t0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1945,9 +2158,10 @@ struct ConvTailMap {
   int taoff[4 * 8];           // the tail's aoff table (its rows per segment)
 };
 
-template <int KIND, bool ADD_SKIP, bool HEAD, int TNT>
+template <int KIND, bool ADD_SKIP, bool HEAD, int TNT, bool FLOW = false>
 __global__ __launch_bounds__(kDThreads, 2) void conv32mt_kernel(ConvDArgs a,
                                                                 ConvTailMap mp) {
+  static_assert(!FLOW || TNT == 1, "FLOW: the single-FoV form");
   const int xcd = blockIdx.x & 7;
   const int idx = blockIdx.x >> 3;
   int item, r;
@@ -1976,8 +2190,8 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32mt_kernel(ConvDArgs a,
   if (main_wg) {
     const int c = xcd * mp.mains_per_xcd + r;
     if (c >= mp.n_main) return;
-    conv32m_body<KIND, ADD_SKIP, HEAD>(a, item, c * kMChunk, item * slots + c,
-                                       blockIdx.x == 0 && a.dbg_wgs != 2);
+    conv32m_body<KIND, ADD_SKIP, HEAD, FLOW>(a, a.L, item, c * kMChunk, item * slots + c,
+                                             blockIdx.x == 0 && a.dbg_wgs != 2);
   } else {
     const int c = xcd * mp.tails_per_xcd + r;
     if (c >= mp.n_tail) return;
@@ -1987,11 +2201,95 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32mt_kernel(ConvDArgs a,
     // W0, dz = -1, W1 in front of the first barrier -- was measured for the
     // single-FoV tail: first barrier at 4.5 K instead of 5.2 K cycles, but the
     // taps 6.9 K instead of 5.8 K: profiles/r02_wg_timeline.txt)
-    conv32d_body<KIND, ADD_SKIP, kPieces, HEAD, TNT, kRows, 2>(
-        a, item, mp.n_main * kMChunk + c * (32 * TNT), item * slots + mp.n_main + c,
+    conv32d_body<KIND, ADD_SKIP, kPieces, HEAD, TNT, kRows, 2, FLOW>(
+        a, a.L, item, mp.n_main * kMChunk + c * (32 * TNT), item * slots + mp.n_main + c,
         mp.taoff, item == 0 && c == 0 && a.dbg_wgs == 2);
   }
-  stamp_workgroup(a, t0);
+  stamp_workgroup(a, a.L, t0);
+}
+
+// ---------------------------------------------------------------------------
+// conv32ps: the whole conv stack of ONE FoV as a single resident launch.
+//
+// conv32mt's workgroups (256 main chunks, one per CU, + the 32-voxel tail
+// workgroups on the CUs' second slots: all resident at once) keep their voxels
+// through all 2 depth - 1 convs; between two convs stands, instead of a kernel
+// boundary, the FLOW hand-off above: a workgroup starts conv l + 1 as soon as
+// the tiles ITS rows come from have been published by conv l.  Each conv's body
+// is the plain kernel's (same instructions, same summation order: same bits);
+// what changes per conv -- the two activation buffers taking turns, the weights
+// and bias of the layer, the sequence numbers -- is derived from the layer
+// index.  conv 0 (conv0_b) sits behind the boundary after conv0_a and waits for
+// nothing; the last conv carries the fused head and publishes nothing (the
+// faces / paste launch behind it is an ordinary dependent launch).
+// ---------------------------------------------------------------------------
+struct ConvStackTab {
+  int nlayers;            // 2 depth - 1
+  int l_begin, l_end;     // the convs of THIS launch ([0, nlayers) unless debugging)
+  int dbg_layer;          // the conv whose clock stamps are recorded (ConvDArgs::L.dbg)
+  const char* sp_t;       // T' (position 0 of plane 0): read by even convs, written by odd
+  char* sp_s;             // X': written by even convs, read by odd
+  const char* wpack0;     // layer 0's weight fragments ...
+  long wpack_stride;      // ... bytes per layer
+  const float* bias0;
+  long bias_stride;       // floats per layer
+  unsigned epoch0;        // conv l publishes epoch0 + l + 1 and waits for epoch0 + l
+};
+
+__global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
+                                                                ConvTailMap mp,
+                                                                ConvStackTab tb) {
+  const int xcd = blockIdx.x & 7;
+  const int r0 = blockIdx.x >> 3;
+  const bool main_wg = r0 < mp.mains_per_xcd;
+  const int r = main_wg ? r0 : r0 - mp.mains_per_xcd;
+  const int c = xcd * (main_wg ? mp.mains_per_xcd : mp.tails_per_xcd) + r;
+  if (c >= (main_wg ? mp.n_main : mp.n_tail)) return;
+  const long long t0 = a.dbg_wgs ? wall_clock64() : 0;
+  const int v0 = main_wg ? c * kMChunk : mp.n_main * kMChunk + c * 32;
+  const int gc = main_wg ? c : mp.n_main + c;
+  ConvLayer Ldbg = a.L;
+  for (int l = tb.l_begin; l < tb.l_end; ++l) {
+    ConvLayer L;
+    L.in_sp = (l & 1) ? tb.sp_s : tb.sp_t;
+    L.out_sp = (l & 1) ? const_cast<char*>(tb.sp_t) : tb.sp_s;
+    L.wpack = tb.wpack0 + (long)l * tb.wpack_stride;
+    L.bias = tb.bias0 + (long)l * tb.bias_stride;
+    L.dbg = l == tb.dbg_layer ? a.L.dbg : nullptr;
+    L.flow_wait = tb.epoch0 + (unsigned)l;
+    L.flow_set = tb.epoch0 + (unsigned)l + 1u;
+    L.flow_wait_on = l > tb.l_begin;
+    L.layer = l;
+    if (a.flow_dbg & 8) L = a.L;  // debug: the host's per-launch descriptor
+    if (L.dbg) Ldbg = L;
+    const bool last = l == tb.nlayers - 1;
+    if (main_wg) {
+      const bool dbg_here = blockIdx.x == 0 && a.dbg_wgs != 2;
+      if (l == 0)
+        conv32m_body<1, false, false, true>(a, L, 0, v0, gc, dbg_here);
+      else if (last)
+        conv32m_body<1, true, true, true>(a, L, 0, v0, gc, dbg_here);
+      else if (l & 1)
+        conv32m_body<0, false, false, true>(a, L, 0, v0, gc, dbg_here);
+      else
+        conv32m_body<1, true, false, true>(a, L, 0, v0, gc, dbg_here);
+    } else {
+      const bool dbg_here = c == 0 && a.dbg_wgs == 2;
+      if (l == 0)
+        conv32d_body<1, false, kTPieces, false, 1, kTRows, 2, true>(a, L, 0, v0, gc,
+                                                                    mp.taoff, dbg_here);
+      else if (last)
+        conv32d_body<1, true, kTPieces, true, 1, kTRows, 2, true>(a, L, 0, v0, gc,
+                                                                  mp.taoff, dbg_here);
+      else if (l & 1)
+        conv32d_body<0, false, kTPieces, false, 1, kTRows, 2, true>(a, L, 0, v0, gc,
+                                                                    mp.taoff, dbg_here);
+      else
+        conv32d_body<1, true, kTPieces, false, 1, kTRows, 2, true>(a, L, 0, v0, gc,
+                                                                   mp.taoff, dbg_here);
+    }
+  }
+  stamp_workgroup(a, Ldbg, t0);
 }
 
 // ---------------------------------------------------------------------------

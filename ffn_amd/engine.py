@@ -211,6 +211,15 @@ class HipEngine:
     check(self._lib.ffn_engine_debug_workgroups(self._h, out.ctypes.data, n))
     return out
 
+  def debug_flow_trace(self, slots: int):
+    """[slots, 64, 8] wall-clock stamps (100 MHz) of the FLOW convs run under
+    debug_clock 4 (ffn_engine_debug_flow_trace): per workgroup slot and conv of
+    the stack {entry, tiles seen, first segment landed, taps over, stores
+    drained, published}."""
+    out = np.zeros((slots, 64, 8), np.int64)
+    check(self._lib.ffn_engine_debug_flow_trace(self._h, out.ctypes.data, slots))
+    return out
+
   def synchronize(self):
     check(self._lib.ffn_engine_synchronize(self._h))
 

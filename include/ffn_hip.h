@@ -317,6 +317,13 @@ int ffn_engine_debug_clocks(ffn_engine* engine, long long* out24);
  * HW_ID, XCC_ID}: out[4 b ..] for blockIdx b < max_wgs <= 4096 (zeros for a
  * block that exited at once).  Clears the records. */
 int ffn_engine_debug_workgroups(ffn_engine* engine, long long* out, int max_wgs);
+/* Debug: with "debug_clock" = 4 every workgroup of a FLOW conv (option "flow" 1
+ * or 2: the resident stack of a single-FoV step) records per conv of the stack
+ * six wall-clock stamps (100 MHz): body entry, input tiles seen, first segment
+ * landed, tap loop over, stores drained, tiles published.
+ * out[(slot * 64 + conv) * 8 + 0..5] for workgroup slot < max_slots (main chunks
+ * first, then the tail chunks).  Clears the records. */
+int ffn_engine_debug_flow_trace(ffn_engine* engine, long long* out, int max_slots);
 /* Blocks until all work queued on the engine's stream has finished. */
 int ffn_engine_synchronize(ffn_engine* engine);
 

@@ -125,6 +125,10 @@ def main():
               'wall %.2f us' % (k, w, c[w, 1] - c[w, 0], c[w, 2] - c[w, 1],
                                 c[w, 3] - c[w, 2], c[w, 3] - c[w, 0],
                                 (c[w, 5] - c[w, 4]) / 100.0))
+  try:
+    print('stat_flow_timeouts', eng.get_option('stat_flow_timeouts'))
+  except Exception as exc:  # an older library
+    print('stat_flow_timeouts: n/a (%s)' % exc)
   eng.close()
 
 
