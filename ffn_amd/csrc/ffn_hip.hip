@@ -1300,6 +1300,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     // fits the LDS at all)
     e->exact_variant = c_ok ? 2 : 0;
     e->conv_variant = e->t_ok ? 9 : e->m_ok ? 8 : e->d_ok ? 6 : e->exact_variant;
+    // a single-FoV step of conv32mt runs its convs as ONE resident launch
+    e->flow = (e->t_ok && depth >= 2) ? 2 : 0;
   }
 
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)

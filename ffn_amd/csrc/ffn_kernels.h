@@ -1092,16 +1092,14 @@ __device__ __forceinline__ void stamp_workgroup(const ConvDArgs& a, const ConvLa
 constexpr unsigned kFlowSpinMax = 1u << 15;
 constexpr int kFlowTraceLayers = 64;
 
-// ONE wave: until every tile that holds inputs of dense voxels [v_first, v_last]
-// has been published by launch L.flow_wait (or a later one)
+// ONE wave: until every tile of dense voxels [d_lo, d_hi] (clipped to the FoV)
+// has been published by conv L.flow_wait (or a later one)
 __device__ __forceinline__ void flow_wait_tiles(const ConvDArgs& a, const ConvLayer& L,
-                                                int v_first,
-                                                int v_last, int lane) {
+                                                int d_lo, int d_hi, int lane) {
   typedef FFN_GLOBAL unsigned gu32;
-  int lo = v_first - a.flow_halo;
-  lo = (lo < 0 ? 0 : lo) >> 5;
-  int hi = v_last + a.flow_halo;
-  hi = (hi > a.V - 1 ? a.V - 1 : hi) >> 5;
+  if (d_lo > a.V - 1 || d_hi < 0) return;
+  int lo = (d_lo < 0 ? 0 : d_lo) >> 5;
+  int hi = (d_hi > a.V - 1 ? a.V - 1 : d_hi) >> 5;
   if (a.flow_dbg & 1) {
     lo = 0;
     hi = (a.V - 1) >> 5;
@@ -1334,7 +1332,8 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const ConvLayer
     hiddenW(btaps[2], W2);
     hiddenW(btaps[3], W3);
     if (L.flow_wait_on) {
-      if (wave == 0) flow_wait_tiles(a, L, v0, v0 + kChunkD - 1, lane);
+      if (wave == 0)
+        flow_wait_tiles(a, L, v0 - a.flow_halo, v0 + kChunkD - 1 + a.flow_halo, lane);
       ft[1] = a.flow_trace ? wall_clock64() : 0;
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -1732,7 +1731,10 @@ constexpr int kMLdsBytes = kMRing + kMRingTaps * 4096;  // 81,920: two per CU
 // batch 1 unchanged and costs batched steps 5 - 8 %, two workgroups per CU hide
 // a one-tap burst better than four taps with a DMA in them:
 // profiles/r03_ab_seg_dma_spread_not_kept.txt.)
-constexpr int m_wait(int S, int D, int NEPI) {
+// FL (FLOW bodies): one more load, the words of the dz = +1 rows' tiles, is
+// queued in tap 1 behind its ring piece; it is older than W10, so tap 9's own
+// wait covers it.
+constexpr int m_wait(int S, int D, int NEPI, bool FL = false) {
   if (S == 0) return kMPieces;      // dz = 0's DMAs are newer than dz = -1 / W1
   if (S + 1 > 26) return -1;
   if (S + 1 <= D - 2) return -1;    // queued in front of everything: landed
@@ -1742,6 +1744,7 @@ constexpr int m_wait(int S, int D, int NEPI) {
     // per tap t, in this order: the ring piece W(t+D-1), the dz = +1 pieces, the
     // epilogue operands
     if (t > tr && t <= 27 - D) n += 1;
+    if (FL && t == 1) n += 1;
     if (t == 9) n += kMPieces;
     if (t == 27 - D) n += NEPI;
   }
@@ -1835,7 +1838,12 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
   if constexpr (FLOW) {
     // W0 .. W3 are on their way; the rows only once their tiles are published
     if (L.flow_wait_on) {
-      if (wave == 0) flow_wait_tiles(a, L, v0, v0 + kMChunk - 1, lane);
+      // the rows of dz = -1 and dz = 0; those of dz = +1 are not needed before
+      // tap 9 queues their DMA: their words are fetched during tap 1 (below)
+      if (wave == 0)
+        flow_wait_tiles(a, L, v0 - a.flow_halo,
+                        (a.flow_dbg & 32) ? v0 + kMChunk - 1 + a.flow_halo
+                                          : v0 + kMChunk - 1 + a.fx + 1, lane);
       ft[1] = a.flow_trace ? wall_clock64() : 0;
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -1909,6 +1917,35 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
                       lbase + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
     }
   };
+  // FLOW: the words of the tiles the dz = +1 rows come from.  Every wave fetches
+  // them for itself during tap 1 (a hidden load: counted in m_wait) and looks at
+  // them in front of tap 9's barrier, behind which its dz = +1 pieces are queued;
+  // a wave that finds a tile unpublished polls until it is.  (A workgroup's own
+  // stores come after every one of its waits, so write-after-read holds as for
+  // the eager form.)
+  unsigned late_word = 0;
+  const int late_d_lo = v0 + a.fyfx - a.fx - 1;
+  const bool late_on =
+      FLOW && L.flow_wait_on && !(a.flow_dbg & 32) && late_d_lo <= a.V - 1;
+  auto flow_late_load = [&]() {
+    if constexpr (FLOW) {
+      const int lo = (late_d_lo < 0 ? 0 : late_d_lo > a.V - 1 ? a.V - 1 : late_d_lo) >> 5;
+      int hi = v0 + kMChunk - 1 + a.flow_halo;
+      hi = (hi > a.V - 1 ? a.V - 1 : hi) >> 5;
+      const int t = lo + lane <= hi ? lo + lane : hi;
+      asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1"
+                   : "=v"(late_word)
+                   : "v"((unsigned)t * 4u), "s"(a.flow_flags)
+                   : "memory");
+    }
+  };
+  auto flow_late_check = [&]() {
+    if constexpr (FLOW) {
+      asm volatile("" : "+v"(late_word));
+      if (late_on && !__all((int)(late_word - L.flow_wait) >= 0))
+        flow_wait_tiles(a, L, late_d_lo, v0 + kMChunk - 1 + a.flow_halo, lane);
+    }
+  };
 #define FFN_MGAP(S, PART, WNEXT, XNEXT)                                         \
   __builtin_amdgcn_sched_barrier(0);                                            \
   if ((PART) < 2 && (S) + 1 <= 26) load_w((S) + 1, PART, WNEXT);                \
@@ -1920,7 +1957,9 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
 #define FFN_MTAP(S, XCUR, WCUR, WNEXT, XNEXT)                                   \
   {                                                                             \
     if ((S) > 0) {                                                              \
-      if constexpr (m_wait(S, D, NEPI) >= 0) wait_vmcnt<m_wait(S, D, NEPI)>();  \
+      if constexpr (m_wait(S, D, NEPI, FLOW) >= 0)                              \
+        wait_vmcnt<m_wait(S, D, NEPI, FLOW)>();                                 \
+      if (FLOW && (S) == 9) flow_late_check();                                  \
       __builtin_amdgcn_s_barrier();                                             \
       asm volatile("" ::: "memory");                                            \
     }                                                                           \
@@ -1928,6 +1967,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
     accC = mma(WCUR.w[0][0], XCUR.x[0][1], accC);                               \
     __builtin_amdgcn_sched_barrier(0);                                          \
     if ((S) > 0 && (S) + D - 1 <= 26) dma_w((S) + D - 1);                       \
+    if (FLOW && (S) == 1) flow_late_load();                                     \
     __builtin_amdgcn_sched_barrier(0);                                          \
     acc = mma(WCUR.w[0][0], XCUR.x[0][0], acc);                                 \
     FFN_MGAP(S, 0, WNEXT, XNEXT)                                                \
