@@ -139,7 +139,7 @@ struct ffn_engine {
   // the poll); 2 the resident stack, conv32ps: ONE launch for the 2 depth - 1 convs
   // of a single-FoV step
   int flow = 0;
-  unsigned* flow_flags = nullptr;  // one word per 32-voxel tile of the FoV
+  unsigned* flow_flags = nullptr;  // one word per producer workgroup, kFlowStride apart
   unsigned* flow_err = nullptr;    // polls that gave up, ever
   unsigned flow_epoch = 0;         // sequence number of the last conv queued
   int flow_debug = 0;              // debug option: ConvDArgs::flow_dbg
@@ -673,6 +673,7 @@ void conv32d_args(ffn_engine* e, int n, const float* raw_in, float* raw_out, int
   a.range_flag = e->range_flag;
   a.range_tag = e->range_tag;
   a.flow_flags = e->flow_flags;
+  a.flow_n_main = e->n_main;
   a.flow_err = e->flow_err;
   a.flow_halo = g.fy * g.fx + g.fx + 1;
   a.flow_dbg = e->flow_debug;
@@ -1330,7 +1331,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
     E_TRY(hipMemset(e->range_flag, 0, sizeof(unsigned)));
     {
-      const size_t words = (size_t)(e->gp.V + 31) / 32 + 64;
+      const size_t words = ((size_t)(e->gp.V + 31) / 32 + 64) * kFlowStride;
       E_TRY(hipMalloc(&e->flow_flags, words * sizeof(unsigned)));
       E_TRY(hipMemset(e->flow_flags, 0, words * sizeof(unsigned)));
       E_TRY(hipMalloc(&e->flow_err, sizeof(unsigned)));

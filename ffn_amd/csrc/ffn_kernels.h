@@ -1023,10 +1023,11 @@ struct ConvDArgs {
   unsigned range_tag;
   int dbg_wgs;           // debug_clock 2: every workgroup stamps dbg[24 + 4 blockIdx ..];
                          // 3 (value 2 here): the clock stamps come from tail chunk 0
-  // FLOW kernels (section "flagged launches" below): one word per 32-voxel tile
-  // of the FoV = sequence number of the last conv launch whose outputs for that
-  // tile are complete in memory
+  // FLOW kernels (section "flagged launches" below): one word per producer
+  // workgroup (kFlowStride words apart): the sequence number of the last conv
+  // whose outputs for its voxels are complete in memory
   unsigned* flow_flags;
+  int flow_n_main;       // main chunks (128 voxels) in front of the tail tiles (32)
   unsigned* flow_err;    // number of polls that gave up (the step is void then)
   int flow_halo;         // dense voxels a 3x3x3 neighbourhood reaches back / ahead
   long long* flow_trace; // debug_clock 4: [workgroup slot][kFlowTraceLayers][8] wall-clock
@@ -1092,52 +1093,82 @@ __device__ __forceinline__ void stamp_workgroup(const ConvDArgs& a, const ConvLa
 constexpr unsigned kFlowSpinMax = 1u << 15;
 constexpr int kFlowTraceLayers = 64;
 
-// ONE wave: until every tile of dense voxels [d_lo, d_hi] (clipped to the FoV)
-// has been published by conv L.flow_wait (or a later one)
+// The words: one per PRODUCER (a main chunk of 128 voxels, then the tail tiles of
+// 32), 256 bytes apart -- polled words that share a line, or a memory channel,
+// with the words other workgroups publish slow both sides down (measured: four
+// flag stores per workgroup instead of one, or two polls in flight instead of
+// one, cost 10 - 25 % of the step).
+constexpr int kFlowStride = 64;  // words between two producers' words
+
+__device__ __forceinline__ int flow_unit(const ConvDArgs& a, int d) {
+  const int m = a.flow_n_main * 128;  // (= kMChunk)
+  return d < m ? d >> 7 : a.flow_n_main + ((d - m) >> 5);
+}
+
+// ONE wave: until every producer of dense voxels [d_lo, d_hi] (clipped to the
+// FoV) has published conv L.flow_wait (or a later one).  The producers finish
+// roughly in index order (the lower planes lead), so the wave first polls ONE
+// word, the last producer's -- one memory transaction per poll -- and then
+// looks at all of them once.
 __device__ __forceinline__ void flow_wait_tiles(const ConvDArgs& a, const ConvLayer& L,
                                                 int d_lo, int d_hi, int lane) {
   typedef FFN_GLOBAL unsigned gu32;
   if (d_lo > a.V - 1 || d_hi < 0) return;
-  int lo = (d_lo < 0 ? 0 : d_lo) >> 5;
-  int hi = (d_hi > a.V - 1 ? a.V - 1 : d_hi) >> 5;
+  int lo = flow_unit(a, d_lo < 0 ? 0 : d_lo);
+  int hi = flow_unit(a, d_hi > a.V - 1 ? a.V - 1 : d_hi);
   if (a.flow_dbg & 1) {
     lo = 0;
-    hi = (a.V - 1) >> 5;
+    hi = flow_unit(a, a.V - 1);
   }
   gu32* flags = (gu32*)a.flow_flags;
   unsigned spins = 0;
+  auto give_up = [&]() {
+    if (lane == 0) {
+      atomicAdd(a.flow_err, 1u);
+      *a.range_flag = a.range_tag;
+    }
+  };
+  auto nap = [&]() {
+    const int sl = (a.flow_dbg >> 8) & 3;
+    if (sl == 0) __builtin_amdgcn_s_sleep(8);
+    else if (sl == 1) __builtin_amdgcn_s_sleep(2);
+    else if (sl == 2) __builtin_amdgcn_s_sleep(16);
+    else __builtin_amdgcn_s_sleep(32);
+  };
+  if (!(a.flow_dbg & 64)) {
+    for (;;) {  // the last producer's word, every lane the same address
+      const unsigned x = __hip_atomic_load(flags + (long)hi * kFlowStride, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(x - L.flow_wait) >= 0) break;
+      if (++spins > kFlowSpinMax) return give_up();
+      nap();
+    }
+  }
   for (int base = lo; base <= hi; base += 64) {
-    const int t = base + lane <= hi ? base + lane : hi;
+    const int u = base + lane <= hi ? base + lane : hi;
     for (;;) {
-      const unsigned x =
-          __hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned x = __hip_atomic_load(flags + (long)u * kFlowStride, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
       if (__all((int)(x - L.flow_wait) >= 0)) break;
-      if (++spins > kFlowSpinMax) {
-        if (lane == 0) {
-          atomicAdd(a.flow_err, 1u);
-          *a.range_flag = a.range_tag;
-        }
-        return;
-      }
-      __builtin_amdgcn_s_sleep(2);
+      if (++spins > kFlowSpinMax) return give_up();
+      nap();
     }
   }
 }
 
 // every wave of the workgroup, behind its last activation store: drain, meet,
-// then lanes 0 .. ntiles-1 publish the workgroup's tiles (first dense voxel v0)
+// then one lane publishes the workgroup's word (first dense voxel v0)
 __device__ __forceinline__ long long flow_publish(const ConvDArgs& a, const ConvLayer& L,
-                                                  int v0, int ntiles, int tid) {
+                                                  int v0, int tid) {
   typedef FFN_GLOBAL unsigned gu32;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (a.flow_dbg & 4) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
   const long long t_drained = a.flow_trace ? wall_clock64() : 0;
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  const int t = (v0 >> 5) + tid;
-  if (tid < ntiles && t * 32 < a.V)
-    __hip_atomic_store((gu32*)a.flow_flags + t, L.flow_set, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0)
+    __hip_atomic_store((gu32*)a.flow_flags + (long)flow_unit(a, v0) * kFlowStride,
+                       L.flow_set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return t_drained;
 }
 
@@ -1655,7 +1686,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const ConvLayer
     // host re-runs it with the exact-f32 kernel (ffn_step_result.range_error)
     if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *a.range_flag = a.range_tag;
-    if constexpr (FLOW) ft[4] = flow_publish(a, L, v0, NT, tid);
+    if constexpr (FLOW) ft[4] = flow_publish(a, L, v0, tid);
   }
   if constexpr (FLOW) {
     ft[5] = a.flow_trace ? wall_clock64() : 0;
@@ -1929,13 +1960,14 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
       FLOW && L.flow_wait_on && !(a.flow_dbg & 32) && late_d_lo <= a.V - 1;
   auto flow_late_load = [&]() {
     if constexpr (FLOW) {
-      const int lo = (late_d_lo < 0 ? 0 : late_d_lo > a.V - 1 ? a.V - 1 : late_d_lo) >> 5;
+      const int lo = flow_unit(
+          a, late_d_lo < 0 ? 0 : late_d_lo > a.V - 1 ? a.V - 1 : late_d_lo);
       int hi = v0 + kMChunk - 1 + a.flow_halo;
-      hi = (hi > a.V - 1 ? a.V - 1 : hi) >> 5;
-      const int t = lo + lane <= hi ? lo + lane : hi;
+      hi = flow_unit(a, hi > a.V - 1 ? a.V - 1 : hi);
+      const int u = lo + lane <= hi ? lo + lane : hi;
       asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1"
                    : "=v"(late_word)
-                   : "v"((unsigned)t * 4u), "s"(a.flow_flags)
+                   : "v"((unsigned)u * (unsigned)(kFlowStride * 4)), "s"(a.flow_flags)
                    : "memory");
     }
   };
@@ -2137,7 +2169,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
     }
     if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *a.range_flag = a.range_tag;
-    if constexpr (FLOW) ft[4] = flow_publish(a, L, v0, kMChunk / 32, tid);
+    if constexpr (FLOW) ft[4] = flow_publish(a, L, v0, tid);
   }
   if constexpr (FLOW) {
     ft[5] = a.flow_trace ? wall_clock64() : 0;
