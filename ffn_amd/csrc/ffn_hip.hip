@@ -834,19 +834,9 @@ int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr) {
   tb.epoch0 = e->flow_epoch;
   e->flow_epoch += (unsigned)tb.nlayers;
   const dim3 grid(8 * (mp.mains_per_xcd + mp.tails_per_xcd)), block(kDThreads);
-  // (debug: flow_debug >> 4 = convs per launch, 0 = the whole stack in one)
-  const int per = (e->flow_debug >> 4) > 0 ? (e->flow_debug >> 4) : tb.nlayers;
-  for (int l0 = 0; l0 < tb.nlayers; l0 += per) {
-    tb.l_begin = l0;
-    tb.l_end = std::min(l0 + per, tb.nlayers);
-    if (e->flow_debug & 8) {
-      const bool odd = l0 & 1;
-      conv32d_args(e, 1, odd ? e->rawS : e->rawT, odd ? e->rawT : e->rawS, l0, hf, a);
-      a.L.dbg = nullptr;
-      a.L.flow_set = tb.epoch0 + l0 + 1;
-    }
-    hipLaunchKernelGGL(conv32ps_kernel, grid, block, kMLdsBytes, e->stream, a, mp, tb);
-  }
+  tb.l_begin = 0;
+  tb.l_end = tb.nlayers;
+  hipLaunchKernelGGL(conv32ps_kernel, grid, block, kMLdsBytes, e->stream, a, mp, tb);
   return FFN_OK;
 }
 

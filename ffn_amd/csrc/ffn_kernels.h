@@ -1092,6 +1092,9 @@ __device__ __forceinline__ void stamp_workgroup(const ConvDArgs& a, const ConvLa
 // ---------------------------------------------------------------------------
 constexpr unsigned kFlowSpinMax = 1u << 15;
 constexpr int kFlowTraceLayers = 64;
+#ifndef FFN_FLOW_TRACE
+#define FFN_FLOW_TRACE 1
+#endif
 
 // The words: one per PRODUCER (a main chunk of 128 voxels, then the tail tiles of
 // 32), 256 bytes apart -- polled words that share a line, or a memory channel,
@@ -1163,7 +1166,7 @@ __device__ __forceinline__ long long flow_publish(const ConvDArgs& a, const Conv
   typedef FFN_GLOBAL unsigned gu32;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (a.flow_dbg & 4) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-  const long long t_drained = a.flow_trace ? wall_clock64() : 0;
+  const long long t_drained = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (tid == 0)
@@ -1283,7 +1286,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const ConvLayer
   const long long dbg_c0 = L.dbg ? clock64() : 0;
   const long long dbg_w0 = L.dbg ? wall_clock64() : 0;
   long long ft[6] = {0, 0, 0, 0, 0, 0};
-  if constexpr (FLOW) ft[0] = a.flow_trace ? wall_clock64() : 0;
+  if constexpr (FLOW) ft[0] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int aoffs[7], btaps[7];
 #pragma unroll
@@ -1365,7 +1368,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const ConvLayer
     if (L.flow_wait_on) {
       if (wave == 0)
         flow_wait_tiles(a, L, v0 - a.flow_halo, v0 + kChunkD - 1 + a.flow_halo, lane);
-      ft[1] = a.flow_trace ? wall_clock64() : 0;
+      ft[1] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (a.flow_dbg & 2) asm volatile("buffer_inv sc1" ::: "memory");
@@ -1444,7 +1447,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const ConvLayer
   asm volatile("" ::: "memory");
   pinW(W0);
   const long long dbg_c1 = L.dbg ? clock64() : 0;
-  if constexpr (FLOW) ft[2] = a.flow_trace ? wall_clock64() : 0;
+  if constexpr (FLOW) ft[2] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
   loadX(0, aoffs[0], X0);
 
   // EXTRA: memory instructions riding on the tile (issued behind its prefetch)
@@ -1569,7 +1572,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const ConvLayer
 #undef FFN_DTILE
 
   const long long dbg_c2 = L.dbg ? clock64() : 0;
-  if constexpr (FLOW) ft[3] = a.flow_trace ? wall_clock64() : 0;
+  if constexpr (FLOW) ft[3] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
   // ---- epilogue: the four waves' partial sums meet in LDS ----
   // P[wave][position 0..159][32 ch] at a 144-B row stride; accumulator register
   // 4 g + i of a lane is channel 8 g + 4 (lane >> 5) + i of position lane & 31.
@@ -1689,7 +1692,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const ConvLayer
     if constexpr (FLOW) ft[4] = flow_publish(a, L, v0, tid);
   }
   if constexpr (FLOW) {
-    ft[5] = a.flow_trace ? wall_clock64() : 0;
+    ft[5] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
     flow_trace_row(a, L, gc, ft);
   }
   if (L.dbg && dbg_here && (tid & 63) == 0) {
@@ -1805,24 +1808,30 @@ __device__ __forceinline__ f32x4 hidden_load16f(const char* sbase, unsigned voff
 
 // The workgroup computes the 128 dense voxels from v0 of FoV `item`; gc = its
 // slot in head_count.
-template <int KIND, bool ADD_SKIP, bool HEAD, bool FLOW = false>
+// RES (the resident stack): the f32 residual stream of the workgroup's voxels
+// stays in `xres` (the lane / register layout of the accumulators, the same in
+// every conv of the stack) instead of going through memory: conv_b neither
+// loads its skip operand nor stores X -- 9.2 MB less per conv_b.
+template <int KIND, bool ADD_SKIP, bool HEAD, bool FLOW = false, bool RES = false>
 __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer& L,
                                              const int item,
                                              const int v0, const int gc,
-                                             const bool dbg_here) {
+                                             const bool dbg_here,
+                                             f32x4* xres = nullptr) {
   typedef f16x8 frag_t;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   constexpr int R = kMRows;
   constexpr int R16 = R * 16;
-  constexpr int NEPI = HEAD ? (ADD_SKIP ? 13 : 9) : (ADD_SKIP ? 8 : 4);
+  constexpr bool kSkipLoad = ADD_SKIP && !RES;
+  constexpr int NEPI = HEAD ? (kSkipLoad ? 13 : 9) : (kSkipLoad ? 8 : 4);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* ldsb = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x;
   const long long dbg_c0 = L.dbg ? clock64() : 0;
   const long long dbg_w0 = L.dbg ? wall_clock64() : 0;
   long long ft[6] = {0, 0, 0, 0, 0, 0};
-  if constexpr (FLOW) ft[0] = a.flow_trace ? wall_clock64() : 0;
+  if constexpr (FLOW) ft[0] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   auto padded = [&](int v) {
     v = v < a.V ? v : a.V - 1;
@@ -1875,7 +1884,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
         flow_wait_tiles(a, L, v0 - a.flow_halo,
                         (a.flow_dbg & 32) ? v0 + kMChunk - 1 + a.flow_halo
                                           : v0 + kMChunk - 1 + a.fx + 1, lane);
-      ft[1] = a.flow_trace ? wall_clock64() : 0;
+      ft[1] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (a.flow_dbg & 2) asm volatile("buffer_inv sc1" ::: "memory");
@@ -1924,7 +1933,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   const long long dbg_c1 = L.dbg ? clock64() : 0;
-  if constexpr (FLOW) ft[2] = a.flow_trace ? wall_clock64() : 0;
+  if constexpr (FLOW) ft[2] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
   dma_w(D - 1);
   load_w(0, 0, W0);
   load_w(0, 1, W0);
@@ -1948,12 +1957,14 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
                       lbase + (u0 >= 8 * R ? u0 - 8 * R : u0) * 16);
     }
   };
-  // FLOW: the words of the tiles the dz = +1 rows come from.  Every wave fetches
-  // them for itself during tap 1 (a hidden load: counted in m_wait) and looks at
-  // them in front of tap 9's barrier, behind which its dz = +1 pieces are queued;
-  // a wave that finds a tile unpublished polls until it is.  (A workgroup's own
-  // stores come after every one of its waits, so write-after-read holds as for
-  // the eager form.)
+  // FLOW: the words of the producers the dz = +1 rows come from.  Wave 0 fetches
+  // them during tap 1 (a hidden load, counted in m_wait: the other waves issue a
+  // load of the bias line in its place so that every wave's queue has the same
+  // length) and looks at them in front of tap 9's barrier, behind which every
+  // wave queues its dz = +1 pieces; if a producer has not published yet it polls
+  // there while the others wait at the barrier.  (A workgroup's own stores come
+  // after every one of its waits, so write-after-read holds as for the eager
+  // form.)
   unsigned late_word = 0;
   const int late_d_lo = v0 + a.fyfx - a.fx - 1;
   const bool late_on =
@@ -1965,16 +1976,22 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
       int hi = v0 + kMChunk - 1 + a.flow_halo;
       hi = flow_unit(a, hi > a.V - 1 ? a.V - 1 : hi);
       const int u = lo + lane <= hi ? lo + lane : hi;
-      asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1"
-                   : "=v"(late_word)
-                   : "v"((unsigned)u * (unsigned)(kFlowStride * 4)), "s"(a.flow_flags)
-                   : "memory");
+      if (wave == 0)
+        asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1"
+                     : "=v"(late_word)
+                     : "v"((unsigned)u * (unsigned)(kFlowStride * 4)), "s"(a.flow_flags)
+                     : "memory");
+      else
+        asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2"
+                     : "=v"(late_word)
+                     : "v"(0u), "s"(L.bias)
+                     : "memory");
     }
   };
   auto flow_late_check = [&]() {
     if constexpr (FLOW) {
       asm volatile("" : "+v"(late_word));
-      if (late_on && !__all((int)(late_word - L.flow_wait) >= 0))
+      if (late_on && wave == 0 && !__all((int)(late_word - L.flow_wait) >= 0))
         flow_wait_tiles(a, L, late_d_lo, v0 + kMChunk - 1 + a.flow_halo, lane);
     }
   };
@@ -2021,7 +2038,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
     bias4[1] = hidden_load16f<32, false, FLOW>(bp, vb);
     bias4[2] = hidden_load16f<64, false, FLOW>(bp, vb);
     bias4[3] = hidden_load16f<96, false, FLOW>(bp, vb);
-    if constexpr (ADD_SKIP) {
+    if constexpr (kSkipLoad) {
       // f32 plane 2 g + lh, 16 B per position
       const char* xs = reinterpret_cast<const char*>(a.x_f32) + (long)item * a.item_bytes;
       const unsigned vs = (unsigned)(lh * (int)a.sp_plane_bytes + ppos * 16);
@@ -2080,16 +2097,20 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
 #undef FFN_MTAP
 #undef FFN_MGAP
   const long long dbg_c2 = L.dbg ? clock64() : 0;
-  if constexpr (FLOW) ft[3] = a.flow_trace ? wall_clock64() : 0;
+  if constexpr (FLOW) ft[3] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
 
   // ---- epilogue: straight from the accumulators (lane = position jpos,
   // register 4 g + i = channel 8 g + 4 lh + i) ----
   wait_vmcnt<0>();
   asm volatile(""
                : "+v"(bias4[0]), "+v"(bias4[1]), "+v"(bias4[2]), "+v"(bias4[3]));
-  if constexpr (ADD_SKIP)
+  if constexpr (kSkipLoad)
     asm volatile(""
                  : "+v"(skip4[0]), "+v"(skip4[1]), "+v"(skip4[2]), "+v"(skip4[3]));
+  if constexpr (ADD_SKIP && RES) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) skip4[g] = xres[g];
+  }
   if constexpr (HEAD)
     asm volatile(""
                  : "+v"(hw4[0]), "+v"(hw4[1]), "+v"(hw4[2]), "+v"(hw4[3]),
@@ -2141,11 +2162,15 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
       v += bias4[g];
       if (KIND == 1) {
         if (ADD_SKIP) v += skip4[g];
-        const unsigned xo =
-            ok ? (unsigned)((2 * g + lh) * (int)a.sp_plane_bytes + ppos * 16)
-               : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_x,
-                                               xo, 0, 16);
+        if constexpr (RES) {
+          xres[g] = v;
+        } else {
+          const unsigned xo =
+              ok ? (unsigned)((2 * g + lh) * (int)a.sp_plane_bytes + ppos * 16)
+                 : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_x,
+                                                 xo, 0, 16);
+        }
       }
       f32x4 vh;
 #pragma unroll
@@ -2172,7 +2197,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
     if constexpr (FLOW) ft[4] = flow_publish(a, L, v0, tid);
   }
   if constexpr (FLOW) {
-    ft[5] = a.flow_trace ? wall_clock64() : 0;
+    ft[5] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
     flow_trace_row(a, L, gc, ft);
   }
   if (L.dbg && dbg_here && lane == 0) {
@@ -2295,6 +2320,12 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32mt_kernel(ConvDArgs a,
 // nothing; the last conv carries the fused head and publishes nothing (the
 // faces / paste launch behind it is an ordinary dependent launch).
 // ---------------------------------------------------------------------------
+// (compile-time switch for same-box A/B builds: tools/build_variant.sh)
+#ifndef FFN_PS_RES
+#define FFN_PS_RES 1
+#endif
+constexpr bool kPsRes = FFN_PS_RES != 0;
+
 struct ConvStackTab {
   int nlayers;            // 2 depth - 1
   int l_begin, l_end;     // the convs of THIS launch ([0, nlayers) unless debugging)
@@ -2321,6 +2352,12 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
   const int v0 = main_wg ? c * kMChunk : mp.n_main * kMChunk + c * 32;
   const int gc = main_wg ? c : mp.n_main + c;
   ConvLayer Ldbg = a.L;
+  // the residual stream of a main workgroup's voxels (conv32m_body: RES); the
+  // tail workgroups keep theirs in memory (their head epilogue has another
+  // thread-to-voxel mapping than their conv epilogue)
+  f32x4 xres[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) xres[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int l = tb.l_begin; l < tb.l_end; ++l) {
     ConvLayer L;
     L.in_sp = (l & 1) ? tb.sp_s : tb.sp_t;
@@ -2332,19 +2369,18 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
     L.flow_set = tb.epoch0 + (unsigned)l + 1u;
     L.flow_wait_on = l > tb.l_begin;
     L.layer = l;
-    if (a.flow_dbg & 8) L = a.L;  // debug: the host's per-launch descriptor
     if (L.dbg) Ldbg = L;
     const bool last = l == tb.nlayers - 1;
     if (main_wg) {
       const bool dbg_here = blockIdx.x == 0 && a.dbg_wgs != 2;
       if (l == 0)
-        conv32m_body<1, false, false, true>(a, L, 0, v0, gc, dbg_here);
+        conv32m_body<1, false, false, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
       else if (last)
-        conv32m_body<1, true, true, true>(a, L, 0, v0, gc, dbg_here);
+        conv32m_body<1, true, true, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
       else if (l & 1)
-        conv32m_body<0, false, false, true>(a, L, 0, v0, gc, dbg_here);
+        conv32m_body<0, false, false, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
       else
-        conv32m_body<1, true, false, true>(a, L, 0, v0, gc, dbg_here);
+        conv32m_body<1, true, false, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
     } else {
       const bool dbg_here = c == 0 && a.dbg_wgs == 2;
       if (l == 0)
