@@ -76,27 +76,27 @@ def configure(args):
 
 
 def model_variables():
-  """TF-named weight arrays: the reference's FIB-25 checkpoint (c1), or -- c5 --
-  seeded random weights (normal, std 0.02) with a head bias that makes the
-  object map grow, so that the flood fill keeps producing FoV steps."""
+  """TF-named weight arrays: the reference's FIB-25 checkpoint (c1), or -- c5,
+  for which the reference ships no checkpoint -- the constructed flood-fill
+  network of `synthetic.flood_fill_weights`: the same architecture and cost per
+  step, and floods that stay inside the cells of the phantom, so that segments
+  end, commit and can be reconciled across sub-boxes."""
   if CONFIG == 'c1':
     with np.load(os.path.join(ROOT, 'tests', 'golden', 'fib25_weights.npz')) as d:
       return {k: d[k] for k in d.files}
-  rng = np.random.RandomState(18)
-  v = {}
+  from ffn_amd import synthetic
+  return synthetic.flood_fill_weights(DEPTH, FEATURES)
 
-  def conv(name, cin, cout, k=3, bias=0.0):
-    v['seed_update/%s/weights' % name] = rng.normal(
-        0, 0.02, (k, k, k, cin, cout)).astype(np.float32)
-    v['seed_update/%s/biases' % name] = np.full((cout,), bias, np.float32)
 
-  conv('conv0_a', 2, FEATURES)
-  conv('conv0_b', FEATURES, FEATURES)
-  for i in range(1, DEPTH):
-    conv('conv%d_a' % i, FEATURES, FEATURES)
-    conv('conv%d_b' % i, FEATURES, FEATURES)
-  conv('conv_lom', FEATURES, 1, k=1, bias=5.5)  # pad (-2.94) + 5.5 > move threshold
-  return v
+def bench_volume(shape, seed):
+  """The cells phantom of a config (c5: thicker membranes -- its network follows
+  26-connected bright voxels)."""
+  from ffn_amd import synthetic
+  if CONFIG == 'c5':
+    return synthetic.cells_volume(shape, seed=seed, membrane_dilate=2)
+  return synthetic.cells_volume(shape, seed=seed)
+
+
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA
 # the split-product kernels (conv_variant >= 6): every f32 product = 3 fp16
@@ -155,6 +155,114 @@ def load_model():
   return model
 
 
+FULL_FIXTURE = os.path.join(ROOT, 'tests', 'golden',
+                            'ref_canvas_cells250_onednn_full.npz')
+
+
+def full_volume_pass(args, rank, world, model, exe, request, image, barrier):
+  """BASELINE.json's metric on a COMPLETE pass: `Canvas.segment_all` over every
+  grid seed of this rank's volume (reference inference.py:538-683; 24 k FoV
+  steps on the 250^3 phantom) -- seed set-up, validity tests, segment commits
+  and all -- timed between barriers; then (rank 0, configs[1] only, untimed)
+  the same pass once more with the FoV positions recorded, against the run the
+  reference's own Canvas made of this volume behind the torch-CPU / oneDNN f32
+  forward (tests/golden/ref_canvas_cells250_onednn_full.npz, tools/make_golden.py
+  --only cells250 --forward onednn --num-seeds 0 --tag _full)."""
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from ffn_amd.inference import seed as seed_lib
+  eng = exe.engine
+  fixture = None
+  if (CONFIG == 'c1' and args.workload == 'cells' and
+      tuple(VOLUME_ZYX) == (250, 250, 250) and os.path.exists(FULL_FIXTURE)):
+    fixture = np.load(FULL_FIXTURE)
+  if fixture is not None:  # the grid of the fixture = every valid seed position
+    policy = functools.partial(seed_lib.PolicyFixed, coords=fixture['seeds'])
+  else:
+    policy = functools.partial(seed_lib.PolicyGrid3d, step=16,
+                               offsets=(0, 8, 4, 12, 2, 10, 14))
+
+  def make(counters, **kw):
+    return inference.DeviceCanvas(
+        model.info, exe.get_client(counters, direct=True), image,
+        request.inference_options, counters=counters,
+        movement_policy_fn=movement.get_policy_fn(request, model.info), **kw)
+
+  mode = eng.get_option('profile_every')
+  eng.set_profiling(0)
+  counters = inference_utils.Counters()
+  canvas = make(counters)
+  eng.synchronize()
+  barrier()
+  t0 = time.perf_counter()
+  canvas.segment_all(seed_policy=policy)
+  eng.synchronize()
+  t_local = time.perf_counter() - t0
+  barrier()
+  t_all = time.perf_counter() - t0
+  steps = counters['update_at-calls'].value
+  voxels = counters['voxels-segmented'].value
+  steps0, voxels0 = steps, voxels
+  if world > 1:  # whole job: every rank's pass, the slowest rank's clock
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(steps), float(voxels)], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    steps, voxels = (float(v) for v in t.tolist())
+  out = {
+      'what': 'one complete segment_all pass over each rank\'s %s volume (%d '
+              'rank(s), summed): every grid seed, segment commits included; wall '
+              'clock between barriers' % ('x'.join(str(v) for v in VOLUME_ZYX), world),
+      'steps': int(steps),
+      'seconds': round(t_all, 4),
+      'fov_steps_per_s': round(steps / t_all, 1),
+      'voxels_segmented': int(voxels),
+      'voxels_segmented_per_s': round(voxels / t_all, 1),
+      'objects': len(canvas.origins),
+      'rank0': {'steps': int(steps0), 'voxels_segmented': int(voxels0)},
+      'seeds_tried': int(len(fixture['seeds'])) if fixture is not None else None,
+      'rank0_seconds': round(t_local, 4),
+  }
+  seg = np.array(np.asarray(canvas.segmentation))
+  canvas.close()
+  if fixture is not None and rank == 0:
+    want = fixture['segmentation'].astype(np.int32)
+    inter = int(np.sum((seg > 0) & (want > 0) & (seg == want)))
+    union = int(np.sum((seg > 0) | (want > 0)))
+    ref_steps = [tuple(int(v) for v in p) for p in fixture['steps']]
+    # untimed: the same pass with the positions kept
+    canvas = make(inference_utils.Counters(), keep_history=True)
+    seen = []
+    inner = canvas._segment_at_native
+
+    def recording(start_pos, *a, **kw):
+      n = inner(start_pos, *a, **kw)
+      if n:
+        seen.extend(tuple(int(v) for v in p) for p in canvas.history[-n:])
+      return n
+
+    canvas._segment_at_native = recording
+    canvas.segment_all(seed_policy=policy)
+    again = np.array(np.asarray(canvas.segmentation))
+    canvas.close()
+    n = min(len(seen), len(ref_steps))
+    first_bad = next((k for k in range(n) if seen[k] != ref_steps[k]), None)
+    out['vs_reference_run'] = {
+        'fixture': 'tests/golden/ref_canvas_cells250_onednn_full.npz (the '
+                   'reference\'s Canvas behind the torch-CPU / oneDNN f32 forward)',
+        'iou': round(inter / max(union, 1), 6),
+        'reference_steps': len(ref_steps),
+        'reference_objects': len(json.loads(str(fixture['origins']))),
+        'first_position_mismatch': first_bad,
+        'positions_compared': n,
+        'repeat_pass_identical': bool(np.array_equal(again, seg)),
+    }
+  eng.set_option('profile_every', mode)
+  eng.set_profiling(args.profile_mode)
+  return out
+
+
 def run_gpu(args, rank, local_rank, world):
   import torch
   import torch.distributed as dist
@@ -196,7 +304,7 @@ def run_gpu(args, rank, local_rank, world):
 
   shape = VOLUME_ZYX
   if args.workload == 'cells':
-    vol = synthetic.cells_volume(shape, seed=1234 + rank)
+    vol = bench_volume(shape, 1234 + rank)
   else:
     vol = synthetic.noise_volume(shape, seed=rank)
   image = synthetic.normalize(vol)
@@ -294,7 +402,10 @@ def run_gpu(args, rank, local_rank, world):
   canvas = new_canvas()
   # HIP-event pairs around every conv32 launch of 1 FoV step in
   # `profile_every` (sampling keeps the event overhead out of `value`).
-  eng.set_option('profile_every', args.profile_every)
+  # (a short timed region -- the driver's 20 steps -- is sampled whole)
+  profile_every = 1 if args.steps <= 50 else args.profile_every
+  state['profile_every'] = profile_every
+  eng.set_option('profile_every', profile_every)
   eng.set_profiling(args.profile_mode)
   policy = functools.partial(seed_lib.PolicyGrid3d, step=16,
                              offsets=(0, 8, 4, 12, 2, 10, 14))
@@ -316,6 +427,8 @@ def run_gpu(args, rank, local_rank, world):
   state['volume_passes_completed'] = passes
 
   conv_ms, conv_launches = eng.get_profile()
+  prof_samples_ms = eng.get_profile_samples()
+  flow = eng.get_option('flow')
   elapsed = state['t1'] - state['t0']
   elapsed_local = state['t1_local'] - state['t0']
   if world > 1:
@@ -348,7 +461,12 @@ def run_gpu(args, rank, local_rank, world):
   canvas._flush_hot()
   cvals = {k: c.value for k, c in counters}
   cvals['gate_rejects'] = canvas.gate_rejects
+  full_volume = None
+  if not args.no_full_volume:
+    full_volume = full_volume_pass(args, rank, world, model, exe, request, image,
+                                   barrier)
   result = {
+      'full_volume': full_volume,
       'merge_ms': merge_ms,
       'merged_ids': merged_ids,
       'counters': cvals,
@@ -369,6 +487,9 @@ def run_gpu(args, rank, local_rank, world):
       'elapsed_local': elapsed_local,
       'conv_ms': conv_ms,
       'conv_launches': conv_launches,
+      'prof_samples_ms': prof_samples_ms,
+      'flow': flow,
+      'profile_every': state['profile_every'],
       'voxels': state['vox1'] - state['vox0'],
       # voxels leg: everything this rank did from its first FoV step (prewarm +
       # warmup + timed steps, segment set-up and commits included) on its own
@@ -427,15 +548,15 @@ def run_sharded(args, rank, local_rank, world):
     torch.cuda.synchronize()
 
   n = args.sharded_volume
-  shape = (n, n, n)
+  shape = tuple(args.sharded_volume_zyx) if args.sharded_volume_zyx else (n, n, n)
   # ONE volume for the job: rank 0 builds it, the others map it (a per-rank
   # build costs a nearest-centre query per voxel -- 10^9 at 1024^3 -- per rank)
   t_setup0 = time.perf_counter()
   shm = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
-  vol_path = os.path.join(shm, 'ffn_amd_bench_cells_%d_%s.npy' % (
-      n, os.environ.get('MASTER_PORT', str(os.getpid()))))
+  vol_path = os.path.join(shm, 'ffn_amd_bench_cells_%s_%s.npy' % (
+      'x'.join(str(v) for v in shape), os.environ.get('MASTER_PORT', str(os.getpid()))))
   vol = synthetic.shared_volume(
-      lambda: synthetic.cells_volume(shape, seed=4321), vol_path, rank,
+      lambda: bench_volume(shape, 4321), vol_path, rank,
       barrier if world > 1 else None)
   t_volume = time.perf_counter() - t_setup0
   # (after the volume: its nearest-centre queries use every CPU the job has)
@@ -445,8 +566,12 @@ def run_sharded(args, rank, local_rank, world):
   request.seed_policy = 'PolicyPeaks'
   out_dir = tempfile.mkdtemp(prefix='ffn_sharded_%d_' % rank)
   request.segmentation_output_dir = out_dir
-  request.model_checkpoint_path = os.path.join(ROOT, 'tests', 'golden',
-                                               'fib25_weights.npz')
+  if CONFIG == 'c1':
+    request.model_checkpoint_path = os.path.join(ROOT, 'tests', 'golden',
+                                                 'fib25_weights.npz')
+  else:
+    request.model_checkpoint_path = os.path.join(out_dir, 'weights.npz')
+    np.savez(request.model_checkpoint_path, **model_variables())
   run = runner_lib.Runner(device_id=local_rank)
   run.start(request, batch_size=args.sharded_batch, direct=True,
             image_volume=vol)
@@ -542,8 +667,9 @@ def run_sharded(args, rank, local_rank, world):
     except OSError:
       pass
   check = None
-  if world == 1 and not args.no_cpu_baseline:
+  if world == 1 and not args.no_assembly_check:
     # checker leg (untimed): the assembly against its numpy specification
+    t_check = time.perf_counter()
     from oracle import labels_oracle
     host_results = [(b, seg.cpu().numpy()) for b, seg in held]
     host_results.sort(key=lambda r: r[0].index)  # ids follow the box index
@@ -554,7 +680,12 @@ def run_sharded(args, rank, local_rank, world):
     check = {'ids_expected': int(len(np.unique(want)) - 1),
              'ids_got': int(len(np.unique(got)) - 1),
              'volume_equal': bool(np.array_equal(got, want)),
-             'edges_equal': bool(np.array_equal(edges, want_edges))}
+             'edges_equal': bool(np.array_equal(edges, want_edges)),
+             'voxels_labelled': int((got > 0).sum()),
+             'what': 'device assembly + reconciliation of every sub-box against '
+                     'oracle/labels_oracle.reconcile (numpy, single process) on '
+                     'the same sub-box labels',
+             'seconds': round(time.perf_counter() - t_check, 1)}
   run.stop_executor()
   if world > 1:
     dist.barrier()
@@ -566,11 +697,13 @@ def run_sharded(args, rank, local_rank, world):
   # batch / the time of the whole resident stack (conv0_a included: it is
   # 1 / (2 depth) of the launches), against the ceiling of the arithmetic used
   fov_launch_us = stack_us / args.sharded_batch / (2 * DEPTH)
-  batched_tflops = CONV32_FLOPS / (fov_launch_us * 1e-6) / 1e12
+  # every flop of the resident stack (conv0_a's 0.124 GFLOP, the 2 depth - 1
+  # convs, the fused head) over its wall time -- NOT 2 depth equal launches
+  batched_tflops = args.sharded_batch * STEP_FLOPS / (stack_us * 1e-6) / 1e12
   batched_peak = PEAK_BF16_MFMA_TFLOPS / 3.0
   out = {
-      'metric': 'FoV-steps/sec (one %d^3 volume sharded by sub-box over %d GPU(s))'
-                % (n, world),
+      'metric': 'FoV-steps/sec (one %s volume sharded by sub-box over %d GPU(s))'
+                % ('x'.join(str(v) for v in shape), world),
       'value': round(steps_all / t_seg, 2),
       'unit': 'FoV-steps/s',
       'n_gpus': world,
@@ -583,15 +716,22 @@ def run_sharded(args, rank, local_rank, world):
       'dtype': 'f32 (split products on the fp16 MFMA)',
       'data': 'synthetic',
       'config': {
-          'workload': ('configs[2] / configs[3]-shaped: ONE synthetic cells %d^3 '
+          'workload': ('%s: ONE synthetic cells %s (zyx) '
                        'uint8 volume, %d overlapping sub-boxes of %s (overlap = '
-                       'FoV), %s deal, %d canvases open per GPU in %d group(s) '
+                       'FoV = %s), %s deal, %d canvases open per GPU in %d group(s) '
                        'of %d (= FoVs per engine call), GPU PolicyPeaks seeds, '
-                       'FIB-25 weights; assembly on the devices'
-                       % (n, len(boxes), 'x'.join(str(v) for v in sub),
-                          args.sharded_deal,
+                       '%s; assembly on the devices'
+                       % ('configs[2] / configs[3]-shaped' if CONFIG == 'c1' else
+                          'configs[4]-shaped (depth %d, FoV zyx %s, deltas %s)'
+                          % (DEPTH, list(FOV), list(DELTAS)),
+                          'x'.join(str(v) for v in shape), len(boxes),
+                          'x'.join(str(v) for v in sub),
+                          'x'.join(str(v) for v in ov), args.sharded_deal,
                           args.sharded_batch * args.sharded_groups,
-                          args.sharded_groups, args.sharded_batch)),
+                          args.sharded_groups, args.sharded_batch,
+                          'FIB-25 weights' if CONFIG == 'c1' else
+                          'constructed flood-fill weights '
+                          '(synthetic.flood_fill_weights)')),
           'volume': list(shape),
           'sub_boxes': len(boxes),
           'conv_variant': conv_variant,
@@ -632,8 +772,17 @@ def run_sharded(args, rank, local_rank, world):
           'unit': 'TFLOP/s',
           'frac': round(batched_tflops / batched_peak, 4),
           'timing': 'wall clock over %d resident stacks of %d FoVs (conv0_a + '
-                    '%d conv launches each), / batch / %d launches'
-                    % (kernel_reps, args.sharded_batch, 2 * DEPTH - 1, 2 * DEPTH),
+                    '%d conv launches each): achieved = batch x %.2f GFLOP (all of '
+                    'a step\'s flops) / stack time; us_per_fov_launch = stack / '
+                    'batch / %d launches'
+                    % (kernel_reps, args.sharded_batch, 2 * DEPTH - 1,
+                       STEP_FLOPS / 1e9, 2 * DEPTH),
+          'whole_run': {
+              'what': 'every flop of the run\'s FoV steps over its end-to-end time',
+              'tflops': round(steps_all / world * STEP_FLOPS / t_seg / 1e12, 1),
+              'frac': round(steps_all / world * STEP_FLOPS / t_seg / 1e12 /
+                            batched_peak, 4),
+          },
       },
       'segmentation_seconds': round(t_seg, 3),
       'voxels_segmented_per_s': round(voxels_all / t_seg, 1),
@@ -669,7 +818,7 @@ def cpu_baseline(args):
   blob = ffn_oracle.weights_blob(variables, DEPTH)
   shape = VOLUME_ZYX
   if args.workload == 'cells':
-    vol = synthetic.cells_volume(shape, seed=1234)
+    vol = bench_volume(shape, 1234)
   else:
     vol = synthetic.noise_volume(shape, seed=0)
   image = synthetic.normalize(vol)
@@ -859,6 +1008,8 @@ def batched_leg(args):
          '--sharded-volume', '512', '--sharded-sub', '153', '--sharded-batch', '16',
          '--sharded-groups', '2', '--sharded-max-steps',
          str(args.batched_max_steps), '--no-cpu-baseline']
+  # (the assembled 512^3 labels are checked against the numpy specification
+  # unless the run is bounded: dropped canvases leave nothing to compare)
   t0 = time.perf_counter()
   try:
     run = subprocess.run(cmd, capture_output=True, text=True,
@@ -880,6 +1031,9 @@ def batched_leg(args):
       'steps': d['steps'],
       'seconds': d['segmentation_seconds'],
       'roofline': d['batched_kernel'],
+      'check_vs_specification': d['assembly']['check_vs_specification'],
+      'voxels_segmented_per_s': d['voxels_segmented_per_s'],
+      'assembly_ms': d['assembly']['merge_plus_reconcile_ms'],
       'engine_calls': d['engine_calls'],
       'host_loop': d['host_loop'],
       'setup_seconds': d['setup_seconds'],
@@ -920,6 +1074,8 @@ def main():
                   help='stream: the headline (one seed stream per GPU); sharded: '
                   'one volume tiled into sub-boxes, timed assembly (configs[3])')
   ap.add_argument('--sharded-volume', type=int, default=320)
+  ap.add_argument('--sharded-volume-zyx', type=int, nargs=3, default=None,
+                  help='a non-cubic volume (configs[4]: 256 2048 2048)')
   ap.add_argument('--sharded-sub', type=int, default=176)
   ap.add_argument('--sharded-sub-zyx', type=int, nargs=3, default=None,
                   help='sub-box size zyx (default: --sharded-sub cubed)')
@@ -950,6 +1106,12 @@ def main():
   ap.add_argument('--cpu-seconds', type=float, default=15.0)
   ap.add_argument('--cpu-steps', type=int, default=60)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-full-volume', action='store_true',
+                  help='skip the complete segment_all pass (and its comparison '
+                  'with the reference-minted run) behind the K timed steps')
+  ap.add_argument('--no-assembly-check', action='store_true',
+                  help='--mode sharded: skip the (untimed) comparison of the '
+                  'assembled volume with the numpy specification')
   ap.add_argument('--no-batched-leg', action='store_true',
                   help='skip the time-boxed batched (configs[2]) leg of the '
                   'default run')
@@ -978,8 +1140,25 @@ def main():
     return
 
   steps_per_s = world * args.steps / res['elapsed']
+  n_convs = 2 * DEPTH - 1
   avg_conv_ms = res['conv_ms'] / max(res['conv_launches'], 1)
-  achieved = CONV32_FLOPS / (avg_conv_ms * 1e-3) / 1e12 if avg_conv_ms else 0.0
+  # one sample = one HIP-event pair (on the engine's stream) around the convs of
+  # a step: the ONE launch of the resident stack (engine option flow 2), or the
+  # chain of 2 depth - 1 dependent launches (then with their gaps), or -- mode 1
+  # -- a single conv launch
+  samples_ms = np.asarray(res['prof_samples_ms'], np.float64)
+  per_sample_convs = n_convs if args.profile_mode == 2 else 1
+  resident = res.get('flow') == 2 and res.get('conv_variant') == 9
+  if len(samples_ms):
+    med_ms, min_ms, mean_ms = (float(np.median(samples_ms)), float(samples_ms.min()),
+                               float(samples_ms.mean()))
+  else:
+    med_ms = min_ms = mean_ms = avg_conv_ms * per_sample_convs
+  # achieved = algorithmic flops of the sampled launches / their MEAN duration
+  # (what rocprofv3 --stats reports as the kernel's average; median and minimum
+  # next to it)
+  achieved = (per_sample_convs * CONV32_FLOPS / (mean_ms * 1e-3) / 1e12
+              if mean_ms else 0.0)
   # HBM traffic of the conv kernel cannot be counted from inside this process
   # (PMC counters need rocprofv3): it is taken from the committed PMC profile of
   # this same command, when present.
@@ -1002,7 +1181,11 @@ def main():
   if variant >= 6:
     products = SPLIT_PRODUCTS
     mfma = 'v_mfma_f32_32x32x16_f16'
-    shape = ('conv32mt (3x3x3 32->32 implicit GEMM on producer-split fp16 planes '
+    shape = (('conv32ps: the %d convs of a step as ONE resident launch -- conv32mt\'s '
+              'workgroups keep their voxels through the stack and hand rows to each '
+              'other through per-producer sequence words instead of kernel '
+              'boundaries; each conv = ' % n_convs if resident else '') +
+             'conv32mt (3x3x3 32->32 implicit GEMM on producer-split fp16 planes '
              'staged by LDS-DMA: 256 conv32m workgroups of 128 voxels, one per '
              'CU -- one 32-position tile per wave for all 27 taps, weights '
              'through an LDS-DMA ring -- and the remaining voxels in 32-voxel '
@@ -1056,7 +1239,8 @@ def main():
               'FIB-25 weights, device-resident canvas, batch 1'
               % (args.workload, args.volume) if CONFIG == 'c1' else
               'configs[4] model on one tile: depth=18 fov zyx %s deltas %s, '
-              'synthetic %s %s uint8 volume per GPU, random weights, '
+              'synthetic %s %s uint8 volume per GPU, constructed flood-fill weights '
+              '(synthetic.flood_fill_weights: no checkpoint of this shape exists), '
               'device-resident canvas, batch 1 (NOT the headline config)'
               % (list(FOV), list(DELTAS), args.workload, list(VOLUME_ZYX))),
           'volume': list(VOLUME_ZYX),
@@ -1068,8 +1252,12 @@ def main():
           'env': {k: os.environ[k] for k in ('HIP_FORCE_DEV_KERNARG',)
                   if k in os.environ},
       },
-      'voxels_segmented_per_s': round(
-          res['voxels_run'] / max(res['seconds_run'], 1e-9), 1),
+      # the second half of BASELINE.json's metric: from the complete pass below
+      # (`full_volume`) when it ran, else from the partial run (`voxels_leg`)
+      'voxels_segmented_per_s': (
+          res['full_volume']['voxels_segmented_per_s'] if res.get('full_volume')
+          else round(res['voxels_run'] / max(res['seconds_run'], 1e-9), 1)),
+      'full_volume': res.get('full_volume'),
       'voxels_leg': {
           'voxels_segmented': int(res['voxels_run']),
           'fov_steps': int(res['steps_run']),
@@ -1115,15 +1303,40 @@ def main():
           'vs_native_f32_mfma_peak': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
           'traffic': traffic,
           'traffic_source': traffic_source,
-          'avg_launch_us': round(avg_conv_ms * 1e3, 3),
-          'timing': ('HIP events around the %d-launch conv chain of every %dth '
-                     'step, / %d (includes inter-kernel gaps)' %
-                     (2 * DEPTH - 1, args.profile_every, 2 * DEPTH - 1)
-                     if args.profile_mode == 2 else
-                     'HIP event pair around each conv launch of every %dth step'
-                     % args.profile_every),
-          'launches': int(res['conv_launches']),
-          'flops_per_launch': CONV32_FLOPS,
+          'launch_kernel': ('conv32ps_kernel' if resident else
+                            'conv32mt_kernel' if variant == 9 else 'conv32*_kernel'),
+          'launches_per_step': 1 if resident else n_convs,
+          'convs_per_launch': n_convs if resident else 1,
+          'flops_per_launch': (n_convs if resident else 1) * CONV32_FLOPS,
+          'avg_launch_us': round(
+              mean_ms * 1e3 / (1 if resident else per_sample_convs), 3),
+          'median_launch_us': round(
+              med_ms * 1e3 / (1 if resident else per_sample_convs), 3),
+          'min_launch_us': round(
+              min_ms * 1e3 / (1 if resident else per_sample_convs), 3),
+          'us_per_conv': round(mean_ms * 1e3 / per_sample_convs, 3),
+          'frac_at_median': round(
+              per_sample_convs * CONV32_FLOPS / (med_ms * 1e-3) / 1e12 / peak, 4)
+              if med_ms else None,
+          'frac_at_min': round(
+              per_sample_convs * CONV32_FLOPS / (min_ms * 1e-3) / 1e12 / peak, 4)
+              if min_ms else None,
+          'samples': int(len(samples_ms)),
+          'timing': ('HIP event pair on the engine\'s stream around the conv '
+                     'launch(es) of %s step of the timed region: %s'
+                     % ('every' if res.get('profile_every', 1) == 1 else
+                        'every %dth' % res['profile_every'],
+                        'the one resident launch' if resident else
+                        'the chain of %d dependent launches, gaps included, / %d'
+                        % (n_convs, n_convs) if args.profile_mode == 2 else
+                        'each launch by itself')),
+          'whole_step': {
+              'what': 'every flop of the step (conv0_a, the %d convs, the head) '
+                      'over the end-to-end time per step (host turn-around, '
+                      'conv0_a, faces + paste included)' % n_convs,
+              'tflops': round(steps_per_s / world * STEP_FLOPS / 1e12, 3),
+              'frac': round(steps_per_s / world * STEP_FLOPS / 1e12 / peak, 4),
+          },
       },
   }
   if world == 1 and not args.no_cpu_baseline:

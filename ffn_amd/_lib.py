@@ -128,6 +128,7 @@ SIGNATURES = {
     'ffn_engine_set_profiling': (_I, [_P, _I]),
     'ffn_engine_get_profile': (_I, [_P, ctypes.POINTER(ctypes.c_double),
                                     ctypes.POINTER(ctypes.c_int64), _I]),
+    'ffn_engine_get_profile_samples': (_I, [_P, _P, _I, _P]),
     'ffn_engine_synchronize': (_I, [_P]),
     'ffn_engine_debug_clocks': (_I, [_P, _P]),
     'ffn_engine_debug_workgroups': (_I, [_P, _P, _I]),

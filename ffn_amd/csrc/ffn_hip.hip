@@ -227,6 +227,7 @@ struct ffn_engine {
   bool prof_now = false;
   int ablate = 0;                     // debug: skip phases of the conv kernel
   std::vector<int> chain_launches_pending;  // mode 2: launches per event pair
+  std::vector<float> prof_samples;  // ms of every event pair since the last reset
 };
 
 struct ffn_canvas {
@@ -490,6 +491,7 @@ int flush_events(ffn_engine* e) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e->events[k], e->events[k + 1]));
     e->conv_ms += ms;
+    if (e->prof_samples.size() < (size_t)(1 << 16)) e->prof_samples.push_back(ms);
     if (e->prof_mode == 2 && !e->chain_launches_pending.empty()) {
       e->conv_launches += e->chain_launches_pending.front();
       e->chain_launches_pending.erase(e->chain_launches_pending.begin());
@@ -1779,7 +1781,20 @@ int ffn_engine_get_profile(ffn_engine* e, double* conv_ms_total,
   if (reset) {
     e->conv_ms = 0.0;
     e->conv_launches = 0;
+    e->prof_samples.clear();
   }
+  return FFN_OK;
+}
+
+int ffn_engine_get_profile_samples(ffn_engine* e, float* out_ms, int max_n, int* n) {
+  EngineLock lock_(e);
+  if (!e || !n || (max_n > 0 && !out_ms)) return fail(FFN_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = flush_events(e);
+  if (rc) return rc;
+  const int k = (int)std::min<size_t>(e->prof_samples.size(), (size_t)std::max(max_n, 0));
+  for (int i = 0; i < k; ++i) out_ms[i] = e->prof_samples[i];
+  *n = (int)e->prof_samples.size();
   return FFN_OK;
 }
 

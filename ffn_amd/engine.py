@@ -199,6 +199,14 @@ class HipEngine:
                                            ctypes.byref(n), int(reset)))
     return ms.value, n.value
 
+  def get_profile_samples(self, max_n: int = 65536) -> np.ndarray:
+    """ms of every sampled event pair since the last get_profile(reset=True)."""
+    out = np.zeros(max_n, np.float32)
+    n = ctypes.c_int()
+    check(self._lib.ffn_engine_get_profile_samples(self._h, out.ctypes.data, max_n,
+                                                   ctypes.byref(n)))
+    return out[:min(n.value, max_n)].copy()
+
   def debug_clocks(self):
     out = np.zeros(24, np.int64)
     check(self._lib.ffn_engine_debug_clocks(self._h, out.ctypes.data))

@@ -75,3 +75,68 @@ def normalize(volume_u8: np.ndarray, mean: float = 128.0,
               stddev: float = 33.0) -> np.ndarray:
   """(u8 -> f32 - mean) / stddev, exactly as reference runner.py:383-385."""
   return (volume_u8.astype(np.float32) - mean) / stddev
+
+
+def flood_fill_weights(depth: int, features: int = 32, gain: float = 8.0,
+                       decay: float = -1.0, texture: float = 0.2) -> dict:
+  """TF-named variables of a ConvStack3DFFNModel of any depth / FoV that floods
+  BRIGHT, 26-CONNECTED regions: a constructed stand-in for a trained network
+  where none exists (BASELINE configs[4]: depth 18, FoV 41 x 41 x 21 -- the
+  reference ships no checkpoint of that shape), with the same architecture and
+  arithmetic cost and a behaviour a segmentation can be judged by: on the
+  `cells_volume` phantom every flood stays inside its cell.
+
+  Two channels of the residual stream carry everything (the others stay 0):
+    X0 = clamp(16 image - 6)   "bright"  (normalised image > 0.44), constant
+    X1 = clamp(4 seed)         "object"  (seed logit > 0.25)
+  with clamp(z) = relu(z) - relu(z - 1).  Every residual module dilates the
+  object by one voxel inside the bright region:
+    X1 <- clamp(boxsum3x3x3(X1) + 27 X0 - 27)
+  (conv_a: u1 = relu(z), u2 = relu(z - 1), u3 = relu(X1); conv_b: u1 - u2 - u3
+  added to the skip), so one FoV step grows the object by depth - 1 voxels, and
+  the head adds `gain + decay` to the logits of object voxels and `decay` to the
+  others -- plus `texture` x clamp(0.5 + a seeded random 3x3x3 filter of the
+  image), a third channel carried through the stack untouched: without it whole faces of
+  the FoV would hold EQUAL logits and the move policy's argmax would be decided
+  by the last bit of each kernel's rounding."""
+  assert features >= 6 and depth >= 2
+  f = features
+  v = {}
+
+  def conv(name, cin, cout, k=3):
+    v['seed_update/%s/weights' % name] = np.zeros((k, k, k, cin, cout), np.float32)
+    v['seed_update/%s/biases' % name] = np.zeros((cout,), np.float32)
+    return v['seed_update/%s/weights' % name], v['seed_update/%s/biases' % name]
+
+  w, b = conv('conv0_a', 2, f)       # input channel 0 = image, 1 = seed
+  w[1, 1, 1, 0, 0] = 16.0; b[0] = -6.0  # relu(16 img - 6)
+  w[1, 1, 1, 0, 1] = 16.0; b[1] = -7.0  # relu(16 img - 7)
+  w[1, 1, 1, 1, 2] = 4.0; b[2] = 0.0    # relu(4 seed)
+  w[1, 1, 1, 1, 3] = 4.0; b[3] = -1.0   # relu(4 seed - 1)
+  # texture: clamp(0.5 + a seeded random 3x3x3 filter of the image), in [0, 1]
+  tex = np.random.RandomState(5).normal(0, 0.03, (3, 3, 3))
+  w[:, :, :, 0, 4] = tex; b[4] = 0.5
+  w[:, :, :, 0, 5] = tex; b[5] = -0.5
+  w, b = conv('conv0_b', f, f)       # linear: the two clamps
+  w[1, 1, 1, 0, 0] = 1.0
+  w[1, 1, 1, 1, 0] = -1.0
+  w[1, 1, 1, 2, 1] = 1.0
+  w[1, 1, 1, 3, 1] = -1.0
+  w[1, 1, 1, 4, 4] = 1.0
+  w[1, 1, 1, 5, 4] = -1.0
+  for i in range(1, depth):
+    w, b = conv('conv%d_a' % i, f, f)
+    for out, bias in ((1, -27.0), (2, -28.0)):
+      w[:, :, :, 1, out] = 1.0       # box sum of the object channel
+      w[1, 1, 1, 0, out] = 27.0      # + 27 bright
+      b[out] = bias
+    w[1, 1, 1, 1, 3] = 1.0           # relu(X1) = X1
+    w, b = conv('conv%d_b' % i, f, f)
+    w[1, 1, 1, 1, 1] = 1.0
+    w[1, 1, 1, 2, 1] = -1.0
+    w[1, 1, 1, 3, 1] = -1.0
+  w, b = conv('conv_lom', f, 1, k=1)
+  w[0, 0, 0, 1, 0] = gain
+  w[0, 0, 0, 4, 0] = texture
+  b[0] = decay
+  return v

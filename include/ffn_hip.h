@@ -268,6 +268,11 @@ int ffn_canvas_write_segmentation(ffn_canvas* canvas, const int32_t lo[3],
 int ffn_engine_set_profiling(ffn_engine* engine, int mode);
 int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
                            int64_t* conv_launches, int reset);
+/* The individual event-pair durations (ms) behind ffn_engine_get_profile since
+ * its last reset -- one per sampled conv launch (mode 1) or per sampled conv
+ * chain of a step (mode 2: 2 depth - 1 launches, or the ONE launch of the
+ * resident stack): *n = how many exist, the first min(*n, max_n) are copied. */
+int ffn_engine_get_profile_samples(ffn_engine* engine, float* out_ms, int max_n, int* n);
 /* Kernel choice and tuning switches.  "conv_variant":
  *   0 = simple exact-f32 MFMA conv over padded positions (takes any FoV that
  *       fits the LDS at all),

@@ -124,6 +124,57 @@ def test_predict_is_deterministic_and_variants_agree(engine):
   engine.restore_default_variant()
 
 
+@pytest.mark.parametrize('fov_xyz,deltas_xyz,depth', [
+    ([33, 33, 33], [8, 8, 8], 2), ([33, 33, 33], [8, 8, 8], 3),
+    ([33, 33, 33], [8, 8, 8], 12), ([41, 41, 21], [10, 10, 5], 5),
+    ([35, 33, 31], [8, 8, 7], 3), ([49, 49, 25], [12, 12, 6], 3)])
+def test_resident_stack_same_bits_as_per_layer_launches(fov_xyz, deltas_xyz, depth):
+  """Engine option flow (ffn_kernels.h, conv32ps): a single-FoV step of conv32mt
+  runs its 2 depth - 1 convs as ONE resident launch whose workgroups hand rows
+  to each other through per-producer sequence words (flow 2, the default), as
+  one launch per conv with the same hand-off compiled in (1), or as plain
+  dependent launches (0).  Every conv's arithmetic is the same instruction
+  sequence: the logits must be equal bit for bit, run after run, whatever the
+  workgroups' relative timing; no poll may ever give up."""
+  from ffn_amd import _lib
+  from ffn_amd import engine as hip_engine
+  from ffn_amd.training.models import convstack_3d
+  from oracle import ffn_oracle
+  m = convstack_3d.ConvStack3DFFNModel(fov_size=fov_xyz, deltas=deltas_xyz,
+                                       depth=depth)
+  m.set_variables(ffn_oracle.random_weights(depth, seed=40 + depth, stddev=0.05))
+  eng = hip_engine.HipEngine.from_model(m, max_batch=1)
+  zyx = fov_xyz[::-1]
+  if eng.get_option('conv_variant') != 9:
+    # conv32mt does not take this FoV (<= 256 chunks): flow must refuse
+    with pytest.raises(_lib.FFNHipError):
+      eng.set_option('flow', 2)
+    assert eng.get_option('flow') == 0
+    eng.close()
+    return
+  assert eng.get_option('flow') == 2
+  rng = np.random.RandomState(7)
+  for trial in range(4):
+    img = rng.normal(0, 1, [1] + zyx).astype(np.float32)
+    seed = rng.normal(0, 1.5, [1] + zyx).astype(np.float32)
+    got = {}
+    for flow in (0, 2, 1, 2, 2):
+      eng.set_option('flow', flow)
+      out = eng.predict(seed, img)
+      if flow in got:
+        assert np.array_equal(out, got[flow]), (trial, flow)
+      got[flow] = out
+    assert np.array_equal(got[0], got[2]), trial
+    assert np.array_equal(got[0], got[1]), trial
+  # many back-to-back resident stacks (no host round trip between them)
+  eng.set_option('flow', 2)
+  eng.forward_resident(1, 200)
+  eng.synchronize()
+  assert np.array_equal(eng.predict(seed, img), got[0])
+  assert eng.get_option('stat_flow_timeouts') == 0
+  eng.close()
+
+
 @pytest.mark.parametrize('fov_xyz,deltas_xyz', [([25, 25, 25], [6, 6, 6]),
                                                 ([29, 21, 17], [7, 5, 4]),
                                                 ([49, 49, 25], [12, 12, 6]),
@@ -179,12 +230,31 @@ def test_c5_model_full_depth(fib25_model):
   seed = rng.normal(0, 2, (2, 21, 41, 41)).astype(np.float32)
   blob = ffn_oracle.weights_blob(variables, 18)
   want = ffn_oracle.forward(img, seed, blob, 18)
-  for variant in sorted({2, 6, eng.get_option('conv_variant')}):
+  default = eng.get_option('conv_variant')
+  assert default == 9 and eng.get_option('flow') == 2  # permuted layout, resident stack
+  for variant in sorted({2, 6, default}):
     eng.set_option('conv_variant', variant)
     got = eng.predict(seed, img)
     err = np.abs(got - want).max()
     print('c5 depth 18 variant %d: max |err| %.3g' % (variant, err))
     assert err <= TOL, (variant, err)
+    # n = 1: the default then runs conv32mt (its K-split tail; as ONE resident
+    # launch of 35 convs under flow 2, as 35 launches under flow 0) on the
+    # permuted layout, n = 2 above ran conv32m
+    flows = (2, 1, 0) if variant == default else (eng.get_option('flow'),)
+    ones = []
+    for flow in flows:
+      eng.set_option('flow', flow)
+      for k in range(2):
+        one = eng.predict(seed[k:k + 1], img[k:k + 1])
+        err1 = np.abs(one[0] - want[k]).max()
+        assert err1 <= TOL, (variant, flow, k, err1)
+        ones.append(one)
+    if variant == default:
+      assert np.array_equal(ones[0], ones[2]) and np.array_equal(ones[0], ones[4])
+      assert np.array_equal(ones[1], ones[3]) and np.array_equal(ones[1], ones[5])
+      assert eng.get_option('stat_flow_timeouts') == 0
+    eng.set_option('flow', 2)
   eng.close()
 
 
@@ -1039,3 +1109,119 @@ def test_native_segment_loop_budget_and_resume(fib25_model):
   assert out[0][0] == out[1][0] > 20 and out[1][4] > 5
   assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
   assert np.array_equal(out[0][3], out[1][3], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_c5_sharded_anisotropic_volume_reconciled(tmp_path):
+  """BASELINE configs[4] as stated, at test size: the depth-18 model with FoV
+  zyx (21, 41, 41) / deltas (5, 10, 10) on ONE anisotropic volume cut into
+  overlapping ANISOTROPIC sub-boxes (overlap = FoV = 21 x 41 x 41), the sub-boxes
+  advanced together through batched engine calls, their labels assembled and
+  reconciled on the device.  The reference ships no checkpoint of this shape:
+  the network is `synthetic.flood_fill_weights` (floods bright 26-connected
+  regions), so segments end at the phantom's membranes and COMMIT.
+
+  Checked: (0) the kernels against the C oracle on real canvas states; (1) every sub-box equals a standalone single-canvas run of the same box
+  (conv32m batched == conv32mt / resident stack single); (2) the assembly
+  equals the numpy specification; (3) objects were committed and merged
+  across the cuts."""
+  from ffn_amd import distributed as ffn_dist
+  from ffn_amd import engine as hip_engine
+  from ffn_amd import synthetic
+  from ffn_amd.inference import request as req_lib
+  from ffn_amd.inference import runner as runner_lib
+  from ffn_amd.training.models import convstack_3d
+  from oracle import ffn_oracle
+  from oracle import labels_oracle
+  depth, fov_xyz, deltas_xyz = 18, [41, 41, 21], [10, 10, 5]
+  shape = (56, 150, 150)
+  vol = synthetic.cells_volume(shape, seed=91, membrane_dilate=2)
+  vol_path = str(tmp_path / 'vol.npy')
+  np.save(vol_path, vol)
+  variables = synthetic.flood_fill_weights(depth)
+  weights = str(tmp_path / 'weights.npz')
+  np.savez(weights, **variables)
+
+  # (0) predict == oracle, exactly, on two FoVs of the volume with a seed blob
+  m = convstack_3d.ConvStack3DFFNModel(fov_size=fov_xyz, deltas=deltas_xyz,
+                                       depth=depth)
+  m.set_variables(variables)
+  eng = hip_engine.HipEngine.from_model(m, max_batch=2)
+  img = synthetic.normalize(vol)
+  blob = ffn_oracle.weights_blob(variables, depth)
+  fovs, seeds = [], []
+  for (z, y, x) in ((10, 30, 40), (30, 90, 70)):
+    fovs.append(img[z:z + 21, y:y + 41, x:x + 41])
+    sd = np.full((21, 41, 41), ffn_oracle.f32_logit(0.05), np.float32)
+    sd[8:13, 18:23, 18:23] = ffn_oracle.f32_logit(0.95)
+    seeds.append(sd)
+  fovs, seeds = np.stack(fovs), np.stack(seeds)
+  want = np.stack([ffn_oracle.forward(fovs[k], seeds[k], blob, depth)
+                   for k in range(2)])
+  grown = (want - seeds) > 3.0
+  assert 1000 < grown[0].sum() < 0.9 * grown[0].size  # it floods, inside its cell
+  for variant, flow in ((2, 0), (6, 0), (9, 2), (9, 0)):
+    eng.set_option('conv_variant', variant)
+    eng.set_option('flow', flow)
+    assert np.abs(eng.predict(seeds, fovs) - want).max() <= TOL, (variant, flow)
+    for k in range(2):
+      one = eng.predict(seeds[k:k + 1], fovs[k:k + 1])[0]
+      assert np.abs(one - want[k]).max() <= TOL, (variant, flow, k)
+  eng.close()
+
+  def make_request(out_dir):
+    return req_lib.request_from_text('''
+      image { npy: "%s" }
+      image_mean: 128
+      image_stddev: 33
+      seed_policy: "PolicyPeaks"
+      model_checkpoint_path: "%s"
+      model_name: "convstack_3d.ConvStack3DFFNModel"
+      model_args: "{\\"depth\\": 18, \\"fov_size\\": [41, 41, 21], \\"deltas\\": [10, 10, 5]}"
+      segmentation_output_dir: "%s"
+      inference_options {
+        init_activation: 0.95
+        pad_value: 0.05
+        move_threshold: 0.9
+        min_boundary_dist { x: 1 y: 1 z: 1}
+        segment_threshold: 0.6
+        min_segment_size: 500
+      }''' % (vol_path, weights, out_dir))
+
+  sub, ov = (40, 100, 100), (21, 41, 41)
+  runner = runner_lib.Runner()
+  runner.start(make_request(str(tmp_path / 'sharded')), batch_size=4, direct=True)
+  merged, info = ffn_dist.segment_volume(
+      runner, (0, 0, 0), shape, sub, ov, batch_size=4, min_overlap_voxels=32,
+      min_overlap_fraction=0.2)
+  runner.stop_executor()
+  boxes = info['boxes']
+  assert len(boxes) == 8 and merged.shape == shape  # 2 x 2 x 2 anisotropic boxes
+  assert all(b.size == sub for b in boxes)
+  voxels = int((merged > 0).sum())
+  assert voxels > 0.3 * merged.size, voxels  # the cells were committed
+
+  # (1) standalone single-canvas runs (batch 1: conv32mt as the resident stack)
+  solo = runner_lib.Runner()
+  solo.start(make_request(str(tmp_path / 'solo')))
+  assert solo.executor.engine.get_option('flow') == 2
+  for box, seg in info['local_results']:
+    canvas = solo.run(box.corner, box.size)
+    want_seg = np.array(np.asarray(canvas.segmentation))
+    want_seg[want_seg < 0] = 0
+    assert np.array_equal(seg, want_seg), box.index
+    assert len(np.unique(seg)) > 2, box.index  # several objects per sub-box
+  assert solo.executor.engine.get_option('stat_flow_timeouts') == 0
+  solo.stop_executor()
+
+  # (2) assembly == specification; (3) objects merged across the cuts
+  want, want_edges, want_roots = labels_oracle.reconcile(
+      info['local_results'], shape, 32, 0.2)
+  assert np.array_equal(merged, want)
+  assert np.array_equal(info['edges'], want_edges)
+  assert info['roots'] == want_roots
+  assert len(want_edges) > 0
+  print('c5 sharded %s: %d sub-boxes of %s, %d voxels labelled (%.0f %%), %d '
+        'objects, %d merge edges' % (shape, len(boxes), sub, voxels,
+                                     100.0 * voxels / merged.size,
+                                     len(np.unique(merged)) - 1, len(want_edges)))

@@ -44,6 +44,17 @@ def hip_exe(fib25_model):
   exe.engine.close()
 
 
+def _assert_shipped_default(eng):
+  """The engine is in the state a fresh one ships in for the 33^3 FIB-25 model:
+  conv32mt for a single FoV, run as ONE resident launch (flow 2), nothing chosen
+  explicitly, next conv0_a launched ahead, faces + paste fused."""
+  assert eng.get_option('conv_variant') == 9
+  assert not eng.variant_is_explicit
+  assert eng.get_option('flow') == 2
+  assert eng.get_option('speculate') == 1
+  assert eng.get_option('fuse_paste') == 1
+
+
 def _device_canvas(exe, model, image, **kwargs):
   from ffn_amd.inference import inference
   from ffn_amd.inference import inference_utils
@@ -118,8 +129,9 @@ def _check_against_fixture(canvas, g):
               int(k): v for k, v in origins.items()}
 
 
-@pytest.mark.parametrize('variant', [2, 6, 8, 9])
-def test_cells250_matches_reference_minted_run(hip_exe, fib25_model, variant):
+@pytest.mark.parametrize('variant,flow', [(2, 0), (6, 0), (8, 0), (9, 0), (9, 1),
+                                          (9, 2)])
+def test_cells250_matches_reference_minted_run(hip_exe, fib25_model, variant, flow):
   """configs[1] at full size: the 250^3 phantom bench.py runs, first row of its
   seed grid.  The fixtures were minted by the reference's own Canvas
   (tools/make_golden.py --only cells250 [--forward onednn]); the GPU must visit
@@ -136,6 +148,9 @@ def test_cells250_matches_reference_minted_run(hip_exe, fib25_model, variant):
   assert hashlib.sha256(vol.tobytes()).hexdigest() == str(g['volume_sha256'])
   eng = hip_exe.engine
   eng.set_option('conv_variant', variant)
+  # (9, 2) is what ships: conv32mt as one resident launch per step; (9, 0) its
+  # per-layer launches, (9, 1) those with the flagged hand-off compiled in
+  eng.set_option('flow', flow)
   try:
     canvas = _device_canvas(hip_exe, fib25_model, synthetic.normalize(vol))
     got_steps, got_moves = _run_recorded(canvas, g['seeds'])
@@ -162,11 +177,13 @@ def test_cells250_matches_reference_minted_run(hip_exe, fib25_model, variant):
     want_s = g['final_seed_sample']
     assert np.array_equal(np.isnan(sample), np.isnan(want_s))
     assert np.nanmax(np.abs(sample - want_s)) <= (TOL if variant == 2 else RUN_TOL)
-    print('variant %d: %d steps, max move-score difference along the run %.3g' %
-          (variant, len(got_steps), max_err))
+    print('variant %d flow %d: %d steps, max move-score difference along the run '
+          '%.3g' % (variant, flow, len(got_steps), max_err))
+    assert eng.get_option('stat_flow_timeouts') == 0
     canvas.close()
   finally:
-    eng.set_option('conv_variant', 8)
+    eng.restore_default_variant()
+    eng.set_option('flow', 2)
 
 
 def test_cells250_logit_tolerance_on_canvas_states(hip_exe, fib25_model):
@@ -225,7 +242,8 @@ def test_cells250_logit_tolerance_on_canvas_states(hip_exe, fib25_model):
     print('max |logit - exact f32 kernel| on canvas states:', worst)
     assert max(worst.values()) <= 2e-5, worst
   finally:
-    eng.set_option('conv_variant', 8)
+    eng.restore_default_variant()
+    eng.set_option('flow', 2)
 
 
 def test_cells250_native_loop_same_result(hip_exe, fib25_model):
@@ -238,6 +256,7 @@ def test_cells250_native_loop_same_result(hip_exe, fib25_model):
   from ffn_amd import synthetic
   g = np.load(path)
   vol = synthetic.cells_volume((250, 250, 250), seed=1234)
+  _assert_shipped_default(hip_exe.engine)
   canvas = _device_canvas(hip_exe, fib25_model, synthetic.normalize(vol))
   assert canvas._native_loop_ok()
   canvas.segment_all(seed_policy=functools.partial(seed_lib_fixed(),
@@ -604,7 +623,7 @@ def test_cells250_whole_volume_against_reference_minted_run(hip_exe, fib25_model
   g = np.load(path)
   vol = synthetic.cells_volume((250, 250, 250), seed=1234)
   eng = hip_exe.engine
-  eng.set_option('conv_variant', 9)
+  _assert_shipped_default(eng)  # nothing chosen: what a user gets
   try:
     canvas = _device_canvas(hip_exe, fib25_model, synthetic.normalize(vol))
     got_steps, _ = _run_recorded(canvas, g['seeds'])
@@ -625,7 +644,8 @@ def test_cells250_whole_volume_against_reference_minted_run(hip_exe, fib25_model
     assert abs(len(got_steps) - len(want_steps)) <= 50
     canvas.close()
   finally:
-    eng.set_option('conv_variant', 8)
+    eng.restore_default_variant()
+    eng.set_option('flow', 2)
 
 
 # ---------------------------------------------------------------------------
@@ -641,6 +661,7 @@ def test_speculative_conv0a_leaves_the_run_unchanged(hip_exe, fib25_model):
   from ffn_amd import synthetic
   g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
   eng = hip_exe.engine
+  _assert_shipped_default(eng)
   steps = len(g['steps'])
   stats = {}
   try:
