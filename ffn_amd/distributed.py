@@ -117,17 +117,26 @@ class BoxDealer:
   other.  world == 1 (or no store): plain iteration in the same order.
 
   Iterating yields the SubBox objects this rank was dealt; `taken` keeps them.
+
+  Every deal of a process has its OWN counter in the store: `key` + '/' + the
+  number of dealers this process has made before (every rank makes its dealers
+  in the same order, one per job), so a second job over the same process group
+  starts at zero instead of at the first job's final count.  `job`: an
+  explicit tag instead (any value all ranks agree on).
   """
 
+  _made = 0  # dealers constructed by this process
+
   def __init__(self, boxes: Sequence[SubBox], rank: int = 0, world: int = 1,
-               store=None, key: str = 'ffn_amd/next_box', cost=None):
+               store=None, key: str = 'ffn_amd/next_box', cost=None, job=None):
     if cost is None:
       cost = lambda b: int(np.prod(b.size))
     # stable: equal costs keep the tiler's z-major order
     self.order = sorted(boxes, key=lambda b: -cost(b))
     self.rank, self.world = rank, world
     self.taken: List[SubBox] = []
-    self._key = key
+    self._key = '%s/%s' % (key, BoxDealer._made if job is None else job)
+    BoxDealer._made += 1
     self._store = store
     self._local = 0
     if world > 1 and store is None:
@@ -326,7 +335,8 @@ def _assembly_for(device, ops=None):
 
 def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
                         device=None, assembly=None, keep_on_device=False,
-                        num_boxes=None, collective='all_reduce'):
+                        num_boxes=None, collective='all_reduce',
+                        allow_missing=False):
   """Assembles one global int32 label volume from per-rank sub-box results.
 
   Args:
@@ -354,6 +364,9 @@ def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
       over each ring link); 'broadcast' = one broadcast per sub-box core from
       its owner (needs num_boxes; (N-1)/N volumes in total, and no zero-filled
       buffer is reduced) -- for volumes of 1024^3 and more.
+    allow_missing: with num_boxes, a sub-box that NO rank holds is an error
+      (the job lost it) unless this is set (a deliberately partial assembly:
+      its core stays 0; not with collective='broadcast').
 
   Returns:
     (global int32 ndarray, list of per-sub-box id offsets of this rank)
@@ -376,6 +389,12 @@ def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
       dist.all_reduce(counts, op=dist.ReduceOp.MAX)
     counts = counts.cpu().numpy()
     owner = counts[num_boxes:] - 1
+    if not allow_missing and (owner < 0).any():
+      # (a dealer that dealt nothing, a rank that failed: without this the
+      # volume would silently have zero holes, or broadcast(src=-1) hang)
+      raise RuntimeError(
+          'merge_segmentations: no rank holds sub-box(es) %s of %d' %
+          (np.nonzero(owner < 0)[0].tolist()[:20], num_boxes))
     starts = np.concatenate([[0], np.cumsum(counts[:num_boxes])])
     total = int(starts[-1])
     offsets = [int(starts[box.index]) for box, _ in local_results]
@@ -571,7 +590,7 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
                    min_overlap_voxels: int = MIN_OVERLAP_VOXELS,
                    min_overlap_fraction: float = MIN_OVERLAP_FRACTION,
                    save: bool = True, deal: str = 'dynamic',
-                   collective: str = 'all_reduce', store=None):
+                   collective: str = 'all_reduce', store=None, deal_job=None):
   """Segments a whole bounding box on `world` GPUs (BASELINE configs C4 / C5).
 
   One process per GPU calls this with its rank.  The box is cut into
@@ -595,6 +614,9 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
     deal: 'dynamic' or 'static'
     collective: 'all_reduce' or 'broadcast' (see merge_segmentations)
     store: the job's torch.distributed store (default: the default group's)
+    deal_job: tag of this job's counter in the store (default: the number of
+      deals this process has made, the same on every rank that calls this the
+      same number of times)
 
   Returns:
     (global int32 label volume of shape size_zyx -- identical on every rank --,
@@ -607,7 +629,7 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
   # FoV could not host a single seed
   boxes = tile_volume(size_zyx, sub_size_zyx, overlap_zyx, back_shift=True)
   if deal == 'dynamic':
-    dealer = BoxDealer(boxes, rank, world, store=store)
+    dealer = BoxDealer(boxes, rank, world, store=store, job=deal_job)
   elif deal == 'static':
     dealer = iter(assign_round_robin(boxes, rank, world))
   else:

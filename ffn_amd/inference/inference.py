@@ -1341,7 +1341,7 @@ class MultiCanvasDriver:
     if self.groups == 1:
       tally = [0, 0, 0.0, 0]
       try:
-        self._run_native_group(pull, window, done, tally)
+        self._run_native_group(pull, window, done, tally, errors)
       finally:
         self.calls += tally[0]
         self.steps += tally[1]
@@ -1349,14 +1349,16 @@ class MultiCanvasDriver:
         self.segments_ended += tally[3]
       return
     # one thread per group; the GIL is released inside the library calls, and a
-    # short switch interval hands it over promptly when one returns
+    # short switch interval hands it over promptly when one returns (the
+    # interval is PROCESS-wide: other Python threads of the caller switch more
+    # often while this runs; it is restored on the way out)
     tallies = [[0, 0, 0.0, 0] for _ in range(self.groups)]
 
     def work(k):
       try:
-        self._run_native_group(pull, window, done, tallies[k])
+        self._run_native_group(pull, window, done, tallies[k], errors)
       except BaseException as e:  # pylint:disable=broad-except
-        errors.append(e)
+        errors.append(e)  # (the other groups see it at their next round)
 
     interval = sys.getswitchinterval()
     sys.setswitchinterval(min(interval, 2e-4))
@@ -1378,15 +1380,31 @@ class MultiCanvasDriver:
     if errors:
       raise errors[0]
 
-  def _run_native_group(self, pull, window, on_done, tally):
+  def _run_native_group(self, pull, window, on_done, tally, errors=()):
     """One group of at most `window` open canvases: the loop of `_run_native`.
     tally = [engine calls, FoV steps, seconds inside segment_many, segments
-    ended] of this group."""
+    ended] of this group.  `errors`: the job's list of failures -- once another
+    group has put one there this group stops at its next round; whichever way
+    the group ends early, its open canvases are closed (generator and HBM)."""
+    live = []
+    try:
+      self._native_group_loop(pull, window, on_done, tally, errors, live)
+    finally:
+      for entry in live:  # empty after a complete run
+        try:
+          entry[1].close()
+        except Exception:  # pylint:disable=broad-except
+          pass
+        try:
+          entry[0].close()
+        except Exception:  # pylint:disable=broad-except
+          pass
+
+  def _native_group_loop(self, pull, window, on_done, tally, errors, live):
     engine = self.engine
     limit = self.max_steps_per_canvas
-    # [canvas, generator, pending request, steps of finished segments,
-    #  steps of the current segment reported so far]
-    live = []
+    # live: [canvas, generator, pending request, steps of finished segments,
+    #        steps of the current segment reported so far]
     state = {'exhausted': False}
 
     def finished(entry):
@@ -1420,6 +1438,8 @@ class MultiCanvasDriver:
     #: steps a library call may make while canvases on the Python loop wait
     mixed_call_steps = 8
     while live:
+      if errors:  # another group failed: the job is over
+        return
       # canvases on the Python loop (restrictor masks, custom policies, hooks:
       # no native segment pending) advance by ONE batched step per round, next
       # to the library calls of the others -- never one canvas at a time

@@ -463,3 +463,17 @@ class SequentialPolicies(BaseSeedPolicy):
 
   def init_coords(self):
     self.coords = np.array(list(itertools.chain(*self._policies))).reshape(-1, 3)
+
+  def set_state(self, state):
+    """A state of this class is the base class's (coords of the whole chain,
+    index): a resumed chain goes on where it stopped.  The reference's own
+    get_state (seed.py:537-549) returns a LIST of the chained policies' states
+    instead -- which are exhausted as soon as the chain has been built, so a
+    run resumed from it seeds nothing more; such a list (a checkpoint written
+    by the reference) is accepted and restored the reference's way."""
+    if isinstance(state, list):
+      for s, p in zip(state, self._policies):
+        p.set_state(s)
+      self.coords, self.idx = None, 0
+      return
+    super().set_state(state)

@@ -249,3 +249,59 @@ def test_shared_volume_is_built_once_world2(tmp_path):
   assert np.array_equal(synthetic.shared_volume(
       lambda: want, str(tmp_path / 'unused.npy')), want)
   assert not (tmp_path / 'unused.npy').exists()
+
+
+class _FakeStore:
+  """The fetch-and-add of a torch.distributed store, in one process."""
+
+  def __init__(self):
+    self.values = {}
+
+  def add(self, key, amount):
+    self.values[key] = self.values.get(key, 0) + amount
+    return self.values[key]
+
+
+def test_box_dealer_second_job_starts_from_zero():
+  """the dealer's counter in the store used one fixed key, so a
+  second job over the same process group was dealt nothing (and the assembly
+  returned zeros).  Every deal now counts under its own key."""
+  from ffn_amd import distributed as ffn_dist
+  boxes = ffn_dist.tile_volume((64, 64, 96), (40, 40, 40), (8, 8, 8))
+  store = _FakeStore()
+  # two ranks of a world-2 job, simulated in turn: each makes one dealer per job
+  made = ffn_dist.BoxDealer._made
+  for job in range(3):
+    ffn_dist.BoxDealer._made = made + job
+    a = ffn_dist.BoxDealer(boxes, 0, 2, store=store)
+    ffn_dist.BoxDealer._made = made + job
+    b = ffn_dist.BoxDealer(boxes, 1, 2, store=store)
+    got = []
+    for k in range(len(boxes) + 2):
+      try:
+        got.append(next(a if k % 3 else b))
+      except StopIteration:
+        break
+    assert sorted(x.index for x in got) == list(range(len(boxes))), job
+  # an explicit job tag does the same
+  a = ffn_dist.BoxDealer(boxes, 0, 2, store=store, job='again')
+  assert len(list(a)) == len(boxes)
+  b = ffn_dist.BoxDealer(boxes, 1, 2, store=store, job='again')
+  assert len(list(b)) == 0
+
+
+def test_merge_reports_a_sub_box_nobody_holds():
+  """with the ids following the sub-box index, a box that no rank
+  segmented used to become a silent hole (or broadcast(src=-1))."""
+  import pytest
+  from ffn_amd import distributed as ffn_dist
+  shape = (32, 32, 48)
+  boxes = ffn_dist.tile_volume(shape, (32, 32, 32), (8, 8, 8))
+  assert len(boxes) == 2
+  seg = np.ones(boxes[0].size, np.int32)
+  with pytest.raises(RuntimeError, match='no rank holds sub-box'):
+    ffn_dist.merge_segmentations([(boxes[0], seg)], shape, 0, 1,
+                                 num_boxes=len(boxes))
+  out, _ = ffn_dist.merge_segmentations([(boxes[0], seg)], shape, 0, 1,
+                                        num_boxes=len(boxes), allow_missing=True)
+  assert out.max() == 1 and (out == 0).any()
