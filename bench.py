@@ -31,7 +31,8 @@ import time
 # the command processor then fetches them from HBM instead of over PCIe -- on a
 # quiet, well-placed host it changes nothing measurable
 # (profiles/r03_ab_hipgraph_conv_chain.txt), on a badly placed one every launch
-# of the 25-launch dependent chain pays for the fetch (ffn_amd/hostenv.py).
+# of a dependent chain pays for the fetch
+# (profiles/r03_ab_dev_kernarg_slow_launch_box.txt).
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 
 import numpy as np
@@ -289,7 +290,6 @@ def full_volume_pass(args, rank, world, model, exe, request, image, barrier):
 def run_gpu(args, rank, local_rank, world):
   import torch
   import torch.distributed as dist
-  from ffn_amd import hostenv
   from ffn_amd import synthetic
   from ffn_amd.inference import executor
   from ffn_amd.inference import inference
@@ -300,9 +300,6 @@ def run_gpu(args, rank, local_rank, world):
   if not torch.cuda.is_available():
     raise RuntimeError('bench.py needs an MI355X: no CPU fallback exists')
   torch.cuda.set_device(local_rank)
-  # this rank's threads -> the CPUs of its GPU's NUMA node (before the engine,
-  # its stream and the runtime's queue / kernel-argument pools exist)
-  host_binding = hostenv.bind_to_gpu_node(local_rank)
   if world > 1:
     dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
@@ -496,7 +493,6 @@ def run_gpu(args, rank, local_rank, world):
       'conv_variant': (args.conv_variant if args.conv_variant is not None
                        else eng.get_option('conv_variant')),
       'prewarm_steps': state.get('prewarm_steps', 0),
-      'host_binding': host_binding,
       'speculation': {
           'conv0a_launched_ahead': eng.get_option('stat_spec_launched'),
           'steps_that_used_one': eng.get_option('stat_spec_hits'),
@@ -583,8 +579,6 @@ def run_sharded(args, rank, local_rank, world):
       barrier if world > 1 else None)
   t_volume = time.perf_counter() - t_setup0
   # (after the volume: its nearest-centre queries use every CPU the job has)
-  from ffn_amd import hostenv
-  host_binding = hostenv.bind_to_gpu_node(local_rank)
   request = make_request()
   request.seed_policy = 'PolicyPeaks'
   out_dir = tempfile.mkdtemp(prefix='ffn_sharded_%d_' % rank)
@@ -786,7 +780,6 @@ def run_sharded(args, rank, local_rank, world):
                   'groups x segmentation_seconds is Python between segments '
                   '(commit, seed policy, next init_seed) and canvas set-up',
       },
-      'host_binding': host_binding,
       'engine_calls': {
           'batched_steps': step_calls,
           'mean_fovs_per_step': round(step_items / max(step_calls, 1), 2),
@@ -1202,11 +1195,14 @@ def main():
   traffic = None
   traffic_source = None
   try:
-    tname = ('conv32_pmc_traffic.json' if CONFIG == 'c1' else
+    resident = res.get('flow') == 2 and res.get('conv_variant') == 9
+    tname = (('r04_conv32ps_pmc_traffic.json' if resident else
+              'conv32_pmc_traffic.json') if CONFIG == 'c1' else
              'r03_conv32mt_c5_pmc_traffic.json')
     with open(os.path.join(ROOT, 'profiles', tname)) as f:
       tj = json.load(f)
-    if tj.get('conv_variant', 9) == res.get('conv_variant', 9):
+    if (tj.get('conv_variant', 9) == res.get('conv_variant', 9) and
+        not (CONFIG != 'c1' and resident)):  # (c5's capture is of the per-conv launches)
       traffic = tj['traffic_bytes_per_launch']
       traffic_source = ('profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / '
                         'WRITE_SIZE passes of this command (NOT measured in '
@@ -1316,7 +1312,6 @@ def main():
                   'movement_policy-calls', 1), 1), 1),
       },
       'speculation': res['speculation'],
-      'host_binding': res['host_binding'],
       'queue_stats': {k: res['counters'].get(k, 0) for k in (
           'update_at-calls', 'skip_threshold', 'skip_invalid_pos',
           'seed_got_too_weak', 'segment_at-loop-calls', 'gate_rejects')},

@@ -122,6 +122,7 @@ SIGNATURES = {
                                ctypes.POINTER(_P)]),
     'ffn_engine_destroy': (None, [_P]),
     'ffn_engine_set_weights': (_I, [_P, _P, ctypes.c_size_t]),
+    'ffn_engine_set_pred_size': (_I, [_P, _I3]),
     'ffn_engine_set_option': (_I, [_P, ctypes.c_char_p, _I]),
     'ffn_engine_get_option': (_I, [_P, ctypes.c_char_p,
                                    ctypes.POINTER(ctypes.c_int)]),

@@ -1064,6 +1064,10 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   g.R = kChunk + 2 * (g.XS + 1);
   g.oa[0] = 0, g.oa[1] = 1, g.oa[2] = 2;
   g.dstr[0] = g.fy * g.fx, g.dstr[1] = g.fx, g.dstr[2] = 1;
+  g.crop = 0;
+  g.c0[0] = g.c0[1] = g.c0[2] = 0;
+  g.c1[0] = g.fz, g.c1[1] = g.fy, g.c1[2] = g.fx;
+  g.Vp = g.V;
   // the geometry with its axes permuted: internal axis a = original axis oa[a]
   auto permute = [&](const int oa[3]) {
     const int f[3] = {g.fz, g.fy, g.fx}, d[3] = {g.dz, g.dy, g.dx};
@@ -1712,6 +1716,34 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   return FFN_OK;
 }
 
+int ffn_engine_set_pred_size(ffn_engine* e, const int32_t pred_zyx[3]) {
+  EngineLock lock_(e);
+  if (!e || !pred_zyx) return fail(FFN_ERR_ARG, "null argument");
+  Geom& g = e->g;
+  const int f[3] = {g.fz, g.fy, g.fx}, d[3] = {g.dz, g.dy, g.dx};
+  for (int a = 0; a < 3; ++a) {
+    if (pred_zyx[a] < 1 || pred_zyx[a] > f[a])
+      return fail(FFN_ERR_ARG, "pred size %d outside 1..%d (axis %d)", pred_zyx[a],
+                  f[a], a);
+    if (d[a] > pred_zyx[a] / 2)
+      return fail(FFN_ERR_ARG, "delta %d beyond the prediction's half size %d (axis %d)",
+                  d[a], pred_zyx[a] / 2, a);
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  drop_spec(e);
+  g.Vp = 1;
+  g.crop = 0;
+  for (int a = 0; a < 3; ++a) {
+    // update_seed's zero padding (model.py:168-183): (seed - pred) // 2 in front
+    g.c0[a] = (f[a] - pred_zyx[a]) / 2;
+    g.c1[a] = g.c0[a] + pred_zyx[a];
+    g.Vp *= pred_zyx[a];
+    g.crop |= pred_zyx[a] != f[a];
+  }
+  return FFN_OK;
+}
+
 int ffn_engine_debug_flow_trace(ffn_engine* e, long long* out, int max_slots) {
   EngineLock lock_(e);
   if (!e || !out) return fail(FFN_ERR_ARG, "null argument");
@@ -2059,7 +2091,8 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   auto paste = [&]() {
     hipLaunchKernelGGL(paste_kernel, dim3(71, n), dim3(512), 0, e->stream, si, g,
                        e->logits, e->seed_raw, e->count, e->count_blocks,
-                       params->disco_seed_threshold, e->range_flag, e->range_tag,
+                       params->move_threshold, params->disco_seed_threshold,
+                       e->range_flag, e->range_tag,
                        e->d_spec_choice, spec_expected);
   };
   if (n > 1) paste();

@@ -47,7 +47,19 @@ struct Geom {
   // oa = {0, 1, 2}, dstr = {fy fx, fx, 1}.
   int oa[3];
   int dstr[3];
+  // A model that predicts a SMALLER mask than the seed it reads (ModelInfo
+  // pred_mask_size < input_seed_size, reference model.py:168-183, inference.py:
+  // 218,410-411): the canvas step scores, counts and pastes only the centred
+  // box [c0, c1) of the FoV (caller's zyx); crop = 0: the whole FoV.
+  int crop;
+  int c0[3], c1[3];
+  int Vp;              // voxels of the box (= V without a crop)
 };
+
+__device__ __forceinline__ bool in_pred_box(const Geom& g, int z, int y, int x) {
+  return z >= g.c0[0] && z < g.c1[0] && y >= g.c0[1] && y < g.c1[1] && x >= g.c0[2] &&
+         x < g.c1[2];
+}
 
 // Per-FoV step descriptor read by the gather / paste kernels.
 struct StepItem {
@@ -2488,6 +2500,28 @@ __device__ __forceinline__ unsigned sum_block_counts(
   return cnt;
 }
 
+// #(logits >= move_thr) of the step: the fused head's per-workgroup partials --
+// or, when the model's prediction is a centred box of the FoV (Geom::crop), a
+// count over that box only (the head counted the whole FoV)
+__device__ __forceinline__ unsigned step_count(
+    const Geom& g, const float* __restrict__ lg, float move_thr,
+    const unsigned* __restrict__ block_count, int head_blocks, int item,
+    unsigned* s_cnt) {
+  if (!g.crop) return sum_block_counts(block_count, head_blocks, item, s_cnt);
+  unsigned part = 0;
+  for (int v = threadIdx.x; v < g.V; v += blockDim.x) {
+    const int x = v % g.fx, t = v / g.fx;
+    part += (in_pred_box(g, t / g.fy, t % g.fy, x) && lg[v] >= move_thr) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = part;
+  __syncthreads();
+  unsigned cnt = 0;
+  for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) cnt += s_cnt[wv];
+  return cnt;
+}
+
 // (Measured, round 3: issuing the face / candidate loads and the segmentation ids
 // under the faces BEFORE the block-count barrier does not shorten the block --
 // 7.1 against 7.0 us for the fused launch; its time is the launch and the two
@@ -2511,10 +2545,10 @@ __device__ __forceinline__ void faces_body(
   __shared__ unsigned s_cnt[8];
   __shared__ ffn_step_result s_res;
   const ItemView it = item_view(si, item);
-  const unsigned cnt = sum_block_counts(block_count, head_blocks, item, s_cnt);
-  const bool disco = disco_on(cnt, g.V, disco_thr);
   const float* lg = logits + (size_t)item * g.V;
   const float* old = in_seed + (size_t)item * g.V;
+  const unsigned cnt = step_count(g, lg, move_thr, block_count, head_blocks, item, s_cnt);
+  const bool disco = disco_on(cnt, g.Vp, disco_thr);
   const int z0 = it.pos[0] - g.fz / 2;
   const int y0 = it.pos[1] - g.fy / 2;
   const int x0 = it.pos[2] - g.fx / 2;
@@ -2524,7 +2558,10 @@ __device__ __forceinline__ void faces_body(
   if (wave < 6) {
     const int axis = wave >> 1;
     const int sign = (wave & 1) ? 1 : -1;
-    const int cz = g.fz / 2, cy = g.fy / 2, cx = g.fx / 2;
+    // centre of the prediction (movement.py:60: the centre of `prob_map`)
+    const int cz = g.c0[0] + (g.c1[0] - g.c0[0]) / 2;
+    const int cy = g.c0[1] + (g.c1[1] - g.c0[1]) / 2;
+    const int cx = g.c0[2] + (g.c1[2] - g.c0[2]) / 2;
     // face rows / cols = the two non-fixed axes in zyx order (selects, not
     // runtime-indexed arrays: those would live in scratch memory)
     const int nr = axis == 0 ? 2 * g.dy + 1 : 2 * g.dz + 1;
@@ -2601,8 +2638,7 @@ __device__ __forceinline__ void faces_body(
       if (z >= 0 && z < it.cz && y >= 0 && y < it.cy && x >= 0 && x < it.cx) {
         const int lz = z - z0, ly = y - y0, lx = x - x0;
         const size_t ci = ((size_t)z * it.cy + y) * it.cx + x;
-        if (lz >= 0 && lz < g.fz && ly >= 0 && ly < g.fy && lx >= 0 &&
-            lx < g.fx) {
+        if (in_pred_box(g, lz, ly, lx)) {  // a voxel this step writes
           const int v = (lz * g.fy + ly) * g.fx + lx;
           sv = post_disco(lg[v], old[v], disco);
         } else {
@@ -2624,8 +2660,11 @@ __device__ __forceinline__ void faces_body(
     // of the object and that this prediction (before the disco bias) deletes
     unsigned deleted = 0;
     if (deleted_thr == deleted_thr) {  // NaN = not requested
-      for (int v = lane; v < g.V; v += 64)
-        deleted += (old[v] >= deleted_thr && lg[v] < 0.0f) ? 1u : 0u;
+      for (int v = lane; v < g.V; v += 64) {
+        const int x = v % g.fx, t = v / g.fx;
+        deleted += ((!g.crop || in_pred_box(g, t / g.fy, t % g.fy, x)) &&
+                    old[v] >= deleted_thr && lg[v] < 0.0f) ? 1u : 0u;
+      }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) deleted += __shfl_xor(deleted, off);
     }
@@ -2671,18 +2710,18 @@ __global__ __launch_bounds__(512) void faces_kernel(
 __device__ __forceinline__ void paste_body(
     const int item, const int bx, const int nbx, const StepItems& si, const Geom& g,
     const float* __restrict__ logits, const float* __restrict__ in_seed,
-    const unsigned* __restrict__ block_count, int head_blocks, float disco_thr,
-    const unsigned* __restrict__ range_flag, unsigned range_tag,
+    const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
+    float disco_thr, const unsigned* __restrict__ range_flag, unsigned range_tag,
     const int* __restrict__ spec_choice, int spec_expected) {
   __shared__ unsigned s_cnt[8];
   if (*range_flag == range_tag) return;  // void step (fp16 range): no paste
   // ... or a step whose speculative conv0_a was made for another position
   if (spec_expected >= 0 && *spec_choice != spec_expected) return;
   const ItemView it = item_view(si, item);
-  const unsigned cnt = sum_block_counts(block_count, head_blocks, item, s_cnt);
-  const bool disco = disco_on(cnt, g.V, disco_thr);
   const float* lg = logits + (size_t)item * g.V;
   const float* old = in_seed + (size_t)item * g.V;
+  const unsigned cnt = step_count(g, lg, move_thr, block_count, head_blocks, item, s_cnt);
+  const bool disco = disco_on(cnt, g.Vp, disco_thr);
   const int z0 = it.pos[0] - g.fz / 2;
   const int y0 = it.pos[1] - g.fy / 2;
   const int x0 = it.pos[2] - g.fx / 2;
@@ -2691,6 +2730,7 @@ __device__ __forceinline__ void paste_body(
     const int t = v / g.fx;
     const int y = t % g.fy;
     const int z = t / g.fy;
+    if (g.crop && !in_pred_box(g, z, y, x)) continue;
     const size_t ci = ((size_t)(z0 + z) * it.cy + (y0 + y)) * it.cx + (x0 + x);
     it.seed[ci] = post_disco(lg[v], old[v], disco);
   }
@@ -2699,11 +2739,11 @@ __device__ __forceinline__ void paste_body(
 __global__ __launch_bounds__(512) void paste_kernel(
     StepItems si, Geom g, const float* __restrict__ logits,
     const float* __restrict__ in_seed,
-    const unsigned* __restrict__ block_count, int head_blocks,
+    const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
     float disco_thr, const unsigned* __restrict__ range_flag,
     unsigned range_tag, const int* __restrict__ spec_choice, int spec_expected) {
   paste_body(blockIdx.y, blockIdx.x, gridDim.x, si, g, logits, in_seed, block_count,
-             head_blocks, disco_thr, range_flag, range_tag, spec_choice,
+             head_blocks, move_thr, disco_thr, range_flag, range_tag, spec_choice,
              spec_expected);
 }
 
@@ -2725,7 +2765,7 @@ __global__ __launch_bounds__(512) void faces_paste_kernel(
                spec_choice, spec_expected);
   else
     paste_body(0, blockIdx.x - 1, gridDim.x - 1, si, g, logits, in_seed, block_count,
-               head_blocks, disco_thr, range_flag, range_tag, spec_choice,
+               head_blocks, move_thr, disco_thr, range_flag, range_tag, spec_choice,
                spec_expected);
 }
 

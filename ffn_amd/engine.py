@@ -134,6 +134,9 @@ class HipEngine:
     #: then keeps its hands off)
     self.variant_is_explicit = False
     self._default_variant = self.get_option('conv_variant')
+    #: the model's prediction box inside the FoV (set_pred_size), zyx slices
+    self.pred_zyx = self.fov_zyx
+    self._pred_sel = None
     self._canvases = weakref.WeakSet()
     _LIVE_ENGINES.add(self)
 
@@ -141,13 +144,16 @@ class HipEngine:
   def from_model(cls, model, max_batch: int = 1, device_id: int = 0):
     """Builds an engine from a ConvStack3DFFNModel (xyz geometry -> zyx)."""
     info = model.info
-    if not (np.array_equal(info.pred_mask_size, info.input_seed_size) and
-            np.array_equal(info.pred_mask_size, info.input_image_size)):
-      raise ValueError('pred/seed/image sizes must be equal for the conv stack')
-    eng = cls(tuple(int(v) for v in info.pred_mask_size[::-1]),
+    if not np.array_equal(info.input_seed_size, info.input_image_size):
+      raise ValueError('seed and image sizes must be equal for the conv stack')
+    if np.any(np.asarray(info.pred_mask_size) > np.asarray(info.input_seed_size)):
+      raise ValueError('pred_mask_size exceeds input_seed_size')
+    eng = cls(tuple(int(v) for v in info.input_seed_size[::-1]),
               tuple(int(v) for v in info.deltas[::-1]), model.depth,
               model.features, max_batch, device_id)
     eng.set_weights(model.weights_blob())
+    if not np.array_equal(info.pred_mask_size, info.input_seed_size):
+      eng.set_pred_size(tuple(int(v) for v in info.pred_mask_size[::-1]))
     return eng
 
   def close(self):
@@ -168,6 +174,21 @@ class HipEngine:
     blob = _f32(blob).ravel()
     check(self._lib.ffn_engine_set_weights(self._h, blob.ctypes.data,
                                            blob.size))
+
+  def set_pred_size(self, pred_zyx):
+    """A model that predicts a smaller mask than the seed it reads (ModelInfo
+    pred_mask_size < input_seed_size, reference model.py:168-183): the centred
+    box of the FoV that canvas steps score and paste, and that `predict`
+    returns (ffn_engine_set_pred_size)."""
+    pred_zyx = tuple(int(v) for v in pred_zyx)
+    check(self._lib.ffn_engine_set_pred_size(self._h, i3(pred_zyx)))
+    self.pred_zyx = pred_zyx
+    if pred_zyx == self.fov_zyx:
+      self._pred_sel = None
+    else:
+      lo = [(f - p) // 2 for f, p in zip(self.fov_zyx, pred_zyx)]
+      self._pred_sel = (slice(None),) + tuple(
+          slice(l, l + p) for l, p in zip(lo, pred_zyx))
 
   def get_option(self, name: str) -> int:
     value = ctypes.c_int(0)
@@ -233,7 +254,8 @@ class HipEngine:
 
   # -- stateless predict (ExecutorClient.predict) ------------------------------
   def predict(self, seed: np.ndarray, image: np.ndarray) -> np.ndarray:
-    """seed, image: [n, z, y, x] f32 -> logits [n, z, y, x] f32."""
+    """seed, image: [n, z, y, x] f32 (input_seed_size) -> logits [n, z', y', x']
+    f32 (pred_mask_size: the same unless set_pred_size made it smaller)."""
     seed = _f32(seed)
     image = _f32(image)
     if seed.shape != image.shape or seed.shape[1:] != self.fov_zyx:
@@ -242,6 +264,8 @@ class HipEngine:
     out = np.empty_like(seed)
     check(self._lib.ffn_predict(self._h, seed.shape[0], seed.ctypes.data,
                                 image.ctypes.data, out.ctypes.data))
+    if self._pred_sel is not None:  # logits = (seed + update) of the pred box
+      out = np.ascontiguousarray(out[self._pred_sel])
     return out
 
   def forward_resident(self, n: int = 1, repeats: int = 1):

@@ -706,8 +706,13 @@ class DeviceCanvas(Canvas):
     self._req_i32 = np.frombuffer(self._step_req, dtype=np.int32)
     self._step_params = _lib.StepParams()
     super().__init__(model_info, exec_client, image, options, **kwargs)
-    if np.any(self._pred_delta != 0):
-      raise NotImplementedError('pred size must equal seed size')
+    # pred_mask_size < input_seed_size (inference.py:218,410-411): the engine
+    # scores and pastes the centred box only (ffn_engine_set_pred_size)
+    engine_pred = getattr(getattr(exec_client, 'engine', None), 'pred_zyx', None)
+    if engine_pred is not None and tuple(engine_pred) != tuple(
+        int(v) for v in self._pred_size):
+      raise ValueError('the engine predicts %r, the model info says %r' % (
+          tuple(engine_pred), tuple(self._pred_size)))
     self._step_params.pad_value = self.options.pad_value
     self._step_params.move_threshold = self.options.move_threshold
     self._step_params.disco_seed_threshold = self.options.disco_seed_threshold
@@ -1095,9 +1100,10 @@ class DeviceCanvas(Canvas):
 
   def _make_reader(self, pos):
     def read():
-      half = self._margin_t
-      lo = (pos[0] - half[0], pos[1] - half[1], pos[2] - half[2])
-      hi = (pos[0] + half[0] + 1, pos[1] + half[1] + 1, pos[2] + half[2] + 1)
+      # the box update_at wrote (inference.py:410-411): pred_mask_size, centred
+      lo = tuple(int(pos[a] - self._input_seed_size[a] // 2 + self._pred_delta[a])
+                 for a in range(3))
+      hi = tuple(int(l + self._pred_size[a]) for a, l in enumerate(lo))
       return self._call(self._handle.read_seed, lo, hi)
     return read
 

@@ -273,6 +273,15 @@ int ffn_engine_get_profile(ffn_engine* engine, double* conv_ms_total,
  * chain of a step (mode 2: 2 depth - 1 launches, or the ONE launch of the
  * resident stack): *n = how many exist, the first min(*n, max_n) are copied. */
 int ffn_engine_get_profile_samples(ffn_engine* engine, float* out_ms, int max_n, int* n);
+/* A model whose prediction is smaller than the seed it reads (ModelInfo
+ * pred_mask_size < input_seed_size; reference ffn/training/model.py:168-183 pads
+ * the update with zeros around the centre, ffn/inference/inference.py:218,410-411
+ * writes only the centred box): canvas steps (ffn_canvas_step*, segment_at /
+ * segment_many) then score the move faces around the CENTRE OF THAT BOX, count
+ * logits >= move_threshold and apply the disco bias inside it, and paste only it;
+ * ffn_predict still returns the whole FoV (the caller crops).  pred_zyx = the
+ * FoV: back to the default.  Deltas must fit the box's half size. */
+int ffn_engine_set_pred_size(ffn_engine* engine, const int32_t pred_zyx[3]);
 /* Kernel choice and tuning switches.  "conv_variant":
  *   0 = simple exact-f32 MFMA conv over padded positions (takes any FoV that
  *       fits the LDS at all),

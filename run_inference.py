@@ -28,7 +28,7 @@ from ffn_amd.inference import request as req_lib  # noqa: E402
 from ffn_amd.inference import runner as runner_lib  # noqa: E402
 
 
-def main(argv=None, bind_host=False):
+def main(argv=None):
   ap = argparse.ArgumentParser(description=__doc__)
   inference_flags.add_flags(ap)
   ap.add_argument('--bounding_box', required=True,
@@ -66,9 +66,6 @@ def main(argv=None, bind_host=False):
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
 
-  if bind_host:  # this process -> the CPUs next to its GPU (ffn_amd/hostenv.py)
-    from ffn_amd import hostenv  # pylint:disable=g-import-not-at-top
-    logging.info('host binding: %r', hostenv.bind_to_gpu_node(local_rank))
   runner = runner_lib.Runner(device_id=local_rank, conv_variant=args.conv_variant)
   runner.start(request, batch_size=args.batch_size,
                direct=True if args.assemble else None)
@@ -119,7 +116,6 @@ def main(argv=None, bind_host=False):
 
 
 if __name__ == '__main__':
-  # (kernel arguments in device memory, the process next to its GPU: see
-  # ffn_amd/hostenv.py; a caller of main() keeps its own placement)
+  # (kernel arguments in device memory: see bench.py)
   os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
-  main(bind_host=True)
+  main()

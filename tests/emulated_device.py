@@ -91,12 +91,15 @@ class EmulatedHandle:
 class EmulatedDeviceClient(executor.ExecutorClient):
   """ExecutorClient with the device-canvas surface, computed on the CPU."""
 
-  def __init__(self, counters, blob, depth, fov_zyx, deltas_zyx):
+  def __init__(self, counters, blob, depth, fov_zyx, deltas_zyx, pred_zyx=None):
     super().__init__(counters, None)
     self.blob = blob
     self.depth = depth
     self.fov = np.array(fov_zyx)
     self.deltas = np.array(deltas_zyx)
+    # ffn_engine_set_pred_size: the centred box of the FoV a step scores / pastes
+    self.pred = np.array(pred_zyx if pred_zyx is not None else fov_zyx)
+    self.pred_lo = (self.fov - self.pred) // 2
     self.steps = 0
 
   def start(self):
@@ -108,7 +111,8 @@ class EmulatedDeviceClient(executor.ExecutorClient):
 
   def predict(self, seed, image, fetches):
     out = ffn_oracle.forward(image, seed, self.blob, self.depth)
-    return {'logits': out[..., None]}
+    box = tuple(slice(l, l + p) for l, p in zip(self.pred_lo, self.pred))
+    return {'logits': np.ascontiguousarray(out[box])[..., None]}
 
   def create_canvas(self, image):
     return EmulatedHandle(image)
@@ -125,6 +129,12 @@ class EmulatedDeviceClient(executor.ExecutorClient):
     seed_in = old.copy()
     seed_in[np.isnan(seed_in)] = np.float32(params.pad_value)
     logits = ffn_oracle.forward(h.image[sel], seed_in, self.blob, self.depth)
+    # the prediction: the centred box of the FoV (the whole FoV by default)
+    box = tuple(slice(l, l + p) for l, p in zip(self.pred_lo, self.pred))
+    sel = tuple(slice(s + l, s + l + p)
+                for s, l, p in zip(start, self.pred_lo, self.pred))
+    old = np.array(old[box])
+    logits = np.ascontiguousarray(logits[box])
     cnt = int(np.sum(logits >= np.float32(params.move_threshold)))
     disco = (params.disco_seed_threshold >= 0 and
              cnt / logits.size > params.disco_seed_threshold)
@@ -139,7 +149,6 @@ class EmulatedDeviceClient(executor.ExecutorClient):
       logits[mask] = old[mask]
     h.seed[sel] = logits
     scores, idx = ffn_oracle.face_maxima(self.deltas, logits)
-    c = self.fov // 2
     k = 0
     for axis in range(3):
       others = [a for a in range(3) if a != axis]

@@ -755,3 +755,65 @@ def test_speculative_conv0a_permuted_layout():
   assert np.array_equal(out[1][2], out[0][2], equal_nan=True)
   assert out[0][3:] == (0, 0)
   assert out[1][4] > 0.5 * out[1][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['cells56_pred25', 'cells72_pred27'])
+def test_pred_smaller_than_seed_on_device(fib25_model, name):
+  """A model that predicts a smaller mask than the seed it reads (ModelInfo
+  pred_mask_size < input_seed_size; reference model.py:168-183, inference.py:
+  218,410-411) on the GPU: `ffn_engine_set_pred_size` makes the canvas step score
+  the faces around the centre of the pred box, count and disco-bias inside it and
+  paste only it.  Against the run the reference's own Canvas made
+  (tools/make_golden.py --only predcrop): every FoV position, the queued moves,
+  the final labels -- through the Python loop and through the in-library one."""
+  import copy
+  from ffn_amd import synthetic
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference_utils
+  path = os.path.join(GOLDEN, 'ref_canvas_%s.npz' % name)
+  if not os.path.exists(path):
+    pytest.skip('fixture not minted')
+  g = np.load(path)
+  pred = tuple(int(v) for v in g['pred_zyx'])
+  model = copy.copy(fib25_model)
+  model.info = copy.copy(fib25_model.info)
+  model.info.pred_mask_size = np.array(pred[::-1])
+  exe = executor.HipBatchExecutor(executor.ExecutorInterface(), model, model.info,
+                                  None, inference_utils.Counters(), 1, device_id=0)
+  try:
+    assert exe.engine.pred_zyx == pred
+    image = synthetic.normalize(g['volume'])
+    # the stateless contract returns the pred box
+    seed = np.full((1, 33, 33, 33), -2.0, np.float32)
+    out = exe.engine.predict(seed, image[None, 4:37, 5:38, 6:39])
+    assert out.shape[1:] == pred
+    # (a) the Python loop, step by step
+    canvas = _device_canvas(exe, model, image)
+    got_steps, got_moves = _run_recorded(canvas, g['seeds'])
+    assert got_steps == [tuple(int(v) for v in p) for p in g['steps']]
+    off = 0
+    for k, moves in enumerate(got_moves):
+      nm = int(g['n_moves'][k])
+      assert len(moves) == nm, k
+      for j, (s, c) in enumerate(moves):
+        assert c == tuple(int(v) for v in g['move_coords'][off + j]), (k, j)
+        assert abs(s - float(g['move_scores'][off + j])) <= RUN_TOL
+      off += nm
+    assert np.array_equal(np.asarray(canvas.segmentation), g['segmentation'])
+    seed_got = np.asarray(canvas.seed)
+    assert np.array_equal(np.isnan(seed_got), np.isnan(g['seed_logits']))
+    assert np.nanmax(np.abs(seed_got - g['seed_logits'])) <= RUN_TOL
+    canvas.close()
+    # (b) the in-library segment loop (speculative conv0_a, fused faces + paste)
+    canvas = _device_canvas(exe, model, image)
+    assert canvas._native_loop_ok()
+    canvas.segment_all(seed_policy=functools.partial(seed_lib_fixed(),
+                                                     coords=g['seeds']))
+    assert np.array_equal(np.asarray(canvas.segmentation), g['segmentation'])
+    ref_c = json.loads(str(g['counters']))
+    for key in ('update_at-calls', 'voxels-segmented', 'skip_invalid_pos'):
+      assert canvas.counters[key].value == ref_c[key], key
+    canvas.close()
+  finally:
+    exe.engine.close()

@@ -574,3 +574,49 @@ def test_update_seed_pads_a_smaller_prediction_around_the_centre():
   same = ffn_model.FFNModel(_info())
   s2 = np.full((33, 33, 33), 2.0, np.float32)
   assert np.all(same.update_seed(s2, np.ones_like(s2)) == 3.0)
+
+
+@pytest.mark.parametrize('name', ['cells56_pred25', 'cells72_pred27'])
+@pytest.mark.parametrize('device', [False, True])
+def test_pred_smaller_than_seed_reproduces_reference_run(fib25_blob, name, device):
+  """ModelInfo.pred_mask_size < input_seed_size (reference model.py:168-183,
+  inference.py:218,410-411): the reference's Canvas, driven with a network that
+  hands back the centred pred box of (seed + update), minted
+  tests/golden/ref_canvas_<name>.npz (tools/make_golden.py --only predcrop); the
+  host Canvas and the DeviceCanvas (emulated device: the specification of
+  ffn_engine_set_pred_size) reproduce it."""
+  path = os.path.join(GOLDEN, 'ref_canvas_%s.npz' % name)
+  if not os.path.exists(path):
+    pytest.skip('fixture not minted')
+  g = np.load(path)
+  pred = tuple(int(v) for v in g['pred_zyx'])
+  assert pred != (33, 33, 33)
+  r = _request()
+  info = ffn_model.ModelInfo(np.array([8, 8, 8]), np.array(pred[::-1]),
+                             np.array([33, 33, 33]), np.array([33, 33, 33]))
+  image = synthetic.normalize(g['volume'])
+  if device:
+    client = EmulatedDeviceClient(inference_utils.Counters(), fib25_blob, 12,
+                                  (33, 33, 33), (8, 8, 8), pred_zyx=pred)
+  else:
+    lo = [(33 - p) // 2 for p in pred]
+    box = tuple(slice(l, l + p) for l, p in zip(lo, pred))
+
+    class Cropping(_OracleClient):
+
+      def predict(self, seed, image, fetches):
+        out = ffn_oracle.forward(image, seed, self.blob, 12)
+        return {'logits': np.ascontiguousarray(out[box])[..., None]}
+
+    client = Cropping(fib25_blob)
+  canvas = inference.make_canvas(info, client, image, r.inference_options,
+                                 movement_policy_fn=movement.get_policy_fn(r, info))
+  assert isinstance(canvas, inference.DeviceCanvas) == device
+  canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                   coords=g['seeds']))
+  assert np.array_equal(np.asarray(canvas.segmentation), g['segmentation'])
+  assert np.array_equal(np.asarray(canvas.seed), g['seed_logits'], equal_nan=True)
+  ref = json.loads(str(g['counters']))
+  for key in ('update_at-calls', 'voxels-segmented', 'voxels-overlapping',
+              'skip_invalid_pos', 'segment_at-loop-calls'):
+    assert canvas.counters[key].value == ref[key], key

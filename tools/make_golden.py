@@ -182,10 +182,13 @@ class OracleClient(ref_executor.ExecutorClient):
 
 def run_reference_canvas(image_f32, blob, depth, fov, deltas, seeds,
                          min_segment_size=1000, forward_fn=None,
-                         restrictor=None):
-  """Drives the reference Canvas exactly as Runner does (runner.py:392-408)."""
+                         restrictor=None, pred=None):
+  """Drives the reference Canvas exactly as Runner does (runner.py:392-408).
+  pred (zyx): a prediction smaller than the seed FoV (ModelInfo.pred_mask_size <
+  input_seed_size; inference.py:218,410-411)."""
   info = ref_model.ModelInfo(
-      deltas=np.array(deltas[::-1]), pred_mask_size=np.array(fov[::-1]),
+      deltas=np.array(deltas[::-1]),
+      pred_mask_size=np.array((pred or fov)[::-1]),
       input_seed_size=np.array(fov[::-1]), input_image_size=np.array(fov[::-1]))
   request = inference_pb2.InferenceRequest()
   o = request.inference_options
@@ -226,7 +229,7 @@ def run_reference_canvas(image_f32, blob, depth, fov, deltas, seeds,
 
 
 def make_canvas_case(name, shape, seed, depth_weights, grid_step, grid_offsets,
-                     dilate):
+                     dilate, pred=None):
   vol = synthetic.cells_volume(shape, seed=seed, membrane_dilate=dilate)
   image = synthetic.normalize(vol)
   blob, depth = depth_weights
@@ -234,8 +237,19 @@ def make_canvas_case(name, shape, seed, depth_weights, grid_step, grid_offsets,
   deltas = (8, 8, 8)
   seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16), step=grid_step,
                                 offsets=grid_offsets)
+  forward_fn = None
+  if pred is not None:
+    # the model's `logits` = (seed + update) of the centred pred box: what a
+    # network with pred_mask_size < input_seed_size hands to Canvas.update_at
+    lo = [(f - p) // 2 for f, p in zip(fov, pred)]
+    sel = tuple(slice(l, l + p) for l, p in zip(lo, pred))
+
+    def forward_fn(img, sd):
+      return np.ascontiguousarray(ffn_oracle.forward(img, sd, blob, depth)[sel])
+
   canvas, trace, counters = run_reference_canvas(image, blob, depth, fov,
-                                                 deltas, seeds)
+                                                 deltas, seeds,
+                                                 forward_fn=forward_fn, pred=pred)
   seg = np.array(canvas.segmentation)
   steps = np.array([t[0] for t in trace], np.int32).reshape(-1, 3)
   n_moves = np.array([len(t[1]) for t in trace], np.int32)
@@ -253,7 +267,8 @@ def make_canvas_case(name, shape, seed, depth_weights, grid_step, grid_offsets,
       volume=vol, seeds=seeds, segmentation=seg, seed_logits=np.array(
           canvas.seed), steps=steps, n_moves=n_moves, move_scores=move_scores,
       move_coords=move_coords, origins=json.dumps(origins),
-      counters=json.dumps(keep), depth=depth)
+      counters=json.dumps(keep), depth=depth,
+      pred_zyx=np.array(pred or fov, np.int32))
   print(name, 'steps', len(steps), 'segments', len(origins), 'counters', keep)
 
 
@@ -420,6 +435,14 @@ def main():
     blob = ffn_oracle.weights_blob(v, 12)
     make_canvas_case('cells56', (56, 56, 56), 11, (blob, 12), 16, (0, 8), 1)
     make_canvas_case('cells72', (72, 64, 80), 5, (blob, 12), 16, (0,), 2)
+  if args.only in ('', 'predcrop'):
+    # pred_mask_size (25^3) < input_seed_size (33^3)
+    v = tf_checkpoint.load_checkpoint(CKPT)
+    blob = ffn_oracle.weights_blob(v, 12)
+    make_canvas_case('cells56_pred25', (56, 56, 56), 11, (blob, 12), 16, (0, 8), 1,
+                     pred=(25, 25, 25))
+    make_canvas_case('cells72_pred27', (72, 64, 80), 5, (blob, 12), 16, (0,), 2,
+                     pred=(27, 29, 25))
   if args.only in ('', 'masks'):
     v = tf_checkpoint.load_checkpoint(CKPT)
     make_masks(ffn_oracle.weights_blob(v, 12), 12)
