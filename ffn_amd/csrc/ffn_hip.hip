@@ -173,6 +173,7 @@ struct ffn_engine {
   int spec_force_mismatch = 0;  // debug option: fail the next N matches
   long stat_spec_mismatch = 0;
   int fuse_paste = 1;       // option: faces + paste of a single FoV as one launch
+  int fuse_conv0a = 1;      // option: ... and the next step's conv0_a in it as well
   int* d_spec_choice = nullptr;
   long stat_spec_launched = 0, stat_spec_hits = 0;
   unsigned range_tag = 0;        // tag of the run being queued
@@ -185,6 +186,13 @@ struct ffn_engine {
   float* up_image = nullptr;  // dense FoVs uploaded by ffn_predict
   float* up_seed = nullptr;
   float* seed_raw = nullptr;  // raw (NaN-preserving) seed FoV of the current step
+  // The conv0_a of the NEXT step may run in the same launch as this step's faces
+  // and paste (faces_paste_conv0a_kernel): what it writes -- the raw seed copy,
+  // a range flag, the position it chose -- goes to the OTHER of two sets, which
+  // run_stack makes the current one when that step is queued.
+  float* seed_raw_alt = nullptr;
+  unsigned* range_flag_alt = nullptr;
+  int* d_spec_choice_alt = nullptr;
   float* logits = nullptr;
   unsigned* count = nullptr;
   uint8_t* valid = nullptr;
@@ -783,31 +791,54 @@ int launch_conv32d(ffn_engine* e, int n, const float* raw_in, float* raw_out,
 
 // FoVs described by `si` -> logits (+ count of logits >= move_thr, + seed_raw)
 // conv0_a of a step whose range tag is `tag` (sp.n > 0: a speculative launch)
+// conv0_a of the split-product family as the argument block of the fused launch;
+// returns its number of tiles.  next: for the step AFTER the current one (its
+// outputs go to the other set: ffn_engine::seed_raw_alt ...)
+int conv0a_split_args(ffn_engine* e, float pad_value, unsigned tag, const SpecArgs& sp,
+                      bool next, Conv0Next& nx) {
+  const float* W = e->weights;
+  const Geom& q = e->gp;  // the split-product kernels' layout of the FoV
+  const int qz = (q.fz + kC0Z - 1) / kC0Z, qy = (q.fy + kC0Y - 1) / kC0Y,
+            qx = (q.fx + kC0X - 1) / kC0X;
+  nx.pad_value = pad_value;
+  nx.w = W + (e->permuted ? e->w0ap_off : e->w0a_off);
+  nx.bias = W + e->b0a_off;
+  nx.out = e->bufT;
+  nx.seed_raw = next ? e->seed_raw_alt : e->seed_raw;
+  nx.q = q;
+  nx.tiles_y = qy;
+  nx.tiles_x = qx;
+  nx.so.out_sp = reinterpret_cast<char*>(e->rawT) + (size_t)q.guard * 16;
+  nx.so.sp_plane_bytes = (q.act_stride / kFeatures) * 16;
+  nx.so.item_bytes = q.act_stride * (long)sizeof(float);
+  nx.so.range_flag = next ? e->range_flag_alt : e->range_flag;
+  nx.so.range_tag = tag;
+  nx.sp = sp;
+  if (sp.n > 0) nx.sp.choice = next ? e->d_spec_choice_alt : e->d_spec_choice;
+  return qz * qy * qx;
+}
+
 void launch_conv0a(ffn_engine* e, int n, const StepItems& si, float pad_value,
-                   unsigned tag, const SpecArgs& sp) {
+                   unsigned tag, const SpecArgs& sp, bool next = false) {
   const Geom& g = e->g;
   const float* W = e->weights;
   const int tz = (g.fz + kC0Z - 1) / kC0Z, ty = (g.fy + kC0Y - 1) / kC0Y,
             tx = (g.fx + kC0X - 1) / kC0X;
   if (e->conv_variant >= 6) {
-    const Geom& q = e->gp;  // the split-product kernels' layout of the FoV
-    const int qz = (q.fz + kC0Z - 1) / kC0Z, qy = (q.fy + kC0Y - 1) / kC0Y,
-              qx = (q.fx + kC0X - 1) / kC0X;
-    Conv0SplitOut so;
-    so.out_sp = reinterpret_cast<char*>(e->rawT) + (size_t)q.guard * 16;
-    so.sp_plane_bytes = (q.act_stride / kFeatures) * 16;
-    so.item_bytes = q.act_stride * (long)sizeof(float);
-    so.range_flag = e->range_flag;
-    so.range_tag = tag;
-    hipLaunchKernelGGL(conv0a_mfma_kernel<true>, dim3(qz * qy * qx, n),
-                       dim3(kC0Threads), 0, e->stream, si, pad_value,
-                       W + (e->permuted ? e->w0ap_off : e->w0a_off), W + e->b0a_off,
-                       e->bufT, e->seed_raw, q, qy, qx, so, sp);
-  } else
+    Conv0Next nx;
+    const int tiles = conv0a_split_args(e, pad_value, tag, sp, next, nx);
+    hipLaunchKernelGGL(conv0a_mfma_kernel<true>, dim3(tiles, n),
+                       dim3(kC0Threads), 0, e->stream, si, pad_value, nx.w, nx.bias,
+                       nx.out, nx.seed_raw, nx.q, nx.tiles_y, nx.tiles_x, nx.so, nx.sp);
+  } else {
+    SpecArgs sp2 = sp;
+    if (sp.n > 0) sp2.choice = next ? e->d_spec_choice_alt : e->d_spec_choice;
     hipLaunchKernelGGL(conv0a_mfma_kernel<false>, dim3(tz * ty * tx, n),
                        dim3(kC0Threads), 0, e->stream, si, pad_value,
-                       W + e->w0a_off, W + e->b0a_off, e->bufT, e->seed_raw, g,
-                       ty, tx, Conv0SplitOut(), sp);
+                       W + e->w0a_off, W + e->b0a_off, e->bufT,
+                       next ? e->seed_raw_alt : e->seed_raw, g, ty, tx,
+                       Conv0SplitOut(), sp2);
+  }
 }
 
 // The 2 depth - 1 convs of ONE FoV as a single resident launch (conv32ps,
@@ -851,6 +882,11 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   if (!conv0a_done) drop_spec(e);
   e->spec.valid = false;
   e->range_tag = next_tag(e->range_tag);
+  // this step's set of conv0_a outputs: what a launch made ahead for it wrote,
+  // what its own conv0_a (below) writes
+  std::swap(e->seed_raw, e->seed_raw_alt);
+  std::swap(e->range_flag, e->range_flag_alt);
+  std::swap(e->d_spec_choice, e->d_spec_choice_alt);
   const bool sampled = (e->stack_calls % e->prof_every) == 0;
   e->stack_calls++;
   e->prof_now = e->prof_mode == 1 && sampled;
@@ -1158,6 +1194,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
   E_TRY(hipMalloc(&e->up_image, vbytes));
   E_TRY(hipMalloc(&e->up_seed, vbytes));
   E_TRY(hipMalloc(&e->seed_raw, vbytes));
+  E_TRY(hipMalloc(&e->seed_raw_alt, vbytes));
   E_TRY(hipMalloc(&e->logits, vbytes));
   E_TRY(hipHostMalloc(&e->h_io, 3 * vbytes, hipHostMallocDefault));
   E_TRY(hipMemset(e->up_image, 0, vbytes));
@@ -1326,6 +1363,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
                                     sizeof(uint16_t)));
     E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
     E_TRY(hipMemset(e->range_flag, 0, sizeof(unsigned)));
+    E_TRY(hipMalloc(&e->range_flag_alt, sizeof(unsigned)));
+    E_TRY(hipMemset(e->range_flag_alt, 0, sizeof(unsigned)));
     {
       const size_t words = ((size_t)(e->gp.V + 31) / 32 + 64) * kFlowStride;
       E_TRY(hipMalloc(&e->flow_flags, words * sizeof(unsigned)));
@@ -1341,6 +1380,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     }
     E_TRY(hipMalloc(&e->d_spec_choice, sizeof(int)));
     E_TRY(hipMemset(e->d_spec_choice, 0xff, sizeof(int)));
+    E_TRY(hipMalloc(&e->d_spec_choice_alt, sizeof(int)));
+    E_TRY(hipMemset(e->d_spec_choice_alt, 0xff, sizeof(int)));
   }
 
   e->events.resize(2 * 64);
@@ -1399,6 +1440,9 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->up_image);
   (void)hipFree(e->up_seed);
   (void)hipFree(e->seed_raw);
+  (void)hipFree(e->seed_raw_alt);
+  (void)hipFree(e->range_flag_alt);
+  (void)hipFree(e->d_spec_choice_alt);
   (void)hipFree(e->logits);
   (void)hipFree(e->count);
   (void)hipFree(e->wpackd);
@@ -1648,6 +1692,11 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->fuse_paste = value != 0;
     return FFN_OK;
   }
+  if (std::strcmp(name, "fuse_conv0a") == 0) {
+    drop_spec(e);
+    e->fuse_conv0a = value != 0;
+    return FFN_OK;
+  }
   if (std::strcmp(name, "speculate") == 0) {
     // single-FoV steps of ffn_canvas_segment_at: queue the next step's conv0_a
     // behind the paste, ahead of the host's turn-around (SpecArgs)
@@ -1691,6 +1740,7 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "stat_step_items") == 0) *value = (int)e->stat_items;
   else if (std::strcmp(name, "speculate") == 0) *value = e->speculate;
   else if (std::strcmp(name, "fuse_paste") == 0) *value = e->fuse_paste;
+  else if (std::strcmp(name, "fuse_conv0a") == 0) *value = e->fuse_conv0a;
   else if (std::strcmp(name, "stat_spec_launched") == 0)
     *value = (int)e->stat_spec_launched;
   else if (std::strcmp(name, "stat_spec_hits") == 0) *value = (int)e->stat_spec_hits;
@@ -2095,8 +2145,44 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
                        e->range_flag, e->range_tag,
                        e->d_spec_choice, spec_expected);
   };
+  // the next step's conv0_a, behind the paste and ahead of the host's turn-around
+  // (SpecArgs): for the positions the segment loop expects to pop next
+  SpecArgs sp;
+  sp.n = 0;
+  sp.move_thr = params->move_threshold;
+  sp.choice = nullptr;  // (launch_conv0a / conv0a_split_args: the next step's word)
+  if (n == 1) {
+    const ffn_canvas* c = canvases[0];
+    const int half[3] = {g.fz / 2, g.fy / 2, g.fx / 2};
+    const int dims[3] = {c->cz, c->cy, c->cx};
+    for (int j = 0; j < hint_n && e->speculate; ++j) {
+      bool inside = true;
+      for (int a = 0; a < 3; ++a)
+        if (hint_pos[j][a] - half[a] < 0 || hint_pos[j][a] + half[a] >= dims[a])
+          inside = false;
+      if (!inside) continue;
+      for (int a = 0; a < 3; ++a) sp.pos[sp.n][a] = hint_pos[j][a];
+      ++sp.n;
+    }
+    for (int j = sp.n; j < kSpecMax && sp.n > 0; ++j)  // unused slots: readable positions
+      for (int a = 0; a < 3; ++a) sp.pos[j][a] = sp.pos[0][a];
+  }
+  // ... in the SAME launch as this step's faces and paste where it can be
+  // (faces_paste_conv0a_kernel: it gathers the canvas as the paste is leaving it)
+  const bool fused_next = n == 1 && sp.n > 0 && e->fuse_paste && e->fuse_conv0a &&
+                          e->conv_variant >= 6;
   if (n > 1) paste();
-  if (n == 1 && e->fuse_paste) {
+  if (fused_next) {
+    Conv0Next nx;
+    const int tiles = conv0a_split_args(e, params->pad_value, next_tag(e->range_tag), sp,
+                                        true, nx);
+    hipLaunchKernelGGL(faces_paste_conv0a_kernel, dim3(1 + kPasteBlocks + tiles),
+                       dim3(512), 0, e->stream, si, g, e->logits, e->seed_raw, e->count,
+                       e->count_blocks, params->move_threshold,
+                       params->disco_seed_threshold, params->deleted_threshold,
+                       e->range_flag, e->range_tag, h_pub, step_id, e->d_spec_choice,
+                       spec_expected, nx);
+  } else if (n == 1 && e->fuse_paste) {
     hipLaunchKernelGGL(faces_paste_kernel, dim3(1 + 71), dim3(512), 0, e->stream, si,
                        g, e->logits, e->seed_raw, e->count, e->count_blocks,
                        params->move_threshold, params->disco_seed_threshold,
@@ -2110,29 +2196,11 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
                        h_pub, step_id, e->d_spec_choice, spec_expected);
     if (n == 1) paste();
   }
-  // the next step's conv0_a, behind the paste and ahead of the host's turn-around
-  // (SpecArgs): for the positions the segment loop expects to pop next
   if (n == 1) {
     ffn_canvas* c = canvases[0];
-    SpecArgs sp;
-    sp.n = 0;
-    sp.move_thr = params->move_threshold;
-    sp.choice = e->d_spec_choice;
-    const int half[3] = {g.fz / 2, g.fy / 2, g.fx / 2};
-    const int dims[3] = {c->cz, c->cy, c->cx};
-    for (int j = 0; j < hint_n && e->speculate; ++j) {
-      bool inside = true;
-      for (int a = 0; a < 3; ++a)
-        if (hint_pos[j][a] - half[a] < 0 || hint_pos[j][a] + half[a] >= dims[a])
-          inside = false;
-      if (!inside) continue;
-      for (int a = 0; a < 3; ++a) sp.pos[sp.n][a] = hint_pos[j][a];
-      ++sp.n;
-    }
     if (sp.n > 0) {
-      for (int j = sp.n; j < kSpecMax; ++j)  // unused slots: readable positions
-        for (int a = 0; a < 3; ++a) sp.pos[j][a] = sp.pos[0][a];
-      launch_conv0a(e, 1, si, params->pad_value, next_tag(e->range_tag), sp);
+      if (!fused_next)
+        launch_conv0a(e, 1, si, params->pad_value, next_tag(e->range_tag), sp, true);
       e->spec.valid = true;
       e->spec.canvas = c;
       e->spec.n = sp.n;

@@ -172,20 +172,45 @@ struct SpecArgs {
   int* choice;
 };
 
+// The canvas as it WILL be once the step whose paste runs next to this conv0_a
+// (the fused faces + paste + next conv0_a launch) has pasted: inside that step's
+// prediction box the seed is post_disco(logits, old seed) -- exactly what its
+// paste blocks are writing meanwhile -- elsewhere the canvas itself.  on = 0: the
+// canvas as it is (a launch of its own, or a void step that pastes nothing).
+struct SeedOverlay {
+  int on;
+  int disco;
+  const float* lg;   // the step's logits, dense [z][y][x] of the caller's FoV
+  const float* old;  // its raw input seed
+  int z0, y0, x0;    // canvas corner of its FoV
+  int fy, fx;        // its FoV's row / plane strides
+  int c0[3], c1[3];  // its prediction box (Geom::c0 / c1)
+};
+
+__device__ __forceinline__ float post_disco(float lg, float old, bool disco);
+
+// index into the overlay's dense arrays of canvas voxel (Z, Y, X), or -1
+__device__ __forceinline__ int overlay_index(const SeedOverlay& ov, int Z, int Y, int X) {
+  const int lz = Z - ov.z0, ly = Y - ov.y0, lx = X - ov.x0;
+  const bool in = ov.on && lz >= ov.c0[0] && lz < ov.c1[0] && ly >= ov.c0[1] &&
+                  ly < ov.c1[1] && lx >= ov.c0[2] && lx < ov.c1[2];
+  return in ? (lz * ov.fy + ly) * ov.fx + lx : -1;
+}
+
 template <bool SPLIT>
-__global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
-    StepItems si, float pad_value, const float* __restrict__ w /*[27][2][32]*/,
+__device__ __forceinline__ void conv0a_body(
+    const int tile_block, const int item, const StepItems& si, float pad_value,
+    const float* __restrict__ w /*[27][2][32]*/,
     const float* __restrict__ bias, float* __restrict__ out,
-    float* __restrict__ seed_raw, Geom g, int tiles_y, int tiles_x,
-    Conv0SplitOut so, SpecArgs sp) {
+    float* __restrict__ seed_raw, const Geom& g, int tiles_y, int tiles_x,
+    const Conv0SplitOut& so, const SpecArgs& sp, const SeedOverlay& ov) {
   constexpr int HZ = kC0Z + 2, HY = kC0Y + 2, HX = kC0X + 2;
   __shared__ float tile[HZ * HY * HX * 2];  // (image, seed) interleaved
   __shared__ float s_lut[256];              // uint8 canvases: normalisation table
   // SPLIT: the block's 256 x 32 outputs, transposed through LDS (36-float rows)
   __shared__ __attribute__((aligned(16))) float otile[SPLIT ? 256 * 36 : 4];
-  const int item = blockIdx.y;
   const ItemView it = item_view(si, item);
-  int b = blockIdx.x;
+  int b = tile_block;
   const int tx = b % tiles_x;
   b /= tiles_x;
   const int ty = b % tiles_y;
@@ -199,13 +224,21 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
     // (all of them in flight at once)
     float sv[kSpecMax];
     int gv[kSpecMax];
+    int ovi[kSpecMax];
+    float ol[kSpecMax], oo[kSpecMax];
 #pragma unroll
     for (int k = 0; k < kSpecMax; ++k) {
       const size_t ci =  // (the host fills unused slots with candidate 0)
           ((size_t)sp.pos[k][0] * it.cy + sp.pos[k][1]) * it.cx + sp.pos[k][2];
       sv[k] = it.seed[ci];
       gv[k] = it.seg[ci];
+      ovi[k] = overlay_index(ov, sp.pos[k][0], sp.pos[k][1], sp.pos[k][2]);
+      ol[k] = ov.on ? ov.lg[ovi[k] < 0 ? 0 : ovi[k]] : 0.f;
+      oo[k] = ov.on ? ov.old[ovi[k] < 0 ? 0 : ovi[k]] : 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < kSpecMax; ++k)
+      if (ovi[k] >= 0) sv[k] = post_disco(ol[k], oo[k], ov.disco != 0);
 #pragma unroll
     for (int k = 0; k < kSpecMax; ++k)  // (no short-circuit into dependent loads)
       asm volatile("" : "+v"(sv[k]), "+v"(gv[k]));
@@ -213,7 +246,7 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
 #pragma unroll
     for (int k = kSpecMax - 1; k >= 0; --k)
       if (k < sp.n && !(sv[k] < sp.move_thr) && gv[k] <= 0) ch = k;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sp.choice = ch;
+    if (tile_block == 0 && threadIdx.x == 0) *sp.choice = ch;
     if (ch < 0) return;
 #pragma unroll
     for (int k = 0; k < kSpecMax; ++k)
@@ -257,6 +290,7 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
   float g_img[kC0Per] = {}, g_seed[kC0Per];
   unsigned g_raw[kC0Per] = {};
   size_t g_ci[kC0Per];
+  int g_ov[kC0Per];  // index into the overlay (a voxel the running paste writes), or -1
   long g_out[kC0Per];  // seed_raw index of an interior voxel, else -1
   bool g_in[kC0Per];
 #pragma unroll
@@ -272,6 +306,14 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
               xx >= 0 && xx < g.fx;
     // (voxel 0 of the canvas stands in outside the FoV: loads without branches)
     g_ci[k] = g_in[k] ? (size_t)((z0 + zz) * sz + (y0 + yy) * sy + (x0 + xx) * sx) : 0;
+    g_ov[k] = -1;
+    if (ov.on && g_in[k]) {
+      int cc[3];  // canvas coordinates: this geometry's axis a is canvas axis oa[a]
+      cc[g.oa[0]] = z0 + zz;
+      cc[g.oa[1]] = y0 + yy;
+      cc[g.oa[2]] = x0 + xx;
+      g_ov[k] = overlay_index(ov, cc[0], cc[1], cc[2]);
+    }
     // interior voxel: keep the raw seed (NaN preserved), at its place in the
     // caller's dense [z][y][x] order
     g_out[k] = (g_in[k] && hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y &&
@@ -289,6 +331,17 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
   }
 #pragma unroll
   for (int k = 0; k < kC0Per; ++k) g_seed[k] = it.seed[g_ci[k]];
+  if (ov.on) {
+    float o_l[kC0Per], o_o[kC0Per];
+#pragma unroll
+    for (int k = 0; k < kC0Per; ++k) {
+      o_l[k] = ov.lg[g_ov[k] < 0 ? 0 : g_ov[k]];
+      o_o[k] = ov.old[g_ov[k] < 0 ? 0 : g_ov[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < kC0Per; ++k)
+      if (g_ov[k] >= 0) g_seed[k] = post_disco(o_l[k], o_o[k], ov.disco != 0);
+  }
   if (u8 && threadIdx.x < 256) s_lut[threadIdx.x] = lut_v;
   __syncthreads();  // the table is in LDS
 #pragma unroll
@@ -389,6 +442,18 @@ __global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
     if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *so.range_flag = so.range_tag;
   }
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(kC0Threads) void conv0a_mfma_kernel(
+    StepItems si, float pad_value, const float* __restrict__ w /*[27][2][32]*/,
+    const float* __restrict__ bias, float* __restrict__ out,
+    float* __restrict__ seed_raw, Geom g, int tiles_y, int tiles_x,
+    Conv0SplitOut so, SpecArgs sp) {
+  SeedOverlay ov;
+  ov.on = 0;
+  conv0a_body<SPLIT>(blockIdx.x, blockIdx.y, si, pad_value, w, bias, out, seed_raw, g,
+                     tiles_y, tiles_x, so, sp, ov);
 }
 
 // ---------------------------------------------------------------------------
@@ -2767,6 +2832,73 @@ __global__ __launch_bounds__(512) void faces_paste_kernel(
     paste_body(0, blockIdx.x - 1, gridDim.x - 1, si, g, logits, in_seed, block_count,
                head_blocks, move_thr, disco_thr, range_flag, range_tag, spec_choice,
                spec_expected);
+}
+
+// ... and the NEXT step's conv0_a in the same launch (engine option fuse_paste 2,
+// the default where a step is followed by a speculative conv0_a): blocks
+// kPasteBlocks + 1 .. gather the next FoV from the canvas AS THE PASTE BLOCKS
+// NEXT TO THEM ARE LEAVING IT (SeedOverlay: inside this step's prediction box the
+// seed is recomputed from the logits, as the faces block does for the queue's
+// candidates), so that nothing waits for the paste: one launch and one kernel
+// boundary less per step, the conv0_a under the faces' PCIe round trips.  The
+// next step's raw seed copy, range flag and choice word are the OTHER of two
+// sets (StepSlot): this step's are still being read.
+constexpr int kPasteBlocks = 71;
+struct Conv0Next {
+  float pad_value;
+  const float* w;
+  const float* bias;
+  float* out;
+  float* seed_raw;   // the next step's
+  Geom q;            // the split-product kernels' layout of the FoV
+  int tiles_y, tiles_x;
+  Conv0SplitOut so;  // (range flag / tag: the next step's)
+  SpecArgs sp;       // (choice: the next step's)
+};
+
+__global__ __launch_bounds__(512) void faces_paste_conv0a_kernel(
+    StepItems si, Geom g, const float* __restrict__ logits,
+    const float* __restrict__ in_seed,
+    const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
+    float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
+    unsigned range_tag, unsigned long long* __restrict__ pub, unsigned step_id,
+    const int* __restrict__ spec_choice, int spec_expected, Conv0Next nx) {
+  static_assert(kC0Threads == 512, "one block size for the three roles");
+  if (blockIdx.x == 0) {
+    faces_body(0, si, g, logits, in_seed, block_count, head_blocks, move_thr,
+               disco_thr, deleted_thr, range_flag, range_tag, pub, step_id,
+               spec_choice, spec_expected);
+    return;
+  }
+  if (blockIdx.x <= kPasteBlocks) {
+    paste_body(0, blockIdx.x - 1, kPasteBlocks, si, g, logits, in_seed, block_count,
+               head_blocks, move_thr, disco_thr, range_flag, range_tag, spec_choice,
+               spec_expected);
+    return;
+  }
+  __shared__ unsigned s_cnt[8];
+  const ItemView it = item_view(si, 0);
+  SeedOverlay ov;
+  // a void step (fp16 range, or a speculative conv0_a made for another position)
+  // pastes nothing: the canvas stays as it is
+  ov.on = !(*range_flag == range_tag ||
+            (spec_expected >= 0 && *spec_choice != spec_expected));
+  const unsigned cnt = step_count(g, logits, move_thr, block_count, head_blocks, 0, s_cnt);
+  ov.disco = disco_on(cnt, g.Vp, disco_thr) ? 1 : 0;
+  ov.lg = logits;
+  ov.old = in_seed;
+  ov.z0 = it.pos[0] - g.fz / 2;
+  ov.y0 = it.pos[1] - g.fy / 2;
+  ov.x0 = it.pos[2] - g.fx / 2;
+  ov.fy = g.fy;
+  ov.fx = g.fx;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    ov.c0[a] = g.c0[a];
+    ov.c1[a] = g.c1[a];
+  }
+  conv0a_body<true>(blockIdx.x - 1 - kPasteBlocks, 0, si, nx.pad_value, nx.w, nx.bias,
+                    nx.out, nx.seed_raw, nx.q, nx.tiles_y, nx.tiles_x, nx.so, nx.sp, ov);
 }
 
 // ---------------------------------------------------------------------------

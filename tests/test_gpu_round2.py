@@ -53,6 +53,7 @@ def _assert_shipped_default(eng):
   assert eng.get_option('flow') == 2
   assert eng.get_option('speculate') == 1
   assert eng.get_option('fuse_paste') == 1
+  assert eng.get_option('fuse_conv0a') == 1
 
 
 def _device_canvas(exe, model, image, **kwargs):
@@ -665,14 +666,18 @@ def test_speculative_conv0a_leaves_the_run_unchanged(hip_exe, fib25_model):
   steps = len(g['steps'])
   stats = {}
   try:
-    # (speculate, fuse_paste: faces + paste of a step as ONE launch)
-    # the last: five steps whose launch is declared a mismatch (test hook) --
+    # (speculate, fuse_paste: faces + paste of a step as ONE launch, fuse_conv0a:
+    # the next step's conv0_a in that launch too -- it then gathers the canvas as
+    # the paste next to it is leaving it)
+    # fuse 2 / 3: five steps whose launch is declared a mismatch (test hook) --
     # they paste nothing and are made again
-    for spec, fuse in ((1, 0), (0, 0), (1, 1), (0, 1), (1, 2)):
+    for spec, fuse, f0a in ((1, 0, 0), (0, 0, 0), (1, 1, 0), (0, 1, 0), (1, 2, 0),
+                            (1, 1, 1), (0, 1, 1), (1, 3, 1)):
       eng.set_option('speculate', spec)
       eng.set_option('fuse_paste', fuse & 1)
+      eng.set_option('fuse_conv0a', f0a)
       eng.set_option('stat_reset', 0)
-      eng.set_option('spec_force_mismatch', 5 if fuse == 2 else 0)
+      eng.set_option('spec_force_mismatch', 5 if fuse >= 2 else 0)
       canvas = _device_canvas(hip_exe, fib25_model,
                               synthetic.normalize(g['volume']), keep_history=True)
       assert canvas._native_loop_ok()
@@ -691,22 +696,25 @@ def test_speculative_conv0a_leaves_the_run_unchanged(hip_exe, fib25_model):
       assert canvas.counters['update_at-calls'].value == steps
       if seen:
         assert np.array_equal(np.array(seen), g['steps'])
-      stats[spec, fuse] = (eng.get_option('stat_spec_launched'),
-                           eng.get_option('stat_spec_hits'))
-      assert eng.get_option('stat_spec_mismatch') == (5 if fuse == 2 else 0)
+      stats[spec, fuse, f0a] = (eng.get_option('stat_spec_launched'),
+                                eng.get_option('stat_spec_hits'))
+      assert eng.get_option('stat_spec_mismatch') == (5 if fuse >= 2 else 0)
       canvas.close()
   finally:
     eng.set_option('speculate', 1)
     eng.set_option('fuse_paste', 1)
+    eng.set_option('fuse_conv0a', 1)
     eng.set_option('spec_force_mismatch', 0)
   print('cells72, %d steps: conv0_a launched ahead %d times, used by %d steps'
-        % ((steps,) + stats[1, 0]))
-  assert stats[0, 0] == stats[0, 1] == (0, 0)
-  assert stats[1, 0] == stats[1, 1]
+        % ((steps,) + stats[1, 0, 0]))
+  assert stats[0, 0, 0] == stats[0, 1, 0] == stats[0, 1, 1] == (0, 0)
+  assert stats[1, 0, 0] == stats[1, 1, 0] == stats[1, 1, 1]
   # (a repeated step carries no hint: the step after it runs without a launch)
-  assert stats[1, 2][0] == stats[1, 0][0]
-  assert stats[1, 0][1] - 5 <= stats[1, 2][1] <= stats[1, 0][1]
-  assert stats[1, 0][0] > steps // 2 and stats[1, 0][1] > 0.6 * stats[1, 0][0]
+  for k in ((1, 2, 0), (1, 3, 1)):
+    assert stats[k][0] == stats[1, 0, 0][0]
+    assert stats[1, 0, 0][1] - 5 <= stats[k][1] <= stats[1, 0, 0][1]
+  assert (stats[1, 0, 0][0] > steps // 2 and
+          stats[1, 0, 0][1] > 0.6 * stats[1, 0, 0][0])
 
 
 def test_speculative_conv0a_permuted_layout():
