@@ -1260,6 +1260,11 @@ __device__ __forceinline__ void flow_trace_row(const ConvDArgs& a, const ConvLay
     long long* d = a.flow_trace + ((long)gc * kFlowTraceLayers + L.layer) * 8;
 #pragma unroll
     for (int i = 0; i < 6; ++i) d[i] = t[i];
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    d[6] = hw;
+    d[7] = xcc;
   }
 }
 
@@ -2429,6 +2434,13 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
   const int v0 = main_wg ? c * kMChunk : mp.n_main * kMChunk + c * 32;
   const int gc = main_wg ? c : mp.n_main + c;
   ConvLayer Ldbg = a.L;
+  // (experiment, flow_dbg 1024: the main workgroups' waves ahead of the tail's in
+  // the CU's arbitration -- a main workgroup that shares its CU with a tail one
+  // is what its neighbours wait for)
+  if (a.flow_dbg & 1024) {
+    if (main_wg) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+  }
   // the residual stream of a main workgroup's voxels (conv32m_body: RES); the
   // tail workgroups keep theirs in memory (their head epilogue has another
   // thread-to-voxel mapping than their conv epilogue)

@@ -50,6 +50,8 @@ def main():
   tr = eng.debug_flow_trace(nslots).astype(np.float64) / 100.0  # us
   eng.set_option('debug_clock', 0)
   nl = 23
+  hw = eng_hw = None
+  raw = tr
   tr = tr[:, :nl, :6]
   t00 = tr[:, 0, 0].min()
   tr = np.where(tr > 0, tr - t00, np.nan)
@@ -100,6 +102,19 @@ def main():
   print('last input tile published -> tiles seen by the consumer (main): median %.2f, 10 %% '
         '%.2f, 90 %% %.2f' % (np.nanmedian(hop), np.nanpercentile(hop, 10),
                                np.nanpercentile(hop, 90)))
+  # which main workgroups share their CU with a tail workgroup?  HW_ID: CU_ID bits
+  # 8-11, SH_ID 12, SE_ID 13-15 (gfx9); XCC_ID separately
+  ids = (raw[:, 1, 6] * 100.0).astype(np.int64)  # (stamps were divided by 100)
+  xcc = (raw[:, 1, 7] * 100.0).astype(np.int64)
+  cu = ((ids >> 8) & 0xff) | (xcc << 8)
+  tail_cus = set(cu[256:].tolist())
+  shared = np.array([c in tail_cus for c in cu[:256]])
+  b_all = tr[:256, 1:nl - 1, 5] - tr[:256, 1:nl - 1, 1]
+  taps = tr[:256, 1:nl - 1, 3] - tr[:256, 1:nl - 1, 2]
+  print('main workgroups that share their CU with a tail workgroup: %d of 256; body '
+        '(tiles seen -> published) median %.2f against %.2f alone; taps %.2f against %.2f'
+        % (shared.sum(), np.nanmedian(b_all[shared]), np.nanmedian(b_all[~shared]),
+           np.nanmedian(taps[shared]), np.nanmedian(taps[~shared])))
   print('timeouts', eng.get_option('stat_flow_timeouts'))
   eng.close()
 
