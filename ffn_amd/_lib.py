@@ -109,6 +109,28 @@ class CommitCounts(ctypes.Structure):
               ('num_overlapped_ids', ctypes.c_int32)]
 
 
+class TurnRequest(ctypes.Structure):
+  """ffn_turn_request (include/ffn_hip.h)."""
+  _fields_ = [('do_commit', ctypes.c_int32),
+              ('lo', ctypes.c_int32 * 3), ('hi', ctypes.c_int32 * 3),
+              ('segment_threshold', ctypes.c_float),
+              ('min_segment_size', ctypes.c_int64),
+              ('segment_id', ctypes.c_int32),
+              ('max_existing_id', ctypes.c_int32),
+              ('mark_mode', ctypes.c_int32),
+              ('mark_pos', ctypes.c_int32 * 3),
+              ('num_candidates', ctypes.c_int32),
+              ('min_boundary_dist', ctypes.c_int32 * 3),
+              ('do_init', ctypes.c_int32),
+              ('init_value', ctypes.c_float)]
+
+
+class TurnResult(ctypes.Structure):
+  """ffn_turn_result (include/ffn_hip.h)."""
+  _fields_ = [('counts', CommitCounts), ('committed', ctypes.c_int32),
+              ('chosen', ctypes.c_int32)]
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _I3 = ctypes.POINTER(ctypes.c_int32)
@@ -167,6 +189,8 @@ SIGNATURES = {
                                      ctypes.c_int32, _P, _P]),
     'ffn_canvas_commit_assign': (_I, [_P, _I3, _I3, ctypes.c_float,
                                       ctypes.c_int32]),
+    'ffn_canvas_segment_turn': (_I, [_P, _P, _P, _P, ctypes.c_int32, _P, _P, _P, _P,
+                                     _P]),
     'ffn_canvas_read_seed': (_I, [_P, _I3, _I3, _P]),
     'ffn_canvas_read_segmentation': (_I, [_P, _I3, _I3, _P]),
     'ffn_canvas_write_seed': (_I, [_P, _I3, _I3, _P]),

@@ -1050,7 +1050,7 @@ int grid_for(long total, int block = 256) {
 
 extern "C" {
 
-int ffn_abi_version(void) { return 8; }
+int ffn_abi_version(void) { return 9; }
 
 const char* ffn_last_error(void) { return g_error.c_str(); }
 
@@ -2613,6 +2613,135 @@ int ffn_canvas_commit_assign(ffn_canvas* c, const int32_t lo[3],
                        segment_id);
   HIP_TRY(hipGetLastError());
   HIP_TRY(lock_.end(e, c));
+  return FFN_OK;
+}
+
+int ffn_canvas_segment_turn(ffn_canvas* c, const ffn_turn_request* rq,
+                            const int32_t* cand, ffn_turn_result* out,
+                            int32_t max_overlaps, int32_t* overlap_ids,
+                            int64_t* overlap_counts, int32_t* cand_flags,
+                            float* cand_seed, int32_t* cand_seg) {
+  UtilLock lock_(c ? c->engine : nullptr);
+  if (!c || !rq || !out) return fail(FFN_ERR_ARG, "null argument");
+  const int n = rq->num_candidates;
+  if (n < 0 || (n > 0 && (!cand || !cand_flags || !cand_seed || !cand_seg)))
+    return fail(FFN_ERR_ARG, "candidate arrays");
+  int rc = FFN_OK;
+  if (rq->do_commit && (rc = check_box(c, rq->lo, rq->hi))) return rc;
+  auto inside = [&](const int32_t* p) {
+    return p[0] >= 0 && p[0] < c->cz && p[1] >= 0 && p[1] < c->cy && p[2] >= 0 &&
+           p[2] < c->cx;
+  };
+  if (rq->mark_mode && !inside(rq->mark_pos))
+    return fail(FFN_ERR_ARG, "marker outside the canvas");
+  for (int k = 0; k < n; ++k)
+    if (!inside(cand + 3 * k)) return fail(FFN_ERR_ARG, "candidate %d outside the canvas", k);
+  for (int a = 0; a < 3; ++a)
+    if (rq->min_boundary_dist[a] < 0) return fail(FFN_ERR_ARG, "min_boundary_dist");
+  ffn_engine* e = c->engine;
+  if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(lock_.begin(e, c));
+  // scratch: [record][histogram][flags, seeds, segs: n each][candidates: 3 n]
+  const int32_t max_id = rq->do_commit ? std::max(rq->max_existing_id, 0) : 0;
+  const size_t hist_n = rq->do_commit ? (size_t)max_id + 1 : 0;
+  const size_t o_hist = sizeof(TurnRecord);
+  const size_t o_flag = (o_hist + hist_n * 4 + 15) & ~(size_t)15;
+  const size_t o_cand = o_flag + 12 * (size_t)n;
+  const size_t bytes = o_cand + 12 * (size_t)n;
+  rc = ensure_scratch(e, bytes);
+  if (rc) return rc;
+  char* ds = static_cast<char*>(e->d_scratch);
+  char* hs = static_cast<char*>(e->h_scratch);
+  auto* d_rec = reinterpret_cast<TurnRecord*>(ds);
+  auto* d_hist = reinterpret_cast<unsigned*>(ds + o_hist);
+  auto* d_flag = reinterpret_cast<int*>(ds + o_flag);
+  auto* d_cseed = reinterpret_cast<float*>(ds + o_flag + 4 * (size_t)n);
+  auto* d_cseg = reinterpret_cast<int32_t*>(ds + o_flag + 8 * (size_t)n);
+  auto* d_cand = reinterpret_cast<int32_t*>(ds + o_cand);
+  // (chosen = -1 until the pick kernel has run: all-ones bytes)
+  HIP_TRY(hipMemsetAsync(ds, 0, o_flag, e->ustream));
+  HIP_TRY(hipMemsetAsync(&d_rec->chosen, 0xff, 4, e->ustream));
+  if (n > 0) {
+    std::memcpy(hs + o_cand, cand, 12 * (size_t)n);
+    HIP_TRY(hipMemcpyAsync(d_cand, hs + o_cand, 12 * (size_t)n, hipMemcpyHostToDevice,
+                           e->ustream));
+  }
+  long total = 0;
+  Box b{};
+  if (rq->do_commit) {
+    b = make_box(c, rq->lo, rq->hi, &total);
+    if (total > 0)
+      hipLaunchKernelGGL(commit_count_kernel, dim3(grid_for(total)), dim3(256), 0,
+                         e->ustream, c->seed, c->seg, b, total, rq->segment_threshold,
+                         max_id, d_rec->counts, d_hist);
+  }
+  if (rq->do_commit || rq->mark_mode) {
+    const long mark_ci =
+        rq->mark_mode ? ((long)rq->mark_pos[0] * c->cy + rq->mark_pos[1]) * c->cx +
+                            rq->mark_pos[2]
+                      : 0;
+    hipLaunchKernelGGL(turn_commit_kernel, dim3(total > 0 ? grid_for(total) : 1),
+                       dim3(256), 0, e->ustream, c->seed, c->seg, b, total,
+                       rq->segment_threshold, rq->segment_id,
+                       (long long)rq->min_segment_size, d_rec, mark_ci, rq->mark_mode);
+  }
+  long dirty_total = 0;
+  if (n > 0) {
+    hipLaunchKernelGGL(turn_eval_kernel, dim3(n), dim3(64), 0, e->ustream, c->seed,
+                       c->seg, c->cz, c->cy, c->cx, d_cand, rq->min_boundary_dist[0],
+                       rq->min_boundary_dist[1], rq->min_boundary_dist[2], d_flag,
+                       d_cseed, d_cseg);
+    hipLaunchKernelGGL(turn_pick_kernel, dim3(1), dim3(64), 0, e->ustream, c->seg,
+                       c->cy, c->cx, d_cand, n, d_flag, d_rec);
+    if (rq->do_init) {
+      if (c->dirty_lo[0] < c->dirty_hi[0]) {
+        Box db = make_box(c, c->dirty_lo, c->dirty_hi, &dirty_total);
+        const int linear = (size_t)dirty_total * 2 >= c->nvox;
+        if (dirty_total > 0)
+          hipLaunchKernelGGL(turn_clear_kernel,
+                             dim3(linear ? 2048 : grid_for(dirty_total)), dim3(256), 0,
+                             e->ustream, reinterpret_cast<uint32_t*>(c->seed), db,
+                             dirty_total, linear, c->nvox, d_rec);
+      }
+      hipLaunchKernelGGL(turn_seed_kernel, dim3(1), dim3(1), 0, e->ustream, c->seed,
+                         c->cy, c->cx, d_cand, rq->init_value, d_rec);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hs, ds, o_cand, hipMemcpyDeviceToHost, e->ustream));
+  HIP_TRY(lock_.wait(e, c));
+  const auto* hr = reinterpret_cast<const TurnRecord*>(hs);
+  std::memset(out, 0, sizeof(*out));
+  out->counts.raw_segmented_voxels = (int64_t)hr->counts[0];
+  out->counts.actual_segmented_voxels = (int64_t)hr->counts[1];
+  out->committed = hr->committed;
+  out->chosen = n > 0 ? hr->chosen : -1;
+  const auto* hh = reinterpret_cast<const unsigned*>(hs + o_hist);
+  int nover = 0;
+  for (size_t id = 1; id < hist_n; ++id) {
+    if (hh[id]) {
+      if (nover < max_overlaps && overlap_ids && overlap_counts) {
+        overlap_ids[nover] = (int32_t)id;
+        overlap_counts[nover] = (int64_t)hh[id];
+      }
+      ++nover;
+    }
+  }
+  out->counts.num_overlapped_ids = nover;
+  if (n > 0) {
+    std::memcpy(cand_flags, hs + o_flag, 4 * (size_t)n);
+    std::memcpy(cand_seed, hs + o_flag + 4 * (size_t)n, 4 * (size_t)n);
+    std::memcpy(cand_seg, hs + o_flag + 8 * (size_t)n, 4 * (size_t)n);
+    if (rq->do_init && out->chosen >= 0) {
+      // as ffn_canvas_init_seed: the volume is clean but for the seed point
+      const int32_t* p = cand + 3 * out->chosen;
+      const int lo[3] = {p[0], p[1], p[2]};
+      const int hi[3] = {p[0] + 1, p[1] + 1, p[2] + 1};
+      c->dirty_lo[0] = c->dirty_hi[0] = 0;
+      c->mark_dirty(lo, hi);
+    }
+  }
   return FFN_OK;
 }
 

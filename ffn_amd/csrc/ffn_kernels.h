@@ -3051,4 +3051,132 @@ __global__ void commit_assign_kernel(const float* __restrict__ seed,
   }
 }
 
+// ---------------------------------------------------------------------------
+// The between-segment turn of Canvas.segment_all (inference.py:573-660) as ONE
+// device-side sequence (ffn_canvas_segment_turn): commit count -> assign if the
+// object is large enough (else the -1 marker at its seed) -> the next seeds of
+// the policy tested in order (already segmented / too close to a segment, the
+// latter marked -1) -> the canvas' seed volume re-initialised at the first one
+// that passes.  The host reads ONE record afterwards instead of waiting for each
+// answer before it queues the next kernel.
+// ---------------------------------------------------------------------------
+struct TurnRecord {
+  unsigned long long counts[2];  // raw, actual (commit_count_kernel)
+  int committed;                 // the id was assigned
+  int chosen;                    // index of the next seed in the candidate list, -1 none
+  int pad[2];
+};
+constexpr int kTurnOk = 0, kTurnSegmented = 1, kTurnTooClose = 2, kTurnNotReached = 3;
+
+// mark_mode 0: no marker; 1: seg[mark] = -1 if it is 0 (inference.py:600-603, a
+// seed that got too weak); 2: the same, but only when nothing is committed
+// (inference.py:632-636, too small).
+__global__ void turn_commit_kernel(const float* __restrict__ seed,
+                                   int32_t* __restrict__ seg, Box b, long total,
+                                   float thr, int32_t sid, long long min_size,
+                                   TurnRecord* __restrict__ rec, long mark_ci,
+                                   int mark_mode) {
+  const bool ok = total > 0 && (long long)rec->counts[1] >= min_size;
+  if (ok) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total;
+         e += (long)gridDim.x * blockDim.x) {
+      const size_t ci = box_index(b, e);
+      if (seed[ci] >= thr && seg[ci] <= 0) seg[ci] = sid;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    rec->committed = ok ? 1 : 0;
+    if ((mark_mode == 1 || (mark_mode == 2 && !ok)) && seg[mark_ci] == 0)
+      seg[mark_ci] = -1;
+  }
+}
+
+// one wavefront per candidate: segmentation[pos] > 0 (Canvas.is_valid_pos,
+// inference.py:341), else any id > 0 in the clipped box pos +- min_boundary_dist
+// (inference.py:575-581)
+__global__ __launch_bounds__(64) void turn_eval_kernel(
+    const float* __restrict__ seed, const int32_t* __restrict__ seg, int cz, int cy,
+    int cx, const int32_t* __restrict__ cand, int mz, int my, int mx,
+    int* __restrict__ flags, float* __restrict__ cand_seed,
+    int32_t* __restrict__ cand_seg) {
+  const int j = blockIdx.x;
+  const int z = cand[3 * j], y = cand[3 * j + 1], x = cand[3 * j + 2];
+  const size_t ci = ((size_t)z * cy + y) * cx + x;
+  const int32_t s = seg[ci];
+  int flag = kTurnOk;
+  if (s > 0) {
+    flag = kTurnSegmented;
+  } else {
+    const int z0 = max(z - mz, 0), z1 = min(z + mz + 1, cz);
+    const int y0 = max(y - my, 0), y1 = min(y + my + 1, cy);
+    const int x0 = max(x - mx, 0), x1 = min(x + mx + 1, cx);
+    const int ny = y1 - y0, nx = x1 - x0;
+    const int total = (z1 - z0) * ny * nx;
+    int hit = 0;
+    for (int e = threadIdx.x; e < total; e += 64) {
+      const int ex = e % nx, t = e / nx;
+      hit |= seg[((size_t)(z0 + t / ny) * cy + (y0 + t % ny)) * cx + (x0 + ex)] > 0;
+    }
+    if (__any(hit)) flag = kTurnTooClose;
+  }
+  if (threadIdx.x == 0) {
+    flags[j] = flag;
+    cand_seed[j] = seed[ci];
+    cand_seg[j] = s;
+  }
+}
+
+// the first candidate that passed; the too-close ones BEFORE it get their -1
+// (the ones after it have not been looked at as far as the caller is concerned)
+__global__ __launch_bounds__(64) void turn_pick_kernel(
+    int32_t* __restrict__ seg, int cy, int cx, const int32_t* __restrict__ cand,
+    int n, int* __restrict__ flags, TurnRecord* __restrict__ rec) {
+  int chosen = -1;
+  for (int base = 0; base < n && chosen < 0; base += 64) {
+    const int j = base + threadIdx.x;
+    const unsigned long long m = __ballot(j < n && flags[j] == kTurnOk);
+    if (m) chosen = base + __ffsll((long long)m) - 1;
+  }
+  const int upto = chosen < 0 ? n : chosen;
+  for (int j = threadIdx.x; j < n; j += 64) {
+    if (j < upto) {
+      if (flags[j] == kTurnTooClose)
+        seg[((size_t)cand[3 * j] * cy + cand[3 * j + 1]) * cx + cand[3 * j + 2]] = -1;
+    } else if (j > upto) {
+      flags[j] = kTurnNotReached;
+    }
+  }
+  if (threadIdx.x == 0) rec->chosen = chosen;
+}
+
+// Canvas.init_seed (inference.py:282-286) at the chosen candidate: the region the
+// last segment touched back to NaN, then the seed point
+__global__ void turn_clear_kernel(uint32_t* __restrict__ seed, Box b, long total,
+                                  int linear, size_t nvox,
+                                  const TurnRecord* __restrict__ rec) {
+  if (rec->chosen < 0) return;
+  if (linear) {
+    const size_t n4 = nvox / 4;
+    const uint4 vv = make_uint4(0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u);
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n4;
+         e += (size_t)gridDim.x * blockDim.x)
+      reinterpret_cast<uint4*>(seed)[e] = vv;
+    if (blockIdx.x == 0 && threadIdx.x < (nvox & 3))
+      seed[n4 * 4 + threadIdx.x] = 0x7fc00000u;
+    return;
+  }
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x)
+    seed[box_index(b, e)] = 0x7fc00000u;
+}
+
+__global__ void turn_seed_kernel(float* __restrict__ seed, int cy, int cx,
+                                 const int32_t* __restrict__ cand, float value,
+                                 const TurnRecord* __restrict__ rec) {
+  const int j = rec->chosen;
+  if (j < 0) return;
+  seed[((size_t)cand[3 * j] * cy + cand[3 * j + 1]) * cx + cand[3 * j + 2]] = value;
+}
+
 }  // namespace ffn
+

@@ -522,6 +522,55 @@ class DeviceCanvasHandle:
                                              float(segment_threshold),
                                              int(segment_id)))
 
+  def segment_turn(self, commit=None, mark=None, candidates=(), mbd=(0, 0, 0),
+                   init_value=None):
+    """The between-segment turn as one device-side sequence
+    (`ffn_canvas_segment_turn`, include/ffn_hip.h; reference
+    inference.py:573-660).
+
+    commit: None or (lo, hi, segment_threshold, min_segment_size, segment_id,
+    max_existing_id); mark: None or (pos, mode) with mode 1 (always) / 2 (when
+    nothing was committed); candidates: the policy's next seeds, zyx, inside the
+    canvas; init_value: `init_seed` at the first candidate that passes.
+    Returns (raw, actual, overlapped ids, counts, committed, chosen, flags,
+    candidate seed values, candidate segmentation values)."""
+    rq = _lib.TurnRequest()
+    cap = 1
+    if commit is not None:
+      lo, hi, thr, min_size, sid, max_id = commit
+      rq.do_commit = 1
+      rq.lo[:] = [int(v) for v in lo]
+      rq.hi[:] = [int(v) for v in hi]
+      rq.segment_threshold = float(thr)
+      rq.min_segment_size = int(min_size)
+      rq.segment_id = int(sid)
+      rq.max_existing_id = int(max_id)
+      cap = max(int(max_id), 1)
+    if mark is not None:
+      rq.mark_pos[:] = [int(v) for v in mark[0]]
+      rq.mark_mode = int(mark[1])
+    cand = np.ascontiguousarray(np.asarray(candidates, np.int32).reshape(-1, 3))
+    n = len(cand)
+    rq.num_candidates = n
+    rq.min_boundary_dist[:] = [int(v) for v in mbd]
+    rq.do_init = 0 if init_value is None else 1
+    rq.init_value = 0.0 if init_value is None else float(init_value)
+    ids = np.zeros(cap, np.int32)
+    cnts = np.zeros(cap, np.int64)
+    flags = np.zeros(max(n, 1), np.int32)
+    cseed = np.zeros(max(n, 1), np.float32)
+    cseg = np.zeros(max(n, 1), np.int32)
+    res = _lib.TurnResult()
+    check(self._lib.ffn_canvas_segment_turn(
+        self._h, ctypes.byref(rq), cand.ctypes.data if n else None,
+        ctypes.byref(res), cap, ids.ctypes.data, cnts.ctypes.data,
+        flags.ctypes.data, cseed.ctypes.data, cseg.ctypes.data))
+    k = res.counts.num_overlapped_ids
+    return (int(res.counts.raw_segmented_voxels),
+            int(res.counts.actual_segmented_voxels), ids[:k].copy(),
+            cnts[:k].copy(), bool(res.committed), int(res.chosen), flags[:n],
+            cseed[:n], cseg[:n])
+
   def _box(self, lo, hi):
     lo = [int(v) for v in lo]
     hi = [int(v) for v in hi]

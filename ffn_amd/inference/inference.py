@@ -700,6 +700,10 @@ class DeviceCanvas(Canvas):
     #: is_valid_pos (seed below threshold / already segmented): the cases a
     #: speculative next step would have mispredicted
     self.gate_rejects = 0
+    #: between-segment turns answered by one device call (`_turn`)
+    self.turns = 0
+    self._turn_rec = None
+    self._turn_armed = False
     self._pending = None
     self._step_req = _lib.StepRequest()
     # the request as a flat int32 view: [pos 3][start 3][n 1][candidates 16 x 3]
@@ -758,6 +762,83 @@ class DeviceCanvas(Canvas):
   def _invalidate_cache(self):
     self._cache = {}
     self._cached_start = None
+    self._turn_rec = None
+
+  # -- the between-segment turn as one device call ---------------------------------------
+  #: seeds of the policy the device tests ahead in one turn (0: one question per
+  #: call, as the reference asks them)
+  TURN_CANDIDATES = int(os.environ.get('FFN_AMD_TURN_CANDIDATES', '128'))
+
+  def _turn_ok(self) -> bool:
+    """True if `ffn_canvas_segment_turn` may answer the seed loop's questions
+    (inference.py:573-660) ahead of time: nothing between two segments that the
+    device does not see -- no restrictor masks, no timed checkpoint, no
+    probability map, the stock validity test."""
+    ok = self.__dict__.get('_turn_static')
+    if ok is None:
+      ok = (hasattr(self._handle, 'segment_turn') and
+            not self.keep_probability_maps and
+            getattr(self.restrictor, 'is_trivial', self.restrictor is None))
+      self._turn_static = ok
+    return (ok and self.TURN_CANDIDATES > 0 and
+            (self.checkpoint_path is None or self.checkpoint_interval_sec <= 0)
+            and getattr(self.is_valid_pos, '__func__', None)
+            is DeviceCanvas.is_valid_pos)
+
+  def _is_current_seed(self, pos) -> bool:
+    policy = self.__dict__.get('seed_policy')
+    coords = getattr(policy, 'coords', None)
+    idx = getattr(policy, 'idx', None)
+    return (coords is not None and idx is not None and
+            1 <= idx <= len(coords) and
+            tuple(int(v) for v in coords[idx - 1]) == pos)
+
+  def _upcoming_seeds(self, first=None):
+    """The next seeds the policy will hand out (`first`: the one it has just
+    handed out, then those), as long as they pass the bounds test."""
+    policy = self.__dict__.get('seed_policy')
+    coords = getattr(policy, 'coords', None)
+    idx = getattr(policy, 'idx', None)
+    if coords is None or idx is None:
+      return [] if first is None else [first]
+    if first is not None:
+      if not (1 <= idx <= len(coords) and
+              tuple(int(v) for v in coords[idx - 1]) == first):
+        return [first]
+      idx -= 1
+    out = []
+    for c in np.asarray(coords[idx:idx + self.TURN_CANDIDATES]).tolist():
+      c = (int(c[0]), int(c[1]), int(c[2]))
+      if not self._in_bounds(c):
+        break
+      out.append(c)
+    return out
+
+  def _turn(self, commit, mark, first=None):
+    """One device-side turn; what it found out is kept for the seed loop's next
+    questions (`_turn_rec`), which are then answered without a device call."""
+    cands = self._upcoming_seeds(first)
+    mbd = self.options.min_boundary_dist
+    init = (float(self.options.init_activation)
+            if self.reset_seed_per_segment else None)
+    self._invalidate_cache()
+    out = self._call(self._handle.segment_turn, commit, mark, cands,
+                     (int(mbd.z), int(mbd.y), int(mbd.x)), init)
+    chosen, flags, cseed, cseg = out[5], out[6], out[7], out[8]
+    seen = {}
+    for k, c in enumerate(cands):
+      f = int(flags[k])
+      if f == 3:  # after the chosen one: not looked at
+        break
+      seen[c] = f
+      self._cache[c] = (float(cseed[k]), -1 if f == 2 else int(cseg[k]))
+    self._turn_rec = {
+        'mark': tuple(int(v) for v in mark[0]) if mark is not None else None,
+        'seen': seen,
+        'init': cands[chosen] if chosen >= 0 and init is not None else None}
+    self._turn_armed = True
+    self.turns += 1
+    return out
 
   #: seeds whose (seed, segmentation) values one device call fetches ahead
   SEED_PREFETCH = 256
@@ -801,6 +882,13 @@ class DeviceCanvas(Canvas):
     if not self._in_bounds(pos):
       self.counters['skip_invalid_pos'].Increment()
       return False
+    if (ignore_move_threshold and self.__dict__.get('_turn_armed') and
+        self._turn_ok()):
+      # the seed loop (inference.py:573) asking about the seed the policy has
+      # just handed out, after the last turn's answers have run out
+      p = (int(pos[0]), int(pos[1]), int(pos[2]))
+      if p not in self._cache and self._is_current_seed(p):
+        self._turn(None, None, first=p)
     if self._read_point(pos)[1] > 0:
       self.counters['skip_invalid_pos'].Increment()
       self.gate_rejects += 1
@@ -1116,8 +1204,12 @@ class DeviceCanvas(Canvas):
         self._cache.setdefault(coord, (score, seg))
 
   def init_seed(self, pos):
+    rec = self.__dict__.get('_turn_rec')
+    served = (rec is not None and rec['init'] is not None and
+              rec['init'] == tuple(int(v) for v in pos))
     self._invalidate_cache()
-    self._call(self._handle.init_seed, pos, self.options.init_activation)
+    if not served:  # (else: the turn that chose this seed has done it)
+      self._call(self._handle.init_seed, pos, self.options.init_activation)
     self._cached_start = (tuple(int(v) for v in pos),
                           float(np.float32(self.options.init_activation)))
 
@@ -1126,11 +1218,25 @@ class DeviceCanvas(Canvas):
     return int(self._read_point(pos)[1])
 
   def _mark_excluded(self, pos):
+    rec = self.__dict__.get('_turn_rec')
+    p = tuple(int(v) for v in pos)
+    if rec is not None and rec['mark'] == p:
+      rec['mark'] = None  # the turn that counted this segment has marked it
+      return
+    if self._turn_ok():
+      self._turn(None, (p, 1))
+      self._turn_rec['mark'] = None
+      return
     if self._seg_point(pos) == 0:
       self._invalidate_cache()
       self._call(self._handle.write_seg_points, [pos], [-1])
 
   def _too_close(self, pos, mbd) -> bool:
+    rec = self.__dict__.get('_turn_rec')
+    if rec is not None:
+      f = rec['seen'].pop(tuple(int(v) for v in pos), None)
+      if f is not None:  # tested (and, if too close, marked) by the last turn
+        return f == 2
     low = [int(p - m) for p, m in zip(pos, mbd)]
     high = [int(p + m + 1) for p, m in zip(pos, mbd)]
     if self._call(self._handle.any_segmented, low, high):
@@ -1142,6 +1248,19 @@ class DeviceCanvas(Canvas):
   def _commit(self, sel_lo, sel_hi, pos):
     thr = self.options.segment_threshold
     max_existing = max(self._max_id, max(self.origins) if self.origins else 0)
+    if self._turn_ok():
+      sid = self._max_id + 1  # what get_next_segment_id will hand out
+      while sid in self.origins:
+        sid += 1
+      out = self._turn(([int(v) for v in sel_lo], [int(v) for v in sel_hi], thr,
+                        int(self.options.min_segment_size), sid, max_existing),
+                       (pos, 2))
+      raw, actual, ids, counts, committed = out[:5]
+      if not committed:
+        return raw, actual, ids, counts, None
+      got = self.get_next_segment_id()
+      assert got == sid, (got, sid)
+      return raw, actual, ids, counts, sid
     raw, actual, ids, counts = self._call(self._handle.commit_count, sel_lo,
                                           sel_hi, thr, max_existing)
     if actual < self.options.min_segment_size:
@@ -1163,6 +1282,9 @@ class DeviceCanvas(Canvas):
 
   def _set_seed(self, seed):
     self.seed[...] = np.asarray(seed, np.float32)
+    # a restored canvas may be inside a segment (partial_segment_iters): no turn
+    # -- it would re-initialise the seed -- before that segment has ended
+    self._turn_armed = False
 
 
 class NativeSegment:

@@ -248,6 +248,52 @@ int ffn_canvas_commit_assign(ffn_canvas* canvas, const int32_t lo[3],
                              const int32_t hi[3], float segment_threshold,
                              int32_t segment_id);
 
+/* The between-segment turn of Canvas.segment_all (inference.py:573-660) as one
+ * device-side sequence, one host wait at its end instead of one per question:
+ *   1. do_commit: the commit reduction over [lo, hi) (ffn_canvas_commit_count);
+ *      if actual_segmented_voxels >= min_segment_size the voxels get segment_id
+ *      (inference.py:614-646) and *committed = 1;
+ *   2. mark_mode 1: segmentation[mark_pos] = -1 if it is 0 ("weak seed",
+ *      inference.py:600-603); 2: the same when step 1 did not commit ("too
+ *      small", inference.py:632-636); 0: no marker;
+ *   3. the next seeds of the policy, `candidates` in its order (all inside the
+ *      canvas): a candidate whose segmentation is > 0 is skipped
+ *      (Canvas.is_valid_pos, inference.py:341), one with an id > 0 within
+ *      min_boundary_dist (clipped box, inference.py:575-581) is marked -1 and
+ *      skipped; the first one that passes is *chosen* (-1: none of them);
+ *   4. do_init: Canvas.init_seed(candidates[chosen], init_value)
+ *      (inference.py:282-286) when there is one.
+ * cand_flags[k]: 0 passed (k = chosen), 1 already segmented, 2 too close (marked),
+ * 3 after the chosen one (untouched); cand_seed / cand_seg: the canvas values at
+ * candidate k as step 3 saw them. */
+typedef struct ffn_turn_request {
+  int32_t do_commit;
+  int32_t lo[3], hi[3];
+  float   segment_threshold;
+  int64_t min_segment_size;
+  int32_t segment_id;
+  int32_t max_existing_id;
+  int32_t mark_mode;
+  int32_t mark_pos[3];
+  int32_t num_candidates;
+  int32_t min_boundary_dist[3];   /* zyx */
+  int32_t do_init;
+  float   init_value;
+} ffn_turn_request;
+
+typedef struct ffn_turn_result {
+  ffn_commit_counts counts;       /* zero without do_commit                     */
+  int32_t committed;
+  int32_t chosen;
+} ffn_turn_result;
+
+int ffn_canvas_segment_turn(ffn_canvas* canvas, const ffn_turn_request* request,
+                            const int32_t* candidates /* [num_candidates][3] */,
+                            ffn_turn_result* result, int32_t max_overlaps,
+                            int32_t* overlap_ids, int64_t* overlap_counts,
+                            int32_t* cand_flags, float* cand_seed,
+                            int32_t* cand_seg);
+
 /* Box transfers between the canvas and host arrays ([hi-lo] C-order):
  * checkpoint/restore and final save (inference.py:728-821, runner.py:433-482). */
 int ffn_canvas_read_seed(ffn_canvas* canvas, const int32_t lo[3],

@@ -71,6 +71,54 @@ class EmulatedHandle:
     mask = (self.seed[sel] >= np.float32(thr)) & (self.seg[sel] <= 0)
     self.seg[sel][mask] = sid
 
+  def segment_turn(self, commit=None, mark=None, candidates=(), mbd=(0, 0, 0),
+                   init_value=None):
+    """ffn_canvas_segment_turn as include/ffn_hip.h specifies it, with the
+    single-question calls above."""
+    self.turns = getattr(self, 'turns', 0) + 1
+    raw = actual = 0
+    ids = np.zeros(0, np.int32)
+    counts = np.zeros(0, np.int64)
+    committed = False
+    if commit is not None:
+      lo, hi, thr, min_size, sid, max_id = commit
+      raw, actual, ids, counts = self.commit_count(lo, hi, thr, max_id)
+      keep = ids <= max_id
+      ids, counts = ids[keep], counts[keep]
+      if actual >= min_size:
+        self.commit_assign(lo, hi, thr, sid)
+        committed = True
+    if mark is not None:
+      pos, mode = mark
+      pos = tuple(int(v) for v in pos)
+      if (mode == 1 or (mode == 2 and not committed)) and self.seg[pos] == 0:
+        self.seg[pos] = -1
+    cand = np.asarray(candidates, np.int32).reshape(-1, 3)
+    n = len(cand)
+    flags = np.full(n, 3, np.int32)
+    cseed = np.zeros(n, np.float32)
+    cseg = np.zeros(n, np.int32)
+    for k, p in enumerate(cand):  # (values: the canvas before any marker)
+      cseed[k], cseg[k] = self.seed[tuple(p)], self.seg[tuple(p)]
+    chosen = -1
+    for k, p in enumerate(cand):
+      p = tuple(int(v) for v in p)
+      if self.seg[p] > 0:
+        flags[k] = 1
+        continue
+      lo = [v - m for v, m in zip(p, mbd)]
+      hi = [v + m + 1 for v, m in zip(p, mbd)]
+      if self.any_segmented(lo, hi):
+        flags[k] = 2
+        self.seg[p] = -1
+        continue
+      flags[k] = 0
+      chosen = k
+      break
+    if chosen >= 0 and init_value is not None:
+      self.init_seed(tuple(int(v) for v in cand[chosen]), init_value)
+    return raw, actual, ids, counts, committed, chosen, flags, cseed, cseg
+
   def read_seed(self, lo=None, hi=None):
     lo = lo or (0, 0, 0)
     hi = hi or self.shape

@@ -402,6 +402,68 @@ def test_canvas_utilities_bit_exact(engine):
   canvas.close()
 
 
+def test_segment_turn_equals_the_single_questions(engine):
+  """ffn_canvas_segment_turn (commit count -> assign or -1 marker -> the next
+  seeds tested in order, too-close ones marked -> init_seed at the first that
+  passes; reference inference.py:573-660) against the numpy statement of the same
+  sequence (tests/emulated_device.py), on random canvases: integer work, exact."""
+  from tests.emulated_device import EmulatedHandle
+  rng = np.random.RandomState(5)
+  shape = (40, 37, 45)
+  for case in range(12):
+    image = np.zeros(shape, np.float32)
+    seed = rng.normal(0, 2, shape).astype(np.float32)
+    seed[rng.rand(*shape) < 0.3] = np.nan
+    # sparse ids, so that some candidates pass / are too close / are inside one
+    seg = np.zeros(shape, np.int32)
+    seg[rng.rand(*shape) < (0.002, 0.02, 0.3)[case % 3]] = rng.randint(1, 6)
+    seg[rng.rand(*shape) < 0.01] = -1
+    canvas = engine.create_canvas(image)
+    emu = EmulatedHandle(image)
+    if case % 2:
+      # the canvas tracks the region that steps and writes touched and init_seed
+      # clears only that: a small one here (box fill), the whole volume otherwise
+      blo, bhi = (4, 6, 8), (30, 31, 40)
+      bsel = tuple(slice(l, h) for l, h in zip(blo, bhi))
+      canvas.init_seed((1, 1, 1), 0.5)
+      emu.init_seed((1, 1, 1), 0.5)
+      canvas.write_seed(blo, bhi, seed[bsel])
+      emu.seed[bsel] = seed[bsel]
+    else:
+      canvas.write_seed((0, 0, 0), shape, seed)
+      emu.seed[...] = seed
+    canvas.write_segmentation((0, 0, 0), shape, seg)
+    emu.seg[...] = seg
+    lo = [int(rng.randint(0, 10)) for _ in range(3)]
+    hi = [int(rng.randint(25, s + 1)) for s in shape]
+    thr = 0.4054652154
+    min_size = (0, 10 ** 9)[case % 2] if case % 4 != 3 else int(
+        EmulatedHandle.commit_count(emu, lo, hi, thr, 5)[1])
+    commit = None if case % 5 == 4 else (lo, hi, thr, min_size, 77, 5)
+    mark_pos = tuple(int(rng.randint(0, s)) for s in shape)
+    mark = (None, (mark_pos, 1), (mark_pos, 2))[case % 3]
+    n = (0, 1, 40, 200)[case % 4]
+    cands = np.stack([rng.randint(0, s, n) for s in shape], axis=1).astype(np.int32)
+    mbd = [(1, 1, 1), (0, 0, 0), (2, 1, 3)][case % 3]
+    init = None if case % 6 == 5 else 2.9444387
+    got = canvas.segment_turn(commit, mark, cands, mbd, init)
+    want = emu.segment_turn(commit, mark, cands, mbd, init)
+    assert got[0] == want[0] and got[1] == want[1], case
+    assert list(got[2]) == list(want[2]) and list(got[3]) == list(want[3]), case
+    assert got[4] == want[4] and got[5] == want[5], case
+    assert np.array_equal(got[6], want[6]), case
+    k = n if want[5] < 0 else want[5] + 1  # candidates that were looked at
+    assert np.array_equal(got[7][:k], want[7][:k], equal_nan=True), case
+    assert np.array_equal(got[8][:k], want[8][:k]), case
+    assert np.array_equal(canvas.read_segmentation(), emu.seg), case
+    assert np.array_equal(canvas.read_seed(), emu.seed, equal_nan=True), case
+    # the canvas goes on as after init_seed: one more (plain) init elsewhere
+    canvas.init_seed((20, 20, 20), 1.0)
+    out = canvas.read_seed()
+    assert np.isnan(out).sum() == out.size - 1 and out[20, 20, 20] == 1.0
+    canvas.close()
+
+
 @pytest.mark.parametrize('name', ['cells56', 'cells72'])
 def test_device_canvas_reproduces_reference_run(fib25_model, name):
   """Full Canvas.segment_all on the GPU vs the fixture minted by the

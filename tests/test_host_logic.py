@@ -177,6 +177,8 @@ def test_canvas_reproduces_reference_run(fib25_blob, device):
     assert type(canvas) is inference.Canvas
   canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
                                                    coords=g['seeds']))
+  if device:  # the between-segment turns went through ffn_canvas_segment_turn
+    assert canvas.turns > 0 and canvas._handle.turns == canvas.turns
   assert np.array_equal(np.asarray(canvas.segmentation), g['segmentation'])
   assert np.array_equal(np.asarray(canvas.seed), g['seed_logits'],
                         equal_nan=True)
@@ -188,6 +190,75 @@ def test_canvas_reproduces_reference_run(fib25_blob, device):
   assert {int(k): [list(v.start_zyx), v.iters]
           for k, v in canvas.origins.items()} == {
               int(k): v for k, v in origins.items()}
+
+
+def _flood_forward(image, seed, blob, depth):
+  """A cheap stand-in for the conv stack: the bright component(s) of the FoV
+  that the seed touches (enough to drive whole segment_all runs through the HOST
+  logic in milliseconds per step)."""
+  del blob, depth
+  from scipy import ndimage
+  lab, _ = ndimage.label(image > 0.5)
+  hit = np.unique(lab[(seed > 0.0) & (lab > 0)])
+  return np.where(np.isin(lab, hit) & (lab > 0), 4.0, -4.0).astype(np.float32)
+
+
+def _blob_volume(shape, centres, radius):
+  zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing='ij')
+  vol = np.zeros(shape, np.float32)
+  for cz, cy, cx in centres:
+    vol[(zz - cz) ** 2 + (yy - cy) ** 2 + (xx - cx) ** 2 <= radius ** 2] = 1.0
+  return vol
+
+
+@pytest.mark.parametrize('min_size', [200, 3500])
+def test_segment_turn_answers_the_seed_loop_like_single_questions(monkeypatch,
+                                                                  min_size):
+  """DeviceCanvas with the between-segment turn as ONE device call
+  (ffn_canvas_segment_turn: commit, -1 markers, the next seeds tested ahead,
+  init_seed) == the same canvas asking one question per call, as the reference's
+  loop does (inference.py:573-660): segmentation including its -1 markers, seed,
+  counters, origins, overlaps -- on a run with committed objects, objects that
+  are too small, weak seeds, seeds inside objects and seeds next to them."""
+  monkeypatch.setattr(ffn_oracle, 'forward', _flood_forward)
+  shape = (72, 96, 96)
+  centres = [(30, 30, 30), (34, 60, 34), (40, 40, 64), (36, 66, 66)]
+  image = _blob_volume(shape, centres, 9)
+  r = _request()
+  r.inference_options.min_segment_size = min_size
+  info = _info()
+  # a dense grid of seeds, bright and dark ones, in raster order
+  grid = np.array([(z, y, x) for z in range(18, 54, 6) for y in range(18, 78, 6)
+                   for x in range(18, 78, 6)], np.int32)
+  runs = []
+  for cands in (inference.DeviceCanvas.TURN_CANDIDATES, 7, 0):
+    client = EmulatedDeviceClient(inference_utils.Counters(), None, 12,
+                                  (33, 33, 33), (8, 8, 8))
+    canvas = inference.make_canvas(info, client, image, r.inference_options,
+                                   movement_policy_fn=movement.get_policy_fn(
+                                       r, info))
+    canvas.TURN_CANDIDATES = cands
+    canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                     coords=grid))
+    h = canvas._handle
+    assert (canvas.turns > 0) == (cands > 0)
+    counters = {k: c.value for k, c in canvas.counters
+                if not k.endswith('-ms')}
+    runs.append((np.asarray(canvas.segmentation).copy(),
+                 np.asarray(canvas.seed).copy(), counters,
+                 {k: (tuple(v.start_zyx), v.iters)
+                  for k, v in canvas.origins.items()},
+                 {k: np.asarray(v).tolist() for k, v in canvas.overlaps.items()},
+                 h.point_reads))
+  ref = runs[-1]
+  assert (len(ref[3]) >= 2 if min_size == 200 else not ref[3])  # objects
+  assert (ref[0] == -1).any()
+  for run in runs[:-1]:
+    assert np.array_equal(run[0], ref[0])
+    assert np.array_equal(run[1], ref[1], equal_nan=True)
+    assert run[2] == ref[2] and run[3] == ref[3] and run[4] == ref[4]
+  # ... with far fewer device questions
+  assert runs[0][5] < ref[5]
 
 
 def test_keep_history_host_and_device_canvas_agree(fib25_blob):
