@@ -176,6 +176,8 @@ SIGNATURES = {
     'ffn_canvas_segment_at': (_I, [_P, _I3, ctypes.POINTER(SegmentParams), _I,
                                    ctypes.POINTER(SegmentResult)]),
     'ffn_canvas_segment_many': (_I, [_P, _I, _P, _P, _P, _P, _P, _P]),
+    'ffn_canvas_segment_many_carry': (_I, [_P, _I, _P, _P, _P, _P, _P, _P,
+                                           ctypes.c_int32]),
     'ffn_canvas_segment_history': (_I, [_P, ctypes.c_size_t, ctypes.c_size_t,
                                         _P, _P,
                                         ctypes.POINTER(ctypes.c_size_t)]),

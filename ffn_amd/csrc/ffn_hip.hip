@@ -86,6 +86,14 @@ struct ffn_engine {
   // utility stream wait for an event recorded behind it.
   hipStream_t ustream = nullptr;
   hipEvent_t main_ev = nullptr;  // "everything queued on `stream` so far"
+  // ffn_canvas_segment_many_carry: the batched step it left in flight when it
+  // returned (one per engine: the driver that runs ONE group of canvases and
+  // does a canvas' between-segment work under the others' next step).  `many_mu`
+  // is taken before `mu`, never the other way round.
+  std::mutex many_mu;
+  ffn_host::ManyCarry many_carry;
+  uint32_t many_ticket = 0;
+  std::vector<ffn_canvas*> many_canvases;  // the carried step's, in batch order
   int device = 0;
   hipStream_t stream = nullptr;
   Geom g{};   // the FoV as the caller sees it (zyx): gather / paste / faces, I/O
@@ -172,6 +180,7 @@ struct ffn_engine {
   int speculate = 1;        // option
   int spec_force_mismatch = 0;  // debug option: fail the next N matches
   long stat_spec_mismatch = 0;
+  long stat_many_carried = 0;  // batched steps left in flight across a return
   int fuse_paste = 1;       // option: faces + paste of a single FoV as one launch
   int fuse_conv0a = 1;      // option: ... and the next step's conv0_a in it as well
   int* d_spec_choice = nullptr;
@@ -1746,6 +1755,8 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "stat_spec_hits") == 0) *value = (int)e->stat_spec_hits;
   else if (std::strcmp(name, "stat_spec_mismatch") == 0)
     *value = (int)e->stat_spec_mismatch;
+  else if (std::strcmp(name, "stat_many_carried") == 0)
+    *value = (int)e->stat_many_carried;
   else if (std::strcmp(name, "flow") == 0) *value = e->flow;
   else if (std::strcmp(name, "stat_flow_timeouts") == 0) {
     unsigned v = 0;
@@ -1968,7 +1979,12 @@ int ffn_canvas_create_u8(ffn_engine* e, const uint8_t* image_u8,
                        out);
 }
 
+namespace {
+int resolve_many_carry(ffn_engine* e, const ffn_canvas* only = nullptr);
+}
+
 void ffn_canvas_destroy(ffn_canvas* c) {
+  if (c && c->engine) (void)resolve_many_carry(c->engine, c);  // a step in flight
   EngineLock lock_(c ? c->engine : nullptr);
   if (!c) return;
   if (c->engine) {
@@ -2368,11 +2384,35 @@ struct HipLoopDevice {
 };
 }  // namespace
 
+namespace {
+// The step ffn_canvas_segment_many_carry left in flight: wait for it and hand its
+// results to the loops of its canvases.  `only`: nothing to do unless that canvas
+// is one of them.  Callers hold neither `mu` nor `many_mu`.
+int resolve_many_carry_locked(ffn_engine* e) {
+  if (!e->many_carry.active) return FFN_OK;
+  HipLoopDevice dev{e->many_canvases.empty() ? nullptr : e->many_canvases[0]};
+  auto wait = [&](ffn_step_result* res) {
+    return step_wait_impl(e, e->many_ticket, res, nullptr);
+  };
+  const int rc = ffn_host::resolve_carry(&e->many_carry, dev, wait);
+  e->many_canvases.clear();
+  return rc;
+}
+int resolve_many_carry(ffn_engine* e, const ffn_canvas* only) {
+  std::lock_guard<std::mutex> guard(e->many_mu);
+  if (only && std::find(e->many_canvases.begin(), e->many_canvases.end(), only) ==
+                  e->many_canvases.end())
+    return FFN_OK;
+  return resolve_many_carry_locked(e);
+}
+}  // namespace
+
 int ffn_canvas_segment_at(ffn_canvas* c, const int32_t start[3],
                           const ffn_segment_params* p, int resume,
                           ffn_segment_result* out) {
   if (!c || !start || !p || !out) return fail(FFN_ERR_ARG, "null argument");
   if (!c->engine) return fail(FFN_ERR_STATE, "canvas outlived its engine");
+  if (int rc = resolve_many_carry(c->engine, c)) return rc;
   if (p->prefetch < 0 || p->prefetch > FFN_MAX_CANDIDATES)
     return fail(FFN_ERR_ARG, "prefetch must be 0..%d", FFN_MAX_CANDIDATES);
   if (p->shape_zyx[0] != c->cz || p->shape_zyx[1] != c->cy ||
@@ -2392,6 +2432,15 @@ int ffn_canvas_segment_many(ffn_engine* e, int n, ffn_canvas* const* canvases,
                             const int32_t (*starts)[3],
                             const ffn_segment_params* params, const int32_t* resume,
                             ffn_segment_result* results, int32_t* finished) {
+  return ffn_canvas_segment_many_carry(e, n, canvases, starts, params, resume, results,
+                                       finished, 0);
+}
+
+int ffn_canvas_segment_many_carry(ffn_engine* e, int n, ffn_canvas* const* canvases,
+                                  const int32_t (*starts)[3],
+                                  const ffn_segment_params* params,
+                                  const int32_t* resume, ffn_segment_result* results,
+                                  int32_t* finished, int32_t carry) {
   if (!e || !canvases || !starts || !params || !resume || !results || !finished)
     return fail(FFN_ERR_ARG, "null argument");
   if (n < 1 || n > e->max_batch)
@@ -2425,13 +2474,42 @@ int ffn_canvas_segment_many(ffn_engine* e, int n, ffn_canvas* const* canvases,
     for (int b = 0; b < nb; ++b) batch[b] = canvases[idx[b]];
     return ffn_canvas_step(e, nb, batch.data(), reqs, &sp, res);
   };
+  // a step left in flight by the last call (of whichever kind) comes first; with
+  // `carry` this call may leave one itself
+  std::unique_lock<std::mutex> many_guard(e->many_mu);
+  if (!carry) {
+    const int rc = resolve_many_carry_locked(e);
+    many_guard.unlock();
+    if (rc) return rc;
+    return ffn_host::segment_many(n, devs.data(), states.data(), starts, params,
+                                  resume, results, finished, batch_step);
+  }
+  auto submit = [&](int nb, const int* idx, const ffn_step_request* reqs,
+                    const ffn_step_params& sp) {
+    for (int b = 0; b < nb; ++b) batch[b] = canvases[idx[b]];
+    const int rc = ffn_canvas_step_submit(e, nb, batch.data(), reqs, &sp,
+                                          &e->many_ticket);
+    if (rc == FFN_OK) {
+      e->many_canvases.assign(batch.begin(), batch.begin() + nb);
+      e->stat_many_carried += 1;
+    }
+    return rc;
+  };
+  auto wait = [&](ffn_step_result* res) {
+    const int rc = step_wait_impl(e, e->many_ticket, res, nullptr);
+    e->many_canvases.clear();
+    return rc;
+  };
   return ffn_host::segment_many(n, devs.data(), states.data(), starts, params, resume,
-                                results, finished, batch_step);
+                                results, finished, batch_step, &e->many_carry, submit,
+                                wait);
 }
 
 int ffn_canvas_segment_history(ffn_canvas* c, size_t first, size_t n,
                                int32_t* pos, uint32_t* deleted, size_t* total) {
   if (!c) return fail(FFN_ERR_ARG, "null canvas");
+  if (c->engine)
+    if (int rc = resolve_many_carry(c->engine, c)) return rc;
   const size_t have = c->loop.history_deleted.size();
   if (total) *total = have;
   if (n == 0) return FFN_OK;

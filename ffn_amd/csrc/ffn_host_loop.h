@@ -80,6 +80,30 @@ struct SegmentState {
 
 constexpr int kHintMax = 3;  // positions per Dev::hint_next call
 
+// One prepared FoV step of a segment loop: the position popped for it, the queue
+// head whose values ride along, the request as the device gets it.
+struct StepPending {
+  Coord pos;
+  Coord cands[FFN_MAX_CANDIDATES];
+  int nc = 0;
+  ffn_step_request req;
+};
+
+// A batched step of segment_many that has been QUEUED but whose results have not
+// been looked at: it stays in flight across the return to the caller, who does
+// the between-segment work of the loop that has just ended meanwhile; the next
+// segment_many call (or whoever needs one of these canvases first) waits for it
+// and feeds the results to the loops it belongs to.
+struct ManyCarry {
+  struct Item {
+    SegmentState* st;
+    ffn_segment_params params;
+    StepPending pd;
+  };
+  bool active = false;
+  std::vector<Item> items;  // in the order of the batch
+};
+
 template <class Dev>
 class SegmentLoop {
  public:
@@ -120,12 +144,7 @@ class SegmentLoop {
 
   // ---- the same loop in phases, for a caller that batches the steps of several
   // canvases into one engine call (ffn_canvas_segment_many) -----------------------
-  struct Pending {
-    Coord pos;
-    Coord cands[FFN_MAX_CANDIDATES];
-    int nc = 0;
-    ffn_step_request req;
-  };
+  typedef StepPending Pending;
 
   int begin(const int32_t start[3], int resume, ffn_segment_result* out) {
     std::memset(out, 0, sizeof(*out));
@@ -442,15 +461,42 @@ class SegmentLoop {
 // same step parameters (one engine call = one set); an error (e.g.
 // FFN_ERR_RANGE) leaves every prepared position pending: after the caller has
 // dealt with it the same call with resume = 1 everywhere repeats the step.
-template <class Dev, class BatchStep>
+// The results of a carried step to the loops it was made for (whichever call they
+// are part of next): wait(results) -> rc for carry->items.size() records.  An
+// error means nothing was pasted: the positions stay pending, as after a failed
+// batch_step.
+template <class Dev, class Wait>
+int resolve_carry(ManyCarry* carry, Dev& any_dev, Wait&& wait) {
+  if (!carry || !carry->active) return FFN_OK;
+  std::vector<ffn_step_result> res(carry->items.size());
+  const int rc = wait(res.data());
+  carry->active = false;
+  if (rc == FFN_OK) {
+    for (size_t b = 0; b < carry->items.size(); ++b) {
+      ManyCarry::Item& it = carry->items[b];
+      SegmentLoop<Dev> loop(any_dev, *it.st, it.params);  // (consume reads no device)
+      loop.consume(it.pd, res[b]);
+      it.st->many_steps += 1;
+    }
+  }
+  carry->items.clear();
+  return rc;
+}
+
+// carry != NULL: when a loop ends, the step the others have prepared is QUEUED
+// (submit(nb, idx, reqs, step_params) -> rc) and the call returns without waiting
+// for it; the next call starts with resolve_carry.  batch_step = submit + wait.
+template <class Dev, class BatchStep, class Submit, class Wait>
 int segment_many(int n, Dev* devs, SegmentState* const* states,
                  const int32_t (*starts)[3], const ffn_segment_params* params,
                  const int32_t* resume, ffn_segment_result* out, int32_t* finished,
-                 BatchStep&& batch_step) {
+                 BatchStep&& batch_step, ManyCarry* carry, Submit&& submit,
+                 Wait&& wait) {
   typedef SegmentLoop<Dev> Loop;
   for (int k = 1; k < n; ++k)
     if (std::memcmp(&params[k].step, &params[0].step, sizeof(ffn_step_params)) != 0)
       return FFN_ERR_ARG;
+  const int rc_carry = resolve_carry(carry, devs[0], wait);
   std::vector<Loop> loops;
   loops.reserve(n);
   std::vector<char> running(n, 1);
@@ -469,6 +515,7 @@ int segment_many(int n, Dev* devs, SegmentState* const* states,
           states[k]->many_skip_invalid_pos = states[k]->many_gate_rejects = 0;
   }
   bool any_ended = false;
+  rc = rc_carry;  // (a voided carried step: no step is made in this call)
   while (!any_ended && rc == FFN_OK) {
     int nb = 0;
     for (int k = 0; k < n && rc == FFN_OK; ++k) {
@@ -489,6 +536,16 @@ int segment_many(int n, Dev* devs, SegmentState* const* states,
     if (rc || nb == 0) break;
     // (the canvases that did prepare a step make it even when another loop has
     // just ended: their positions are popped, the batch slot costs nothing)
+    if (carry && any_ended) {
+      rc = submit(nb, idx.data(), reqs.data(), params[0].step);
+      if (rc) break;
+      carry->items.clear();
+      for (int b = 0; b < nb; ++b)
+        carry->items.push_back(
+            ManyCarry::Item{states[idx[b]], params[idx[b]], pend[idx[b]]});
+      carry->active = true;
+      break;
+    }
     rc = batch_step(nb, idx.data(), reqs.data(), params[0].step, results.data());
     if (rc) break;  // nothing was pasted: every prepared position stays pending
     for (int b = 0; b < nb; ++b) loops[idx[b]].consume(pend[idx[b]], results[b]);
@@ -506,6 +563,18 @@ int segment_many(int n, Dev* devs, SegmentState* const* states,
     out[k].gate_rejects = st.many_gate_rejects;
   }
   return rc;
+}
+
+template <class Dev, class BatchStep>
+int segment_many(int n, Dev* devs, SegmentState* const* states,
+                 const int32_t (*starts)[3], const ffn_segment_params* params,
+                 const int32_t* resume, ffn_segment_result* out, int32_t* finished,
+                 BatchStep&& batch_step) {
+  auto no_submit = [](int, const int*, const ffn_step_request*,
+                      const ffn_step_params&) { return (int)FFN_ERR_STATE; };
+  auto no_wait = [](ffn_step_result*) { return (int)FFN_ERR_STATE; };
+  return segment_many(n, devs, states, starts, params, resume, out, finished,
+                      batch_step, static_cast<ManyCarry*>(nullptr), no_submit, no_wait);
 }
 
 }  // namespace ffn_host

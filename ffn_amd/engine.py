@@ -303,14 +303,19 @@ class HipEngine:
                                      ctypes.byref(params), self._res_arr)
     check(rc)
 
+  #: `segment_many(..., carry=True)`: ffn_canvas_segment_many_carry
+  can_carry = True
+
   def segment_many(self, canvases: Sequence['DeviceCanvasHandle'], starts,
-                   params: Sequence['_lib.SegmentParams'], resumes):
+                   params: Sequence['_lib.SegmentParams'], resumes, carry=False):
     """ffn_canvas_segment_many: the segment loops of several canvases advanced
     together inside the library, one batched step per round; returns once at
     least one of them has ended.  -> (results, finished), one entry per canvas;
     results count from the start of each canvas' segment.  A round voided by
     the fp16 range check is repeated with the exact-f32 kernel and the call
-    resumed for the canvases still running."""
+    resumed for the canvases still running.  carry: when a loop ends, the step
+    the others have prepared is left in flight across the return (see
+    ffn_canvas_segment_many_carry; one driving thread, no step budgets)."""
     n = len(canvases)
     carr = (ctypes.c_void_p * n)(*[c._h for c in canvases])
     sarr = (ctypes.c_int32 * 3 * n)()
@@ -322,8 +327,8 @@ class HipEngine:
       ctypes.pointer(parr[k])[0] = params[k]
     def once(keys, sa, pa, ra, res, fin):
       ca = (ctypes.c_void_p * len(keys))(*[canvases[k]._h for k in keys])
-      return self._lib.ffn_canvas_segment_many(self._h, len(keys), ca, sa, pa, ra,
-                                               res, fin)
+      return self._lib.ffn_canvas_segment_many_carry(
+          self._h, len(keys), ca, sa, pa, ra, res, fin, 1 if carry else 0)
 
     def fallback():
       self.range_fallbacks += 1

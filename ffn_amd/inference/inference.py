@@ -1319,7 +1319,7 @@ class MultiCanvasDriver:
   """
 
   def __init__(self, engine, batch_size=None, overlap=True,
-               max_steps_per_canvas=None, native=None, groups=1):
+               max_steps_per_canvas=None, native=None, groups=1, carry=None):
     """groups (native mode): 2 = the open canvases form two groups, each driven
     by its own host thread and its own library calls, `batch_size` canvases per
     call.  The library interleaves the two calls' steps on the engine's stream
@@ -1344,6 +1344,11 @@ class MultiCanvasDriver:
       native = os.environ.get('FFN_AMD_NATIVE_MANY', '1') != '0'
     self.native = bool(native) and hasattr(engine, 'segment_many')
     self.groups = max(1, int(groups)) if self.native else 1
+    #: one group: leave the running canvases' next step in flight while a canvas
+    #: is between two segments (`ffn_canvas_segment_many_carry`)
+    if carry is None:
+      carry = os.environ.get('FFN_AMD_MANY_CARRY', '1') != '0'
+    self.carry = bool(carry)
     #: benchmarking / bounded runs: a canvas is dropped after this many steps
     self.max_steps_per_canvas = max_steps_per_canvas
     self.calls = 0
@@ -1601,9 +1606,17 @@ class MultiCanvasDriver:
           left = min(left, mixed_call_steps) if limit is not None else mixed_call_steps
         e[2].params.max_steps = max(left, 1) if (limit is not None or mixed) else 0
       t_call = time.perf_counter()
+      # one group: the others' next step stays in flight while this thread does
+      # the between-segment work of the canvas whose loop has just ended (what a
+      # second group's steps provide otherwise); step budgets are per call and
+      # canvases on the Python loop need the engine's step slots: neither then
+      kw = {}
+      if (self.carry and self.groups == 1 and limit is None and not mixed and
+          len(batch) == len(nat) and getattr(engine, 'can_carry', False)):
+        kw['carry'] = True
       results, fin = engine.segment_many(
           [e[0]._handle for e in batch], [e[2].start_pos for e in batch],
-          [e[2].params for e in batch], [e[2].started for e in batch])
+          [e[2].params for e in batch], [e[2].started for e in batch], **kw)
       tally[2] += time.perf_counter() - t_call
       tally[3] += sum(1 for d in fin if d)
       tally[0] += 1

@@ -219,6 +219,29 @@ int ffn_canvas_segment_many(ffn_engine* engine, int n, ffn_canvas* const* canvas
                             const ffn_segment_params* params,
                             const int32_t* resume, ffn_segment_result* results,
                             int32_t* finished);
+
+/* ... with the others' next step left IN FLIGHT when a loop ends (carry != 0):
+ * the call queues the batched step the still-running loops have prepared and
+ * returns without waiting for it, so that the caller's between-segment work on
+ * the canvas that ended (ffn_canvas_segment_turn, its bookkeeping, the next
+ * call's arguments) runs under that step instead of in front of it -- what a
+ * second group of canvases on a second host thread otherwise provides
+ * (executor.py:266-340: the reference's client threads).  The next
+ * ffn_canvas_segment_many[_carry] call on the engine waits for the step first and
+ * feeds its results to the loops it was made for; so does any entry point that
+ * needs one of those canvases' loops earlier (ffn_canvas_segment_at,
+ * ffn_canvas_segment_history, ffn_canvas_destroy).  results[k].num_steps counts
+ * a carried step once its results are in.  One carried step per engine: meant
+ * for ONE driving thread; max_steps budgets are per call and do not see the
+ * carried step (callers with budgets pass carry = 0).  carry = 0:
+ * ffn_canvas_segment_many. */
+int ffn_canvas_segment_many_carry(ffn_engine* engine, int n,
+                                  ffn_canvas* const* canvases,
+                                  const int32_t (*starts_zyx)[3],
+                                  const ffn_segment_params* params,
+                                  const int32_t* resume,
+                                  ffn_segment_result* results, int32_t* finished,
+                                  int32_t carry);
 /* keep_history: entries [first, first + n) of the current segment's history
  * (positions zyx, deleted-voxel counts); *total = entries recorded. */
 int ffn_canvas_segment_history(ffn_canvas* canvas, size_t first, size_t n,

@@ -75,6 +75,48 @@ int shim_segment_many(int n, void* const* states, shim_batch_fn batch_cb,
                                 finished, batch_step);
 }
 
+// ... with the step the running loops have prepared left "in flight" when a loop
+// ends (ffn_canvas_segment_many_carry).  The emulated device makes the step when
+// it is queued; its results (or, with defer_error, its error) are handed over
+// when the next call waits for it -- the protocol of the real thing, whose
+// between-segment work touches another canvas than the step in flight.
+static ffn_host::ManyCarry g_carry;
+static std::vector<ffn_step_result> g_carry_res;
+static int g_carry_rc = 0;
+
+int shim_carry_active() { return g_carry.active ? 1 : 0; }
+
+int shim_segment_many_carry(int n, void* const* states, shim_batch_fn batch_cb,
+                            shim_read_k_fn read_cb, const int32_t (*starts)[3],
+                            const ffn_segment_params* params, const int32_t* resume,
+                            ffn_segment_result* out, int32_t* finished,
+                            int defer_error) {
+  std::vector<ShimManyDevice> devs(n);
+  std::vector<ffn_host::SegmentState*> st(n);
+  for (int k = 0; k < n; ++k) {
+    devs[k] = ShimManyDevice{read_cb, k};
+    st[k] = static_cast<ffn_host::SegmentState*>(states[k]);
+  }
+  auto batch_step = [&](int nb, const int* idx, const ffn_step_request* reqs,
+                        const ffn_step_params& sp, ffn_step_result* res) {
+    return batch_cb(nb, idx, reqs, &sp, res);
+  };
+  auto submit = [&](int nb, const int* idx, const ffn_step_request* reqs,
+                    const ffn_step_params& sp) {
+    g_carry_res.assign(nb, ffn_step_result());
+    g_carry_rc = batch_cb(nb, idx, reqs, &sp, g_carry_res.data());
+    if (g_carry_rc && !defer_error) return g_carry_rc;
+    return 0;
+  };
+  auto wait = [&](ffn_step_result* res) {
+    if (g_carry_rc == 0)
+      std::memcpy(res, g_carry_res.data(), sizeof(ffn_step_result) * g_carry_res.size());
+    return g_carry_rc;
+  };
+  return ffn_host::segment_many(n, devs.data(), st.data(), starts, params, resume, out,
+                                finished, batch_step, &g_carry, submit, wait);
+}
+
 size_t shim_history(void* state, int32_t* pos, uint32_t* deleted, size_t cap) {
   auto& st = *static_cast<ffn_host::SegmentState*>(state);
   const size_t n = st.history_deleted.size() < cap ? st.history_deleted.size() : cap;

@@ -52,6 +52,10 @@ def build_shim(out_dir):
   lib.shim_segment_many.argtypes = [
       ctypes.c_int, ctypes.c_void_p, _BATCH_CB, _READ_K_CB, ctypes.c_void_p,
       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+  lib.shim_segment_many_carry.restype = ctypes.c_int
+  lib.shim_segment_many_carry.argtypes = lib.shim_segment_many.argtypes + [
+      ctypes.c_int]
+  lib.shim_carry_active.restype = ctypes.c_int
   lib.shim_history.restype = ctypes.c_size_t
   lib.shim_history.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
                                ctypes.c_void_p, ctypes.c_size_t]
@@ -172,11 +176,17 @@ class ShimEngine:
     # ended -- the round carries fewer steps than the call has canvases
     self.rounds = 0
     self.range_fallbacks = 0
+    #: ffn_canvas_segment_many_carry: calls that asked for it, calls that left a
+    #: step in flight; defer_error: a voided carried step shows at the next call
+    self.can_carry = True
+    self.carry_calls = 0
+    self.carried = 0
+    self.defer_error = False
 
   def step(self, handles, requests, params):
     return [self.client.step(h, r, params) for h, r in zip(handles, requests)]
 
-  def _segment_many_once(self, handles, sarr, parr, rarr, res, fin):
+  def _segment_many_once(self, handles, sarr, parr, rarr, res, fin, carry=False):
     n = len(handles)
 
     def batch_cb(nb, idx, reqs, par, out):
@@ -200,11 +210,19 @@ class ShimEngine:
       return 0
 
     states = (ctypes.c_void_p * n)(*[h._state for h in handles])
+    if carry:
+      self.carry_calls += 1
+      rc = ShimHandle.shim.shim_segment_many_carry(
+          n, states, _BATCH_CB(batch_cb), _READ_K_CB(read_cb), sarr, parr, rarr,
+          res, fin, int(self.defer_error))
+      self.carried += ShimHandle.shim.shim_carry_active()
+      return rc
+    assert not ShimHandle.shim.shim_carry_active()
     return ShimHandle.shim.shim_segment_many(
         n, states, _BATCH_CB(batch_cb), _READ_K_CB(read_cb), sarr, parr, rarr, res,
         fin)
 
-  def segment_many(self, handles, starts, params, resumes):
+  def segment_many(self, handles, starts, params, resumes, carry=False):
     """Mirrors HipEngine.segment_many, ERR_RANGE handling included."""
     n = len(handles)
     assert n <= self.max_batch
@@ -218,7 +236,7 @@ class ShimEngine:
       ctypes.pointer(parr[k])[0] = params[k]
     def once(keys, sa, pa, ra, res, fin):
       return self._segment_many_once([handles[k] for k in keys], sa, pa, ra, res,
-                                     fin)
+                                     fin, carry)
 
     def fallback():
       self.range_fallbacks += 1

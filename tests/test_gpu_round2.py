@@ -506,7 +506,9 @@ def test_segment_many_in_the_library(fib25_model):
           for n in set(names)}
   request = bench.make_request()
   runs = {}
-  for native in (True, False):
+  # 'carry' / True: the library's loops with / without the running canvases' next
+  # step left in flight when a loop ends (ffn_canvas_segment_many_carry)
+  for native in ('carry', True, False):
     counters = inference_utils.Counters()
     exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
                                     fib25_model.info, None, counters, 4)
@@ -519,10 +521,12 @@ def test_segment_many_in_the_library(fib25_model):
           synthetic.normalize(gold[n]['volume']), request.inference_options,
           counters=sub, keep_history=True,
           movement_policy_fn=movement.get_policy_fn(request, fib25_model.info)))
-    drv = inference.MultiCanvasDriver(exe.engine, batch_size=4, native=native)
-    assert drv.native == native
+    drv = inference.MultiCanvasDriver(exe.engine, batch_size=4, native=bool(native),
+                                      carry=native == 'carry')
+    assert drv.native == bool(native)
     drv.run((c, functools.partial(seed_lib.PolicyFixed, coords=gold[n]['seeds']))
             for c, n in zip(canvases, names))
+    assert (exe.engine.get_option('stat_many_carried') > 0) == (native == 'carry')
     out = []
     for c, n in zip(canvases, names):
       out.append(dict(
@@ -537,11 +541,12 @@ def test_segment_many_in_the_library(fib25_model):
       c.close()
     runs[native] = (out, drv.calls, drv.steps)
   total = sum(len(gold[n]['steps']) for n in names)
-  for a, b in zip(runs[True][0], runs[False][0]):
-    assert a['counters'] == b['counters'] and a['rejects'] == b['rejects']
-    assert np.array_equal(a['seg'], b['seg'])
-    assert np.array_equal(a['seed'], b['seed'], equal_nan=True)
-  assert runs[True][2] == runs[False][2] == total
+  for mode in (True, 'carry'):
+    for a, b in zip(runs[mode][0], runs[False][0]):
+      assert a['counters'] == b['counters'] and a['rejects'] == b['rejects']
+      assert np.array_equal(a['seg'], b['seg'])
+      assert np.array_equal(a['seed'], b['seed'], equal_nan=True)
+  assert runs[True][2] == runs['carry'][2] == runs[False][2] == total
   # Python entered per segment, not per batched step
   print('engine calls: native %d, per-step %d, for %d FoV steps' % (
       runs[True][1], runs[False][1], total))

@@ -356,20 +356,26 @@ def _many_canvases(shim, blob, names, **kwargs):
   return client, native_shim.ShimEngine(client, 4), canvases, gold
 
 
+@pytest.mark.parametrize('carry', [False, True, 'deferred'])
 @pytest.mark.parametrize('fail_round', [None, 37, 'short'])
-def test_segment_many_reproduces_reference_runs(shim, fib25_blob, fail_round):
+def test_segment_many_reproduces_reference_runs(shim, fib25_blob, fail_round, carry):
   """ffn_host::segment_many (ffn_canvas_segment_many's loop) under the
   MultiCanvasDriver: five canvases, at most four per engine call, whole segments
   inside the C++ loop, Python only between segments.  Every canvas repeats the
   reference's own run step for step whatever it shared its calls with -- also
   when a batched round is voided once (FFN_ERR_RANGE) and the call resumed;
   'short' voids the round in which a canvas' loop has just ENDED (that canvas
-  keeps its result and is not resumed: resuming it would be FFN_ERR_STATE)."""
+  keeps its result and is not resumed: resuming it would be FFN_ERR_STATE).
+  carry: the running loops' next step stays in flight when a loop ends
+  (ffn_canvas_segment_many_carry), 'deferred': and a voided one shows only when
+  the next call waits for it."""
   import json
   names = ['cells72', 'cells56', 'cells72', 'cells56', 'cells56']
   client, engine, canvases, gold = _many_canvases(shim, fib25_blob, names)
   engine.fail_round = fail_round
-  drv = inference.MultiCanvasDriver(engine, batch_size=4, native=True)
+  engine.defer_error = carry == 'deferred'
+  drv = inference.MultiCanvasDriver(engine, batch_size=4, native=True,
+                                    carry=bool(carry))
   assert drv.native
   done = []
   drv.run(((c, functools.partial(seed_lib.PolicyFixed, coords=gold[n]['seeds']))
@@ -391,6 +397,9 @@ def test_segment_many_reproduces_reference_runs(shim, fib25_blob, fail_round):
   assert max(engine.batch_sizes) == 4 and engine.rounds < total
   assert engine.many_calls < total / 3
   assert engine.range_fallbacks == (0 if fail_round is None else 1)
+  # steps were left in flight across returns, and none is left at the end
+  assert (engine.carried > 0) == bool(carry)
+  assert not shim.shim_carry_active()
 
 
 def test_segment_many_step_budget_per_canvas(shim, fib25_blob):
