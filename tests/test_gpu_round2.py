@@ -86,7 +86,11 @@ def _device_canvas(exe, model, image, **kwargs):
 # first fixture; the split-product kernels (f32 accumulation of exact 16-term
 # products) reproduce the oneDNN / f64 run -- step for step, voxel for voxel.
 _FIXTURE_OF_VARIANT = {2: '', 6: '_f64', 8: '_f64', 9: '_f64'}
-RUN_TOL = 5e-3  # move scores ALONG a run (amplified noise); per step: TOL
+# move scores and seed logits ALONG a run, against the fixture of the trajectory the
+# kernel is on: the per-step bound holds for the whole run (measured over the 3,725
+# steps of the 250^3 runs: 1.9e-5 - 2.0e-5, final seed logits 5.8e-6; the pred < seed
+# runs 1.4e-5; profiles/r04_pytest_gpu_run_tolerance.txt)
+RUN_TOL = 1e-4
 
 
 def _run_recorded(canvas, seeds):
@@ -177,9 +181,11 @@ def test_cells250_matches_reference_minted_run(hip_exe, fib25_model, variant, fl
     sample = np.asarray(canvas.seed[0:33, 0:33, 192:225])
     want_s = g['final_seed_sample']
     assert np.array_equal(np.isnan(sample), np.isnan(want_s))
-    assert np.nanmax(np.abs(sample - want_s)) <= (TOL if variant == 2 else RUN_TOL)
+    seed_err = float(np.nanmax(np.abs(sample - want_s)))
     print('variant %d flow %d: %d steps, max move-score difference along the run '
-          '%.3g' % (variant, flow, len(got_steps), max_err))
+          '%.3g, final seed sample %.3g' % (variant, flow, len(got_steps), max_err,
+                                            seed_err))
+    assert seed_err <= (TOL if variant == 2 else RUN_TOL)
     assert eng.get_option('stat_flow_timeouts') == 0
     canvas.close()
   finally:
@@ -816,6 +822,8 @@ def test_pred_smaller_than_seed_on_device(fib25_model, name):
     assert np.array_equal(np.asarray(canvas.segmentation), g['segmentation'])
     seed_got = np.asarray(canvas.seed)
     assert np.array_equal(np.isnan(seed_got), np.isnan(g['seed_logits']))
+    print('pred %r: final seed difference %.3g' % (
+        pred, float(np.nanmax(np.abs(seed_got - g['seed_logits'])))))
     assert np.nanmax(np.abs(seed_got - g['seed_logits'])) <= RUN_TOL
     canvas.close()
     # (b) the in-library segment loop (speculative conv0_a, fused faces + paste)
