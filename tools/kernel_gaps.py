@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Gaps between the two launches of a single-FoV step in a rocprofv3 --kernel-trace
+CSV: resident stack -> faces + paste + next conv0_a -> next stack."""
+import csv
+import statistics as st
+import sys
+
+rows = []
+for r in csv.DictReader(open(sys.argv[1])):
+  rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'][:40]))
+rows.sort()
+g1, g2, d1, d2 = [], [], [], []
+for a, b in zip(rows, rows[1:]):
+  if 'conv32ps' in a[2] and 'faces_paste_conv0a' in b[2]:
+    g1.append(b[0] - a[1])
+    d1.append(a[1] - a[0])
+  if 'faces_paste_conv0a' in a[2] and 'conv32ps' in b[2]:
+    g2.append(b[0] - a[1])
+    d2.append(a[1] - a[0])
+starts = [r[0] for r in rows if 'conv32ps' in r[2]]
+per = [b - a for a, b in zip(starts, starts[1:]) if b - a < 400000]
+q = lambda v, p: sorted(v)[int(p * (len(v) - 1))] / 1e3
+print('stack %.1f us (median), fused launch %.2f us; gap stack -> fused %.2f us (90 %%: %.2f), '
+      'fused -> next stack %.2f us (90 %%: %.2f); period %.1f us over %d steps' % (
+          st.median(d1) / 1e3, st.median(d2) / 1e3, st.median(g1) / 1e3, q(g1, 0.9),
+          st.median(g2) / 1e3, q(g2, 0.9), st.median(per) / 1e3, len(per)))
