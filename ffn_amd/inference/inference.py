@@ -772,17 +772,21 @@ class DeviceCanvas(Canvas):
   def _turn_ok(self) -> bool:
     """True if `ffn_canvas_segment_turn` may answer the seed loop's questions
     (inference.py:573-660) ahead of time: nothing between two segments that the
-    device does not see -- no restrictor masks, no timed checkpoint, no
-    probability map, the stock validity test."""
+    device does not see -- no restrictor masks, no timed checkpoint about to
+    be taken, no probability map, the stock validity test."""
     ok = self.__dict__.get('_turn_static')
     if ok is None:
       ok = (hasattr(self._handle, 'segment_turn') and
             not self.keep_probability_maps and
             getattr(self.restrictor, 'is_trivial', self.restrictor is None))
       self._turn_static = ok
-    return (ok and self.TURN_CANDIDATES > 0 and
-            (self.checkpoint_path is None or self.checkpoint_interval_sec <= 0)
-            and getattr(self.is_valid_pos, '__func__', None)
+    # (a timed checkpoint is taken BETWEEN the loop's questions, of a canvas the
+    # turn has already moved past them: no turn while one is nearly due -- the
+    # answers of a turn are used up within milliseconds)
+    far = (self.checkpoint_path is None or self.checkpoint_interval_sec <= 0 or
+           time.time() - self.checkpoint_last < self.checkpoint_interval_sec - 2.0)
+    return (ok and far and self.TURN_CANDIDATES > 0 and
+            getattr(self.is_valid_pos, '__func__', None)
             is DeviceCanvas.is_valid_pos)
 
   def _is_current_seed(self, pos) -> bool:

@@ -261,6 +261,39 @@ def test_segment_turn_answers_the_seed_loop_like_single_questions(monkeypatch,
   assert runs[0][5] < ref[5]
 
 
+def test_segment_turn_and_timed_checkpoints(monkeypatch, tmp_path):
+  """A canvas with a timed checkpoint configured (every Runner canvas: the sample
+  config asks for one every 1800 s) still uses the device-side turn -- except
+  when the checkpoint is about to be taken, which then happens between the
+  single questions of the reference's loop, as before."""
+  monkeypatch.setattr(ffn_oracle, 'forward', _flood_forward)
+  shape = (72, 96, 96)
+  image = _blob_volume(shape, [(30, 30, 30), (34, 60, 34), (40, 40, 64)], 9)
+  r = _request()
+  r.inference_options.min_segment_size = 200
+  info = _info()
+  grid = np.array([(z, y, x) for z in range(18, 54, 12) for y in range(18, 78, 6)
+                   for x in range(18, 78, 6)], np.int32)
+  runs = {}
+  for interval in (1800.0, 1e-6):
+    path = str(tmp_path / ('cp_%g.npz' % interval))
+    client = EmulatedDeviceClient(inference_utils.Counters(), None, 12,
+                                  (33, 33, 33), (8, 8, 8))
+    canvas = inference.make_canvas(info, client, image, r.inference_options,
+                                   movement_policy_fn=movement.get_policy_fn(
+                                       r, info),
+                                   checkpoint_path=path,
+                                   checkpoint_interval_sec=interval)
+    canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                     coords=grid))
+    runs[interval] = (np.asarray(canvas.segmentation).copy(), canvas.turns,
+                      os.path.exists(path))
+  assert runs[1800.0][1] > 0 and not runs[1800.0][2]
+  assert runs[1e-6][1] == 0 and runs[1e-6][2]
+  assert np.array_equal(runs[1800.0][0], runs[1e-6][0])
+  assert len(np.unique(runs[1800.0][0])) >= 3
+
+
 def test_keep_history_host_and_device_canvas_agree(fib25_blob):
   """keep_history (inference.py:420-423, 520-521): the device canvas gets the
   per-step deleted-voxel count from the step result."""
