@@ -789,10 +789,16 @@ class DeviceCanvas(Canvas):
             getattr(self.is_valid_pos, '__func__', None)
             is DeviceCanvas.is_valid_pos)
 
-  def _is_current_seed(self, pos) -> bool:
+  def _policy_list(self):
+    """(coords, idx) of the seed policy if it hands its seeds out the stock way
+    (BaseSeedPolicy.__next__: coords[idx], idx += 1), else (None, None)."""
     policy = self.__dict__.get('seed_policy')
-    coords = getattr(policy, 'coords', None)
-    idx = getattr(policy, 'idx', None)
+    if getattr(type(policy), '__next__', None) is not seed_lib.BaseSeedPolicy.__next__:
+      return None, None
+    return getattr(policy, 'coords', None), getattr(policy, 'idx', None)
+
+  def _is_current_seed(self, pos) -> bool:
+    coords, idx = self._policy_list()
     return (coords is not None and idx is not None and
             1 <= idx <= len(coords) and
             tuple(int(v) for v in coords[idx - 1]) == pos)
@@ -800,9 +806,7 @@ class DeviceCanvas(Canvas):
   def _upcoming_seeds(self, first=None):
     """The next seeds the policy will hand out (`first`: the one it has just
     handed out, then those), as long as they pass the bounds test."""
-    policy = self.__dict__.get('seed_policy')
-    coords = getattr(policy, 'coords', None)
-    idx = getattr(policy, 'idx', None)
+    coords, idx = self._policy_list()
     if coords is None or idx is None:
       return [] if first is None else [first]
     if first is not None:
