@@ -220,6 +220,88 @@ __device__ __forceinline__ void conv0a_body(
   const long cstr[3] = {(long)it.cy * it.cx, (long)it.cx, 1};
   const long sz = cstr[g.oa[0]], sy = cstr[g.oa[1]], sx = cstr[g.oa[2]];
   int pos[3] = {it.pos[0], it.pos[1], it.pos[2]};
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15;   // A row (position) / B column (cout) of this lane
+  const int grp = lane >> 4;  // k index inside a k-step
+
+  // Gather: every canvas load of the block is issued before any is waited for
+  // (<= kC0Per elements per thread), and a uint8 canvas' normalisation table
+  // ((x - mean) / stddev of runner.py:383-385 as a 256-entry look-up) goes
+  // through LDS -- one global round trip for the whole gather instead of one
+  // per pass and another per look-up.
+  constexpr int kC0Per = (HZ * HY * HX + kC0Threads - 1) / kC0Threads;
+  const bool u8 = it.image == nullptr;
+  float g_img[kC0Per] = {}, g_seed[kC0Per];
+  unsigned g_raw[kC0Per] = {};
+  float o_l[kC0Per] = {}, o_o[kC0Per] = {};
+  int g_ov[kC0Per];  // index into the overlay (a voxel the running paste writes), or -1
+  long g_out[kC0Per];  // seed_raw index of an interior voxel, else -1
+  bool g_in[kC0Per];
+  int g_zz[kC0Per], g_yy[kC0Per], g_xx[kC0Per];
+#pragma unroll
+  for (int k = 0; k < kC0Per; ++k) {
+    const int e = threadIdx.x + k * kC0Threads;
+    const int ec = e < HZ * HY * HX ? e : 0;
+    const int hx = ec % HX;
+    const int t = ec / HX;
+    const int hy = t % HY;
+    const int hz = t / HY;
+    const int zz = oz + hz - 1, yy = oy + hy - 1, xx = ox + hx - 1;
+    g_zz[k] = zz, g_yy[k] = yy, g_xx[k] = xx;
+    g_in[k] = e < HZ * HY * HX && zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy &&
+              xx >= 0 && xx < g.fx;
+    // interior voxel: keep the raw seed (NaN preserved), at its place in the
+    // caller's dense [z][y][x] order
+    g_out[k] = (g_in[k] && hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y &&
+                hx >= 1 && hx <= kC0X)
+                   ? (long)((size_t)item * g.V + (size_t)zz * g.dstr[0] +
+                            yy * g.dstr[1] + xx * g.dstr[2])
+                   : -1;
+  }
+  // the loads of the FoV at canvas position p3 (zyx), all in flight at once
+  auto issue_gather = [&](const int* p3) {
+    const int pz = g.oa[0] == 0 ? p3[0] : g.oa[0] == 1 ? p3[1] : p3[2];
+    const int py = g.oa[1] == 0 ? p3[0] : g.oa[1] == 1 ? p3[1] : p3[2];
+    const int px = g.oa[2] == 0 ? p3[0] : g.oa[2] == 1 ? p3[1] : p3[2];
+    const int z0 = pz - g.fz / 2;
+    const int y0 = py - g.fy / 2;
+    const int x0 = px - g.fx / 2;
+    size_t g_ci[kC0Per];
+#pragma unroll
+    for (int k = 0; k < kC0Per; ++k) {
+      // (voxel 0 of the canvas stands in outside the FoV: loads without branches)
+      g_ci[k] = g_in[k] ? (size_t)((z0 + g_zz[k]) * sz + (y0 + g_yy[k]) * sy +
+                                   (x0 + g_xx[k]) * sx)
+                        : 0;
+      g_ov[k] = -1;
+      if (ov.on && g_in[k]) {
+        int cc[3];  // canvas coordinates: this geometry's axis a is canvas axis oa[a]
+        cc[g.oa[0]] = z0 + g_zz[k];
+        cc[g.oa[1]] = y0 + g_yy[k];
+        cc[g.oa[2]] = x0 + g_xx[k];
+        g_ov[k] = overlay_index(ov, cc[0], cc[1], cc[2]);
+      }
+    }
+    if (u8) {
+#pragma unroll
+      for (int k = 0; k < kC0Per; ++k) g_raw[k] = it.image_u8[g_ci[k]];
+    } else {
+#pragma unroll
+      for (int k = 0; k < kC0Per; ++k) g_img[k] = it.image[g_ci[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < kC0Per; ++k) g_seed[k] = it.seed[g_ci[k]];
+    if (ov.on) {
+#pragma unroll
+      for (int k = 0; k < kC0Per; ++k) {
+        o_l[k] = ov.lg[g_ov[k] < 0 ? 0 : g_ov[k]];
+        o_o[k] = ov.old[g_ov[k] < 0 ? 0 : g_ov[k]];
+      }
+    }
+  };
+
   if (sp.n > 0) {  // every block makes the same choice from the same loads
     // (all of them in flight at once)
     float sv[kSpecMax];
@@ -236,6 +318,10 @@ __device__ __forceinline__ void conv0a_body(
       ol[k] = ov.on ? ov.lg[ovi[k] < 0 ? 0 : ovi[k]] : 0.f;
       oo[k] = ov.on ? ov.old[ovi[k] < 0 ? 0 : ovi[k]] : 0.f;
     }
+    // ... and behind them, before their values are back, the gather for the FIRST
+    // position of the list: it is the one chosen unless the step about to end
+    // has invalidated it, and then its round trip is the choice's own
+    issue_gather(sp.pos[0]);
 #pragma unroll
     for (int k = 0; k < kSpecMax; ++k)
       if (ovi[k] >= 0) sv[k] = post_disco(ol[k], oo[k], ov.disco != 0);
@@ -255,18 +341,11 @@ __device__ __forceinline__ void conv0a_body(
         pos[1] = sp.pos[k][1];
         pos[2] = sp.pos[k][2];
       }
+    if (ch != 0) issue_gather(pos);  // (every block and lane alike)
+  } else {
+    issue_gather(pos);
   }
-  const int pz = g.oa[0] == 0 ? pos[0] : g.oa[0] == 1 ? pos[1] : pos[2];
-  const int py = g.oa[1] == 0 ? pos[0] : g.oa[1] == 1 ? pos[1] : pos[2];
-  const int px = g.oa[2] == 0 ? pos[0] : g.oa[2] == 1 ? pos[1] : pos[2];
-  const int z0 = pz - g.fz / 2;
-  const int y0 = py - g.fy / 2;
-  const int x0 = px - g.fx / 2;
 
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = lane & 15;   // A row (position) / B column (cout) of this lane
-  const int grp = lane >> 4;  // k index inside a k-step
   // B fragments: k = 4 s + grp -> w[k][16 nhalf + i]; k >= 54 is zero padding
   float bw[2][14];
 #pragma unroll
@@ -277,67 +356,9 @@ __device__ __forceinline__ void conv0a_body(
       bw[h][s] = kk < 54 ? w[kk * kFeatures + 16 * h + i] : 0.0f;
   }
   const float bias0 = bias[i], bias1 = bias[16 + i];
-
-  // Gather: every canvas load of the block is issued before any is waited for
-  // (<= kC0Per elements per thread), and a uint8 canvas' normalisation table
-  // ((x - mean) / stddev of runner.py:383-385 as a 256-entry look-up) goes
-  // through LDS -- one global round trip for the whole gather instead of one
-  // per pass and another per look-up.
-  constexpr int kC0Per = (HZ * HY * HX + kC0Threads - 1) / kC0Threads;
-  const bool u8 = it.image == nullptr;
-  float lut_v = 0.0f;  // in flight with the canvas loads below
+  float lut_v = 0.0f;  // in flight with the canvas loads
   if (u8 && threadIdx.x < 256) lut_v = it.image_lut[threadIdx.x];
-  float g_img[kC0Per] = {}, g_seed[kC0Per];
-  unsigned g_raw[kC0Per] = {};
-  size_t g_ci[kC0Per];
-  int g_ov[kC0Per];  // index into the overlay (a voxel the running paste writes), or -1
-  long g_out[kC0Per];  // seed_raw index of an interior voxel, else -1
-  bool g_in[kC0Per];
-#pragma unroll
-  for (int k = 0; k < kC0Per; ++k) {
-    const int e = threadIdx.x + k * kC0Threads;
-    const int ec = e < HZ * HY * HX ? e : 0;
-    const int hx = ec % HX;
-    const int t = ec / HX;
-    const int hy = t % HY;
-    const int hz = t / HY;
-    const int zz = oz + hz - 1, yy = oy + hy - 1, xx = ox + hx - 1;
-    g_in[k] = e < HZ * HY * HX && zz >= 0 && zz < g.fz && yy >= 0 && yy < g.fy &&
-              xx >= 0 && xx < g.fx;
-    // (voxel 0 of the canvas stands in outside the FoV: loads without branches)
-    g_ci[k] = g_in[k] ? (size_t)((z0 + zz) * sz + (y0 + yy) * sy + (x0 + xx) * sx) : 0;
-    g_ov[k] = -1;
-    if (ov.on && g_in[k]) {
-      int cc[3];  // canvas coordinates: this geometry's axis a is canvas axis oa[a]
-      cc[g.oa[0]] = z0 + zz;
-      cc[g.oa[1]] = y0 + yy;
-      cc[g.oa[2]] = x0 + xx;
-      g_ov[k] = overlay_index(ov, cc[0], cc[1], cc[2]);
-    }
-    // interior voxel: keep the raw seed (NaN preserved), at its place in the
-    // caller's dense [z][y][x] order
-    g_out[k] = (g_in[k] && hz >= 1 && hz <= kC0Z && hy >= 1 && hy <= kC0Y &&
-                hx >= 1 && hx <= kC0X)
-                   ? (long)((size_t)item * g.V + (size_t)zz * g.dstr[0] +
-                            yy * g.dstr[1] + xx * g.dstr[2])
-                   : -1;
-  }
-  if (u8) {
-#pragma unroll
-    for (int k = 0; k < kC0Per; ++k) g_raw[k] = it.image_u8[g_ci[k]];
-  } else {
-#pragma unroll
-    for (int k = 0; k < kC0Per; ++k) g_img[k] = it.image[g_ci[k]];
-  }
-#pragma unroll
-  for (int k = 0; k < kC0Per; ++k) g_seed[k] = it.seed[g_ci[k]];
   if (ov.on) {
-    float o_l[kC0Per], o_o[kC0Per];
-#pragma unroll
-    for (int k = 0; k < kC0Per; ++k) {
-      o_l[k] = ov.lg[g_ov[k] < 0 ? 0 : g_ov[k]];
-      o_o[k] = ov.old[g_ov[k] < 0 ? 0 : g_ov[k]];
-    }
 #pragma unroll
     for (int k = 0; k < kC0Per; ++k)
       if (g_ov[k] >= 0) g_seed[k] = post_disco(o_l[k], o_o[k], ov.disco != 0);
