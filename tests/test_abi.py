@@ -66,3 +66,42 @@ def test_product_never_imports_the_oracle():
         elif isinstance(node, ast.ImportFrom):
           names = [node.module or '']
         assert not any(n.split('.')[0] == 'oracle' for n in names), (fn, names)
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+  """include/ffn_hip.h compiled as plain C: sizeof / offsetof of the structs the
+  Python side mirrors with ctypes (ffn_amd/_lib.py) are what ctypes lays out."""
+  import ctypes
+  import subprocess
+  from ffn_amd import _lib
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  structs = {
+      'ffn_turn_request': (_lib.TurnRequest, [
+          'do_commit', 'lo', 'hi', 'segment_threshold', 'min_segment_size',
+          'segment_id', 'max_existing_id', 'mark_mode', 'mark_pos',
+          'num_candidates', 'min_boundary_dist', 'do_init', 'init_value']),
+      'ffn_turn_result': (_lib.TurnResult, ['counts', 'committed', 'chosen']),
+      'ffn_commit_counts': (_lib.CommitCounts, [
+          'raw_segmented_voxels', 'actual_segmented_voxels', 'num_overlapped_ids']),
+      'ffn_segment_result': (_lib.SegmentResult, ['num_steps']),
+      'ffn_segment_params': (_lib.SegmentParams, ['step', 'score_threshold']),
+      'ffn_step_result': (_lib.StepResult, ['face_score', 'start_logit']),
+      'ffn_step_request': (_lib.StepRequest, ['pos', 'num_candidates']),
+  }
+  lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ffn_hip.h"',
+           'int main(void) {']
+  for name, (_, fields) in structs.items():
+    lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (name, name))
+    for f in fields:
+      lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
+  lines += ['  return 0;', '}']
+  src = tmp_path / 'layout.c'
+  src.write_text('\n'.join(lines))
+  exe = tmp_path / 'layout'
+  subprocess.check_call(['gcc', '-std=c11', '-I', os.path.join(root, 'include'),
+                         '-o', str(exe), str(src)])
+  out = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+  for name, (cls, fields) in structs.items():
+    assert int(out[name]) == ctypes.sizeof(cls), name
+    for f in fields:
+      assert int(out['%s.%s' % (name, f)]) == getattr(cls, f).offset, (name, f)
