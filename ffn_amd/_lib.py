@@ -36,7 +36,18 @@ class FFNRangeError(FFNHipError):
   exact-f32 kernel (conv_variant -1)."""
 
 
+class FFNFlowError(FFNHipError):
+  """FFN_ERR_FLOW: the resident conv launch (engine option flow = 2) timed out
+  waiting for one of its own workgroups (a shared or partitioned GPU); the step
+  changed nothing and is simply repeated -- the library runs the repeat as one
+  launch per conv (same arithmetic) and turns the resident launch off by itself
+  after three such steps in a row."""
+
+
 ERR_RANGE = -4
+ERR_FLOW = -5
+#: return codes of a step that changed nothing and is to be repeated
+ERR_VOIDED = (ERR_RANGE, ERR_FLOW)
 
 
 class StepParams(ctypes.Structure):
@@ -304,7 +315,8 @@ def load() -> ctypes.CDLL:
 def check(rc: int):
   if rc != 0:
     msg = load().ffn_last_error()
-    cls = FFNRangeError if rc == ERR_RANGE else FFNHipError
+    cls = (FFNRangeError if rc == ERR_RANGE else
+           FFNFlowError if rc == ERR_FLOW else FFNHipError)
     raise cls('libffn_hip error %d: %s' %
                       (rc, msg.decode('utf-8', 'replace') if msg else '?'))
 

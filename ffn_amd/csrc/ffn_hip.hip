@@ -151,6 +151,20 @@ struct ffn_engine {
   unsigned* flow_err = nullptr;    // polls that gave up, ever
   unsigned flow_epoch = 0;         // sequence number of the last conv queued
   int flow_debug = 0;              // debug option: ConvDArgs::flow_dbg
+  // The resident launch needs every one of its workgroups on the chip at once.
+  // flow_fits: the device can hold them (CU count x occupancy, checked at create);
+  // at run time a poll that gives up voids the step (FFN_ERR_FLOW): the repeat
+  // runs per-layer launches (flow_skip, one stack), and kFlowStrikes voided
+  // resident steps in a row turn the resident launch off for this engine
+  // (flow_auto_off; option "flow" turns it on again).
+  bool flow_fits = false;
+  unsigned flow_err_seen = 0;      // *flow_err as of the last voided step
+  int flow_strikes = 0;            // voided resident steps since the last good one
+  int flow_skip = 0;               // the next single-FoV stack runs per-layer launches
+  int flow_auto_off = 0;
+  long stat_flow_voids = 0;
+  bool last_stack_resident = false;  // what run_stack queued last
+  bool slot_resident[2] = {false, false};
   long long* flow_trace = nullptr; // debug_clock 4: ConvDArgs::flow_trace
   int flow_trace_slots = 0;
   int n_main = 0, n_tail = 0, n_tail3 = 0;  // tail workgroups of 32 / 96 voxels
@@ -297,6 +311,42 @@ struct EngineLock {
     if (e) lk = std::unique_lock<std::recursive_mutex>(e->mu);
   }
 };
+constexpr int kFlowStrikes = 3;
+
+// A step came back void.  Was it the resident launch giving up on a producer
+// (conv32ps: a poll reached its bound -- some workgroup was not on the chip, or
+// far too late) rather than the fp16 range check?  Then the caller gets
+// FFN_ERR_FLOW instead of FFN_ERR_RANGE: same contract (nothing was pasted,
+// repeat the step), but the arithmetic stays -- the repeat runs the same convs as
+// per-layer launches (same bits) -- and after kFlowStrikes such steps in a row
+// the engine stops using the resident launch.  0: not a flow time-out.
+int flow_voided(ffn_engine* e, bool resident) {
+  if (!resident || !e->flow_err) return 0;
+  unsigned v = 0;
+  if (hipMemcpy(&v, e->flow_err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  EngineLock lock_(e);
+  if (v == e->flow_err_seen) return 0;
+  e->flow_err_seen = v;
+  e->stat_flow_voids += 1;
+  e->flow_strikes += 1;
+  e->flow_skip = 1;
+  if (e->flow_strikes >= kFlowStrikes && e->flow == 2) {
+    e->flow = 0;
+    e->flow_auto_off = 1;
+    e->flow_skip = 0;
+    return fail(FFN_ERR_FLOW,
+                "the resident conv launch timed out waiting for one of its own "
+                "workgroups %d steps in a row (is the GPU shared or partitioned?): "
+                "the step changed nothing; this engine now runs one launch per conv "
+                "(option flow = 0; set flow = 2 to try again) -- repeat the step",
+                kFlowStrikes);
+  }
+  return fail(FFN_ERR_FLOW,
+              "the resident conv launch timed out waiting for one of its own "
+              "workgroups: the step changed nothing; repeat it (the repeat runs one "
+              "launch per conv, same arithmetic)");
+}
+
 // util_mu, then mu (the step path takes only mu: no lock-order inversion)
 struct UtilLock {
   std::unique_lock<std::mutex> ul;
@@ -890,6 +940,7 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   const float* W = e->weights;
   if (!conv0a_done) drop_spec(e);
   e->spec.valid = false;
+  e->last_stack_resident = false;
   e->range_tag = next_tag(e->range_tag);
   // this step's set of conv0_a outputs: what a launch made ahead for it wrote,
   // what its own conv0_a (below) writes
@@ -929,8 +980,14 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
       return fail(FFN_ERR_ARG, "conv_variant 6 needs depth >= 2 (fused head)");
     // T' -> (X, X') -> T' -> ... ; the head is always fused into the last conv_b
     auto chain = [&]() -> int {
-      if (e->t_now && n == 1 && e->flow == 2)
-        return launch_conv32ps(e, pad_value, move_thr);
+      if (e->t_now && n == 1 && e->flow == 2) {
+        if (e->flow_skip > 0) {
+          e->flow_skip -= 1;  // the repeat of a voided resident step
+        } else {
+          e->last_stack_resident = true;
+          return launch_conv32ps(e, pad_value, move_thr);
+        }
+      }
       int r = launch_conv32d<1, false>(e, n, e->rawT, e->rawS, 0);
       for (int i = 1; i < e->depth && !r; ++i) {
         r = launch_conv32d<0, false>(e, n, e->rawS, e->rawT, 2 * i - 1);
@@ -1059,7 +1116,7 @@ int grid_for(long total, int block = 256) {
 
 extern "C" {
 
-int ffn_abi_version(void) { return 9; }
+int ffn_abi_version(void) { return 10; }
 
 const char* ffn_last_error(void) { return g_error.c_str(); }
 
@@ -1343,8 +1400,23 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     // fits the LDS at all)
     e->exact_variant = c_ok ? 2 : 0;
     e->conv_variant = e->t_ok ? 9 : e->m_ok ? 8 : e->d_ok ? 6 : e->exact_variant;
-    // a single-FoV step of conv32mt runs its convs as ONE resident launch
-    e->flow = (e->t_ok && depth >= 2) ? 2 : 0;
+    // a single-FoV step of conv32mt runs its convs as ONE resident launch --
+    // where the device can hold all of its workgroups at once: they wait for
+    // each other, so one that is not on the chip stalls the rest until their
+    // polls give up (a partitioned device, fewer CUs than main chunks)
+    if (e->t_ok && depth >= 2) {
+      int cus = 0, per_cu = 0;
+      E_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id));
+      E_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv32ps_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kMLdsBytes));
+      E_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv32ps_kernel,
+                                                         kDThreads, kMLdsBytes));
+      ConvTailMap mp;
+      tail_map(e, 1, mp);
+      const int grid = 8 * (mp.mains_per_xcd + mp.tails_per_xcd);
+      e->flow_fits = cus >= e->n_main && (long)cus * per_cu >= grid;
+    }
+    e->flow = e->flow_fits ? 2 : 0;
   }
 
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)
@@ -1592,9 +1664,13 @@ int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
                            hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (e->conv_variant >= 6 && flag == e->range_tag) {
-    // an operand left the fp16 range: this engine stays on the exact-f32 kernel
-    rc = switch_variant(e, e->exact_variant);
-    if (rc) return rc;
+    // void: the resident launch gave up on a producer (the repeat runs per-layer
+    // launches: same bits), or an operand left the fp16 range (this engine then
+    // stays on the exact-f32 kernel)
+    if (flow_voided(e, e->last_stack_resident) == 0) {
+      rc = switch_variant(e, e->exact_variant);
+      if (rc) return rc;
+    }
     rc = run_stack(e, n, si, std::nanf(""), INFINITY);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h_logits, e->logits, bytes, hipMemcpyDeviceToHost,
@@ -1689,8 +1765,14 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     if (value && !e->t_ok)
       return fail(FFN_ERR_ARG, "flow needs conv32mt's geometry (conv_variant 9)");
     if (value && e->depth < 2) return fail(FFN_ERR_ARG, "flow needs depth >= 2");
+    if (value == 2 && !e->flow_fits)
+      return fail(FFN_ERR_ARG, "flow 2: this device cannot hold the resident launch's "
+                  "workgroups all at once (compute units x occupancy)");
     drop_spec(e);
     e->flow = value;
+    e->flow_auto_off = 0;
+    e->flow_strikes = 0;
+    e->flow_skip = 0;
     return FFN_OK;
   }
   if (std::strcmp(name, "spec_force_mismatch") == 0) {
@@ -1758,6 +1840,8 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "stat_many_carried") == 0)
     *value = (int)e->stat_many_carried;
   else if (std::strcmp(name, "flow") == 0) *value = e->flow;
+  else if (std::strcmp(name, "flow_auto_off") == 0) *value = e->flow_auto_off;
+  else if (std::strcmp(name, "stat_flow_voids") == 0) *value = (int)e->stat_flow_voids;
   else if (std::strcmp(name, "stat_flow_timeouts") == 0) {
     unsigned v = 0;
     HIP_TRY(hipSetDevice(e->device));
@@ -2232,6 +2316,7 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
   e->stat_items += n;
   e->stat_hist[n < 64 ? n : 64] += 1;
   e->slot_n[slot] = n;
+  e->slot_resident[slot] = e->last_stack_resident;
   e->slot_ticket[slot] = step_id;
   e->slot_canvas[slot].assign(canvases, canvases + n);
   e->next_slot = other;
@@ -2329,6 +2414,20 @@ int step_wait_impl(ffn_engine* e, uint32_t ticket, ffn_step_result* results,
                   "than the segment loop; the step changed nothing (speculate 0 "
                   "turns the launches off)", step_id);
     }
+  bool any_void = false;
+  for (int k = 0; k < n; ++k) any_void = any_void || results[k].range_error != 0;
+  if (any_void) {
+    bool resident;
+    {
+      EngineLock lock_(e);
+      resident = e->slot_resident[slot];
+    }
+    const int frc = flow_voided(e, resident);
+    if (frc) return frc;
+  } else {
+    EngineLock lock_(e);
+    if (e->slot_resident[slot]) e->flow_strikes = 0;
+  }
   for (int k = 0; k < n; ++k)
     if (results[k].range_error)
       return fail(FFN_ERR_RANGE,

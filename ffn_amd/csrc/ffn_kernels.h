@@ -1190,9 +1190,39 @@ __device__ __forceinline__ void stamp_workgroup(const ConvDArgs& a, const ConvLa
 // ---------------------------------------------------------------------------
 constexpr unsigned kFlowSpinMax = 1u << 15;
 constexpr int kFlowTraceLayers = 64;
-#ifndef FFN_FLOW_TRACE
-#define FFN_FLOW_TRACE 1
+// FFN_EXPERIMENTS (tools/build_variant.sh exp -DFFN_EXPERIMENTS=1): the arms the
+// rounds' A/B runs selected through engine option flow_debug (bits 1, 2, 4, 32,
+// 64, 1024, the sleep selector in bits 8-9) and the debug_clock 4 stamps of
+// tools/gpu_flow_trace.py.  The shipped build has none of them: flow_debug keeps
+// one bit, 2048 = fault injection (main chunk 3 stops publishing: what a
+// producer that is not resident looks like; tests/test_gpu_round5.py).
+#ifndef FFN_EXPERIMENTS
+#define FFN_EXPERIMENTS 0
 #endif
+constexpr bool kExp = FFN_EXPERIMENTS != 0;
+#ifndef FFN_FLOW_TRACE
+#define FFN_FLOW_TRACE FFN_EXPERIMENTS
+#endif
+constexpr int kFlowFaultBit = 2048;
+// FFN_ABLATE (tools/build_variant.sh NAME -DFFN_ABLATE=bits): timing-only builds
+// of the resident stack with pieces removed -- the results are WRONG; what each
+// piece costs is read off tools/gpu_flow_trace.py.  Bits: 1 publish without the
+// drain of the stores; 2 main bodies without the per-tap barriers; 4 without the
+// weight ring's DMAs inside the tap loop; 8 without the LDS fragment reads inside
+// it; 64 no dz = +1 DMA; 128 main bodies wait for nobody.  (Round 5's table:
+// profiles/r05_ablation_resident_stack.txt.)
+#ifndef FFN_ABLATE
+#define FFN_ABLATE 0
+#endif
+constexpr int kAbl = FFN_ABLATE;
+// the consumer's poll: 1 = one round asks for every producer's word and the
+// later rounds only for those still missing; 0 = round 4's form (poll the LAST
+// producer's word, then look at all of them once: one more memory round trip
+// between the last word's arrival and the first DMA)
+#ifndef FFN_POLL_MERGED
+#define FFN_POLL_MERGED 1
+#endif
+constexpr bool kPollMerged = FFN_POLL_MERGED != 0;
 
 // The words: one per PRODUCER (a main chunk of 128 voxels, then the tail tiles of
 // 32), 256 bytes apart -- polled words that share a line, or a memory channel,
@@ -1217,31 +1247,67 @@ __device__ __forceinline__ void flow_wait_tiles(const ConvDArgs& a, const ConvLa
   if (d_lo > a.V - 1 || d_hi < 0) return;
   int lo = flow_unit(a, d_lo < 0 ? 0 : d_lo);
   int hi = flow_unit(a, d_hi > a.V - 1 ? a.V - 1 : d_hi);
-  if (a.flow_dbg & 1) {
+  if (kExp && (a.flow_dbg & 1)) {
     lo = 0;
     hi = flow_unit(a, a.V - 1);
   }
   gu32* flags = (gu32*)a.flow_flags;
+  gu32* vflag = (gu32*)a.range_flag;
   unsigned spins = 0;
+  // A poll that gives up voids the step: the word the faces / paste launch looks
+  // at, written so that the other XCDs' polls see it (agent scope) ...
   auto give_up = [&]() {
     if (lane == 0) {
       atomicAdd(a.flow_err, 1u);
-      *a.range_flag = a.range_tag;
+      __hip_atomic_store(vflag, a.range_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
+  // ... and a step that is void already is not waited for again: every later
+  // poll of the launch that reaches its 256th round looks at that word and
+  // leaves (one time-out costs the launch ~25 ms, not one per conv and consumer)
+  auto void_already = [&]() {
+    return (spins & 255u) == 255u &&
+           __hip_atomic_load(vflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+               a.range_tag;
+  };
   auto nap = [&]() {
-    const int sl = (a.flow_dbg >> 8) & 3;
+    const int sl = kExp ? (a.flow_dbg >> 8) & 3 : 0;
     if (sl == 0) __builtin_amdgcn_s_sleep(8);
     else if (sl == 1) __builtin_amdgcn_s_sleep(2);
     else if (sl == 2) __builtin_amdgcn_s_sleep(16);
     else __builtin_amdgcn_s_sleep(32);
   };
-  if (!(a.flow_dbg & 64)) {
+  if constexpr (kPollMerged) {
+    // every lane its own producer's word; a lane whose word has arrived stops
+    // asking.  The first round costs one transaction per producer (~20), the
+    // later ones only ask for the stragglers (the last producers by index, one
+    // to three words) -- and no second look at everything stands between the
+    // last word's arrival and the barrier the other waves wait at.
+    for (int base = lo; base <= hi; base += 64) {
+      const int u = base + lane;
+      const int last = base + 63 <= hi ? base + 63 : hi;
+      bool pending = u <= hi;
+      for (;;) {
+        // (no divergent branch: a lane that is done asks for the block's last
+        // word along with that word's own lane -- the same transaction)
+        const unsigned x = __hip_atomic_load(flags + (long)(pending ? u : last) * kFlowStride,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = pending && (int)(x - L.flow_wait) < 0;
+        if (!__any(pending)) break;
+        if (++spins > kFlowSpinMax) return give_up();
+        if (void_already()) return;
+        nap();
+      }
+    }
+    return;
+  }
+  if (!(kExp && (a.flow_dbg & 64))) {
     for (;;) {  // the last producer's word, every lane the same address
       const unsigned x = __hip_atomic_load(flags + (long)hi * kFlowStride, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
       if ((int)(x - L.flow_wait) >= 0) break;
       if (++spins > kFlowSpinMax) return give_up();
+      if (void_already()) return;
       nap();
     }
   }
@@ -1252,6 +1318,7 @@ __device__ __forceinline__ void flow_wait_tiles(const ConvDArgs& a, const ConvLa
                                            __HIP_MEMORY_SCOPE_AGENT);
       if (__all((int)(x - L.flow_wait) >= 0)) break;
       if (++spins > kFlowSpinMax) return give_up();
+      if (void_already()) return;
       nap();
     }
   }
@@ -1262,13 +1329,17 @@ __device__ __forceinline__ void flow_wait_tiles(const ConvDArgs& a, const ConvLa
 __device__ __forceinline__ long long flow_publish(const ConvDArgs& a, const ConvLayer& L,
                                                   int v0, int tid) {
   typedef FFN_GLOBAL unsigned gu32;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (a.flow_dbg & 4) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (!(kAbl & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (kExp && (a.flow_dbg & 4))
+    asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
   const long long t_drained = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (tid == 0)
-    __hip_atomic_store((gu32*)a.flow_flags + (long)flow_unit(a, v0) * kFlowStride,
+  const int unit = flow_unit(a, v0);
+  // (fault injection, flow_debug 2048: producer 3 stays silent after the first conv)
+  const bool silent = (a.flow_dbg & kFlowFaultBit) && unit == 3 && L.layer >= 1;
+  if (tid == 0 && !silent)
+    __hip_atomic_store((gu32*)a.flow_flags + (long)unit * kFlowStride,
                        L.flow_set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return t_drained;
 }
@@ -1474,7 +1545,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const ConvLayer
       ft[1] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (a.flow_dbg & 2) asm volatile("buffer_inv sc1" ::: "memory");
+      if (kExp && (a.flow_dbg & 2)) asm volatile("buffer_inv sc1" ::: "memory");
     }
 #pragma unroll
     for (int seg = 0; seg < 3; ++seg)
@@ -1790,7 +1861,7 @@ __device__ __forceinline__ void conv32d_body(const ConvDArgs& a, const ConvLayer
     }
     // an operand of the next layer left the fp16 range: the step is void, the
     // host re-runs it with the exact-f32 kernel (ffn_step_result.range_error)
-    if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
+    if (!(FLOW && kAbl) && __ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *a.range_flag = a.range_tag;
     if constexpr (FLOW) ft[4] = flow_publish(a, L, v0, tid);
   }
@@ -1980,17 +2051,18 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
   };
   if constexpr (FLOW) {
     // W0 .. W3 are on their way; the rows only once their tiles are published
-    if (L.flow_wait_on) {
+    if (L.flow_wait_on && !(kAbl & 128)) {
       // the rows of dz = -1 and dz = 0; those of dz = +1 are not needed before
       // tap 9 queues their DMA: their words are fetched during tap 1 (below)
       if (wave == 0)
         flow_wait_tiles(a, L, v0 - a.flow_halo,
-                        (a.flow_dbg & 32) ? v0 + kMChunk - 1 + a.flow_halo
-                                          : v0 + kMChunk - 1 + a.fx + 1, lane);
+                        (kExp && (a.flow_dbg & 32)) ? v0 + kMChunk - 1 + a.flow_halo
+                                                    : v0 + kMChunk - 1 + a.fx + 1,
+                        lane);
       ft[1] = (FFN_FLOW_TRACE && a.flow_trace) ? wall_clock64() : 0;
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (a.flow_dbg & 2) asm volatile("buffer_inv sc1" ::: "memory");
+      if (kExp && (a.flow_dbg & 2)) asm volatile("buffer_inv sc1" ::: "memory");
     }
   }
   dma_seg(0);
@@ -2071,7 +2143,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
   unsigned late_word = 0;
   const int late_d_lo = v0 + a.fyfx - a.fx - 1;
   const bool late_on =
-      FLOW && L.flow_wait_on && !(a.flow_dbg & 32) && late_d_lo <= a.V - 1;
+      FLOW && L.flow_wait_on && !(kExp && (a.flow_dbg & 32)) && late_d_lo <= a.V - 1;
   auto flow_late_load = [&]() {
     if constexpr (FLOW) {
       const int lo = flow_unit(
@@ -2100,9 +2172,11 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
   };
 #define FFN_MGAP(S, PART, WNEXT, XNEXT)                                         \
   __builtin_amdgcn_sched_barrier(0);                                            \
-  if ((PART) < 2 && (S) + 1 <= 26) load_w((S) + 1, PART, WNEXT);                \
-  if ((PART) >= 2 && (S) + 2 <= 26) load_x((S) + 2, (PART) - 2, XNEXT);         \
-  if ((S) == 9) dma_seg_part(2 * (PART), 2 * (PART) + 2);                       \
+  if (!(FLOW && (kAbl & 8)) && (PART) < 2 && (S) + 1 <= 26)                     \
+    load_w((S) + 1, PART, WNEXT);                                               \
+  if (!(FLOW && (kAbl & 8)) && (PART) >= 2 && (S) + 2 <= 26)                    \
+    load_x((S) + 2, (PART) - 2, XNEXT);                                         \
+  if (!(FLOW && (kAbl & 64)) && (S) == 9) dma_seg_part(2 * (PART), 2 * (PART) + 2); \
   __builtin_amdgcn_sched_barrier(0);
   // tap S: XCUR / WCUR hold its fragments; WNEXT takes tap S + 1's weights,
   // XNEXT tap S + 2's activations
@@ -2111,14 +2185,14 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
     if ((S) > 0) {                                                              \
       if constexpr (m_wait(S, D, NEPI, FLOW) >= 0)                              \
         wait_vmcnt<m_wait(S, D, NEPI, FLOW)>();                                 \
-      if (FLOW && (S) == 9) flow_late_check();                                  \
-      __builtin_amdgcn_s_barrier();                                             \
+      if (FLOW && !(kAbl & 128) && (S) == 9) flow_late_check();                 \
+      if (!(FLOW && (kAbl & 2))) __builtin_amdgcn_s_barrier();                  \
       asm volatile("" ::: "memory");                                            \
     }                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                          \
     accC = mma(WCUR.w[0][0], XCUR.x[0][1], accC);                               \
     __builtin_amdgcn_sched_barrier(0);                                          \
-    if ((S) > 0 && (S) + D - 1 <= 26) dma_w((S) + D - 1);                       \
+    if (!(FLOW && (kAbl & 4)) && (S) > 0 && (S) + D - 1 <= 26) dma_w((S) + D - 1); \
     if (FLOW && (S) == 1) flow_late_load();                                     \
     __builtin_amdgcn_sched_barrier(0);                                          \
     acc = mma(WCUR.w[0][0], XCUR.x[0][0], acc);                                 \
@@ -2295,7 +2369,7 @@ __device__ __forceinline__ void conv32m_body(const ConvDArgs& a, const ConvLayer
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, r4), rs_sp, so,
                                             (int)(4 * a.sp_plane_bytes), 16);
     }
-    if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
+    if (!(FLOW && kAbl) && __ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *a.range_flag = a.range_tag;
     if constexpr (FLOW) ft[4] = flow_publish(a, L, v0, tid);
   }
@@ -2458,7 +2532,7 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
   // (experiment, flow_dbg 1024: the main workgroups' waves ahead of the tail's in
   // the CU's arbitration -- a main workgroup that shares its CU with a tail one
   // is what its neighbours wait for)
-  if (a.flow_dbg & 1024) {
+  if (kExp && (a.flow_dbg & 1024)) {
     if (main_wg) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
   }

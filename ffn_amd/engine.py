@@ -60,6 +60,9 @@ def segment_many_with_retry(once, n, sarr, parr, rarr, before, fallback):
   the fp16 range check (FFN_ERR_RANGE), shared by HipEngine and the CPU shim of
   the tests.  once(keys, starts, params, resumes, results, finished) -> rc makes
   the call for the canvases `keys` (indices into the caller's list);
+  fallback(rc) is told which kind of void it was (FFN_ERR_RANGE: switch to the
+  exact-f32 kernel; FFN_ERR_FLOW: nothing to switch, the library already runs
+  the repeat without the resident launch);
   before[k] = steps canvas k's segment had made before this call (results count
   from the start of the segment, budgets are per call).
 
@@ -72,9 +75,9 @@ def segment_many_with_retry(once, n, sarr, parr, rarr, before, fallback):
   res = (_lib.SegmentResult * n)()
   fin = (ctypes.c_int32 * n)()
   rc = once(list(range(n)), sarr, parr, rarr, res, fin)
-  if rc != _lib.ERR_RANGE:
+  if rc not in _lib.ERR_VOIDED:
     return rc, res, fin
-  fallback()
+  fallback(rc)
   live = [k for k in range(n) if not fin[k]]
   if not live:
     return 0, res, fin
@@ -130,6 +133,8 @@ class HipEngine:
     self._step_lock = threading.RLock()
     #: steps repeated because a split-product kernel met a value outside the fp16 range
     self.range_fallbacks = 0
+    #: steps repeated because the resident conv launch timed out (FFN_ERR_FLOW)
+    self.flow_fallbacks = 0
     #: True once a caller has chosen the conv kernel (pin_batched_arithmetic
     #: then keeps its hands off)
     self.variant_is_explicit = False
@@ -296,12 +301,23 @@ class HipEngine:
     exponent range, and the engine stays on it."""
     rc = self._lib.ffn_canvas_step(self._h, n, self._canvas_arr, req,
                                    ctypes.byref(params), self._res_arr)
-    if rc == _lib.ERR_RANGE:
-      self.range_fallbacks += 1
-      self.set_option('conv_variant', -1, explicit=False)
+    if rc in _lib.ERR_VOIDED:
+      self.voided(rc)
       rc = self._lib.ffn_canvas_step(self._h, n, self._canvas_arr, req,
                                      ctypes.byref(params), self._res_arr)
     check(rc)
+
+  def voided(self, rc):
+    """Bookkeeping of a step that came back void (it changed nothing and is
+    repeated by the caller).  FFN_ERR_RANGE: the engine moves to its exact-f32
+    kernel and stays there.  FFN_ERR_FLOW: the resident launch timed out; the
+    arithmetic stays, the library repeats with per-layer launches and disables
+    the resident launch itself if that keeps happening."""
+    if rc == _lib.ERR_FLOW:
+      self.flow_fallbacks += 1
+    else:
+      self.range_fallbacks += 1
+      self.set_option('conv_variant', -1, explicit=False)
 
   #: `segment_many(..., carry=True)`: ffn_canvas_segment_many_carry
   can_carry = True
@@ -330,9 +346,7 @@ class HipEngine:
       return self._lib.ffn_canvas_segment_many_carry(
           self._h, len(keys), ca, sa, pa, ra, res, fin, 1 if carry else 0)
 
-    def fallback():
-      self.range_fallbacks += 1
-      self.set_option('conv_variant', -1, explicit=False)
+    fallback = self.voided
 
     before = [c._many_steps if rarr[k] else 0 for k, c in enumerate(canvases)]
     rc, res, fin = segment_many_with_retry(once, n, sarr, parr, rarr, before,
@@ -367,12 +381,12 @@ class HipEngine:
     slot, n, params = self._ticket_slot.pop(ticket)
     res = self._slot_res_arr[slot]
     rc = self._lib.ffn_canvas_step_wait(self._h, ticket, res)
-    if rc == _lib.ERR_RANGE:
-      # voided by the fp16 range check: nothing was pasted.  Repeat this batch
-      # with the exact-f32 kernel (its descriptor arrays are still intact); a step
-      # of the other group that is already queued finishes first.
-      self.range_fallbacks += 1
-      self.set_option('conv_variant', -1, explicit=False)
+    if rc in _lib.ERR_VOIDED:
+      # voided (fp16 range check, or the resident launch timed out): nothing was
+      # pasted.  Repeat this batch (its descriptor arrays are still intact) with
+      # the exact-f32 kernel / without the resident launch; a step of the other
+      # group that is already queued finishes first.
+      self.voided(rc)
       again = ctypes.c_uint32(0)
       check(self._lib.ffn_canvas_step_submit(
           self._h, n, self._slot_canvas_arr[slot], self._slot_req_arr[slot],
@@ -452,11 +466,10 @@ class DeviceCanvasHandle:
     rc = self._lib.ffn_canvas_segment_at(self._h, i3(start_pos),
                                          ctypes.byref(params), int(resume),
                                          ctypes.byref(res))
-    if rc == _lib.ERR_RANGE:
+    if rc in _lib.ERR_VOIDED:
       # the voided step changed nothing on the device; the loop keeps the
       # position pending, so resuming repeats exactly that step
-      self.engine.range_fallbacks += 1
-      self.engine.set_option('conv_variant', -1, explicit=False)
+      self.engine.voided(rc)
       first = _lib.SegmentResult.from_buffer_copy(res)
       budget = params.max_steps
       if budget > 0:

@@ -32,6 +32,13 @@ extern "C" {
                                 range; the step changed nothing -- switch to
                                 conv_variant -1 (exact f32) and repeat it       */
 
+#define FFN_ERR_FLOW (-5)    /* option flow = 2 only: the resident conv launch
+                                timed out waiting for one of its own workgroups
+                                (a shared or partitioned GPU); the step changed
+                                nothing -- repeat it: the repeat runs one launch
+                                per conv (same arithmetic), and after 3 such steps
+                                in a row the engine sets flow = 0 by itself      */
+
 #define FFN_MAX_CANDIDATES 16
 
 typedef struct ffn_engine ffn_engine;

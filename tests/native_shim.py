@@ -71,7 +71,8 @@ class ShimHandle(EmulatedHandle):
 
   shim = None
   client = None
-  fail_step = None  # step number at which the device reports FFN_ERR_RANGE once
+  fail_step = None  # step number at which the device reports a voided step once
+  fail_code = _lib.ERR_RANGE  # ... as FFN_ERR_RANGE, or FFN_ERR_FLOW
   total_native_calls = 0  # over all handles
   # the speculative conv0_a launch of the HIP device (ffn_hip.hip SpecArgs),
   # emulated: [hints taken, steps made at a hinted position]; every such step
@@ -98,7 +99,7 @@ class ShimHandle(EmulatedHandle):
     def step_cb(req, par, res):
       if self.fail_step is not None and len(self.steps_seen) == self.fail_step:
         self.fail_step = None
-        return _lib.ERR_RANGE
+        return self.fail_code
       pos = tuple(req.contents.pos)
       if spec and pos in spec['list']:
         assert spec['list'].index(pos) == spec['choice'], (pos, spec)
@@ -133,7 +134,7 @@ class ShimHandle(EmulatedHandle):
                                    _READ_CB(read_cb), start,
                                    ctypes.byref(params), int(resume),
                                    ctypes.byref(res))
-    if rc == _lib.ERR_RANGE:  # what DeviceCanvasHandle.segment_at does
+    if rc in _lib.ERR_VOIDED:  # what DeviceCanvasHandle.segment_at does
       first = _lib.SegmentResult.from_buffer_copy(res)
       rc = self.shim.shim_segment_at(self._state, _STEP_CB(step_cb),
                                      _READ_CB(read_cb), start,
@@ -171,7 +172,9 @@ class ShimEngine:
     self.max_batch = max_batch
     self.many_calls = 0
     self.batch_sizes = []
-    self.fail_round = None  # batched round at which the device reports ERR_RANGE once
+    self.fail_round = None  # batched round at which the device reports a voided step once
+    self.fail_code = _lib.ERR_RANGE
+    self.flow_fallbacks = 0
     # 'short': void (once) the first round in which a loop of the call has just
     # ended -- the round carries fewer steps than the call has canvases
     self.rounds = 0
@@ -193,7 +196,7 @@ class ShimEngine:
       if self.fail_round is not None and (
           nb < n if self.fail_round == 'short' else self.rounds == self.fail_round):
         self.fail_round = None
-        return _lib.ERR_RANGE
+        return self.fail_code
       self.rounds += 1
       self.batch_sizes.append(nb)
       for b in range(nb):
@@ -238,8 +241,11 @@ class ShimEngine:
       return self._segment_many_once([handles[k] for k in keys], sa, pa, ra, res,
                                      fin, carry)
 
-    def fallback():
-      self.range_fallbacks += 1
+    def fallback(rc):
+      if rc == _lib.ERR_FLOW:
+        self.flow_fallbacks += 1
+      else:
+        self.range_fallbacks += 1
 
     before = [getattr(h, '_many_steps', 0) if rarr[k] else 0
               for k, h in enumerate(handles)]

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_weight_count():
   lib = _lib.load()
-  assert lib.ffn_abi_version() == 9
+  assert lib.ffn_abi_version() == 10
   assert lib.ffn_engine_weight_count(12, 32) == 638433
   assert lib.ffn_engine_weight_count(18, 32) == 27 * 2 * 32 + 32 + 35 * (
       27 * 32 * 32 + 32) + 33

@@ -1,0 +1,119 @@
+"""GPU tests added in round 5: the resident conv launch (engine option flow = 2)
+when one of its workgroups never shows up, and the InferenceOptions the sample
+configuration does not use.  All through the C-ABI.
+"""
+
+import functools
+import os
+import time
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+from tests.test_gpu_round2 import (_assert_shipped_default, _device_canvas, hip_exe,  # noqa: F401
+                                   seed_lib_fixed)
+
+pytestmark = pytest.mark.gpu
+
+FAULT = 2048  # flow_debug: main chunk 3 stops publishing after the first conv
+
+
+def test_resident_launch_times_out_repeats_and_turns_itself_off():
+  """A producer that never publishes is what a workgroup that is not on the chip
+  looks like to the others (a shared or partitioned GPU).  Contract
+  (include/ffn_hip.h, FFN_ERR_FLOW; the fail-fast rule of
+  ffn/inference/executor.py:187-200 applied to a recoverable condition): the
+  polls give up, the step is void and is repeated with per-layer launches -- the
+  SAME arithmetic, not the exact-f32 kernel -- and after three such steps in a row
+  the engine stops using the resident launch and says so."""
+  from ffn_amd import engine as hip_engine
+  from ffn_amd.training.models import convstack_3d
+  from oracle import ffn_oracle
+  depth = 3
+  m = convstack_3d.ConvStack3DFFNModel(fov_size=[33, 33, 33], deltas=[8, 8, 8],
+                                       depth=depth)
+  variables = ffn_oracle.random_weights(depth, seed=5, stddev=0.05)
+  m.set_variables(variables)
+  eng = hip_engine.HipEngine.from_model(m, max_batch=1)
+  assert eng.get_option('flow') == 2 and eng.get_option('conv_variant') == 9
+  rng = np.random.RandomState(11)
+  img = rng.normal(0, 1, [1, 33, 33, 33]).astype(np.float32)
+  seed = rng.normal(0, 1.5, [1, 33, 33, 33]).astype(np.float32)
+  good = eng.predict(seed, img)
+  want = ffn_oracle.forward(img[0], seed[0], ffn_oracle.weights_blob(variables, depth),
+                            depth)
+  assert np.abs(good[0] - want).max() <= 1e-4
+  assert eng.get_option('stat_flow_timeouts') == 0
+
+  eng.set_option('flow_debug', FAULT)
+  for k in range(1, 4):
+    t0 = time.perf_counter()
+    got = eng.predict(seed, img)
+    dt = time.perf_counter() - t0
+    # the repeat ran one launch per conv: bit for bit what the resident launch gives
+    assert np.array_equal(got, good), k
+    assert eng.get_option('stat_flow_voids') == k
+    assert eng.get_option('stat_flow_timeouts') >= k
+    assert eng.get_option('conv_variant') == 9  # NOT the exact-f32 kernel
+    # one time-out per launch, not one per conv and consumer (2^15 polls ~ 25 ms)
+    assert dt < 0.5, dt
+    assert eng.get_option('flow') == (2 if k < 3 else 0)
+  assert eng.get_option('flow_auto_off') == 1
+  voids = eng.get_option('stat_flow_voids')
+  t0 = time.perf_counter()
+  for _ in range(100):
+    got = eng.predict(seed, img)
+  per_call = (time.perf_counter() - t0) / 100
+  assert np.array_equal(got, good)
+  assert eng.get_option('stat_flow_voids') == voids  # no resident launch any more
+  assert per_call < 5e-3, per_call                    # ... and no time-out either
+  # asking for it again is honoured (and, the fault still on, fails again)
+  eng.set_option('flow', 2)
+  assert eng.get_option('flow_auto_off') == 0
+  assert np.array_equal(eng.predict(seed, img), good)
+  assert eng.get_option('stat_flow_voids') == voids + 1
+  eng.set_option('flow_debug', 0)
+  assert np.array_equal(eng.predict(seed, img), good)
+  assert eng.get_option('stat_flow_voids') == voids + 1
+  eng.close()
+
+
+def test_segment_loop_survives_resident_timeouts(hip_exe, fib25_model):  # noqa: F811
+  """The same through the library's segment loop (ffn_canvas_segment_at, what
+  bench.py and Runner.run drive): FFN_ERR_FLOW leaves the position pending, the
+  caller resumes, and the run is the run of a healthy engine -- same steps, same
+  seed logits bit for bit, same segmentation."""
+  from ffn_amd import synthetic
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
+  image = synthetic.normalize(g['volume'])
+  eng = hip_exe.engine
+  _assert_shipped_default(eng)
+  policy = functools.partial(seed_lib_fixed(), coords=g['seeds'])
+  healthy = _device_canvas(hip_exe, fib25_model, image)
+  assert healthy._native_loop_ok()
+  healthy.segment_all(seed_policy=policy)
+  assert eng.flow_fallbacks == 0 and eng.range_fallbacks == 0
+  try:
+    eng.set_option('flow_debug', FAULT)
+    faulty = _device_canvas(hip_exe, fib25_model, image)
+    t0 = time.perf_counter()
+    faulty.segment_all(seed_policy=policy)
+    dt = time.perf_counter() - t0
+    assert eng.flow_fallbacks == 3 and eng.range_fallbacks == 0
+    assert eng.get_option('flow') == 0 and eng.get_option('flow_auto_off') == 1
+    assert eng.get_option('conv_variant') == 9
+    steps = faulty.counters['update_at-calls'].value
+    assert steps == healthy.counters['update_at-calls'].value > 50
+    # three time-outs of ~25 ms, then the per-layer rate
+    assert dt < 0.5 + steps * 2e-3, (dt, steps)
+    assert np.array_equal(np.asarray(faulty.segmentation), np.asarray(healthy.segmentation))
+    assert np.array_equal(np.asarray(faulty.seed), np.asarray(healthy.seed), equal_nan=True)
+    assert np.array_equal(np.asarray(faulty.segmentation), g['segmentation'])
+    faulty.close()
+  finally:
+    eng.set_option('flow_debug', 0)
+    eng.set_option('flow', 2)
+    eng.flow_fallbacks = 0
+  healthy.close()
+  _assert_shipped_default(eng)

@@ -133,9 +133,11 @@ def test_native_and_python_loops_leave_the_same_canvas_state(shim, fib25_blob):
   assert np.array_equal(a['seed'], b['seed'], equal_nan=True)
 
 
-def test_budgeted_calls_resume_to_the_same_result(shim, fib25_blob):
+@pytest.mark.parametrize('fail_code', [_lib.ERR_RANGE, _lib.ERR_FLOW])
+def test_budgeted_calls_resume_to_the_same_result(shim, fib25_blob, fail_code):
   """max_steps + resume (what bench.py uses to time exactly K steps), and a
-  voided step (FFN_ERR_RANGE) repeated on resume."""
+  voided step (FFN_ERR_RANGE: fp16 range; FFN_ERR_FLOW: the resident launch timed
+  out) repeated on resume."""
   g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))
   image = synthetic.normalize(g['volume'])
   seed0 = (16, 16, 32)  # 13 FoV steps in the reference run
@@ -145,6 +147,7 @@ def test_budgeted_calls_resume_to_the_same_result(shim, fib25_blob):
 
   part = _canvas(shim, fib25_blob, image, True, keep_history=True)
   ShimHandle.fail_step = 4
+  ShimHandle.fail_code = fail_code
   try:
     got = part._segment_at_native(seed0, max_steps=3)
     assert got == 3 and part._native_active
@@ -152,6 +155,7 @@ def test_budgeted_calls_resume_to_the_same_result(shim, fib25_blob):
       got += part._segment_at_native(seed0, max_steps=3, resume=True)
   finally:
     ShimHandle.fail_step = None
+    ShimHandle.fail_code = _lib.ERR_RANGE
   assert got == n_full
   assert part._handle.steps_seen == full._handle.steps_seen
   assert part.history == full.history
@@ -356,9 +360,11 @@ def _many_canvases(shim, blob, names, **kwargs):
   return client, native_shim.ShimEngine(client, 4), canvases, gold
 
 
-@pytest.mark.parametrize('fail_round,carry', [(None, True), (37, True),
-                                              ('short', False), ('short', 'deferred')])
-def test_segment_many_reproduces_reference_runs(shim, fib25_blob, fail_round, carry):
+@pytest.mark.parametrize('fail_round,carry,fail_code', [
+    (None, True, _lib.ERR_RANGE), (37, True, _lib.ERR_RANGE), (37, True, _lib.ERR_FLOW),
+    ('short', False, _lib.ERR_RANGE), ('short', 'deferred', _lib.ERR_FLOW)])
+def test_segment_many_reproduces_reference_runs(shim, fib25_blob, fail_round, carry,
+                                                fail_code):
   """ffn_host::segment_many (ffn_canvas_segment_many's loop) under the
   MultiCanvasDriver: five canvases, at most four per engine call, whole segments
   inside the C++ loop, Python only between segments.  Every canvas repeats the
@@ -373,6 +379,7 @@ def test_segment_many_reproduces_reference_runs(shim, fib25_blob, fail_round, ca
   names = ['cells72', 'cells56', 'cells72', 'cells56', 'cells56']
   client, engine, canvases, gold = _many_canvases(shim, fib25_blob, names)
   engine.fail_round = fail_round
+  engine.fail_code = fail_code
   engine.defer_error = carry == 'deferred'
   drv = inference.MultiCanvasDriver(engine, batch_size=4, native=True,
                                     carry=bool(carry))
@@ -396,7 +403,9 @@ def test_segment_many_reproduces_reference_runs(shim, fib25_blob, fail_round, ca
   # the steps really shared engine rounds, and Python was entered per SEGMENT
   assert max(engine.batch_sizes) == 4 and engine.rounds < total
   assert engine.many_calls < total / 3
-  assert engine.range_fallbacks == (0 if fail_round is None else 1)
+  voided = 0 if fail_round is None else 1
+  assert engine.range_fallbacks == (voided if fail_code == _lib.ERR_RANGE else 0)
+  assert engine.flow_fallbacks == (voided if fail_code == _lib.ERR_FLOW else 0)
   # steps were left in flight across returns, and none is left at the end
   assert (engine.carried > 0) == bool(carry)
   assert not shim.shim_carry_active()

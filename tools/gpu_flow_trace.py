@@ -43,6 +43,13 @@ def main():
   while time.perf_counter() < t_end:  # clocks up
     eng.forward_resident(1, 20)
     eng.synchronize()
+  eng.synchronize()
+  t0 = time.perf_counter()
+  eng.forward_resident(1, 400)
+  eng.synchronize()
+  print('library %s: %.2f us per stack (conv0_a + the resident launch, 400 back to back)'
+        % (os.path.basename(os.environ.get('FFN_AMD_LIB', 'libffn_hip.so')),
+           (time.perf_counter() - t0) / 400 * 1e6))
   eng.set_option('debug_clock', 4)
   eng.forward_resident(1, 1)
   eng.synchronize()
