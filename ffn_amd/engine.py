@@ -55,6 +55,12 @@ def pin_batched_arithmetic(engine):
     engine.set_option('conv_variant', 8, explicit=False)
 
 
+#: how often one step may come back void before the error is raised: the fp16
+#: range check voids at most once per engine (it then stays on the exact kernel),
+#: the resident launch three times in a row (the library then turns it off)
+MAX_VOID_REPEATS = 5
+
+
 def segment_many_with_retry(once, n, sarr, parr, rarr, before, fallback):
   """One `ffn_canvas_segment_many` call plus the handling of a round voided by
   the fp16 range check (FFN_ERR_RANGE), shared by HipEngine and the CPU shim of
@@ -74,30 +80,33 @@ def segment_many_with_retry(once, n, sarr, parr, rarr, before, fallback):
   their budgets."""
   res = (_lib.SegmentResult * n)()
   fin = (ctypes.c_int32 * n)()
-  rc = once(list(range(n)), sarr, parr, rarr, res, fin)
-  if rc not in _lib.ERR_VOIDED:
-    return rc, res, fin
-  fallback(rc)
-  live = [k for k in range(n) if not fin[k]]
-  if not live:
-    return 0, res, fin
-  m = len(live)
-  sarr2 = (ctypes.c_int32 * 3 * m)()
-  parr2 = (_lib.SegmentParams * m)()
-  rarr2 = (ctypes.c_int32 * m)(*([1] * m))
-  res2 = (_lib.SegmentResult * m)()
-  fin2 = (ctypes.c_int32 * m)()
-  for j, k in enumerate(live):
-    for a in range(3):
-      sarr2[j][a] = sarr[k][a]
-    ctypes.pointer(parr2[j])[0] = parr[k]
-    if parr[k].max_steps > 0:
-      spent = int(res[k].num_steps) - before[k]
-      parr2[j].max_steps = max(parr[k].max_steps - spent, 1)
-  rc = once(live, sarr2, parr2, rarr2, res2, fin2)
-  for j, k in enumerate(live):
-    ctypes.pointer(res[k])[0] = res2[j]
-    fin[k] = fin2[j]
+  keys = list(range(n))
+  sa, pa, ra, cur_res, cur_fin = sarr, parr, rarr, res, fin
+  for attempt in range(MAX_VOID_REPEATS + 1):
+    rc = once(keys, sa, pa, ra, cur_res, cur_fin)
+    if cur_res is not res:
+      for j, k in enumerate(keys):
+        ctypes.pointer(res[k])[0] = cur_res[j]
+        fin[k] = cur_fin[j]
+    if rc not in _lib.ERR_VOIDED or attempt == MAX_VOID_REPEATS:
+      return rc, res, fin
+    fallback(rc)
+    keys = [k for k in keys if not fin[k]]
+    if not keys:
+      return 0, res, fin
+    m = len(keys)
+    sa = (ctypes.c_int32 * 3 * m)()
+    pa = (_lib.SegmentParams * m)()
+    ra = (ctypes.c_int32 * m)(*([1] * m))
+    cur_res = (_lib.SegmentResult * m)()
+    cur_fin = (ctypes.c_int32 * m)()
+    for j, k in enumerate(keys):
+      for a in range(3):
+        sa[j][a] = sarr[k][a]
+      ctypes.pointer(pa[j])[0] = parr[k]
+      if parr[k].max_steps > 0:
+        spent = int(res[k].num_steps) - before[k]
+        pa[j].max_steps = max(parr[k].max_steps - spent, 1)
   return rc, res, fin
 
 
@@ -301,7 +310,9 @@ class HipEngine:
     exponent range, and the engine stays on it."""
     rc = self._lib.ffn_canvas_step(self._h, n, self._canvas_arr, req,
                                    ctypes.byref(params), self._res_arr)
-    if rc in _lib.ERR_VOIDED:
+    for _ in range(MAX_VOID_REPEATS):
+      if rc not in _lib.ERR_VOIDED:
+        break
       self.voided(rc)
       rc = self._lib.ffn_canvas_step(self._h, n, self._canvas_arr, req,
                                      ctypes.byref(params), self._res_arr)
@@ -381,7 +392,9 @@ class HipEngine:
     slot, n, params = self._ticket_slot.pop(ticket)
     res = self._slot_res_arr[slot]
     rc = self._lib.ffn_canvas_step_wait(self._h, ticket, res)
-    if rc in _lib.ERR_VOIDED:
+    for _ in range(MAX_VOID_REPEATS):
+      if rc not in _lib.ERR_VOIDED:
+        break
       # voided (fp16 range check, or the resident launch timed out): nothing was
       # pasted.  Repeat this batch (its descriptor arrays are still intact) with
       # the exact-f32 kernel / without the resident launch; a step of the other
@@ -460,27 +473,31 @@ class DeviceCanvasHandle:
   def segment_at(self, start_pos, params: '_lib.SegmentParams',
                  resume: bool = False) -> '_lib.SegmentResult':
     """ffn_canvas_segment_at: the whole FoV loop of a segment inside the
-    library.  A step voided by the fp16 range check is repeated with the
-    exact-f32 kernel (as `HipEngine._blocking_step` does) and the loop resumed."""
+    library.  A voided step (`HipEngine.voided`: fp16 range check, resident
+    launch timed out) is repeated and the loop resumed."""
     res = _lib.SegmentResult()
     rc = self._lib.ffn_canvas_segment_at(self._h, i3(start_pos),
                                          ctypes.byref(params), int(resume),
                                          ctypes.byref(res))
-    if rc in _lib.ERR_VOIDED:
+    budget = params.max_steps
+    summed = ('num_steps', 'skip_threshold', 'skip_invalid_pos', 'gate_rejects')
+    before = dict.fromkeys(summed, 0)
+    for _ in range(MAX_VOID_REPEATS):
+      if rc not in _lib.ERR_VOIDED:
+        break
       # the voided step changed nothing on the device; the loop keeps the
       # position pending, so resuming repeats exactly that step
       self.engine.voided(rc)
-      first = _lib.SegmentResult.from_buffer_copy(res)
-      budget = params.max_steps
+      for name in summed:
+        before[name] += getattr(res, name)
       if budget > 0:
-        params.max_steps = max(budget - first.num_steps, 1)
+        params.max_steps = max(budget - before['num_steps'], 1)
       rc = self._lib.ffn_canvas_segment_at(self._h, i3(start_pos),
                                            ctypes.byref(params), 1,
                                            ctypes.byref(res))
-      params.max_steps = budget
-      for name in ('num_steps', 'skip_threshold', 'skip_invalid_pos',
-                   'gate_rejects'):
-        setattr(res, name, getattr(res, name) + getattr(first, name))
+    params.max_steps = budget
+    for name in summed:
+      setattr(res, name, getattr(res, name) + before[name])
     check(rc)
     return res
 

@@ -134,14 +134,18 @@ class ShimHandle(EmulatedHandle):
                                    _READ_CB(read_cb), start,
                                    ctypes.byref(params), int(resume),
                                    ctypes.byref(res))
-    if rc in _lib.ERR_VOIDED:  # what DeviceCanvasHandle.segment_at does
-      first = _lib.SegmentResult.from_buffer_copy(res)
+    summed = ('num_steps', 'skip_threshold', 'skip_invalid_pos', 'gate_rejects')
+    before = dict.fromkeys(summed, 0)
+    for _ in range(hip_engine.MAX_VOID_REPEATS):  # what DeviceCanvasHandle.segment_at does
+      if rc not in _lib.ERR_VOIDED:
+        break
+      for name in summed:
+        before[name] += getattr(res, name)
       rc = self.shim.shim_segment_at(self._state, _STEP_CB(step_cb),
                                      _READ_CB(read_cb), start,
                                      ctypes.byref(params), 1, ctypes.byref(res))
-      for name in ('num_steps', 'skip_threshold', 'skip_invalid_pos',
-                   'gate_rejects'):
-        setattr(res, name, getattr(res, name) + getattr(first, name))
+    for name in summed:
+      setattr(res, name, getattr(res, name) + before[name])
     self.shim.shim_set_hint_cb(_HINT_CB())
     assert rc == 0, rc
     return res

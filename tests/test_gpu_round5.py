@@ -117,3 +117,56 @@ def test_segment_loop_survives_resident_timeouts(hip_exe, fib25_model):  # noqa:
     eng.flow_fallbacks = 0
   healthy.close()
   _assert_shipped_default(eng)
+
+
+@pytest.mark.parametrize('name', ['nodisco', 'disco002', 'disco30', 'mbd2', 'mbd3',
+                                  'seg05_probmap', 'seg08_probmap'])
+def test_non_default_inference_options_on_the_gpu(fib25_model, name):
+  """InferenceOptions away from the sample configuration (inference.proto:131-168):
+  disco bias off (disco_seed_threshold < 0, inference.py:416) or needing a
+  fraction of active voxels (:427), min_boundary_dist > 1 (:556), other segment
+  thresholds / size filters / move threshold (:624,639), quantised probability
+  maps kept on a DeviceCanvas (:229-232,656).  Each case is a run of the
+  reference's own Canvas (tools/make_golden.py --only options); the device canvas
+  reproduces it twice -- through the library's segment loop (the default drive)
+  and with Python between the steps (positions recorded): same steps, ids,
+  counters, origins; logits within 1e-4; probability bytes within one bucket."""
+  from ffn_amd.inference import executor
+  from ffn_amd.inference import inference
+  from ffn_amd.inference import inference_utils
+  from ffn_amd.inference import movement
+  from tests import option_cases
+  g = option_cases.load(name)
+  r = option_cases.request_for(g)
+  exe = executor.HipBatchExecutor(executor.ExecutorInterface(), fib25_model,
+                                  fib25_model.info, None, inference_utils.Counters(),
+                                  1, device_id=0)
+  _assert_shipped_default(exe.engine)
+
+  def make(cls):
+    counters = inference_utils.Counters()
+    return cls(fib25_model.info, exe.get_client(counters, direct=True), g['image'],
+               r.inference_options, counters=counters,
+               movement_policy_fn=movement.get_policy_fn(r, fib25_model.info),
+               keep_probability_maps=g['probmap'])
+
+  canvas = make(inference.DeviceCanvas)
+  assert canvas._native_loop_ok()
+  option_cases.run(canvas, g)
+  option_cases.check(canvas, g)
+  canvas.close()
+
+  steps = []
+
+  class Rec(inference.DeviceCanvas):
+
+    def update_at(self, pos):
+      steps.append(tuple(pos))
+      return super().update_at(pos)
+
+  canvas = make(Rec)
+  option_cases.run(canvas, g)
+  option_cases.check(canvas, g, steps=steps)
+  canvas.close()
+  assert exe.engine.range_fallbacks == 0 and exe.engine.flow_fallbacks == 0
+  exe.engine.close()

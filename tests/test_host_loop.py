@@ -521,3 +521,29 @@ def test_segment_many_two_groups_in_two_threads(shim, fib25_blob):
     total += len(g['steps'])
   assert drv.steps == total
   assert max(engine.batch_sizes) <= 2
+
+
+@pytest.mark.parametrize('name,native', [('nodisco', True), ('disco30', False),
+                                         ('mbd3', True), ('seg08_probmap', True)])
+def test_non_default_inference_options(shim, fib25_blob, name, native):
+  """InferenceOptions away from the sample configuration (disco bias off /
+  needing a fraction of active voxels, min_boundary_dist > 1, other segment
+  thresholds and size filters, quantised probability maps kept; reference
+  inference.py:416-439,556,624-660): the reference's own runs reproduced by the
+  device-canvas host logic over the emulated device, with the Python loop or
+  with the library's segment loop (all seven cases, both loops: the GPU suite,
+  tests/test_gpu_round5.py)."""
+  from tests import option_cases
+  g = option_cases.load(name)
+  ShimHandle.shim = shim
+  r = option_cases.request_for(g)
+  info = _info()
+  cls = ShimClient if native else EmulatedDeviceClient
+  client = cls(inference_utils.Counters(), fib25_blob, 12, (33, 33, 33), (8, 8, 8))
+  c = inference.make_canvas(info, client, g['image'], r.inference_options,
+                            counters=inference_utils.Counters(),
+                            movement_policy_fn=movement.get_policy_fn(r, info),
+                            keep_probability_maps=g['probmap'])
+  assert c._native_loop_ok() == native
+  option_cases.run(c, g)
+  option_cases.check(c, g, steps=c._handle.steps_seen if native else None)

@@ -15,6 +15,11 @@ Outputs (committed):
   tests/golden/ref_canvas_*.npz    Canvas.segment_all runs: per-step FoV
                                    positions + queued moves, final
                                    segmentation, counters, origins
+  tests/golden/ref_canvas_options.npz   (--only options) Canvas.segment_all runs
+                                   under InferenceOptions away from the sample
+                                   configuration: disco off / positive,
+                                   min_boundary_dist > 1, other segment
+                                   thresholds and size filters, probability maps
   tests/golden/ref_masks.npz       storage.build_mask KATs and a Canvas run
                                    under a MovementRestrictor (mask, seed
                                    mask, shift mask)
@@ -182,7 +187,8 @@ class OracleClient(ref_executor.ExecutorClient):
 
 def run_reference_canvas(image_f32, blob, depth, fov, deltas, seeds,
                          min_segment_size=1000, forward_fn=None,
-                         restrictor=None, pred=None):
+                         restrictor=None, pred=None, options=None,
+                         keep_probability_maps=False):
   """Drives the reference Canvas exactly as Runner does (runner.py:392-408).
   pred (zyx): a prediction smaller than the seed FoV (ModelInfo.pred_mask_size <
   input_seed_size; inference.py:218,410-411)."""
@@ -200,12 +206,18 @@ def run_reference_canvas(image_f32, blob, depth, fov, deltas, seeds,
   o.min_boundary_dist.x = 1
   o.min_boundary_dist.y = 1
   o.min_boundary_dist.z = 1
+  for key, value in (options or {}).items():  # InferenceOptions the sample config leaves alone
+    if key == 'min_boundary_dist':
+      o.min_boundary_dist.x, o.min_boundary_dist.y, o.min_boundary_dist.z = value
+    else:
+      setattr(o, key, value)
   counters = ref_utils.Counters()
   trace = []
   canvas = ref_inference.Canvas(
       info, OracleClient(blob, depth, trace, forward_fn), image_f32, o,
       counters=counters, restrictor=restrictor,
-      movement_policy_fn=ref_movement.get_policy_fn(request, info))
+      movement_policy_fn=ref_movement.get_policy_fn(request, info),
+      keep_probability_maps=keep_probability_maps)
 
   # Record each FoV step: position + the moves the policy queued.
   orig_update = canvas.movement_policy.update
@@ -270,6 +282,56 @@ def make_canvas_case(name, shape, seed, depth_weights, grid_step, grid_offsets,
       counters=json.dumps(keep), depth=depth,
       pred_zyx=np.array(pred or fov, np.int32))
   print(name, 'steps', len(steps), 'segments', len(origins), 'counters', keep)
+
+
+# InferenceOptions (inference.proto:131-168) away from the sample configuration's
+# values: each case is a whole reference Canvas.segment_all run
+OPTION_CASES = [
+    # disco bias off (inference.py:416)
+    ('nodisco', 'cells72', {'disco_seed_threshold': -1.0}, False),
+    # ... and with a positive active-voxel fraction (inference.py:427)
+    ('disco002', 'cells72', {'disco_seed_threshold': 0.002}, False),
+    ('disco30', 'cells72', {'disco_seed_threshold': 0.3}, False),
+    # seeds further from what is segmented already (inference.py:556-562)
+    ('mbd2', 'cells72', {'min_boundary_dist': (2, 2, 2)}, False),
+    ('mbd3', 'cells72', {'min_boundary_dist': (3, 2, 4)}, False),
+    # another mask threshold / size filter (inference.py:624,639) + quantised
+    # probabilities kept (inference.py:229-232,656)
+    ('seg05_probmap', 'cells72', {'segment_threshold': 0.5, 'min_segment_size': 100}, True),
+    ('seg08_probmap', 'cells72', {'segment_threshold': 0.8, 'min_segment_size': 3000,
+                                  'move_threshold': 0.8}, True),
+]
+PHANTOMS = {'cells56': ((56, 56, 56), 11, 16, (0, 8), 1),
+            'cells72': ((72, 64, 80), 5, 16, (0,), 2)}
+
+
+def make_option_cases(blob, depth):
+  out = {}
+  for name, phantom, options, probmap in OPTION_CASES:
+    shape, vseed, step, offsets, dilate = PHANTOMS[phantom]
+    vol = synthetic.cells_volume(shape, seed=vseed, membrane_dilate=dilate)
+    seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16), step=step, offsets=offsets)
+    canvas, trace, counters = run_reference_canvas(
+        synthetic.normalize(vol), blob, depth, (33, 33, 33), (8, 8, 8), seeds,
+        options=options, keep_probability_maps=probmap)
+    cdict = {k: c.value for k, c in counters}
+    keep = {k: v for k, v in cdict.items() if not k.endswith('-time-ms')}
+    out[name + '/phantom'] = phantom
+    out[name + '/options'] = json.dumps(options)
+    out[name + '/seeds'] = seeds
+    out[name + '/steps'] = np.array([t[0] for t in trace], np.int32).reshape(-1, 3)
+    out[name + '/move_scores'] = np.array([s for t in trace for s, _ in t[1]], np.float32)
+    out[name + '/segmentation'] = np.array(canvas.segmentation).astype(np.int16)
+    out[name + '/seed_logits'] = np.array(canvas.seed)
+    out[name + '/counters'] = json.dumps(keep)
+    out[name + '/origins'] = json.dumps({
+        int(k): [list(int(x) for x in v.start_zyx), int(v.iters)]
+        for k, v in canvas.origins.items()})
+    if probmap:
+      out[name + '/seg_prob'] = np.array(canvas.seg_prob)
+    print(name, phantom, options, 'steps', len(trace), 'segments', len(canvas.origins),
+          keep)
+  np.savez_compressed(os.path.join(GOLD, 'ref_canvas_options.npz'), **out)
 
 
 def make_masks(blob, depth):
@@ -443,6 +505,9 @@ def main():
                      pred=(25, 25, 25))
     make_canvas_case('cells72_pred27', (72, 64, 80), 5, (blob, 12), 16, (0,), 2,
                      pred=(27, 29, 25))
+  if args.only in ('', 'options'):
+    v = tf_checkpoint.load_checkpoint(CKPT)
+    make_option_cases(ffn_oracle.weights_blob(v, 12), 12)
   if args.only in ('', 'masks'):
     v = tf_checkpoint.load_checkpoint(CKPT)
     make_masks(ffn_oracle.weights_blob(v, 12), 12)
