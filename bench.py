@@ -140,6 +140,84 @@ def _dist_env():
   return rank, local_rank, world
 
 
+class Comm:
+  """The ranks of the job as far as the bench talks to them: a barrier and
+  small reductions over `torch.distributed` (backend nccl = RCCL on the GPUs;
+  gloo in tests/test_bench_ranks.py, where tests/emulated_device.py stands in for
+  the engine).  world == 1: no process group is needed or touched."""
+
+  def __init__(self, rank, world, device=None):
+    self.rank, self.world, self.device = rank, world, device
+
+  def _tensor(self, values):
+    import torch
+    return torch.tensor([float(v) for v in values], dtype=torch.float64,
+                        device=self.device if self.device is not None else 'cpu')
+
+  def barrier(self):
+    if self.world > 1:
+      import torch.distributed as dist
+      dist.barrier()
+
+  def _reduce(self, values, op):
+    if self.world == 1:
+      return [float(v) for v in values]
+    import torch.distributed as dist
+    t = self._tensor(values)
+    dist.all_reduce(t, op=op)
+    return [float(v) for v in t.tolist()]
+
+  def all_sum(self, values):
+    import torch.distributed as dist
+    return self._reduce(values, dist.ReduceOp.SUM)
+
+  def all_max(self, values):
+    import torch.distributed as dist
+    return self._reduce(values, dist.ReduceOp.MAX)
+
+  def all_gather(self, values):
+    """-> one list of floats per rank."""
+    if self.world == 1:
+      return [[float(v) for v in values]]
+    import torch
+    import torch.distributed as dist
+    t = self._tensor(values)
+    out = [torch.zeros_like(t) for _ in range(self.world)]
+    dist.all_gather(out, t)
+    return [[float(v) for v in g.tolist()] for g in out]
+
+
+def full_volume_totals(comm, steps, voxels, t_local, t_all, objects, volume_zyx):
+  """The complete pass of every rank as ONE job: steps and voxels summed over
+  the ranks, the clock of the slowest (t_all was taken behind a barrier)."""
+  steps_all, voxels_all = comm.all_sum([steps, voxels])
+  return {
+      'what': 'one complete segment_all pass over each rank\'s %s volume (%d '
+              'rank(s), summed): every grid seed, segment commits included; wall '
+              'clock between barriers' % ('x'.join(str(v) for v in volume_zyx),
+                                          comm.world),
+      'steps': int(steps_all),
+      'seconds': round(t_all, 4),
+      'fov_steps_per_s': round(steps_all / t_all, 1),
+      'voxels_segmented': int(voxels_all),
+      'voxels_segmented_per_s': round(voxels_all / t_all, 1),
+      'objects': objects,
+      'rank0': {'steps': int(steps), 'voxels_segmented': int(voxels)},
+      'rank0_seconds': round(t_local, 4),
+  }
+
+
+def stream_totals(comm, local):
+  """Per-rank numbers of the stream mode -> the job's: the timed region ends
+  with the slowest rank (MAX), steps and voxels add up (SUM)."""
+  out = dict(local)
+  out['elapsed'] = comm.all_max([local['elapsed']])[0]
+  out['voxels_run'], out['steps_run'], out['voxels'] = comm.all_sum(
+      [local['voxels_run'], local['steps_run'], local['voxels']])
+  out['seconds_run'] = comm.all_max([local['seconds_run']])[0]
+  return out
+
+
 def make_request():
   from ffn_amd.inference import request as req_lib
   r = req_lib.InferenceRequest()
@@ -183,7 +261,7 @@ FULL_FIXTURE = os.path.join(ROOT, 'tests', 'golden',
                             'ref_canvas_cells250_onednn_full.npz')
 
 
-def full_volume_pass(args, rank, world, model, exe, request, image, barrier):
+def full_volume_pass(args, comm, model, exe, request, image, barrier):
   """BASELINE.json's metric on a COMPLETE pass: `Canvas.segment_all` over every
   grid seed of this rank's volume (reference inference.py:538-683; 24 k FoV
   steps on the 250^3 phantom) -- seed set-up, validity tests, segment commits
@@ -227,30 +305,12 @@ def full_volume_pass(args, rank, world, model, exe, request, image, barrier):
   t_all = time.perf_counter() - t0
   steps = counters['update_at-calls'].value
   voxels = counters['voxels-segmented'].value
-  steps0, voxels0 = steps, voxels
-  if world > 1:  # whole job: every rank's pass, the slowest rank's clock
-    import torch
-    import torch.distributed as dist
-    t = torch.tensor([float(steps), float(voxels)], dtype=torch.float64, device='cuda')
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    steps, voxels = (float(v) for v in t.tolist())
-  out = {
-      'what': 'one complete segment_all pass over each rank\'s %s volume (%d '
-              'rank(s), summed): every grid seed, segment commits included; wall '
-              'clock between barriers' % ('x'.join(str(v) for v in VOLUME_ZYX), world),
-      'steps': int(steps),
-      'seconds': round(t_all, 4),
-      'fov_steps_per_s': round(steps / t_all, 1),
-      'voxels_segmented': int(voxels),
-      'voxels_segmented_per_s': round(voxels / t_all, 1),
-      'objects': len(canvas.origins),
-      'rank0': {'steps': int(steps0), 'voxels_segmented': int(voxels0)},
-      'seeds_tried': int(len(fixture['seeds'])) if fixture is not None else None,
-      'rank0_seconds': round(t_local, 4),
-  }
+  out = full_volume_totals(comm, steps, voxels, t_local, t_all, len(canvas.origins),
+                           VOLUME_ZYX)
+  out['seeds_tried'] = int(len(fixture['seeds'])) if fixture is not None else None
   seg = np.array(np.asarray(canvas.segmentation))
   canvas.close()
-  if fixture is not None and rank == 0:
+  if fixture is not None and comm.rank == 0:
     want = fixture['segmentation'].astype(np.int32)
     inter = int(np.sum((seg > 0) & (want > 0) & (seg == want)))
     union = int(np.sum((seg > 0) | (want > 0)))
@@ -302,10 +362,10 @@ def run_gpu(args, rank, local_rank, world):
   torch.cuda.set_device(local_rank)
   if world > 1:
     dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+  comm = Comm(rank, world, torch.device('cuda', local_rank))
 
   def barrier():
-    if world > 1:
-      dist.barrier()
+    comm.barrier()
     torch.cuda.synchronize()
 
   model = load_model()
@@ -451,10 +511,6 @@ def run_gpu(args, rank, local_rank, world):
   flow = eng.get_option('flow')
   elapsed = state['t1'] - state['t0']
   elapsed_local = state['t1_local'] - state['t0']
-  if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
   # Final segmentation merge (the ONLY collective of the path): the N per-rank
   # volumes are treated as N sub-boxes stacked along z of one virtual volume;
   # id offsets by all_gather, union by all_reduce(MAX) over RCCL.  Untimed
@@ -483,8 +539,7 @@ def run_gpu(args, rank, local_rank, world):
   cvals['gate_rejects'] = canvas.gate_rejects
   full_volume = None
   if not args.no_full_volume:
-    full_volume = full_volume_pass(args, rank, world, model, exe, request, image,
-                                   barrier)
+    full_volume = full_volume_pass(args, comm, model, exe, request, image, barrier)
   result = {
       'full_volume': full_volume,
       'merge_ms': merge_ms,
@@ -523,16 +578,8 @@ def run_gpu(args, rank, local_rank, world):
       'request': request,
       'image': image,
   }
+  result = stream_totals(comm, result)
   if world > 1:
-    vr = torch.tensor([result['voxels_run'], result['steps_run']],
-                      dtype=torch.float64, device='cuda')
-    dist.all_reduce(vr, op=dist.ReduceOp.SUM)
-    sr = torch.tensor([result['seconds_run']], dtype=torch.float64,
-                      device='cuda')
-    dist.all_reduce(sr, op=dist.ReduceOp.MAX)
-    result['voxels_run'] = float(vr[0].item())
-    result['steps_run'] = float(vr[1].item())
-    result['seconds_run'] = float(sr.item())
     dist.barrier()
     dist.destroy_process_group()
   return result
@@ -560,10 +607,10 @@ def run_sharded(args, rank, local_rank, world):
   device = torch.device('cuda', local_rank)
   if world > 1:
     dist.init_process_group('nccl', device_id=device)
+  comm = Comm(rank, world, device)
 
   def barrier():
-    if world > 1:
-      dist.barrier()
+    comm.barrier()
     torch.cuda.synchronize()
 
   n = args.sharded_volume
@@ -676,17 +723,9 @@ def run_sharded(args, rank, local_rank, world):
   barrier()
   reconcile_total_ms = (time.perf_counter() - tr) * 1e3
   final_ids = int(torch.unique(merged).numel()) - 1
-  tot = torch.tensor([float(steps), float(voxels), t_seg_local, t_seg_local,
-                      float(len(mine))], dtype=torch.float64, device=device)
-  per_rank = None
-  if world > 1:
-    gathered = [torch.zeros_like(tot) for _ in range(world)]
-    dist.all_gather(gathered, tot)
-    per_rank = [[float(v) for v in g.tolist()] for g in gathered]
-    part = tot.clone()
-    dist.all_reduce(tot[:2], op=dist.ReduceOp.SUM)
-    dist.all_reduce(part[2:3], op=dist.ReduceOp.MAX)
-    tot[2] = part[2]
+  totals = sharded_totals(comm, steps, voxels, t_seg_local, len(mine))
+  merge_bytes = dict(ffn_dist.merge_collective_bytes(shape, boxes, world),
+                     used=args.sharded_collective)
   if rank == 0 and world > 1:
     try:
       os.remove(vol_path)
@@ -718,7 +757,47 @@ def run_sharded(args, rank, local_rank, world):
     dist.destroy_process_group()
   if rank != 0:
     return
-  steps_all, voxels_all, t_seg_max = (float(v) for v in tot.tolist()[:3])
+  m = dict(shape=shape, boxes=boxes, sub=sub, ov=ov, t_seg=t_seg,
+           conv_variant=conv_variant, step_calls=step_calls, step_items=step_items,
+           step_hist=step_hist, stack_us=stack_us,
+           stack_us_run_weights=stack_us_run_weights, kernel_reps=kernel_reps,
+           t_setup=t_setup, t_volume=t_volume, merge_ms=merge_ms,
+           reconcile_total_ms=reconcile_total_ms, plain_ids=plain_ids,
+           final_ids=final_ids, edges_n=len(edges), check=check,
+           driver_calls=run.last_driver.calls,
+           driver_library_seconds=run.last_driver.library_seconds,
+           driver_segments_ended=run.last_driver.segments_ended,
+           merge_bytes=merge_bytes)
+  print(json.dumps(sharded_line(args, world, totals, m)))
+
+
+def sharded_totals(comm, steps, voxels, busy_seconds, n_boxes):
+  """Per-rank numbers of the sharded mode -> the job's: FoV steps and voxels add
+  up, every rank's share is kept (`per_rank`: how even the dynamic deal was)."""
+  rows = comm.all_gather([steps, voxels, busy_seconds, n_boxes])
+  return {
+      'steps': sum(r[0] for r in rows),
+      'voxels': sum(r[1] for r in rows),
+      'busy_max': max(r[2] for r in rows),
+      'per_rank': None if comm.world == 1 else [
+          {'fov_steps': int(r[0]), 'busy_seconds': round(r[2], 3),
+           'sub_boxes': int(r[3])} for r in rows],
+  }
+
+
+def sharded_line(args, world, totals, m):
+  """The one JSON line of the sharded mode from the job's totals and rank 0's
+  measurements `m` (pure bookkeeping; tests/test_bench_ranks.py)."""
+  steps_all, voxels_all = totals['steps'], totals['voxels']
+  shape, boxes, sub, ov, t_seg = m['shape'], m['boxes'], m['sub'], m['ov'], m['t_seg']
+  conv_variant, check, merge_bytes = m['conv_variant'], m['check'], m['merge_bytes']
+  step_calls, step_items, step_hist = m['step_calls'], m['step_items'], m['step_hist']
+  stack_us, stack_us_run_weights = m['stack_us'], m['stack_us_run_weights']
+  kernel_reps, t_setup, t_volume = m['kernel_reps'], m['t_setup'], m['t_volume']
+  merge_ms, reconcile_total_ms = m['merge_ms'], m['reconcile_total_ms']
+  plain_ids, final_ids, edges_n = m['plain_ids'], m['final_ids'], m['edges_n']
+  driver_calls, driver_library_seconds = m['driver_calls'], m['driver_library_seconds']
+  driver_segments_ended = m['driver_segments_ended']
   # batched roofline: algorithmic flops of the conv launches of one stack at this
   # batch / the time of the whole resident stack (conv0_a included: it is
   # 1 / (2 depth) of the launches), against the ceiling of the arithmetic used
@@ -769,13 +848,11 @@ def run_sharded(args, rank, local_rank, world):
       'setup_seconds': {'total': round(t_setup, 2), 'volume': round(t_volume, 2),
                         'how': 'rank 0 builds the synthetic volume once, the '
                                'other ranks map it (/dev/shm); untimed'},
-      'per_rank': None if per_rank is None else [
-          {'fov_steps': int(r[0]), 'busy_seconds': round(r[3], 3),
-           'sub_boxes': int(r[4])} for r in per_rank],
+      'per_rank': totals['per_rank'],
       'host_loop': {
-          'library_calls': run.last_driver.calls,
-          'seconds_inside_library_calls': round(run.last_driver.library_seconds, 3),
-          'segments_ended': run.last_driver.segments_ended,
+          'library_calls': driver_calls,
+          'seconds_inside_library_calls': round(driver_library_seconds, 3),
+          'segments_ended': driver_segments_ended,
           'note': 'rank 0, summed over the group threads: the rest of '
                   'groups x segmentation_seconds is Python between segments '
                   '(commit, seed policy, next init_seed) and canvas set-up',
@@ -821,17 +898,82 @@ def run_sharded(args, rank, local_rank, world):
       'assembly': {
           'merge_ms': round(merge_ms, 2),
           'merge_plus_reconcile_ms': round(reconcile_total_ms, 2),
-          'how': 'all_gather(id offsets) + cores -> one device int32 volume + '
-                 'all_reduce(MAX) over RCCL; then margin pair histograms on the '
-                 'GPU, all_gather(edges), union-find, table relabel in place; '
-                 'wall clock between barriers, max over ranks',
+          'how': 'all_reduce(id counts by sub-box) + cores -> one device int32 '
+                 'volume + %s over RCCL; then margin pair histograms on the GPU, '
+                 'all_gather(edges), union-find, table relabel in place; wall clock '
+                 'between barriers, max over ranks'
+                 % ('one broadcast per sub-box core from its owner'
+                    if merge_bytes['used'] == 'broadcast' else
+                    'all_reduce(MAX) of the zero-filled volume'),
+          'collective_bytes': merge_bytes,
           'ids_before_reconcile': plain_ids,
           'ids_after_reconcile': final_ids,
-          'merge_edges': int(len(edges)),
+          'merge_edges': int(edges_n),
           'check_vs_specification': check,
       },
   }
-  print(json.dumps(out))
+  return out
+
+
+def _cpu_run(image, blob, variables, seeds, impl, threads, budget_s, max_steps,
+             keep_trace=False):
+  """The oracle's canvas loop (oracle/ffn_oracle.py: the reference's
+  Canvas.segment_all restated) behind one CPU conv stack -- 'c_oracle' (plain C,
+  OpenMP) or 'torch_onednn' -- on `threads` threads, until `max_steps` FoV steps
+  or `budget_s` seconds; the first step is warm-up and not counted.
+  -> (steps per second, steps, seconds, trace)."""
+  from oracle import ffn_oracle
+  forward_fn = None
+  if impl == 'torch_onednn':
+    forward_fn = functools.partial(ffn_oracle.forward_torch, variables=variables,
+                                   depth=DEPTH, threads=threads)
+  else:
+    ffn_oracle.set_threads(threads)
+
+  class _Stop(Exception):
+    pass
+
+  oc = ffn_oracle.OracleCanvas(image, blob, DEPTH, FOV, DELTAS, ffn_oracle.Options())
+  oc.forward_fn = forward_fn
+  t0 = [None]
+  inner = oc.update_at
+  n = [0]
+
+  def timed_update(pos):
+    if n[0] == 1:  # first step = warm-up (thread spin-up, page faults)
+      t0[0] = time.perf_counter()
+    out = inner(pos)
+    n[0] += 1
+    if n[0] > 1 and (n[0] - 1 >= max_steps or
+                     time.perf_counter() - t0[0] > budget_s):
+      raise _Stop()
+    return out
+
+  oc.update_at = timed_update
+  try:
+    oc.segment_all(seeds)
+  except _Stop:
+    pass
+  steps = n[0] - 1
+  dt = time.perf_counter() - t0[0]
+  return steps / dt, steps, dt, (list(oc.trace) if keep_trace else None)
+
+
+def cpu_worker(args):
+  """`bench.py --cpu-worker K`: one of the P concurrent oracle processes of the
+  whole-box CPU figure (cpu_baseline).  Its own canvas over the same volume, its
+  own part of the seed grid; prints {"steps", "seconds"}."""
+  from oracle import ffn_oracle
+  variables = model_variables()
+  blob = ffn_oracle.weights_blob(variables, DEPTH)
+  image = np.load(args.cpu_image, mmap_mode='r')
+  seeds = ffn_oracle.grid_seeds(VOLUME_ZYX, tuple(f // 2 for f in FOV))
+  k, p = args.cpu_worker, args.cpu_workers
+  first = (len(seeds) * k) // p
+  seeds = np.concatenate([seeds[first:], seeds[:first]])
+  _, steps, dt, _ = _cpu_run(np.asarray(image), blob, variables, seeds, args.cpu_impl,
+                             args.cpu_threads, args.cpu_seconds, 10 ** 9)
+  print(json.dumps({'steps': steps, 'seconds': dt}))
 
 
 def cpu_baseline(args):
@@ -855,73 +997,74 @@ def cpu_baseline(args):
   seeds = ffn_oracle.grid_seeds(shape, tuple(f // 2 for f in FOV))
   ncpu = os.cpu_count() or 1
 
-  class _Stop(Exception):
-    pass
-
-  traces = {}
-
-  def run(forward_fn, budget_s, max_steps):
-    oc = ffn_oracle.OracleCanvas(image, blob, DEPTH, FOV, DELTAS,
-                                 ffn_oracle.Options())
-    oc.forward_fn = forward_fn
-    t0 = [None]
-    inner = oc.update_at
-    n = [0]
-
-    def timed_update(pos):
-      if n[0] == 1:  # first step = warm-up (thread spin-up, page faults)
-        t0[0] = time.perf_counter()
-      out = inner(pos)
-      n[0] += 1
-      if n[0] > 1 and (n[0] - 1 >= max_steps or
-                       time.perf_counter() - t0[0] > budget_s):
-        raise _Stop()
-      return out
-
-    oc.update_at = timed_update
-    try:
-      oc.segment_all(seeds)
-    except _Stop:
-      pass
-    steps = n[0] - 1
-    dt = time.perf_counter() - t0[0]
-    traces['torch_onednn' if forward_fn is not None else 'c_oracle'] = list(oc.trace)
-    return steps / dt, steps, dt
-
-  results = {}
-  # plain-C oracle: pick the best OpenMP thread count with a short probe
-  best_thr, best_rate = None, 0.0
-  for thr in sorted({ncpu, max(ncpu // 2, 1), min(64, ncpu), min(32, ncpu),
-                     min(16, ncpu)}, reverse=True):
-    ffn_oracle.set_threads(thr)
-    rate, _, _ = run(None, 1.5, 4)
-    if rate > best_rate:
-      best_thr, best_rate = thr, rate
-  ffn_oracle.set_threads(best_thr)
-  rate_c, steps_c, dt_c = run(None, args.cpu_seconds / 2, args.cpu_steps)
-  results['c_oracle'] = (rate_c, steps_c, dt_c, best_thr)
-  # (FoV position, queued moves) of the C oracle's run; the oneDNN-forward
-  # run is kept too: the GPU replays both (gpu_parity_leg)
-  oracle_trace = {'c_oracle': traces['c_oracle']}
+  results, oracle_trace = {}, {}
+  impls = ['c_oracle']
   try:
-    import torch
-    best_t, best_rate = None, 0.0
-    for thr in sorted({ncpu, min(64, ncpu), min(32, ncpu), min(16, ncpu)},
-                      reverse=True):
-      fn = functools.partial(ffn_oracle.forward_torch, variables=variables,
-                             depth=DEPTH, threads=thr)
-      rate, _, _ = run(fn, 1.5, 4)
-      if rate > best_rate:
-        best_t, best_rate = thr, rate
-    fn = functools.partial(ffn_oracle.forward_torch, variables=variables,
-                           depth=DEPTH, threads=best_t)
-    rate_t, steps_t, dt_t = run(fn, args.cpu_seconds / 2, args.cpu_steps)
-    results['torch_onednn'] = (rate_t, steps_t, dt_t, best_t)
-    oracle_trace['torch_onednn'] = traces['torch_onednn']
+    import torch  # noqa: F401
+    impls.append('torch_onednn')
   except ImportError:
     pass
+  probes = {}
+  for impl in impls:
+    # thread count: probes of >= 20 FoV steps each (4-step probes mostly time the
+    # thread pool's spin-up)
+    best_thr, best_rate = None, 0.0
+    for thr in sorted({ncpu, max(ncpu // 2, 1), min(64, ncpu), min(32, ncpu),
+                       min(16, ncpu), min(8, ncpu)}, reverse=True):
+      rate, n, _, _ = _cpu_run(image, blob, variables, seeds, impl, thr, 4.0,
+                               args.cpu_probe_steps)
+      probes.setdefault(impl, {})[str(thr)] = [round(rate, 2), n]
+      if rate > best_rate:
+        best_thr, best_rate = thr, rate
+    rate, steps, dt, trace = _cpu_run(image, blob, variables, seeds, impl, best_thr,
+                                      args.cpu_seconds / len(impls), args.cpu_steps,
+                                      keep_trace=True)
+    results[impl] = (rate, steps, dt, best_thr)
+    # (FoV position, queued moves) of the run: the GPU replays it (gpu_parity_leg),
+    # its first cpu_parity_steps steps
+    oracle_trace[impl] = trace[:args.cpu_parity_steps]
   name = max(results, key=lambda k: results[k][0])
   rate, steps, dt, thr = results[name]
+  # The whole box: floor(host cores / threads) such processes at once, each with
+  # its own canvas and its own part of the seed grid -- what "this box's host
+  # cores" deliver on this workload when none of them idles.
+  whole = None
+  procs = max(ncpu // max(thr, 1), 1)
+  if procs > 1 and not args.no_cpu_whole_box:
+    import subprocess
+    import tempfile
+    shm = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
+    img_path = os.path.join(shm, 'ffn_amd_bench_cpu_image_%d.npy' % os.getpid())
+    np.save(img_path, image)
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-workers', str(procs),
+           '--cpu-threads', str(thr), '--cpu-impl', name, '--cpu-image', img_path,
+           '--cpu-seconds', str(args.cpu_box_seconds), '--config', CONFIG,
+           '--workload', args.workload, '--volume', str(args.volume)]
+    t0 = time.perf_counter()
+    try:
+      ps = [subprocess.Popen(cmd + ['--cpu-worker', str(k)], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, text=True) for k in range(procs)]
+      outs = [json.loads(p.communicate(timeout=args.cpu_box_seconds * 6 + 120)[0]
+                         .strip().splitlines()[-1]) for p in ps]
+      whole = {
+          'value': round(sum(o['steps'] for o in outs) / max(o['seconds'] for o in outs), 2),
+          'unit': 'FoV-steps/s',
+          'processes': procs, 'threads_each': int(thr), 'cores': int(procs * thr),
+          'steps': int(sum(o['steps'] for o in outs)),
+          'seconds': round(max(o['seconds'] for o in outs), 2),
+          'what': '%d concurrent oracle processes (%s, %d threads each), each with '
+                  'its own canvas over the same volume and its own part of the seed '
+                  'grid; sum of their FoV steps / the longest of their clocks'
+                  % (procs, name, thr),
+          'wall_seconds_of_this_leg': round(time.perf_counter() - t0, 1),
+      }
+    except Exception as e:  # pylint:disable=broad-except
+      whole = {'error': repr(e)}
+    finally:
+      try:
+        os.remove(img_path)
+      except OSError:
+        pass
   return oracle_trace, {
       'value': round(rate, 3),
       'unit': 'FoV-steps/s',
@@ -930,11 +1073,14 @@ def cpu_baseline(args):
       'kind': 'port',
       'implementation': name,
       'all': {k: round(v[0], 3) for k, v in results.items()},
+      'thread_probes': probes,
+      'whole_box': whole,
       'sample': ('first %d FoV steps of the same %s %s workload (same seeds, '
                  'options, weights) through the oracle canvas loop with the %s '
-                 'conv stack on %d threads, %.1f s'
-                 % (steps, args.workload, 'x'.join(str(v) for v in VOLUME_ZYX),
-                    name, thr, dt)),
+                 'conv stack on %d threads, %.1f s; thread count = the best of '
+                 '%d-step probes' % (steps, args.workload,
+                                     'x'.join(str(v) for v in VOLUME_ZYX), name, thr,
+                                     dt, args.cpu_probe_steps)),
   }
 
 
@@ -1088,87 +1234,10 @@ def _self_launch(args):
   os.execve(sys.executable, cmd, env)
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=1500)
-  ap.add_argument('--warmup', type=int, default=100)
-  ap.add_argument('--prewarm-max-steps', type=int, default=2500)
-  ap.add_argument('--prewarm-seconds', type=float, default=1.0,
-                  help='untimed spin-up (extra FoV steps) before the warmup '
-                  'steps are counted')
-  ap.add_argument('--volume', type=int, default=250)
-  ap.add_argument('--volume-zyx', type=int, nargs=3, default=None,
-                  help='canvas size zyx (overrides --volume)')
-  ap.add_argument('--mode', choices=['stream', 'sharded'], default='stream',
-                  help='stream: the headline (one seed stream per GPU); sharded: '
-                  'one volume tiled into sub-boxes, timed assembly (configs[3])')
-  ap.add_argument('--sharded-volume', type=int, default=320)
-  ap.add_argument('--sharded-volume-zyx', type=int, nargs=3, default=None,
-                  help='a non-cubic volume (configs[4]: 256 2048 2048)')
-  ap.add_argument('--sharded-sub', type=int, default=176)
-  ap.add_argument('--sharded-sub-zyx', type=int, nargs=3, default=None,
-                  help='sub-box size zyx (default: --sharded-sub cubed)')
-  ap.add_argument('--sharded-batch', type=int, default=8,
-                  help='FoVs per engine call (= canvases per group)')
-  ap.add_argument('--sharded-groups', type=int, default=2,
-                  help='canvas groups, each with its own host thread and engine '
-                  'calls (canvases open = groups x batch)')
-  ap.add_argument('--sharded-deal', choices=['dynamic', 'static'],
-                  default='dynamic')
-  ap.add_argument('--sharded-collective', choices=['all_reduce', 'broadcast'],
-                  default='all_reduce')
-  ap.add_argument('--sharded-max-steps', type=int, default=0,
-                  help='bound the run: a canvas is dropped after this many FoV '
-                  'steps (0 = segment everything)')
-  ap.add_argument('--config', choices=['c1', 'c5'], default='c1',
-                  help='c1: BASELINE configs[1] (the headline); c5: the depth-18 '
-                  'anisotropic model of configs[4], random weights')
-  ap.add_argument('--workload', choices=['cells', 'noise'], default='cells')
-  ap.add_argument('--conv-variant', type=int, default=None)
-  ap.add_argument('--engine-option', action='append', default=[],
-                  metavar='NAME=VALUE', help='ffn_engine_set_option switch '
-                  '(e.g. use_graph=1); may be given several times')
-  ap.add_argument('--profile-every', type=int, default=8)
-  ap.add_argument('--sync-mode', type=int, default=None)
-  ap.add_argument('--profile-mode', type=int, default=2,
-                  help='1 = event pair per conv launch, 2 = per 23-conv chain')
-  ap.add_argument('--cpu-seconds', type=float, default=15.0)
-  ap.add_argument('--cpu-steps', type=int, default=60)
-  ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--no-full-volume', action='store_true',
-                  help='skip the complete segment_all pass (and its comparison '
-                  'with the reference-minted run) behind the K timed steps')
-  ap.add_argument('--no-assembly-check', action='store_true',
-                  help='--mode sharded: skip the (untimed) comparison of the '
-                  'assembled volume with the numpy specification')
-  ap.add_argument('--no-batched-leg', action='store_true',
-                  help='skip the time-boxed batched (configs[2]) leg of the '
-                  'default run')
-  ap.add_argument('--batched-max-steps', type=int, default=0)
-  ap.add_argument('--batched-timeout', type=float, default=420.0)
-  ap.add_argument('--host-loop', choices=['native', 'python'], default='native',
-                  help='native: ffn_canvas_segment_at runs each segment\'s FoV '
-                  'loop inside the library; python: one ffn_canvas_step call '
-                  'per step from the interpreter')
-  args = ap.parse_args()
-  configure(args)
-
-  rank, local_rank, world = _dist_env()
-  if world != args.gpus:
-    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
-      _self_launch(args)  # does not return
-    raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.'
-                     'distributed.run --nproc-per-node %d' %
-                     (args.gpus, world, args.gpus))
-
-  if args.mode == 'sharded':
-    run_sharded(args, rank, local_rank, world)
-    return
-  res = run_gpu(args, rank, local_rank, world)
-  if rank != 0:
-    return
-
+def stream_line(args, world, res):
+  """The one JSON line of the stream mode from the job's totals (`stream_totals`,
+  `full_volume_totals`) and rank 0's kernel timing: pure bookkeeping, no device
+  (tests/test_bench_ranks.py runs it under gloo with world 2 and 4)."""
   steps_per_s = world * args.steps / res['elapsed']
   n_convs = 2 * DEPTH - 1
   avg_conv_ms = res['conv_ms'] / max(res['conv_launches'], 1)
@@ -1194,19 +1263,28 @@ def main():
   # this same command, when present.
   traffic = None
   traffic_source = None
+  pmc_commit = None
+  pmc_busy_cycles = None
   try:
     resident = res.get('flow') == 2 and res.get('conv_variant') == 9
-    tname = (('r04_conv32ps_pmc_traffic.json' if resident else
+    tname = (('r05_conv32ps_pmc.json' if resident else
               'conv32_pmc_traffic.json') if CONFIG == 'c1' else
              'r03_conv32mt_c5_pmc_traffic.json')
+    if not os.path.exists(os.path.join(ROOT, 'profiles', tname)) and resident:
+      tname = 'r04_conv32ps_pmc_traffic.json'
     with open(os.path.join(ROOT, 'profiles', tname)) as f:
       tj = json.load(f)
     if (tj.get('conv_variant', 9) == res.get('conv_variant', 9) and
         not (CONFIG != 'c1' and resident)):  # (c5's capture is of the per-conv launches)
       traffic = tj['traffic_bytes_per_launch']
       traffic_source = ('profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / '
-                        'WRITE_SIZE passes of this command (NOT measured in '
-                        'this run)' % tname)
+                        'WRITE_SIZE passes of this command on the tree at commit %s '
+                        '(NOT measured in this run)' % (tname, tj.get('commit') or
+                                                        '(not recorded)'))
+      pmc_commit = tj.get('commit')
+      busy = (tj.get('sq_per_launch') or {}).get('SQ_VALU_MFMA_BUSY_CYCLES')
+      if busy:
+        pmc_busy_cycles = float(busy)
   except (OSError, KeyError, ValueError):
     pass
   variant = res.get('conv_variant', 9)
@@ -1248,18 +1326,37 @@ def main():
     peak_basis = 'dense f32 MFMA peak'
     executed_ratio = 1
     dtype = 'f32'
+  # The metric: delta(update_at-calls) / wall(segment_all) --
+  # the COMPLETE pass over the volume(s), seed set-up, validity tests and segment
+  # commits included (`full_volume`).  The K timed steps of the contract, all
+  # inside one segment, are the steady-state rate next to it.  Without the
+  # complete pass (--no-full-volume, c5) `value` falls back to the steady state.
+  fv = res.get('full_volume')
+  value = fv['fov_steps_per_s'] if fv else round(steps_per_s, 2)
   out = {
       'metric': ('FoV-steps/sec (flood-filling inference loop, 250^3 volume)'
                  if CONFIG == 'c1' else
                  'FoV-steps/sec (flood-filling inference loop, configs[4] model)'),
-      'value': round(steps_per_s, 2),
+      'value': value,
+      'value_is': ('update_at-calls / wall clock of one complete segment_all pass over '
+                   'every rank\'s volume (full_volume: %d FoV steps in %.3f s)'
+                   % (fv['steps'], fv['seconds']) if fv else
+                   'the K timed steps (steady_state): no complete pass was run'),
       'unit': 'FoV-steps/s',
       'n_gpus': world,
       'steps': args.steps,
       'warmup': args.warmup,
       'prewarm_steps_untimed': res.get('prewarm_steps', 0),
       'volume_passes_completed': res.get('volume_passes_completed', 0),
-      'ms_per_step': round(1e3 * res['elapsed'] / args.steps, 4),
+      'ms_per_step': round(1e3 * world / value, 4) if fv else round(
+          1e3 * res['elapsed'] / args.steps, 4),
+      'steady_state': {
+          'what': 'exactly K = %d FoV steps after %d warm-up steps, all inside running '
+                  'segments, between barriers, max over ranks' % (args.steps, args.warmup),
+          'value': round(steps_per_s, 2),
+          'ms_per_step': round(1e3 * res['elapsed'] / args.steps, 4),
+          'seconds': round(res['elapsed'], 6),
+      },
       'higher_is_better': True,
       'scaling': 'weak',
       'vs_baseline': None,
@@ -1298,7 +1395,7 @@ def main():
           'region': 'all ranks, from the first FoV step of the run to the end '
                     'of the timed region (prewarm + warmup + timed steps, '
                     'seed set-up and segment commits included); the K timed '
-                    'steps alone held %d voxels' % int(world * res['voxels']),
+                    'steps alone held %d voxels' % int(res['voxels']),
       },
       'host_breakdown_us_per_step': {
           'c_abi_step_call': round(1e3 * res['counters'].get(
@@ -1322,7 +1419,7 @@ def main():
                  'volume over RCCL (no-op collective at n_gpus = 1); untimed',
       },
       'step_gflop': round(STEP_FLOPS / 1e9, 3),
-      'end_to_end_tflops': round(steps_per_s * STEP_FLOPS / 1e12, 3),
+      'end_to_end_tflops': round(value * STEP_FLOPS / 1e12, 3),
       'roofline': {
           'bound': 'mfma',
           'kernel': kernel_name,
@@ -1335,6 +1432,14 @@ def main():
           'vs_native_f32_mfma_peak': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
           'traffic': traffic,
           'traffic_source': traffic_source,
+          'traffic_commit': pmc_commit,
+          # matrix-pipe occupancy: SQ_VALU_MFMA_BUSY_CYCLES of one launch (summed
+          # over the chip's 1,024 SIMDs, from the same committed PMC capture) over
+          # the SIMD-cycles of THIS run's mean launch at the 2.1 GHz the chip holds
+          # under a single FoV
+          'mfma_busy': (round(pmc_busy_cycles / (1024 * mean_ms * 1e-3 * 2.1e9), 4)
+                        if pmc_busy_cycles and mean_ms and resident else None),
+          'mfma_busy_cycles_per_launch': pmc_busy_cycles,
           'launch_kernel': ('conv32ps_kernel' if resident else
                             'conv32mt_kernel' if variant == 9 else 'conv32*_kernel'),
           'launches_per_step': 1 if resident else n_convs,
@@ -1366,11 +1471,119 @@ def main():
               'what': 'every flop of the step (conv0_a, the %d convs, the head) '
                       'over the end-to-end time per step (host turn-around, '
                       'conv0_a, faces + paste included)' % n_convs,
-              'tflops': round(steps_per_s / world * STEP_FLOPS / 1e12, 3),
-              'frac': round(steps_per_s / world * STEP_FLOPS / 1e12 / peak, 4),
+              'tflops': round(value / world * STEP_FLOPS / 1e12, 3),
+              'frac': round(value / world * STEP_FLOPS / 1e12 / peak, 4),
           },
       },
   }
+  return out
+
+
+def build_parser():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=1500)
+  ap.add_argument('--warmup', type=int, default=100)
+  ap.add_argument('--prewarm-max-steps', type=int, default=2500)
+  ap.add_argument('--prewarm-seconds', type=float, default=1.0,
+                  help='untimed spin-up (extra FoV steps) before the warmup '
+                  'steps are counted')
+  ap.add_argument('--volume', type=int, default=250)
+  ap.add_argument('--volume-zyx', type=int, nargs=3, default=None,
+                  help='canvas size zyx (overrides --volume)')
+  ap.add_argument('--mode', choices=['stream', 'sharded'], default='stream',
+                  help='stream: the headline (one seed stream per GPU); sharded: '
+                  'one volume tiled into sub-boxes, timed assembly (configs[3])')
+  ap.add_argument('--sharded-volume', type=int, default=320)
+  ap.add_argument('--sharded-volume-zyx', type=int, nargs=3, default=None,
+                  help='a non-cubic volume (configs[4]: 256 2048 2048)')
+  ap.add_argument('--sharded-sub', type=int, default=176)
+  ap.add_argument('--sharded-sub-zyx', type=int, nargs=3, default=None,
+                  help='sub-box size zyx (default: --sharded-sub cubed)')
+  ap.add_argument('--sharded-batch', type=int, default=8,
+                  help='FoVs per engine call (= canvases per group)')
+  ap.add_argument('--sharded-groups', type=int, default=2,
+                  help='canvas groups, each with its own host thread and engine '
+                  'calls (canvases open = groups x batch)')
+  ap.add_argument('--sharded-deal', choices=['dynamic', 'static'],
+                  default='dynamic')
+  ap.add_argument('--sharded-collective', choices=['all_reduce', 'broadcast'],
+                  default='broadcast',
+                  help='assembly of the label volume over RCCL: every sub-box core '
+                  'broadcast once by its owner (default), or north_star\'s '
+                  'all_reduce(MAX) of a zero-filled volume (same result, 2 N x the '
+                  'bytes sent per GPU: assembly.collective_bytes)')
+  ap.add_argument('--sharded-max-steps', type=int, default=0,
+                  help='bound the run: a canvas is dropped after this many FoV '
+                  'steps (0 = segment everything)')
+  ap.add_argument('--config', choices=['c1', 'c5'], default='c1',
+                  help='c1: BASELINE configs[1] (the headline); c5: the depth-18 '
+                  'anisotropic model of configs[4], random weights')
+  ap.add_argument('--workload', choices=['cells', 'noise'], default='cells')
+  ap.add_argument('--conv-variant', type=int, default=None)
+  ap.add_argument('--engine-option', action='append', default=[],
+                  metavar='NAME=VALUE', help='ffn_engine_set_option switch '
+                  '(e.g. use_graph=1); may be given several times')
+  ap.add_argument('--profile-every', type=int, default=8)
+  ap.add_argument('--sync-mode', type=int, default=None)
+  ap.add_argument('--profile-mode', type=int, default=2,
+                  help='1 = event pair per conv launch, 2 = per 23-conv chain')
+  ap.add_argument('--cpu-seconds', type=float, default=24.0,
+                  help='cpu_baseline: seconds of CPU work for the samples (split '
+                  'over the implementations timed)')
+  ap.add_argument('--cpu-steps', type=int, default=100000)
+  ap.add_argument('--cpu-probe-steps', type=int, default=20)
+  ap.add_argument('--cpu-parity-steps', type=int, default=60,
+                  help='steps of the CPU runs the GPU replays (gpu_parity_leg)')
+  ap.add_argument('--cpu-box-seconds', type=float, default=10.0)
+  ap.add_argument('--no-cpu-whole-box', action='store_true')
+  ap.add_argument('--cpu-worker', type=int, default=None, help=argparse.SUPPRESS)
+  ap.add_argument('--cpu-workers', type=int, default=1, help=argparse.SUPPRESS)
+  ap.add_argument('--cpu-threads', type=int, default=1, help=argparse.SUPPRESS)
+  ap.add_argument('--cpu-impl', default='c_oracle', help=argparse.SUPPRESS)
+  ap.add_argument('--cpu-image', default='', help=argparse.SUPPRESS)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-full-volume', action='store_true',
+                  help='skip the complete segment_all pass (and its comparison '
+                  'with the reference-minted run) behind the K timed steps')
+  ap.add_argument('--no-assembly-check', action='store_true',
+                  help='--mode sharded: skip the (untimed) comparison of the '
+                  'assembled volume with the numpy specification')
+  ap.add_argument('--no-batched-leg', action='store_true',
+                  help='skip the time-boxed batched (configs[2]) leg of the '
+                  'default run')
+  ap.add_argument('--batched-max-steps', type=int, default=0)
+  ap.add_argument('--batched-timeout', type=float, default=420.0)
+  ap.add_argument('--host-loop', choices=['native', 'python'], default='native',
+                  help='native: ffn_canvas_segment_at runs each segment\'s FoV '
+                  'loop inside the library; python: one ffn_canvas_step call '
+                  'per step from the interpreter')
+  return ap
+
+
+def main():
+  args = build_parser().parse_args()
+  configure(args)
+  if args.cpu_worker is not None:
+    cpu_worker(args)
+    return
+
+  rank, local_rank, world = _dist_env()
+  if world != args.gpus:
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+      _self_launch(args)  # does not return
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.'
+                     'distributed.run --nproc-per-node %d' %
+                     (args.gpus, world, args.gpus))
+
+  if args.mode == 'sharded':
+    run_sharded(args, rank, local_rank, world)
+    return
+  res = run_gpu(args, rank, local_rank, world)
+  if rank != 0:
+    return
+
+  out = stream_line(args, world, res)
   if world == 1 and not args.no_cpu_baseline:
     oracle_trace, out['cpu_baseline'] = cpu_baseline(args)
     try:

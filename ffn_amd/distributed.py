@@ -333,6 +333,31 @@ def _assembly_for(device, ops=None):
   return _HostAssembly(device, ops)
 
 
+def merge_collective_bytes(shape_zyx, boxes, world: int):
+  """What the two assembly collectives move, per GPU, for an int32 label volume
+  of `shape_zyx` cut into `boxes` (ring algorithms over xGMI):
+    all_reduce(MAX) of the zero-filled volume: 2 (N-1)/N x 4 V bytes sent (and as
+      many received) by EVERY rank, whatever it owns;
+    broadcast of the owned cores: every core crosses each ring link once --
+      (N-1)/N x 4 V in total over the job, i.e. each rank receives the cores it
+      does not own (~ (N-1)/N x 4 V) and sends on average 1/N of that.
+  -> {'volume_bytes', 'all_reduce_sent_per_gpu', 'broadcast_received_per_gpu',
+      'broadcast_sent_per_gpu_mean', 'ratio'}"""
+  vol = 4 * int(np.prod([int(v) for v in shape_zyx]))
+  core = 4 * sum(int(np.prod([h - l for l, h in zip(b.core_lo, b.core_hi)]))
+                 for b in boxes)
+  n = max(int(world), 1)
+  ar = 2.0 * (n - 1) / n * vol
+  bc_recv = (n - 1) / n * core
+  return {
+      'volume_bytes': vol,
+      'all_reduce_sent_per_gpu': int(ar),
+      'broadcast_received_per_gpu': int(bc_recv),
+      'broadcast_sent_per_gpu_mean': int(bc_recv / n) if n > 1 else 0,
+      'ratio': round(ar / (bc_recv / n), 1) if n > 1 and bc_recv else None,
+  }
+
+
 def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
                         device=None, assembly=None, keep_on_device=False,
                         num_boxes=None, collective='all_reduce',
@@ -590,7 +615,7 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
                    min_overlap_voxels: int = MIN_OVERLAP_VOXELS,
                    min_overlap_fraction: float = MIN_OVERLAP_FRACTION,
                    save: bool = True, deal: str = 'dynamic',
-                   collective: str = 'all_reduce', store=None, deal_job=None):
+                   collective: str = 'broadcast', store=None, deal_job=None):
   """Segments a whole bounding box on `world` GPUs (BASELINE configs C4 / C5).
 
   One process per GPU calls this with its rank.  The box is cut into
@@ -612,7 +637,9 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
       collective is issued)
     batch_size: sub-boxes advanced per engine call on one GPU
     deal: 'dynamic' or 'static'
-    collective: 'all_reduce' or 'broadcast' (see merge_segmentations)
+    collective: 'broadcast' (default: every sub-box core sent once by its owner)
+      or 'all_reduce' (north_star's wording: a zero-filled volume reduced with
+      MAX) -- same result; `merge_collective_bytes` prices both
     store: the job's torch.distributed store (default: the default group's)
     deal_job: tag of this job's counter in the store (default: the number of
       deals this process has made, the same on every rank that calls this the

@@ -411,7 +411,7 @@ def make_masks(blob, depth):
 
 
 def make_cells250(blob, depth, forward='oracle', variables=None, num_seeds=14,
-                  threads=None, tag=''):
+                  threads=None, tag='', volume_seed=1234):
   """BASELINE configs[1] at its full size: the 250^3 cells phantom of bench.py
   (synthetic.cells_volume seed 1234), the first row of the bench's seed grid
   (14 seeds, 5 of which start a segment) -> 3,658 FoV steps through the
@@ -420,7 +420,7 @@ def make_cells250(blob, depth, forward='oracle', variables=None, num_seeds=14,
   import hashlib
   import time
   shape = (250, 250, 250)
-  vol = synthetic.cells_volume(shape, seed=1234)
+  vol = synthetic.cells_volume(shape, seed=volume_seed)  # (1234: bench.py's volume)
   image = synthetic.normalize(vol)
   seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))
   if num_seeds > 0:  # 14 = the first row of the grid; 0 = the WHOLE volume
@@ -459,6 +459,7 @@ def make_cells250(blob, depth, forward='oracle', variables=None, num_seeds=14,
   np.savez_compressed(
       os.path.join(GOLD, 'ref_canvas_cells250%s.npz' % suffix),
       forward=forward, volume_sha256=hashlib.sha256(vol.tobytes()).hexdigest(), seeds=seeds,
+      volume_seed=volume_seed,
       segmentation=seg.astype(np.int8 if seg.max() < 128 else np.int16),
       steps=steps, n_moves=n_moves, num_seeds=len(seeds),
       move_scores=move_scores, move_coords=move_coords,
@@ -484,6 +485,8 @@ def main():
                   '0 = all of them: the whole volume)')
   ap.add_argument('--threads', type=int, default=0)
   ap.add_argument('--tag', default='', help='cells250: file-name suffix')
+  ap.add_argument('--volume-seed', type=int, default=1234,
+                  help="cells250: seed of the synthetic phantom (1234 = bench.py's)")
   args = ap.parse_args()
   os.makedirs(GOLD, exist_ok=True)
   if args.only in ('', 'weights'):
@@ -514,7 +517,7 @@ def main():
   if args.only == 'cells250':  # slow: only on request
     v = tf_checkpoint.load_checkpoint(CKPT)
     make_cells250(ffn_oracle.weights_blob(v, 12), 12, args.forward, v,
-                  args.num_seeds, args.threads or None, args.tag)
+                  args.num_seeds, args.threads or None, args.tag, args.volume_seed)
 
 
 if __name__ == '__main__':

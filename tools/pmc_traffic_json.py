@@ -32,6 +32,10 @@ def main():
   ap.add_argument('--depth', type=int, default=12)
   ap.add_argument('--fov', type=int, nargs=3, default=[33, 33, 33])
   ap.add_argument('--command', default='')
+  ap.add_argument('--commit', default='', help='git revision of the tree the capture ran on')
+  ap.add_argument('--sq-csv', default='', help='counter dump of an SQ pass '
+                  '(SQ_VALU_MFMA_BUSY_CYCLES ...): per-launch means go into the JSON')
+  ap.add_argument('--script', default='tools/gpu_profile_r5.sh')
   args = ap.parse_args()
   fetch = per_kernel(args.fetch_csv, 'FETCH_SIZE')
   write = per_kernel(args.write_csv, 'WRITE_SIZE')
@@ -55,7 +59,8 @@ def main():
   stack = [k for k in kernels if 'conv32ps' in k]
   out = {
       'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, '
-                '--kernel-trace only; tools/gpu_profile_r4.sh; ' + args.command,
+                '--kernel-trace only; %s; %s' % (args.script, args.command),
+      'commit': args.commit or None,
       'units': 'KiB per dispatch; fetched bytes = 2 x FETCH_SIZE x 1024 on gfx950 '
                '(MI355X_MICROARCH.md, HBM section)',
       'conv_variant': 9,
@@ -73,6 +78,14 @@ def main():
     out['algorithmic_bytes_per_launch'] = int(algorithmic_stack)
     out['traffic_over_algorithmic'] = round(
         out['traffic_bytes_per_launch'] / algorithmic_stack, 3)
+  if args.sq_csv and stack:
+    # matrix-pipe occupancy of the stack kernel: busy cycles summed over the SIMDs
+    sq = collections.defaultdict(list)
+    for r in csv.DictReader(open(args.sq_csv)):
+      if r['Kernel_Name'].split('(')[0] == stack[0]:
+        sq[r['Counter_Name']].append(float(r['Counter_Value']))
+    out['sq_per_launch'] = {c: round(sum(v) / len(v), 1) for c, v in sorted(sq.items())}
+    out['sq_dispatches'] = len(next(iter(sq.values()))) if sq else 0
   with open(args.out_json, 'w') as f:
     json.dump(out, f, indent=1)
   print(json.dumps({k: out.get(k) for k in (
