@@ -697,6 +697,8 @@ def run_sharded(args, rank, local_rank, world):
   t_seg = time.perf_counter() - t0
   steps = run.counters['update_at-calls'].value
   voxels = run.counters['voxels-segmented'].value
+  if args.sharded_deal == 'dynamic':
+    dealer.check_complete()
   conv_variant = eng.get_option('conv_variant')  # after the run: what it used
   step_calls = eng.get_option('stat_step_calls')
   step_items = eng.get_option('stat_step_items')

@@ -1873,6 +1873,12 @@ int ffn_engine_set_pred_size(ffn_engine* e, const int32_t pred_zyx[3]) {
     if (d[a] > pred_zyx[a] / 2)
       return fail(FFN_ERR_ARG, "delta %d beyond the prediction's half size %d (axis %d)",
                   d[a], pred_zyx[a] / 2, a);
+    // the reference pastes into [start + delta, end - delta) with delta = (seed -
+    // pred) // 2 (inference.py:218,410-411): an odd difference gives it a box of
+    // pred + 1 voxels and a shape mismatch -- not a geometry it can run
+    if ((f[a] - pred_zyx[a]) % 2 != 0)
+      return fail(FFN_ERR_ARG, "seed size %d - pred size %d is odd (axis %d): the "
+                  "prediction cannot be centred in the seed FoV", f[a], pred_zyx[a], a);
   }
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));

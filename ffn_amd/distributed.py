@@ -118,14 +118,19 @@ class BoxDealer:
 
   Iterating yields the SubBox objects this rank was dealt; `taken` keeps them.
 
-  Every deal of a process has its OWN counter in the store: `key` + '/' + the
-  number of dealers this process has made before (every rank makes its dealers
-  in the same order, one per job), so a second job over the same process group
-  starts at zero instead of at the first job's final count.  `job`: an
-  explicit tag instead (any value all ranks agree on).
-  """
+  Every deal of a process group has its OWN counter in the store: `key` + '/' +
+  a job number that rank 0 draws from a second counter in the store and
+  broadcasts (one small collective per deal: every rank of the job constructs
+  its dealer, as it must anyway to be dealt anything), so a second job over the
+  same process group -- or a process that restarts against a store that is
+  still alive -- starts at zero instead of at an earlier job's final count, and
+  dealers that only SOME ranks construct (a local tiling with world == 1, a rank
+  that takes deal='static' once) cannot shift the ranks' keys apart.  `job`: an
+  explicit tag instead (any value all ranks agree on; no collective then).
 
-  _made = 0  # dealers constructed by this process
+  `check_complete()` (collective, after the job): every box was taken exactly
+  once over all ranks, else RuntimeError.
+  """
 
   def __init__(self, boxes: Sequence[SubBox], rank: int = 0, world: int = 1,
                store=None, key: str = 'ffn_amd/next_box', cost=None, job=None):
@@ -135,13 +140,49 @@ class BoxDealer:
     self.order = sorted(boxes, key=lambda b: -cost(b))
     self.rank, self.world = rank, world
     self.taken: List[SubBox] = []
-    self._key = '%s/%s' % (key, BoxDealer._made if job is None else job)
-    BoxDealer._made += 1
     self._store = store
     self._local = 0
     if world > 1 and store is None:
       import torch.distributed as dist  # pylint:disable=g-import-not-at-top
       self._store = dist.distributed_c10d._get_default_store()
+    if world > 1 and job is None:
+      job = self._draw_job(key)
+    self._key = '%s/%s' % (key, job)
+
+  def _draw_job(self, key: str) -> int:
+    """A job number all ranks agree on: rank 0 takes the next value of the
+    store's '<key>/jobs' counter, the others receive it."""
+    import torch  # pylint:disable=g-import-not-at-top
+    import torch.distributed as dist  # pylint:disable=g-import-not-at-top
+    n = int(self._store.add(key + '/jobs', 1)) if self.rank == 0 else 0
+    if dist.is_initialized() and dist.get_world_size() == self.world:
+      dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+      t = torch.tensor([n], dtype=torch.int64, device=dev)
+      dist.broadcast(t, src=0)
+      return int(t.item())
+    # no process group of this size (a bare store): rank 0 publishes the number
+    tag = key + '/job_of_round/%d' % int(self._store.add(key + '/round/%d' % self.rank, 1))
+    if self.rank == 0:
+      self._store.set(tag, str(n))
+      return n
+    return int(self._store.get(tag))
+
+  def check_complete(self):
+    """Collective over the job's ranks: every box of the deal was taken exactly
+    once (a rank that used another key would have been dealt every box)."""
+    if self.world == 1:
+      n = len(self.taken)
+    else:
+      import torch  # pylint:disable=g-import-not-at-top
+      import torch.distributed as dist  # pylint:disable=g-import-not-at-top
+      dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+      t = torch.tensor([len(self.taken)], dtype=torch.int64, device=dev)
+      dist.all_reduce(t)
+      n = int(t.item())
+    if n != len(self.order):
+      raise RuntimeError('BoxDealer: %d sub-boxes were taken over all ranks, the job '
+                         'has %d (did every rank deal from the same key %r?)'
+                         % (n, len(self.order), self._key))
 
   def _next_index(self) -> int:
     if self.world > 1:
@@ -641,9 +682,8 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
       or 'all_reduce' (north_star's wording: a zero-filled volume reduced with
       MAX) -- same result; `merge_collective_bytes` prices both
     store: the job's torch.distributed store (default: the default group's)
-    deal_job: tag of this job's counter in the store (default: the number of
-      deals this process has made, the same on every rank that calls this the
-      same number of times)
+    deal_job: tag of this job's counter in the store (default: a number rank 0
+      draws from the store and broadcasts, see BoxDealer)
 
   Returns:
     (global int32 label volume of shape size_zyx -- identical on every rank --,
@@ -680,6 +720,8 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
   runner.run_many(subvolumes(), batch_size=batch_size, save=save,
                   on_done=collect)
   t_seg = time.perf_counter() - t0
+  if deal == 'dynamic':
+    dealer.check_complete()  # (collective) every sub-box was dealt exactly once
   for b, r in zip(mine, results):
     if r is None:
       raise RuntimeError('sub-box %r was skipped (output exists / masked); '

@@ -162,6 +162,11 @@ class HipEngine:
       raise ValueError('seed and image sizes must be equal for the conv stack')
     if np.any(np.asarray(info.pred_mask_size) > np.asarray(info.input_seed_size)):
       raise ValueError('pred_mask_size exceeds input_seed_size')
+    if np.any((np.asarray(info.input_seed_size) - np.asarray(info.pred_mask_size)) % 2):
+      # the reference's update_at (inference.py:218,410-411) would build a box of
+      # pred + 1 voxels and fail on the shape: not a geometry it can run
+      raise ValueError('input_seed_size - pred_mask_size must be even on every axis: '
+                       'the prediction is centred in the seed FoV')
     eng = cls(tuple(int(v) for v in info.input_seed_size[::-1]),
               tuple(int(v) for v in info.deltas[::-1]), model.depth,
               model.features, max_batch, device_id)

@@ -564,10 +564,12 @@ class Canvas:
             **aux)
     self.log_info('Inference checkpoint saved.')
 
+  def _checkpoint_due(self) -> bool:
+    return (self.checkpoint_path is not None and self.checkpoint_interval_sec > 0 and
+            time.time() - self.checkpoint_last >= self.checkpoint_interval_sec)
+
   def _maybe_save_checkpoint(self, partial_segment_iters=0):
-    if self.checkpoint_path is None or self.checkpoint_interval_sec <= 0:
-      return
-    if time.time() - self.checkpoint_last < self.checkpoint_interval_sec:
+    if not self._checkpoint_due():
       return
     with Canvas.io_lock:
       self.save_checkpoint(self.checkpoint_path,
@@ -780,12 +782,14 @@ class DeviceCanvas(Canvas):
             not self.keep_probability_maps and
             getattr(self.restrictor, 'is_trivial', self.restrictor is None))
       self._turn_static = ok
-    # (a timed checkpoint is taken BETWEEN the loop's questions, of a canvas the
-    # turn has already moved past them: no turn while one is nearly due -- the
-    # answers of a turn are used up within milliseconds)
-    far = (self.checkpoint_path is None or self.checkpoint_interval_sec <= 0 or
-           time.time() - self.checkpoint_last < self.checkpoint_interval_sec - 2.0)
-    return (ok and far and self.TURN_CANDIDATES > 0 and
+    # A timed checkpoint is taken BETWEEN the loop's questions, and a turn moves
+    # the canvas past them (the next seed initialised, too-close seeds marked).
+    # So: no turn while a checkpoint is DUE -- the loop then asks its questions
+    # one by one and the checkpoint sees the state the reference would save --
+    # and no checkpoint while a turn's answers are still being used up
+    # (`_maybe_save_checkpoint` below: it waits for the next opportunity, where
+    # this test keeps the turn from running).
+    return (ok and not self._checkpoint_due() and self.TURN_CANDIDATES > 0 and
             getattr(self.is_valid_pos, '__func__', None)
             is DeviceCanvas.is_valid_pos)
 
@@ -814,13 +818,21 @@ class DeviceCanvas(Canvas):
               tuple(int(v) for v in coords[idx - 1]) == first):
         return [first]
       idx -= 1
-    out = []
+    out, listed = [], set()
     for c in np.asarray(coords[idx:idx + self.TURN_CANDIDATES]).tolist():
       c = (int(c[0]), int(c[1]), int(c[2]))
-      if not self._in_bounds(c):
+      # (a policy that lists a seed twice: the turn's record answers by
+      # coordinate, so the list ends in front of the repeat)
+      if not self._in_bounds(c) or c in listed:
         break
+      listed.add(c)
       out.append(c)
     return out
+
+  def _maybe_save_checkpoint(self, partial_segment_iters=0):
+    if self.__dict__.get('_turn_rec') is not None:
+      return  # (became due after the turn was made: taken at the next opportunity)
+    super()._maybe_save_checkpoint(partial_segment_iters)
 
   def _turn(self, commit, mark, first=None):
     """One device-side turn; what it found out is kept for the seed loop's next
@@ -840,8 +852,11 @@ class DeviceCanvas(Canvas):
         break
       seen[c] = f
       self._cache[c] = (float(cseed[k]), -1 if f == 2 else int(cseg[k]))
+    # the -1 marker was written in mode 1 always, in mode 2 (commit) only when
+    # the segment was NOT committed (ffn_canvas_segment_turn)
+    marked = mark is not None and (mark[1] == 1 or not out[4])
     self._turn_rec = {
-        'mark': tuple(int(v) for v in mark[0]) if mark is not None else None,
+        'mark': tuple(int(v) for v in mark[0]) if marked else None,
         'seen': seen,
         'init': cands[chosen] if chosen >= 0 and init is not None else None}
     self._turn_armed = True

@@ -105,3 +105,20 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
     assert int(out[name]) == ctypes.sizeof(cls), name
     for f in fields:
       assert int(out['%s.%s' % (name, f)]) == getattr(cls, f).offset, (name, f)
+
+
+def test_from_model_refuses_a_prediction_that_cannot_be_centred():
+  """(seed - pred) odd on an axis is not a geometry the reference can
+  run (inference.py:218,410-411); refused before any device is touched."""
+  import pytest
+  from ffn_amd import engine as hip_engine
+  from ffn_amd.training import model as model_lib
+
+  class _Odd:
+    info = model_lib.ModelInfo(deltas=(8, 8, 8), pred_mask_size=(28, 33, 33),
+                               input_seed_size=(33, 33, 33),
+                               input_image_size=(33, 33, 33))
+    depth, features = 12, 32
+
+  with pytest.raises(ValueError, match='even'):
+    hip_engine.HipEngine.from_model(_Odd(), max_batch=1)

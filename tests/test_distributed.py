@@ -146,6 +146,8 @@ def _deal_worker(rank, world, port, tmpdir, mode):
   busy_until = time.perf_counter() - t0
   dist.barrier()
   makespan = time.perf_counter() - t0
+  if mode != 'static':
+    dealer.check_complete()
   out = {}
   for coll in ('all_reduce', 'broadcast'):
     asm = ffn_dist._assembly_for('cpu')
@@ -261,21 +263,30 @@ class _FakeStore:
     self.values[key] = self.values.get(key, 0) + amount
     return self.values[key]
 
+  def set(self, key, value):
+    self.values[key] = value
+
+  def get(self, key):
+    return self.values[key]
+
 
 def test_box_dealer_second_job_starts_from_zero():
   """the dealer's counter in the store used one fixed key, so a
   second job over the same process group was dealt nothing (and the assembly
-  returned zeros).  Every deal now counts under its own key."""
+  returned zeros).  ADVICE r4: the per-job key came from a process-global count
+  of dealers, which dealers made by only SOME ranks shifted apart.  Every deal
+  now counts under a job number rank 0 draws from the store itself."""
+  import pytest
   from ffn_amd import distributed as ffn_dist
   boxes = ffn_dist.tile_volume((64, 64, 96), (40, 40, 40), (8, 8, 8))
   store = _FakeStore()
   # two ranks of a world-2 job, simulated in turn: each makes one dealer per job
-  made = ffn_dist.BoxDealer._made
   for job in range(3):
-    ffn_dist.BoxDealer._made = made + job
+    # a dealer only ONE "rank" makes in between (a local tiling) changes nothing
+    assert len(list(ffn_dist.BoxDealer(boxes[:2]))) == 2
     a = ffn_dist.BoxDealer(boxes, 0, 2, store=store)
-    ffn_dist.BoxDealer._made = made + job
     b = ffn_dist.BoxDealer(boxes, 1, 2, store=store)
+    assert a._key == b._key
     got = []
     for k in range(len(boxes) + 2):
       try:
@@ -288,6 +299,13 @@ def test_box_dealer_second_job_starts_from_zero():
   assert len(list(a)) == len(boxes)
   b = ffn_dist.BoxDealer(boxes, 1, 2, store=store, job='again')
   assert len(list(b)) == 0
+  # one process: the completeness check counts what was taken
+  c = ffn_dist.BoxDealer(boxes)
+  next(c)
+  with pytest.raises(RuntimeError, match='sub-boxes were taken'):
+    c.check_complete()
+  list(c)
+  c.check_complete()
 
 
 def test_merge_reports_a_sub_box_nobody_holds():

@@ -170,3 +170,17 @@ def test_non_default_inference_options_on_the_gpu(fib25_model, name):
   canvas.close()
   assert exe.engine.range_fallbacks == 0 and exe.engine.flow_fallbacks == 0
   exe.engine.close()
+
+
+def test_pred_size_must_centre_in_the_seed_fov(fib25_model):
+  """(seed - pred) odd on an axis is a geometry the reference cannot
+  run (update_at builds [start + delta, end - delta) with delta = (seed - pred)
+  // 2: pred + 1 voxels, a shape mismatch); the library refuses it instead of
+  floor-centring."""
+  from ffn_amd import _lib
+  from ffn_amd import engine as hip_engine
+  eng = hip_engine.HipEngine.from_model(fib25_model, max_batch=1)
+  eng.set_pred_size((25, 27, 29))
+  with pytest.raises(_lib.FFNHipError, match='odd'):
+    eng.set_pred_size((25, 26, 29))
+  eng.close()

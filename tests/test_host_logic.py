@@ -292,6 +292,31 @@ def test_segment_turn_and_timed_checkpoints(monkeypatch, tmp_path):
   assert runs[1e-6][1] == 0 and runs[1e-6][2]
   assert np.array_equal(runs[1800.0][0], runs[1e-6][0])
   assert len(np.unique(runs[1800.0][0])) >= 3
+  # The guard is deterministic in both directions: a checkpoint that
+  # becomes due while a turn's answers are still in use waits for the next
+  # opportunity, and the seed policy may list a seed twice.
+  path = str(tmp_path / 'cp_due.npz')
+  client = EmulatedDeviceClient(inference_utils.Counters(), None, 12, (33, 33, 33),
+                                (8, 8, 8))
+  canvas = inference.make_canvas(info, client, image, r.inference_options,
+                                 movement_policy_fn=movement.get_policy_fn(r, info),
+                                 checkpoint_path=path, checkpoint_interval_sec=1800.0)
+  saves = []
+  monkeypatch.setattr(type(canvas), 'save_checkpoint',
+                      lambda self, p, **kw: saves.append(self._turn_rec))
+  inner = canvas._turn
+
+  def turn_then_due(*a, **kw):  # the interval runs out right behind a turn
+    out = inner(*a, **kw)
+    canvas.checkpoint_last = -1e9
+    return out
+
+  canvas._turn = turn_then_due
+  doubled = np.concatenate([grid[:40], grid[30:]])
+  canvas.segment_all(seed_policy=functools.partial(seed_lib.PolicyFixed,
+                                                   coords=doubled))
+  assert canvas.turns > 0 and saves and all(rec is None for rec in saves)
+  assert np.array_equal(np.asarray(canvas.segmentation), runs[1800.0][0])
 
 
 def test_keep_history_host_and_device_canvas_agree(fib25_blob):
