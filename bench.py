@@ -965,12 +965,21 @@ def cpu_worker(args):
   """`bench.py --cpu-worker K`: one of the P concurrent oracle processes of the
   whole-box CPU figure (cpu_baseline).  Its own canvas over the same volume, its
   own part of the seed grid; prints {"steps", "seconds"}."""
+  k, p = args.cpu_worker, args.cpu_workers
+  # this worker's own cores (the thread pools of P processes would otherwise all
+  # start on the same first cores)
+  try:
+    cores = sorted(os.sched_getaffinity(0))
+    mine = cores[k * args.cpu_threads:(k + 1) * args.cpu_threads]
+    if len(mine) == args.cpu_threads:
+      os.sched_setaffinity(0, mine)
+  except (AttributeError, OSError):
+    pass
   from oracle import ffn_oracle
   variables = model_variables()
   blob = ffn_oracle.weights_blob(variables, DEPTH)
   image = np.load(args.cpu_image, mmap_mode='r')
   seeds = ffn_oracle.grid_seeds(VOLUME_ZYX, tuple(f // 2 for f in FOV))
-  k, p = args.cpu_worker, args.cpu_workers
   first = (len(seeds) * k) // p
   seeds = np.concatenate([seeds[first:], seeds[:first]])
   _, steps, dt, _ = _cpu_run(np.asarray(image), blob, variables, seeds, args.cpu_impl,
@@ -1011,8 +1020,10 @@ def cpu_baseline(args):
     # thread count: probes of >= 20 FoV steps each (4-step probes mostly time the
     # thread pool's spin-up)
     best_thr, best_rate = None, 0.0
-    for thr in sorted({ncpu, max(ncpu // 2, 1), min(64, ncpu), min(32, ncpu),
-                       min(16, ncpu), min(8, ncpu)}, reverse=True):
+    # (a 33^3 FoV does not feed more than a few dozen threads: 128 and 256 ran
+    # at 1/5 and 1/300 of the 16-thread rate on the round's 256-core boxes)
+    for thr in sorted({min(64, ncpu), min(32, ncpu), min(16, ncpu), min(8, ncpu)},
+                      reverse=True):
       rate, n, _, _ = _cpu_run(image, blob, variables, seeds, impl, thr, 4.0,
                                args.cpu_probe_steps)
       probes.setdefault(impl, {})[str(thr)] = [round(rate, 2), n]

@@ -1,0 +1,109 @@
+// conv32ps: the conv stack of a single-FoV step as ONE resident launch (engine option flow = 2).
+// (part of ffn_kernels.h: included from there, in this order, inside no namespace)
+#pragma once
+
+namespace ffn {
+
+// ---------------------------------------------------------------------------
+// conv32ps: the whole conv stack of ONE FoV as a single resident launch.
+//
+// conv32mt's workgroups (256 main chunks, one per CU, + the 32-voxel tail
+// workgroups on the CUs' second slots: all resident at once) keep their voxels
+// through all 2 depth - 1 convs; between two convs stands, instead of a kernel
+// boundary, the FLOW hand-off above: a workgroup starts conv l + 1 as soon as
+// the tiles ITS rows come from have been published by conv l.  Each conv's body
+// is the plain kernel's (same instructions, same summation order: same bits);
+// what changes per conv -- the two activation buffers taking turns, the weights
+// and bias of the layer, the sequence numbers -- is derived from the layer
+// index.  conv 0 (conv0_b) sits behind the boundary after conv0_a and waits for
+// nothing; the last conv carries the fused head and publishes nothing (the
+// faces / paste launch behind it is an ordinary dependent launch).
+// ---------------------------------------------------------------------------
+// (compile-time switch for same-box A/B builds: tools/build_variant.sh)
+#ifndef FFN_PS_RES
+#define FFN_PS_RES 1
+#endif
+constexpr bool kPsRes = FFN_PS_RES != 0;
+
+struct ConvStackTab {
+  int nlayers;            // 2 depth - 1
+  int l_begin, l_end;     // the convs of THIS launch ([0, nlayers) unless debugging)
+  int dbg_layer;          // the conv whose clock stamps are recorded (ConvDArgs::L.dbg)
+  const char* sp_t;       // T' (position 0 of plane 0): read by even convs, written by odd
+  char* sp_s;             // X': written by even convs, read by odd
+  const char* wpack0;     // layer 0's weight fragments ...
+  long wpack_stride;      // ... bytes per layer
+  const float* bias0;
+  long bias_stride;       // floats per layer
+  unsigned epoch0;        // conv l publishes epoch0 + l + 1 and waits for epoch0 + l
+};
+
+__global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
+                                                                ConvTailMap mp,
+                                                                ConvStackTab tb) {
+  const int xcd = blockIdx.x & 7;
+  const int r0 = blockIdx.x >> 3;
+  const bool main_wg = r0 < mp.mains_per_xcd;
+  const int r = main_wg ? r0 : r0 - mp.mains_per_xcd;
+  const int c = xcd * (main_wg ? mp.mains_per_xcd : mp.tails_per_xcd) + r;
+  if (c >= (main_wg ? mp.n_main : mp.n_tail)) return;
+  const long long t0 = a.dbg_wgs ? wall_clock64() : 0;
+  const int v0 = main_wg ? c * kMChunk : mp.n_main * kMChunk + c * 32;
+  const int gc = main_wg ? c : mp.n_main + c;
+  ConvLayer Ldbg = a.L;
+  // (experiment, flow_dbg 1024: the main workgroups' waves ahead of the tail's in
+  // the CU's arbitration -- a main workgroup that shares its CU with a tail one
+  // is what its neighbours wait for)
+  if (kExp && (a.flow_dbg & 1024)) {
+    if (main_wg) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+  // the residual stream of a main workgroup's voxels (conv32m_body: RES); the
+  // tail workgroups keep theirs in memory (their head epilogue has another
+  // thread-to-voxel mapping than their conv epilogue)
+  f32x4 xres[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) xres[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int l = tb.l_begin; l < tb.l_end; ++l) {
+    ConvLayer L;
+    L.in_sp = (l & 1) ? tb.sp_s : tb.sp_t;
+    L.out_sp = (l & 1) ? const_cast<char*>(tb.sp_t) : tb.sp_s;
+    L.wpack = tb.wpack0 + (long)l * tb.wpack_stride;
+    L.bias = tb.bias0 + (long)l * tb.bias_stride;
+    L.dbg = l == tb.dbg_layer ? a.L.dbg : nullptr;
+    L.flow_wait = tb.epoch0 + (unsigned)l;
+    L.flow_set = tb.epoch0 + (unsigned)l + 1u;
+    L.flow_wait_on = l > tb.l_begin;
+    L.layer = l;
+    if (L.dbg) Ldbg = L;
+    const bool last = l == tb.nlayers - 1;
+    if (main_wg) {
+      const bool dbg_here = blockIdx.x == 0 && a.dbg_wgs != 2;
+      if (l == 0)
+        conv32m_body<1, false, false, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
+      else if (last)
+        conv32m_body<1, true, true, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
+      else if (l & 1)
+        conv32m_body<0, false, false, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
+      else
+        conv32m_body<1, true, false, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
+    } else {
+      const bool dbg_here = c == 0 && a.dbg_wgs == 2;
+      if (l == 0)
+        conv32d_body<1, false, kTPieces, false, 1, kTRows, 2, true>(a, L, 0, v0, gc,
+                                                                    mp.taoff, dbg_here);
+      else if (last)
+        conv32d_body<1, true, kTPieces, true, 1, kTRows, 2, true>(a, L, 0, v0, gc,
+                                                                  mp.taoff, dbg_here);
+      else if (l & 1)
+        conv32d_body<0, false, kTPieces, false, 1, kTRows, 2, true>(a, L, 0, v0, gc,
+                                                                    mp.taoff, dbg_here);
+      else
+        conv32d_body<1, true, kTPieces, false, 1, kTRows, 2, true>(a, L, 0, v0, gc,
+                                                                   mp.taoff, dbg_here);
+    }
+  }
+  stamp_workgroup(a, Ldbg, t0);
+}
+
+}  // namespace ffn

@@ -141,7 +141,7 @@ struct ffn_engine {
   bool t_ok = false;
   bool t_now = false;
   int tail_batched = 0;  // option: steps with >= 2 FoVs take the tail form too
-  // FLOW (ffn_kernels.h "flagged launches"): 0 off; 1 conv32mt's launches with
+  // FLOW (ffn_conv_split.h "flagged launches"): 0 off; 1 conv32mt's launches with
   // the flagged hand-off compiled in (still one dependent launch per conv: the
   // words are always there already -- isolates the cost of the sc1 reads and
   // the poll); 2 the resident stack, conv32ps: ONE launch for the 2 depth - 1 convs
@@ -901,7 +901,7 @@ void launch_conv0a(ffn_engine* e, int n, const StepItems& si, float pad_value,
 }
 
 // The 2 depth - 1 convs of ONE FoV as a single resident launch (conv32ps,
-// ffn_kernels.h): conv32mt's workgroups keep their voxels through the stack and
+// ffn_conv_resident.h): conv32mt's workgroups keep their voxels through the stack and
 // hand rows to each other through the tile words instead of kernel boundaries.
 int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr) {
   HeadFusion hf;

@@ -129,7 +129,7 @@ def test_predict_is_deterministic_and_variants_agree(engine):
     ([33, 33, 33], [8, 8, 8], 12), ([41, 41, 21], [10, 10, 5], 5),
     ([35, 33, 31], [8, 8, 7], 3), ([49, 49, 25], [12, 12, 6], 3)])
 def test_resident_stack_same_bits_as_per_layer_launches(fov_xyz, deltas_xyz, depth):
-  """Engine option flow (ffn_kernels.h, conv32ps): a single-FoV step of conv32mt
+  """Engine option flow (ffn_conv_resident.h, conv32ps): a single-FoV step of conv32mt
   runs its 2 depth - 1 convs as ONE resident launch whose workgroups hand rows
   to each other through per-producer sequence words (flow 2, the default), as
   one launch per conv with the same hand-off compiled in (1), or as plain
