@@ -734,7 +734,10 @@ def run_sharded(args, rank, local_rank, world):
     except OSError:
       pass
   check = None
-  if world == 1 and not args.no_assembly_check:
+  if world == 1 and not args.no_assembly_check and args.assembly_check_stride > 1:
+    check = sampled_assembly_check(held, offsets, merged, edges, shape,
+                                   args.assembly_check_stride)
+  elif world == 1 and not args.no_assembly_check:
     # checker leg (untimed): the assembly against its numpy specification
     t_check = time.perf_counter()
     from oracle import labels_oracle
@@ -771,6 +774,84 @@ def run_sharded(args, rank, local_rank, world):
            driver_segments_ended=run.last_driver.segments_ended,
            merge_bytes=merge_bytes)
   print(json.dumps(sharded_line(args, world, totals, m)))
+
+
+def sampled_assembly_check(held, offsets, merged, edges, shape, stride):
+  """Checker leg for volumes too large for the whole-volume comparison (configs[4]
+  at 256 x 2048 x 2048: the numpy specification would sort a billion voxel pairs):
+  the id offsets of EVERY sub-box, and for every `stride`-th sub-box (by index)
+  (a) the merge edges its margin contributes -- oracle/labels_oracle.margin_edges
+  on the volume assembled from all cores, against the device's edges that start
+  in that sub-box's id range -- and (b) the final labels of its core: its own
+  labels + offset, relabelled through the oracle's union-find over the (device's)
+  edge list, against the device's volume.  held: [(SubBox, device labels)] in
+  this rank's order, offsets: the device's, same order."""
+  from oracle import labels_oracle
+  t0 = time.perf_counter()
+  order = sorted(range(len(held)), key=lambda j: held[j][0].index)
+  to_host = lambda a: a.cpu().numpy() if hasattr(a, 'cpu') else np.asarray(a)
+  host = {held[j][0].index: to_host(held[j][1]) for j in order}
+  boxes = {held[j][0].index: held[j][0] for j in order}
+  n = len(order)
+  maxes = [int(host[i].max()) if host[i].size else 0 for i in range(n)]
+  want_off = np.concatenate([[0], np.cumsum(maxes)])[:-1]
+  offsets_equal = all(int(offsets[j]) == int(want_off[held[j][0].index]) for j in order)
+  # the volume as assembled from the cores (ids in the global space, no merges yet)
+  plain = np.zeros(tuple(shape), np.int32)
+  for i in range(n):
+    b, seg = boxes[i], host[i]
+    lo = [c - k for c, k in zip(b.core_lo, b.corner)]
+    hi = [c - k for c, k in zip(b.core_hi, b.corner)]
+    core = seg[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+    plain[b.core_lo[0]:b.core_hi[0], b.core_lo[1]:b.core_hi[1],
+          b.core_lo[2]:b.core_hi[2]] = np.where(core > 0, core + int(want_off[i]), 0)
+  uf = labels_oracle.UnionFind()
+  for x, y, _ in sorted(map(tuple, np.asarray(edges).tolist())):
+    uf.union(int(x), int(y))
+  roots = {x: uf.find(x) for x in list(uf.parent)}
+  keys = np.array(sorted(k for k, v in roots.items() if k != v), np.uint64)
+  vals = np.array([roots[int(k)] for k in keys], np.uint64)
+  got = to_host(merged)
+  edges = np.asarray(edges, np.int64).reshape(-1, 3)
+  sampled = list(range(0, n, stride))
+  edges_equal = volume_equal = True
+  edges_checked = voxels_checked = 0
+  for i in sampled:
+    b, seg = boxes[i], host[i]
+    shifted = np.where(seg > 0, seg.astype(np.int64) + int(want_off[i]), 0)
+    sel = tuple(slice(c, c + k) for c, k in zip(b.corner, b.size))
+    lo = [c - k for c, k in zip(b.core_lo, b.corner)]
+    hi = [c - k for c, k in zip(b.core_hi, b.corner)]
+    want_e = labels_oracle.margin_edges(shifted, plain[sel], lo, hi,
+                                        ffn_dist_min_overlap()[0], ffn_dist_min_overlap()[1])
+    mine = edges[(edges[:, 0] > want_off[i]) & (edges[:, 0] <= want_off[i] + maxes[i])]
+    mine = mine[np.lexsort((mine[:, 2], mine[:, 1], mine[:, 0]))]
+    edges_equal = edges_equal and bool(np.array_equal(mine, want_e))
+    edges_checked += len(want_e)
+    core = (slice(b.core_lo[0], b.core_hi[0]), slice(b.core_lo[1], b.core_hi[1]),
+            slice(b.core_lo[2], b.core_hi[2]))
+    want_core = labels_oracle.remap(plain[core], keys, vals, keep_missing=True)
+    volume_equal = volume_equal and bool(np.array_equal(got[core], want_core))
+    voxels_checked += int(want_core.size)
+  return {
+      'sampled': True, 'stride': stride, 'sub_boxes': n, 'sub_boxes_checked': len(sampled),
+      'offsets_equal': bool(offsets_equal),
+      'edges_equal': bool(edges_equal), 'edges_checked': int(edges_checked),
+      'edges_total': int(len(edges)),
+      'volume_equal': bool(volume_equal), 'voxels_checked': int(voxels_checked),
+      'voxels_labelled': int((got > 0).sum()),
+      'what': 'id offsets of every sub-box; for every %d-th sub-box (by index): the merge '
+              'edges of its margin (oracle/labels_oracle.margin_edges on the volume '
+              'assembled from all cores) against the device\'s edges from its id range, '
+              'and the final labels of its core (own labels + offset, relabelled by the '
+              'oracle\'s union-find over the edge list) against the device\'s volume'
+              % stride,
+      'seconds': round(time.perf_counter() - t0, 1)}
+
+
+def ffn_dist_min_overlap():
+  from ffn_amd import distributed as ffn_dist
+  return ffn_dist.MIN_OVERLAP_VOXELS, ffn_dist.MIN_OVERLAP_FRACTION
 
 
 def sharded_totals(comm, steps, voxels, busy_seconds, n_boxes):
@@ -1559,6 +1640,11 @@ def build_parser():
   ap.add_argument('--no-full-volume', action='store_true',
                   help='skip the complete segment_all pass (and its comparison '
                   'with the reference-minted run) behind the K timed steps')
+  ap.add_argument('--assembly-check-stride', type=int, default=1,
+                  help='--mode sharded: 1 = the whole assembled volume against the '
+                  'numpy specification; k > 1 = every k-th sub-box (its margin\'s '
+                  'merge edges and its core\'s final labels) + every id offset -- for '
+                  'volumes of a billion voxels')
   ap.add_argument('--no-assembly-check', action='store_true',
                   help='--mode sharded: skip the (untimed) comparison of the '
                   'assembled volume with the numpy specification')

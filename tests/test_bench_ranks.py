@@ -230,3 +230,58 @@ def test_sharded_mode_rank_aggregation(tmp_path):
   assert cb['all_reduce_sent_per_gpu'] == vol_bytes          # 2 (N-1)/N V at N = 2
   assert cb['broadcast_received_per_gpu'] == vol_bytes // 2  # cores partition the volume
   assert cb['ratio'] == 4.0
+
+
+def test_sampled_assembly_check_agrees_with_the_whole_volume_check():
+  """bench.py --assembly-check-stride k (configs[4] at its stated size): the
+  sampled checker accepts what the whole-volume specification accepts, and sees
+  a wrong offset, a missing edge and a wrong voxel."""
+  import bench
+  from scipy import ndimage
+  from ffn_amd import distributed as ffn_dist
+  from oracle import labels_oracle
+  shape = (40, 72, 88)
+  rng = np.random.RandomState(3)
+  gt, _ = ndimage.label(ndimage.gaussian_filter(rng.rand(*shape), 2.0) > 0.5)
+  boxes = ffn_dist.tile_volume(shape, (40, 40, 40), (12, 12, 12), back_shift=True)
+  results = []
+  for b in boxes:
+    sel = tuple(slice(c, c + n) for c, n in zip(b.corner, b.size))
+    local = gt[sel]
+    ids = np.unique(local[local > 0])
+    lut = np.zeros(int(gt.max()) + 1, np.int32)
+    lut[ids] = rng.permutation(len(ids)) + 1  # ids local to the sub-box
+    results.append((b, lut[local]))
+  asm = ffn_dist._assembly_for('cpu')
+  asm.job_boxes = boxes
+  merged, offsets, held, _ = ffn_dist.merge_segmentations(
+      results, shape, 0, 1, 'cpu', assembly=asm, keep_on_device=True,
+      num_boxes=len(boxes))
+  merged, offsets, edges, _ = ffn_dist.reconcile_segmentations(
+      results, shape, 0, 1, 'cpu', keep_on_device=True, assembly=asm,
+      num_boxes=len(boxes))
+  assert len(edges) > 3
+  want, want_edges, _ = labels_oracle.reconcile(
+      sorted(results, key=lambda r: r[0].index), shape, ffn_dist.MIN_OVERLAP_VOXELS,
+      ffn_dist.MIN_OVERLAP_FRACTION)
+  assert np.array_equal(np.asarray(merged), want) and np.array_equal(edges, want_edges)
+  for stride in (1, 2, 3):
+    c = bench.sampled_assembly_check(held, offsets, merged, edges, shape, stride)
+    assert c['offsets_equal'] and c['edges_equal'] and c['volume_equal'], (stride, c)
+    assert c['sub_boxes_checked'] == len(range(0, len(boxes), stride))
+  assert c['edges_checked'] < bench.sampled_assembly_check(
+      held, offsets, merged, edges, shape, 1)['edges_checked'] == len(edges)
+  bad_off = list(offsets)
+  bad_off[1] += 1
+  assert not bench.sampled_assembly_check(held, bad_off, merged, edges, shape, 2)[
+      'offsets_equal']
+  first_box_edges = np.nonzero(edges[:, 0] <= int(np.asarray(held[0][1]).max()))[0]
+  assert len(first_box_edges)
+  assert not bench.sampled_assembly_check(
+      held, offsets, merged, np.delete(edges, first_box_edges[0], axis=0), shape, 2)[
+          'edges_equal']
+  wrong = np.array(np.asarray(merged))
+  b0 = boxes[0]
+  wrong[b0.core_lo[0], b0.core_lo[1], b0.core_lo[2]] += 1
+  assert not bench.sampled_assembly_check(held, offsets, wrong, edges, shape, 2)[
+      'volume_equal']
