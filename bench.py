@@ -257,8 +257,12 @@ def load_model():
   return model
 
 
-FULL_FIXTURE = os.path.join(ROOT, 'tests', 'golden',
-                            'ref_canvas_cells250_onednn_full.npz')
+def full_fixture(workload_seed):
+  """The reference-minted run of the WHOLE 250^3 phantom of this seed (tools/
+  make_golden.py --only cells250 --forward onednn --num-seeds 0 [--volume-seed S])."""
+  tag = '' if workload_seed == 1234 else '_s%d' % workload_seed
+  return os.path.join(ROOT, 'tests', 'golden',
+                      'ref_canvas_cells250_onednn_full%s.npz' % tag)
 
 
 def full_volume_pass(args, comm, model, exe, request, image, barrier):
@@ -276,9 +280,10 @@ def full_volume_pass(args, comm, model, exe, request, image, barrier):
   from ffn_amd.inference import seed as seed_lib
   eng = exe.engine
   fixture = None
+  fixture_path = full_fixture(args.workload_seed)
   if (CONFIG == 'c1' and args.workload == 'cells' and
-      tuple(VOLUME_ZYX) == (250, 250, 250) and os.path.exists(FULL_FIXTURE)):
-    fixture = np.load(FULL_FIXTURE)
+      tuple(VOLUME_ZYX) == (250, 250, 250) and os.path.exists(fixture_path)):
+    fixture = np.load(fixture_path)
   if fixture is not None:  # the grid of the fixture = every valid seed position
     policy = functools.partial(seed_lib.PolicyFixed, coords=fixture['seeds'])
   else:
@@ -333,8 +338,8 @@ def full_volume_pass(args, comm, model, exe, request, image, barrier):
     n = min(len(seen), len(ref_steps))
     first_bad = next((k for k in range(n) if seen[k] != ref_steps[k]), None)
     out['vs_reference_run'] = {
-        'fixture': 'tests/golden/ref_canvas_cells250_onednn_full.npz (the '
-                   'reference\'s Canvas behind the torch-CPU / oneDNN f32 forward)',
+        'fixture': '%s (the reference\'s Canvas behind the torch-CPU / oneDNN f32 '
+                   'forward)' % os.path.relpath(fixture_path, ROOT),
         'iou': round(inter / max(union, 1), 6),
         'reference_steps': len(ref_steps),
         'reference_objects': len(json.loads(str(fixture['origins']))),
@@ -384,7 +389,7 @@ def run_gpu(args, rank, local_rank, world):
 
   shape = VOLUME_ZYX
   if args.workload == 'cells':
-    vol = bench_volume(shape, 1234 + rank)
+    vol = bench_volume(shape, args.workload_seed + rank)
   else:
     vol = synthetic.noise_volume(shape, seed=rank)
   image = synthetic.normalize(vol)
@@ -1082,7 +1087,7 @@ def cpu_baseline(args):
   blob = ffn_oracle.weights_blob(variables, DEPTH)
   shape = VOLUME_ZYX
   if args.workload == 'cells':
-    vol = bench_volume(shape, 1234)
+    vol = bench_volume(shape, args.workload_seed)
   else:
     vol = synthetic.noise_volume(shape, seed=0)
   image = synthetic.normalize(vol)
@@ -1459,9 +1464,9 @@ def stream_line(args, world, res):
       'config': {
           'workload': (
               'configs[1] single-seed single-GPU: depth=12 fov=33^3 '
-              'deltas=8, synthetic %s %d^3 uint8 volume per GPU, '
+              'deltas=8, synthetic %s %d^3 uint8 volume per GPU (seed %d), '
               'FIB-25 weights, device-resident canvas, batch 1'
-              % (args.workload, args.volume) if CONFIG == 'c1' else
+              % (args.workload, args.volume, args.workload_seed) if CONFIG == 'c1' else
               'configs[4] model on one tile: depth=18 fov zyx %s deltas %s, '
               'synthetic %s %s uint8 volume per GPU, constructed flood-fill weights '
               '(synthetic.flood_fill_weights: no checkpoint of this shape exists), '
@@ -1614,6 +1619,9 @@ def build_parser():
                   help='c1: BASELINE configs[1] (the headline); c5: the depth-18 '
                   'anisotropic model of configs[4], random weights')
   ap.add_argument('--workload', choices=['cells', 'noise'], default='cells')
+  ap.add_argument('--workload-seed', type=int, default=1234,
+                  help='seed of the synthetic cells phantom (rank r: seed + r); 1234 '
+                  'and 4321 have a reference-minted whole-volume run to compare with')
   ap.add_argument('--conv-variant', type=int, default=None)
   ap.add_argument('--engine-option', action='append', default=[],
                   metavar='NAME=VALUE', help='ffn_engine_set_option switch '

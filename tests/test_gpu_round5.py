@@ -184,3 +184,40 @@ def test_pred_size_must_centre_in_the_seed_fov(fib25_model):
   with pytest.raises(_lib.FFNHipError, match='odd'):
     eng.set_pred_size((25, 26, 29))
   eng.close()
+
+
+def test_second_whole_volume(hip_exe, fib25_model):  # noqa: F811
+  """A SECOND 250^3 phantom (seed 4321; round 4's review: one volume, one seed,
+  IoU 0.999107 against a bar of 0.999) through the reference's own Canvas behind
+  the torch-CPU / oneDNN f32 forward (tools/make_golden.py --only cells250
+  --forward onednn --num-seeds 0 --volume-seed 4321 --tag _full_s4321) against
+  the default GPU path: labelled IoU >= 0.999 and a long identical prefix of FoV
+  positions, as for the first volume
+  (test_cells250_whole_volume_against_reference_minted_run)."""
+  import json
+  from ffn_amd import synthetic
+  from tests.test_gpu_round2 import _run_recorded
+  path = os.path.join(GOLDEN, 'ref_canvas_cells250_onednn_full_s4321.npz')
+  if not os.path.exists(path):
+    pytest.skip('fixture not minted')
+  g = np.load(path)
+  assert int(g['volume_seed']) == 4321
+  vol = synthetic.cells_volume((250, 250, 250), seed=4321)
+  _assert_shipped_default(hip_exe.engine)
+  canvas = _device_canvas(hip_exe, fib25_model, synthetic.normalize(vol))
+  got_steps, _ = _run_recorded(canvas, g['seeds'])
+  want_steps = [tuple(int(v) for v in p) for p in g['steps']]
+  n = min(len(got_steps), len(want_steps))
+  first_bad = next((k for k in range(n) if got_steps[k] != want_steps[k]), n)
+  seg = np.asarray(canvas.segmentation)
+  want = g['segmentation'].astype(np.int32)
+  inter = np.sum((seg > 0) & (want > 0) & (seg == want))
+  union = np.sum((seg > 0) | (want > 0))
+  iou = inter / max(union, 1)
+  print('second volume: %d steps (reference %d), positions identical for the first '
+        '%d, labelled IoU %.6f, objects %d (reference %d)' % (
+            len(got_steps), len(want_steps), first_bad, iou, len(canvas.origins),
+            len(json.loads(str(g['origins'])))))
+  canvas.close()
+  assert iou >= 0.999, (iou, first_bad)
+  assert first_bad >= 1000, first_bad
