@@ -1073,6 +1073,31 @@ def cpu_worker(args):
   print(json.dumps({'steps': steps, 'seconds': dt}))
 
 
+def usable_cpus():
+  """Cores this process may actually run on: the affinity mask and the cgroup's
+  CPU quota, not os.cpu_count() (a container on a 256-thread host may own 16)."""
+  n = os.cpu_count() or 1
+  try:
+    n = min(n, len(os.sched_getaffinity(0)))
+  except (AttributeError, OSError):
+    pass
+  for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+    try:
+      with open(path) as f:
+        parts = f.read().split()
+      if path.endswith('cpu.max'):
+        if parts[0] != 'max':
+          n = min(n, max(int(int(parts[0]) / int(parts[1])), 1))
+      else:
+        quota = int(parts[0])
+        if quota > 0:
+          with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+            n = min(n, max(quota // int(f.read()), 1))
+    except (OSError, ValueError, IndexError):
+      pass
+  return n
+
+
 def cpu_baseline(args):
   """Oracle port on a bounded sample of the same workload, on this host's cores.
 
@@ -1092,7 +1117,7 @@ def cpu_baseline(args):
     vol = synthetic.noise_volume(shape, seed=0)
   image = synthetic.normalize(vol)
   seeds = ffn_oracle.grid_seeds(shape, tuple(f // 2 for f in FOV))
-  ncpu = os.cpu_count() or 1
+  ncpu = usable_cpus()
 
   results, oracle_trace = {}, {}
   impls = ['c_oracle']
@@ -1129,6 +1154,13 @@ def cpu_baseline(args):
   # cores" deliver on this workload when none of them idles.
   whole = None
   procs = max(ncpu // max(thr, 1), 1)
+  if procs <= 1:
+    whole = {'value': round(rate, 3), 'unit': 'FoV-steps/s', 'processes': 1,
+             'threads_each': int(thr), 'cores': int(thr),
+             'what': 'this process may run on %d of the host\'s %d logical CPUs '
+                     '(affinity mask / cgroup quota): the %d-thread sample above IS '
+                     'the whole box as far as this job can use it'
+                     % (ncpu, os.cpu_count() or 1, thr)}
   if procs > 1 and not args.no_cpu_whole_box:
     import subprocess
     import tempfile
@@ -1168,7 +1200,8 @@ def cpu_baseline(args):
       'value': round(rate, 3),
       'unit': 'FoV-steps/s',
       'cores': int(thr),
-      'host_cores': ncpu,
+      'host_cores': os.cpu_count() or 1,
+      'usable_cores': ncpu,
       'kind': 'port',
       'implementation': name,
       'all': {k: round(v[0], 3) for k, v in results.items()},

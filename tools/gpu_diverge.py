@@ -44,7 +44,9 @@ def main():
   print('fixture ref_canvas_cells250%s.npz: %d FoV steps, %d seeds, forward %s, '
         'minted in %.0f s' % (args.fixture, len(g['steps']), len(g['seeds']),
                               str(g['forward']), float(g['mint_wall_seconds'])))
-  vol = synthetic.cells_volume((250, 250, 250), seed=1234)
+  vol_seed = int(g['volume_seed']) if 'volume_seed' in g.files else 1234
+  vol = synthetic.cells_volume((250, 250, 250), seed=vol_seed)
+  print('volume: cells 250^3, seed %d' % vol_seed)
   want_steps = [tuple(int(v) for v in p) for p in g['steps']]
   want_moves, off = [], 0
   for nm in g['n_moves']:
