@@ -361,7 +361,7 @@ def _many_canvases(shim, blob, names, **kwargs):
 
 
 @pytest.mark.parametrize('fail_round,carry,fail_code', [
-    (None, True, _lib.ERR_RANGE), (37, True, _lib.ERR_RANGE), (37, True, _lib.ERR_FLOW),
+    (None, True, _lib.ERR_RANGE), (37, True, _lib.ERR_FLOW),
     ('short', False, _lib.ERR_RANGE), ('short', 'deferred', _lib.ERR_FLOW)])
 def test_segment_many_reproduces_reference_runs(shim, fib25_blob, fail_round, carry,
                                                 fail_code):
@@ -523,8 +523,8 @@ def test_segment_many_two_groups_in_two_threads(shim, fib25_blob):
   assert max(engine.batch_sizes) <= 2
 
 
-@pytest.mark.parametrize('name,native', [('nodisco', True), ('disco30', False),
-                                         ('mbd3', True), ('seg08_probmap', True)])
+@pytest.mark.parametrize('name,native', [('nodisco', True), ('mbd3', False),
+                                         ('seg08_probmap', True)])
 def test_non_default_inference_options(shim, fib25_blob, name, native):
   """InferenceOptions away from the sample configuration (disco bias off /
   needing a fraction of active voxels, min_boundary_dist > 1, other segment
