@@ -265,6 +265,42 @@ def full_fixture(workload_seed):
                       'ref_canvas_cells250_onednn_full%s.npz' % tag)
 
 
+def segmentation_agreement(seg, want):
+  """Three views of how two label volumes agree.  `iou_labelled`: voxels carrying
+  the SAME id in both / voxels labelled in either -- the strictest, and void as
+  soon as the two runs number their objects apart (one object more or less shifts
+  every later id).  `iou_foreground`: labelled in both / labelled in either.
+  `iou_best_match`: every reference object against the object of `seg` that covers
+  most of it, weighted by the reference object's size (id-agnostic)."""
+  seg = np.asarray(seg)
+  want = np.asarray(want).astype(np.int32)
+  both = (seg > 0) & (want > 0)
+  union = int(np.sum((seg > 0) | (want > 0)))
+  inter = int(np.sum(both & (seg == want)))
+  size_w = np.bincount(want[want > 0].ravel())
+  size_g = np.bincount(seg[seg > 0].ravel())
+  keys, cnt = np.unique(want[both].astype(np.int64) * (1 << 32) +
+                        seg[both].astype(np.int64), return_counts=True)
+  best = {}
+  for kk, c in zip(keys.tolist(), cnt.tolist()):
+    w, gid = kk >> 32, kk & 0xffffffff
+    iou = c / float(size_w[w] + size_g[gid] - c)
+    if iou > best.get(w, 0.0):
+      best[w] = iou
+  ref_ids = np.nonzero(size_w)[0]
+  matched = sum(best.get(int(w), 0.0) * size_w[w] for w in ref_ids) / max(
+      float(size_w.sum()), 1.0)
+  return {
+      'iou_labelled': round(inter / max(union, 1), 6),
+      'iou_foreground': round(int(both.sum()) / max(union, 1), 6),
+      'iou_best_match': round(float(matched), 6),
+      'objects': int(np.count_nonzero(size_g)),
+      'reference_objects': int(len(ref_ids)),
+      'objects_matched_at_0999': int(sum(1 for w in ref_ids
+                                         if best.get(int(w), 0.0) >= 0.999)),
+  }
+
+
 def full_volume_pass(args, comm, model, exe, request, image, barrier):
   """BASELINE.json's metric on a COMPLETE pass: `Canvas.segment_all` over every
   grid seed of this rank's volume (reference inference.py:538-683; 24 k FoV
@@ -316,9 +352,7 @@ def full_volume_pass(args, comm, model, exe, request, image, barrier):
   seg = np.array(np.asarray(canvas.segmentation))
   canvas.close()
   if fixture is not None and comm.rank == 0:
-    want = fixture['segmentation'].astype(np.int32)
-    inter = int(np.sum((seg > 0) & (want > 0) & (seg == want)))
-    union = int(np.sum((seg > 0) | (want > 0)))
+    agree = segmentation_agreement(seg, fixture['segmentation'])
     ref_steps = [tuple(int(v) for v in p) for p in fixture['steps']]
     # untimed: the same pass with the positions kept
     canvas = make(inference_utils.Counters(), keep_history=True)
@@ -340,7 +374,14 @@ def full_volume_pass(args, comm, model, exe, request, image, barrier):
     out['vs_reference_run'] = {
         'fixture': '%s (the reference\'s Canvas behind the torch-CPU / oneDNN f32 '
                    'forward)' % os.path.relpath(fixture_path, ROOT),
-        'iou': round(inter / max(union, 1), 6),
+        'iou': agree['iou_labelled'],
+        'iou_what': 'same id in both / labelled in either (ids must agree); '
+                    'iou_foreground and iou_best_match (per reference object, '
+                    'size-weighted) do not depend on the numbering',
+        'iou_foreground': agree['iou_foreground'],
+        'iou_best_match': agree['iou_best_match'],
+        'objects': agree['objects'],
+        'objects_matched_at_0999': agree['objects_matched_at_0999'],
         'reference_steps': len(ref_steps),
         'reference_objects': len(json.loads(str(fixture['origins']))),
         'first_position_mismatch': first_bad,

