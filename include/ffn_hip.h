@@ -388,11 +388,26 @@ int ffn_engine_set_pred_size(ffn_engine* engine, const int32_t pred_zyx[3]);
  * Canvas.is_valid_pos on the pasted canvas; the host makes the same choice from
  * the step result and then queues the rest of the step behind it; a step whose
  * launch chose otherwise pastes nothing and is made again).  "fuse_paste"
- * (default 1): faces and paste of a single-FoV step as one launch.  Neither
- * changes any result. */
+ * (default 1): faces and paste of a single-FoV step as one launch; "fuse_conv0a"
+ * (default 1): ... and the next step's conv0_a in it as well.  None changes any
+ * result.
+ * "flow": how the 2 depth - 1 convs of a single-FoV step of conv_variant 9 run:
+ *   0 = one dependent launch per conv, 1 = the same launches with the flagged
+ *   hand-off compiled in, 2 = ONE resident launch whose workgroups hand rows to
+ *   each other (conv32ps) -- bit-identical in every mode.  2 is the default where
+ *   the device can hold all of the launch's workgroups at once (checked at
+ *   ffn_engine_create: compute units x occupancy >= grid; else 0, and setting 2
+ *   is FFN_ERR_ARG).  A resident launch that times out waiting for one of its
+ *   own workgroups voids its step with FFN_ERR_FLOW (see above); after three such
+ *   steps in a row the engine sets "flow" = 0 itself ("flow_auto_off" reads 1;
+ *   setting "flow" again re-arms).  "flow_debug" 2048: fault injection for
+ *   tests (a producer stops publishing); its other bits and "debug_clock" 4 act
+ *   only in -DFFN_EXPERIMENTS=1 builds. */
 int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
 /* Current value of an option ("conv_variant", "exact_variant", "fuse_head",
- * "store_policy", "sync_mode", "profile_every", "speculate", "fuse_paste"), or
+ * "store_policy", "sync_mode", "profile_every", "speculate", "fuse_paste",
+ * "fuse_conv0a", "flow", "flow_auto_off"), "stat_flow_timeouts" (polls of the
+ * resident launch that gave up, ever) / "stat_flow_voids" (steps voided by one), or
  * a statistic of the step calls since set_option("stat_reset", 0):
  * "stat_step_calls", "stat_step_items" (FoVs in them), "stat_hist_<n>" (calls
  * with n FoVs), "stat_spec_launched" / "stat_spec_hits" / "stat_spec_mismatch"
