@@ -265,6 +265,32 @@ def full_fixture(workload_seed):
                       'ref_canvas_cells250_onednn_full%s.npz' % tag)
 
 
+def sample_shader_clock(eng, batch=1):
+  """The shader clock the chip holds under this engine's conv stack, in GHz: the
+  in-kernel cycle counter against the 100 MHz wall clock over one conv body of
+  workgroup 0 (engine option debug_clock 1; a burst of resident stacks on whatever
+  FoVs the engine last saw -- timing only).  The dense MFMA peak is quoted at the
+  2.4 GHz boost clock (256 CUs x 4 SIMDs x 1,024 flop/clk); boxes of one pool hold
+  1.85 - 2.1 GHz under a single FoV and ~1.45 GHz under batched steps, which is
+  most of why identical code measures +- 6 % from box to box.  None on failure."""
+  try:
+    eng.set_option('debug_layer', 3)
+    eng.set_option('debug_clock', 1)
+    eng.forward_resident(batch, 12)
+    eng.synchronize()
+    c = eng.debug_clocks().astype(np.float64)
+    ghz = [(c[w, 3] - c[w, 0]) / ((c[w, 5] - c[w, 4]) * 10.0)
+           for w in range(4) if c[w, 5] > c[w, 4] and c[w, 3] > c[w, 0]]
+    return round(float(np.median(ghz)), 3) if ghz else None
+  except Exception:  # pylint:disable=broad-except
+    return None
+  finally:
+    try:
+      eng.set_option('debug_clock', 0)
+    except Exception:  # pylint:disable=broad-except
+      pass
+
+
 def segmentation_agreement(seg, want):
   """Three views of how two label volumes agree.  `iou_labelled`: voxels carrying
   the SAME id in both / voxels labelled in either -- the strictest, and void as
@@ -581,6 +607,7 @@ def run_gpu(args, rank, local_rank, world):
   except Exception as e:  # pylint:disable=broad-except
     print('merge skipped: %r' % (e,), file=sys.stderr)
   canvas._flush_hot()
+  shader_ghz = sample_shader_clock(eng, 1)
   cvals = {k: c.value for k, c in counters}
   cvals['gate_rejects'] = canvas.gate_rejects
   full_volume = None
@@ -588,6 +615,7 @@ def run_gpu(args, rank, local_rank, world):
     full_volume = full_volume_pass(args, comm, model, exe, request, image, barrier)
   result = {
       'full_volume': full_volume,
+      'shader_clock_ghz': shader_ghz,
       'merge_ms': merge_ms,
       'merged_ids': merged_ids,
       'counters': cvals,
@@ -726,6 +754,7 @@ def run_sharded(args, rank, local_rank, world):
 
   stack_us_run_weights = time_stack()
   stack_us = stack_us_run_weights
+  batched_ghz = sample_shader_clock(eng, args.sharded_batch)
   if CONFIG != 'c1':  # (dense_random_blob: why)
     eng.set_weights(dense_random_blob())
     stack_us = time_stack()
@@ -818,7 +847,7 @@ def run_sharded(args, rank, local_rank, world):
            driver_calls=run.last_driver.calls,
            driver_library_seconds=run.last_driver.library_seconds,
            driver_segments_ended=run.last_driver.segments_ended,
-           merge_bytes=merge_bytes)
+           merge_bytes=merge_bytes, batched_ghz=batched_ghz)
   print(json.dumps(sharded_line(args, world, totals, m)))
 
 
@@ -1007,6 +1036,10 @@ def sharded_line(args, world, totals, m):
           'peak': round(batched_peak, 1),
           'unit': 'TFLOP/s',
           'frac': round(batched_tflops / batched_peak, 4),
+          'shader_clock_ghz': m.get('batched_ghz'),
+          'frac_of_peak_at_that_clock': (
+              round(batched_tflops / (batched_peak * m['batched_ghz'] / 2.4), 4)
+              if m.get('batched_ghz') else None),
           'timing': 'wall clock over %d resident stacks of %d FoVs (conv0_a + '
                     '%d conv launches each): achieved = batch x %.2f GFLOP (all of '
                     'a step\'s flops) / stack time; us_per_fov_launch = stack / '
@@ -1613,6 +1646,12 @@ def stream_line(args, world, res):
           'mfma_busy': (round(pmc_busy_cycles / (1024 * mean_ms * 1e-3 * 2.1e9), 4)
                         if pmc_busy_cycles and mean_ms and resident else None),
           'mfma_busy_cycles_per_launch': pmc_busy_cycles,
+          # the clock this box held under the kernel (sample_shader_clock): the peak
+          # above is at the 2.4 GHz boost clock
+          'shader_clock_ghz': res.get('shader_clock_ghz'),
+          'frac_of_peak_at_that_clock': (
+              round(achieved / (peak * res['shader_clock_ghz'] / 2.4), 4)
+              if res.get('shader_clock_ghz') else None),
           'launch_kernel': ('conv32ps_kernel' if resident else
                             'conv32mt_kernel' if variant == 9 else 'conv32*_kernel'),
           'launches_per_step': 1 if resident else n_convs,
