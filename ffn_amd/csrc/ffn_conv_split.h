@@ -144,7 +144,7 @@ __device__ __forceinline__ void stamp_workgroup(const ConvDArgs& a, const ConvLa
 }
 
 // ---------------------------------------------------------------------------
-// Flagged launches (FLOW; DESIGN.md section 3.9): the conv chain of a single
+// Flagged launches (FLOW; DESIGN.md section 3.3): the conv chain of a single
 // FoV without its kernel boundaries.
 //
 // A dependent launch costs 1.7 us of boundary + 0.3 of start-up + ~1 us of

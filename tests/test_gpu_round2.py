@@ -730,7 +730,7 @@ def test_speculative_conv0a_leaves_the_run_unchanged(hip_exe, fib25_model):
 
 def test_speculative_conv0a_permuted_layout():
   """The same on BASELINE configs[4]'s FoV (zyx 21 x 41 x 41: the split-product
-  kernels lay it out with permuted axes, DESIGN.md section 3.7): a flood through a
+  kernels lay it out with permuted axes, DESIGN.md section 2): a flood through a
   40 x 90 x 96 canvas (random weights, a move threshold below the pad value, so
   every face queues a move), speculation on and off."""
   from ffn_amd import synthetic

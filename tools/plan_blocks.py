@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Work-sheet for DESIGN.md §3.1: what 3-D output blocks would stage per
+"""Work-sheet of round 1 (3-D output-block splits, then DESIGN.md §3.1): what 3-D output blocks would stage per
 workgroup, against today's dense 144-voxel runs, for a given FoV.
 
 For every split of the FoV into nz x ny x nx near-equal boxes it prints the
