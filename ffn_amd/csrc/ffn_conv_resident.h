@@ -79,23 +79,25 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
     const bool last = l == tb.nlayers - 1;
     if (main_wg) {
       const bool dbg_here = blockIdx.x == 0 && a.dbg_wgs != 2;
-      if (l == 0)
+      if (l == 0 && !(kAbl & 512))
         conv32m_body<1, false, false, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
-      else if (last)
+      else if (last && !(kAbl & 512))
         conv32m_body<1, true, true, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
-      else if (l & 1)
+      else if ((l & 1) && !(kAbl & 256))  // (256: ONE code body for every middle conv;
+        // 512: every conv of the stack -- timing only: how much of a layer is
+        // instruction delivery when odd and even convs run different code?)
         conv32m_body<0, false, false, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
       else
         conv32m_body<1, true, false, true, kPsRes>(a, L, 0, v0, gc, dbg_here, xres);
     } else {
       const bool dbg_here = c == 0 && a.dbg_wgs == 2;
-      if (l == 0)
+      if (l == 0 && !(kAbl & 512))
         conv32d_body<1, false, kTPieces, false, 1, kTRows, 2, true>(a, L, 0, v0, gc,
                                                                     mp.taoff, dbg_here);
-      else if (last)
+      else if (last && !(kAbl & 512))
         conv32d_body<1, true, kTPieces, true, 1, kTRows, 2, true>(a, L, 0, v0, gc,
                                                                   mp.taoff, dbg_here);
-      else if (l & 1)
+      else if ((l & 1) && !(kAbl & 256))
         conv32d_body<0, false, kTPieces, false, 1, kTRows, 2, true>(a, L, 0, v0, gc,
                                                                     mp.taoff, dbg_here);
       else

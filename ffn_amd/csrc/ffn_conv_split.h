@@ -189,7 +189,8 @@ constexpr int kFlowFaultBit = 2048;
 // piece costs is read off tools/gpu_flow_trace.py.  Bits: 1 publish without the
 // drain of the stores; 2 main bodies without the per-tap barriers; 4 without the
 // weight ring's DMAs inside the tap loop; 8 without the LDS fragment reads inside
-// it; 64 no dz = +1 DMA; 128 main bodies wait for nobody.  (Round 5's table:
+// it; 64 no dz = +1 DMA; 128 main bodies wait for nobody; 256 / 512 one code body for
+// the middle / for all convs of the stack (ffn_conv_resident.h).  (Round 5's table:
 // profiles/r05_ablation_resident_stack.txt.)
 #ifndef FFN_ABLATE
 #define FFN_ABLATE 0

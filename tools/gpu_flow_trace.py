@@ -80,6 +80,25 @@ def main():
     print('%2d | %6.2f %6.2f %6.2f | %6.2f %6.2f %6.2f | %s | %s' %
           (l, np.nanmin(e0), np.nanmedian(e0), np.nanmax(e0), np.nanmin(e5),
            np.nanmedian(e5), np.nanmax(e5), phases(main), phases(tail)))
+  # by region of the FoV: the bottom / middle / top main chunks and the tail tiles
+  # (the FoV's last voxels): who runs at which period, and where its time goes
+  print('region           | period | wait / stage / taps / epilogue+drain (median over layers 2..%d)'
+        % (nl - 2))
+  for name, rows in (('main   0 -  31', slice(0, 32)), ('main  96 - 127', slice(96, 128)),
+                     ('main 192 - 223', slice(192, 224)), ('main 224 - 255', slice(224, 256)),
+                     ('main 240 - 255', slice(240, 256)), ('tail   0 -  49', slice(256, 306)),
+                     ('tail  50 -  99', slice(306, 356))):
+    x = tr[rows, 2:nl - 1, :]
+    per_r = np.nanmedian(np.diff(tr[rows, 1:nl - 1, 0], axis=1))
+    d = np.diff(x, axis=2)
+    print('%s |  %5.2f | %s' % (name, per_r, ' / '.join(
+        '%5.2f' % np.nanmedian(d[:, :, k]) for k in range(4))))
+  gap = tr[:256, 2:nl - 1, 0] - tr[:256, 1:nl - 2, 5]  # published (conv l) -> entry (conv l + 1)
+  body = tr[:256, 1:nl - 2, 5] - tr[:256, 1:nl - 2, 0]
+  print('main workgroups, per workgroup and layer: entry -> published median %.2f; published -> '
+        'next entry median %.2f (10 %% %.2f, 90 %% %.2f); their sum = the period'
+        % (np.nanmedian(body), np.nanmedian(gap), np.nanpercentile(gap, 10),
+           np.nanpercentile(gap, 90)))
   per = np.diff(np.nanmedian(tr[:256, :, 0], axis=0))
   print('median entry-to-entry period of the main workgroups, per layer: %s; mean %.2f us'
         % (' '.join('%.2f' % v for v in per), per[1:].mean()))
