@@ -472,6 +472,40 @@ def make_cells250(blob, depth, forward='oracle', variables=None, num_seeds=14,
         % wall, 'counters', keep)
 
 
+def make_phantoms(blob, depth, variables, vol_seeds, size, threads):
+  """An ENSEMBLE of whole-volume runs: `size`^3 cells phantoms of several seeds, every
+  grid seed, through the reference's Canvas behind the torch-CPU / oneDNN f32
+  forward (the configuration of the 250^3 whole-volume fixtures, at a size that
+  takes minutes instead of an hour).  What it is for: how OFTEN two correct
+  implementations of the forward leave each other's trajectory on this kind of
+  volume, and what the segmentations then still share (tests/test_gpu_round5.py::
+  test_phantom_ensemble, profiles/r05_phantom_ensemble.txt)."""
+  import functools
+  import time
+  out = {'vol_seeds': np.array(vol_seeds, np.int32), 'size': np.int32(size)}
+  shape = (size,) * 3
+  forward_fn = functools.partial(ffn_oracle.forward_torch, variables=variables,
+                                 depth=depth, threads=threads)
+  for vs in vol_seeds:
+    vol = synthetic.cells_volume(shape, seed=int(vs))
+    seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))
+    t0 = time.time()
+    canvas, trace, counters = run_reference_canvas(
+        synthetic.normalize(vol), blob, depth, (33, 33, 33), (8, 8, 8), seeds,
+        forward_fn=forward_fn)
+    seg = np.array(canvas.segmentation)
+    k = 's%d/' % vs
+    out[k + 'seeds'] = seeds.astype(np.int16)
+    out[k + 'steps'] = np.array([t[0] for t in trace], np.int16).reshape(-1, 3)
+    out[k + 'segmentation'] = seg.astype(np.int8 if seg.max() < 128 else np.int16)
+    out[k + 'objects'] = np.int32(len(canvas.origins))
+    out[k + 'voxels'] = np.int64((seg > 0).sum())
+    print('phantom seed %d: %d steps, %d objects, %d voxels, %.0f s' % (
+        vs, len(trace), len(canvas.origins), int((seg > 0).sum()), time.time() - t0),
+          flush=True)
+  np.savez_compressed(os.path.join(GOLD, 'ref_canvas_phantoms%d.npz' % size), **out)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--only', default='')
@@ -485,6 +519,9 @@ def main():
                   '0 = all of them: the whole volume)')
   ap.add_argument('--threads', type=int, default=0)
   ap.add_argument('--tag', default='', help='cells250: file-name suffix')
+  ap.add_argument('--phantom-seeds', type=int, nargs='+',
+                  default=[101, 102, 103, 104, 105, 106])
+  ap.add_argument('--phantom-size', type=int, default=128)
   ap.add_argument('--volume-seed', type=int, default=1234,
                   help="cells250: seed of the synthetic phantom (1234 = bench.py's)")
   args = ap.parse_args()
@@ -514,6 +551,10 @@ def main():
   if args.only in ('', 'masks'):
     v = tf_checkpoint.load_checkpoint(CKPT)
     make_masks(ffn_oracle.weights_blob(v, 12), 12)
+  if args.only == 'phantoms':  # ~40 minutes: only on request
+    v = tf_checkpoint.load_checkpoint(CKPT)
+    make_phantoms(ffn_oracle.weights_blob(v, 12), 12, v, args.phantom_seeds,
+                  args.phantom_size, args.threads or 8)
   if args.only == 'cells250':  # slow: only on request
     v = tf_checkpoint.load_checkpoint(CKPT)
     make_cells250(ffn_oracle.weights_blob(v, 12), 12, args.forward, v,
