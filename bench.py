@@ -4,20 +4,30 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one full FoV step of the hot path on a device-resident canvas:
-gather -> conv0_a -> 23 x (3x3x3, 32->32) MFMA convs -> logit head -> disco ->
-paste-back -> 6-face argmax, plus the Python move-queue bookkeeping that picks
-the next position (Canvas.segment_all -> segment_at -> update_at).
+gather -> conv0_a -> 23 x (3x3x3, 32->32) convs on the matrix pipe -> logit head ->
+disco -> paste-back -> 6-face argmax, plus the move-queue bookkeeping that picks
+the next position (Canvas.segment_all -> segment_at -> update_at; the segment
+loop runs inside the library).
 
 Workload (BASELINE.json configs[1]): single seed stream on ONE synthetic 250^3
 uint8 volume per GPU, depth 12, FoV 33^3, deltas 8, FIB-25 weights
 (tests/golden/fib25_weights.npz), options of configs/inference_training_sample2.
 With N > 1 every rank owns an independent 250^3 volume (weak scaling, no
-data-path collective; one barrier-bracketed timed region, MAX over ranks).
+data-path collective; barrier-bracketed regions, MAX over ranks).
 
-Rank 0 prints ONE JSON line (see the contract in the task description) that also
-carries `roofline` (dominant kernel = conv32, exact-f32 MFMA, HIP-event timed on
-the engine's own stream) and, at N == 1, `cpu_baseline` (the oracle port timed
-on this host's cores over a bounded sample of the same workload).
+Rank 0 prints ONE JSON line:
+  value         update_at-calls / wall clock of one COMPLETE segment_all pass over
+                every rank's volume (`full_volume`; the metric's definition)
+  steady_state  exactly K steps after W warm-up steps, inside running segments
+                (the contract's timed region)
+  roofline      the resident conv stack (conv32ps): algorithmic flops / HIP-event
+                time of every timed step's launch against the fp16 MFMA peak / 3;
+                HBM traffic and matrix-pipe occupancy from the committed PMC
+                capture; the shader clock the box held
+  cpu_baseline  (N == 1) the oracle port on this host's usable cores, a bounded
+                sample of the same workload; its first steps replayed on the GPU
+                (parity_*)
+  batched       (N == 1) configs[2]: --mode sharded on a 512^3 volume, 32 canvases
 """
 
 import argparse
