@@ -64,17 +64,35 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
   f32x4 xres[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) xres[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // what changes from conv to conv, carried in registers from one to the next
+  // (rebuilt from the kernel arguments in every loop header it cost two scalar
+  // loads and their waits per conv; same bits either way)
+  const char* wp = tb.wpack0 + (long)tb.l_begin * tb.wpack_stride;
+  const float* bp = tb.bias0 + (long)tb.l_begin * tb.bias_stride;
+  const long wstride = tb.wpack_stride, bstride = tb.bias_stride;
+  unsigned epoch = tb.epoch0 + (unsigned)tb.l_begin;
+  const char* sp_in = (tb.l_begin & 1) ? tb.sp_s : tb.sp_t;
+  const char* sp_out = (tb.l_begin & 1) ? tb.sp_t : tb.sp_s;
+  const int l_first = tb.l_begin, l_dbg = tb.dbg_layer;
   for (int l = tb.l_begin; l < tb.l_end; ++l) {
     ConvLayer L;
-    L.in_sp = (l & 1) ? tb.sp_s : tb.sp_t;
-    L.out_sp = (l & 1) ? const_cast<char*>(tb.sp_t) : tb.sp_s;
-    L.wpack = tb.wpack0 + (long)l * tb.wpack_stride;
-    L.bias = tb.bias0 + (long)l * tb.bias_stride;
-    L.dbg = l == tb.dbg_layer ? a.L.dbg : nullptr;
-    L.flow_wait = tb.epoch0 + (unsigned)l;
-    L.flow_set = tb.epoch0 + (unsigned)l + 1u;
-    L.flow_wait_on = l > tb.l_begin;
+    L.in_sp = sp_in;    // T' for even convs, X' for odd ones ...
+    L.out_sp = const_cast<char*>(sp_out);  // ... and the other one written
+    L.wpack = wp;
+    L.bias = bp;
+    L.dbg = l == l_dbg ? a.L.dbg : nullptr;
+    L.flow_wait = epoch;
+    L.flow_set = epoch + 1u;
+    L.flow_wait_on = l > l_first;
     L.layer = l;
+    wp += wstride;
+    bp += bstride;
+    epoch += 1u;
+    {
+      const char* t = sp_in;
+      sp_in = sp_out;
+      sp_out = t;
+    }
     if (L.dbg) Ldbg = L;
     const bool last = l == tb.nlayers - 1;
     if (main_wg) {
