@@ -285,3 +285,40 @@ def test_sampled_assembly_check_agrees_with_the_whole_volume_check():
   wrong[b0.core_lo[0], b0.core_lo[1], b0.core_lo[2]] += 1
   assert not bench.sampled_assembly_check(held, offsets, wrong, edges, shape, 2)[
       'volume_equal']
+
+
+def test_self_launch_command(monkeypatch):
+  """`python bench.py --gpus N` outside torch.distributed.run re-executes itself
+  under it: one rank per GPU on this node, rendezvous on 127.0.0.1 (the container
+  hostname may not resolve), dmabuf IPC for RCCL.  (What runs behind the exec needs
+  GPUs; the command itself is checked here.)"""
+  import sys
+  import bench
+  seen = {}
+
+  def fake_execve(path, argv, env):
+    seen.update(path=path, argv=list(argv), env=dict(env))
+    raise SystemExit(0)
+
+  monkeypatch.setattr(os, 'execve', fake_execve)
+  monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '20',
+                                    '--warmup', '5'])
+  monkeypatch.delenv('WORLD_SIZE', raising=False)
+  monkeypatch.delenv('HSA_ENABLE_IPC_MODE_LEGACY', raising=False)
+  with pytest.raises(SystemExit):
+    bench.main()
+  argv = seen['argv']
+  assert seen['path'] == sys.executable and argv[:3] == [sys.executable, '-m',
+                                                         'torch.distributed.run']
+  assert '--nnodes=1' in argv
+  assert argv[argv.index('--nproc-per-node') + 1] == '4'
+  assert argv[argv.index('--master-addr') + 1] == '127.0.0.1'
+  assert int(argv[argv.index('--master-port') + 1]) > 0
+  assert argv[-7].endswith('bench.py') and argv[-6:] == ['--gpus', '4', '--steps', '20',
+                                                         '--warmup', '5']
+  assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+  # under the launcher (WORLD_SIZE set) a mismatch is an error, not another exec
+  monkeypatch.setenv('WORLD_SIZE', '2')
+  monkeypatch.setenv('RANK', '0')
+  with pytest.raises(SystemExit, match='--gpus 4 but WORLD_SIZE=2'):
+    bench.main()
