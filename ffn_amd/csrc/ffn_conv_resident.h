@@ -36,6 +36,8 @@ struct ConvStackTab {
   const float* bias0;
   long bias_stride;       // floats per layer
   unsigned epoch0;        // conv l publishes epoch0 + l + 1 and waits for epoch0 + l
+  int pace;               // 10-ns ticks between two convs of a workgroup (0: free-running)
+  int pace_tail;          // conv32ps: the tail workgroups' offset inside a period
 };
 
 __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
@@ -74,7 +76,18 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
   const char* sp_in = (tb.l_begin & 1) ? tb.sp_s : tb.sp_t;
   const char* sp_out = (tb.l_begin & 1) ? tb.sp_t : tb.sp_s;
   const int l_first = tb.l_begin, l_dbg = tb.dbg_layer;
+  // Pacing (tb.pace > 0; engine option flow_pace): conv l of a workgroup does not start
+  // before  t0 + l pace + phi,  phi = pace x (its first voxel / V) for a main workgroup and
+  // half a period more for a tail one -- a tail's taps then fall into the wait / stage /
+  // drain of the main workgroup it shares a CU with instead of wherever the free-running
+  // hand-off leaves them.  Timing only: the arithmetic does not know about it.
+  const long long t_pace0 =
+      wall_clock64() + (long long)tb.pace * v0 / a.V + (main_wg ? 0 : tb.pace_tail);
   for (int l = tb.l_begin; l < tb.l_end; ++l) {
+    if (tb.pace > 0) {
+      const long long target = t_pace0 + (long long)(l - l_first) * tb.pace;
+      while (wall_clock64() < target) __builtin_amdgcn_s_sleep(1);
+    }
     ConvLayer L;
     L.in_sp = sp_in;    // T' for even convs, X' for odd ones ...
     L.out_sp = const_cast<char*>(sp_out);  // ... and the other one written

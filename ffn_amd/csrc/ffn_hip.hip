@@ -177,6 +177,12 @@ struct ffn_engine {
   bool d_weights_ok = true;      // every |weight| x 2^11 inside the fp16 range
   uint16_t* wpackd = nullptr;    // [28][khalf][plane hi, res][64][8] fp16 per layer
   size_t wpackd_layer = 0;       // halves per layer
+  // conv32h (flow = 3): 64-voxel workgroups on 16x16x32 tiles
+  uint16_t* wpackh = nullptr;    // [28][out half][plane hi, res][64][8] fp16 per layer
+  bool h_ok = false;             // geometry + residency
+  int n_half = 0;                // 64-voxel chunks of the FoV
+  int flow_pace = 0;             // ConvStackTab::pace (10-ns ticks)
+  int flow_pace_tail = 0;        // ConvStackTab::pace_tail
   size_t lds_bytes_d = 0;        // 3 slots x 8 planes x Rc_k rows x 16 B
   int dsched_aoff[4 * 8] = {};
   int dsched_btap[4 * 8] = {};
@@ -924,11 +930,51 @@ int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr) {
   tb.bias0 = e->weights + e->bias_off[0];
   tb.bias_stride = e->depth > 1 ? (long)(e->bias_off[1] - e->bias_off[0]) : 0;
   tb.epoch0 = e->flow_epoch;
+  tb.pace = e->flow_pace;
+  tb.pace_tail = e->flow_pace_tail;
   e->flow_epoch += (unsigned)tb.nlayers;
   const dim3 grid(8 * (mp.mains_per_xcd + mp.tails_per_xcd)), block(kDThreads);
   tb.l_begin = 0;
   tb.l_end = tb.nlayers;
   hipLaunchKernelGGL(conv32ps_kernel, grid, block, kMLdsBytes, e->stream, a, mp, tb);
+  return FFN_OK;
+}
+
+// The same stack on 64-voxel workgroups, two per CU (conv32hs, ffn_conv_half.h).
+void half_map(const ffn_engine* e, ConvHalfMap& mp) {
+  mp.n_chunks = e->n_half;
+  mp.n_first = (e->n_half + 1) / 2;
+  mp.per_slot = (mp.n_first + 7) / 8;
+}
+
+int launch_conv32hs(ffn_engine* e, float pad_value, float move_thr) {
+  HeadFusion hf;
+  hf.on = true;
+  hf.pad_value = pad_value;
+  hf.move_thr = move_thr;
+  ConvDArgs a;
+  conv32d_args(e, 1, e->rawT, e->rawS, 0, hf, a);
+  a.flow_n_main = -1;
+  ConvHalfMap mp;
+  half_map(e, mp);
+  const Geom& g = e->gp;
+  ConvStackTab tb;
+  tb.nlayers = 2 * e->depth - 1;
+  tb.dbg_layer = e->dbg_layer;
+  tb.sp_t = reinterpret_cast<const char*>(e->rawT) + (size_t)g.guard * 16;
+  tb.sp_s = reinterpret_cast<char*>(e->rawS) + (size_t)g.guard * 16;
+  tb.wpack0 = reinterpret_cast<const char*>(e->wpackh);
+  tb.wpack_stride = (long)(e->wpackd_layer * sizeof(uint16_t));
+  tb.bias0 = e->weights + e->bias_off[0];
+  tb.bias_stride = e->depth > 1 ? (long)(e->bias_off[1] - e->bias_off[0]) : 0;
+  tb.epoch0 = e->flow_epoch;
+  e->flow_epoch += (unsigned)tb.nlayers;
+  tb.l_begin = 0;
+  tb.l_end = tb.nlayers;
+  tb.pace = e->flow_pace;
+  tb.pace_tail = 0;
+  const dim3 grid(8 * 2 * mp.per_slot), block(kDThreads);
+  hipLaunchKernelGGL(conv32hs_kernel, grid, block, kHLdsBytes, e->stream, a, mp, tb);
   return FFN_OK;
 }
 
@@ -980,6 +1026,10 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
       return fail(FFN_ERR_ARG, "conv_variant 6 needs depth >= 2 (fused head)");
     // T' -> (X, X') -> T' -> ... ; the head is always fused into the last conv_b
     auto chain = [&]() -> int {
+      if (e->t_now && n == 1 && e->flow == 3) {
+        e->last_stack_resident = true;
+        return launch_conv32hs(e, pad_value, move_thr);
+      }
       if (e->t_now && n == 1 && e->flow == 2) {
         if (e->flow_skip > 0) {
           e->flow_skip -= 1;  // the repeat of a voided resident step
@@ -1417,6 +1467,22 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
       e->flow_fits = cus >= e->n_main && (long)cus * per_cu >= grid;
     }
     e->flow = e->flow_fits ? 2 : 0;
+    // conv32hs: 64-voxel workgroups, two per CU, all resident at once
+    if (e->t_ok && depth >= 2) {
+      const Geom& q = e->gp;
+      e->n_half = FFN_H_VCLIP ? FFN_H_VCLIP / kHChunk : (q.V + kHChunk - 1) / kHChunk;
+      const int span_h = chunk_span(q, 0, kHChunk, e->n_half);
+      int cus = 0, per_cu = 0;
+      E_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id));
+      E_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv32hs_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kHLdsBytes));
+      E_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv32hs_kernel, kDThreads,
+                                                         kHLdsBytes));
+      ConvHalfMap mp;
+      half_map(e, mp);
+      e->h_ok = (FFN_H_VCLIP || span_h + 2 * (q.XS + 1) <= kHRows) &&
+                (long)cus * per_cu >= 8 * 2 * mp.per_slot;
+    }
   }
 
   // weights: [w0a 27*2*32][b0a 32] ([wpack 27*32*32][bias 32]) x (2*depth-1)
@@ -1442,6 +1508,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     e->wpackd_layer = (size_t)kDTaps * 2 * 2 * 64 * 8;  // + the all-zero tap
     E_TRY(hipMalloc(&e->wpackd, e->wpackd_layer * (2 * depth - 1) *
                                     sizeof(uint16_t)));
+    E_TRY(hipMalloc(&e->wpackh, e->wpackd_layer * (2 * depth - 1) * sizeof(uint16_t)));
     E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
     E_TRY(hipMemset(e->range_flag, 0, sizeof(unsigned)));
     E_TRY(hipMalloc(&e->range_flag_alt, sizeof(unsigned)));
@@ -1453,7 +1520,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
       E_TRY(hipMalloc(&e->flow_err, sizeof(unsigned)));
       E_TRY(hipMemset(e->flow_err, 0, sizeof(unsigned)));
       if (e->t_ok) {
-        e->flow_trace_slots = e->n_main + e->n_tail;
+        e->flow_trace_slots = std::max(e->n_main + e->n_tail, (e->gp.V + kHChunk - 1) / kHChunk);
         const size_t bytes = (size_t)e->flow_trace_slots * kFlowTraceLayers * 8 * sizeof(long long);
         E_TRY(hipMalloc(&e->flow_trace, bytes));
         E_TRY(hipMemset(e->flow_trace, 0, bytes));
@@ -1527,6 +1594,7 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->logits);
   (void)hipFree(e->count);
   (void)hipFree(e->wpackd);
+  (void)hipFree(e->wpackh);
   (void)hipFree(e->range_flag);
   (void)hipFree(e->flow_flags);
   (void)hipFree(e->flow_err);
@@ -1561,6 +1629,7 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   const float* src = blob;
   // conv0_a: [27][2][32] + bias, used as stored
   std::vector<uint16_t> hostd(e->wpackd_layer * (2 * e->depth - 1));  // zero tap 27
+  std::vector<uint16_t> hosth(hostd.size());
   bool d_weights_ok = true;
   bool weights_in_fp16_range = true;
   // tap (kz', ky', kx') of the permuted layout = the original tap whose offset
@@ -1613,11 +1682,29 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
               wd[base + 64 * 8] = part[1];
             }
     }
+    // conv32h: the 16x16x32 A operand (rows = cout of half h, K = all 32 cin)
+    //   wpackh[tap][h][plane hi, res][lane][c] = part(W[tap][8 (lane >> 4) + c][16 h + (lane & 15)])
+    {
+      uint16_t* wd = &hosth[(size_t)l * e->wpackd_layer];
+      for (int tap = 0; tap < 27; ++tap)
+        for (int h = 0; h < 2; ++h)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int c = 0; c < 8; ++c) {
+              const int ci = 8 * (lane >> 4) + c, co = 16 * h + (lane & 15);
+              uint16_t part[2];
+              split_fp16x2(src[((size_t)tap_of[tap] * F + ci) * F + co], part);
+              const size_t base = ((((size_t)tap * 2 + h) * 2) * 64 + lane) * 8 + c;
+              wd[base] = part[0];
+              wd[base + 64 * 8] = part[1];
+            }
+    }
     src += 27 * F * F;
     std::memcpy(&host[e->bias_off[l]], src, sizeof(float) * F);
     src += F;
   }
   HIP_TRY(hipMemcpy(e->wpackd, hostd.data(), hostd.size() * sizeof(uint16_t),
+                    hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->wpackh, hosth.data(), hosth.size() * sizeof(uint16_t),
                     hipMemcpyHostToDevice));
   e->d_weights_ok = d_weights_ok;
   e->fp16_ok = weights_in_fp16_range;
@@ -1757,11 +1844,23 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->flow_debug = value;
     return FFN_OK;
   }
+  if (std::strcmp(name, "flow_pace") == 0) {
+    if (value < 0 || value > 5000) return fail(FFN_ERR_ARG, "flow_pace: 0 .. 5000 (10-ns ticks)");
+    e->flow_pace = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "flow_pace_tail") == 0) {
+    if (value < 0 || value > 5000) return fail(FFN_ERR_ARG, "flow_pace_tail: 0 .. 5000");
+    e->flow_pace_tail = value;
+    return FFN_OK;
+  }
   if (std::strcmp(name, "flow") == 0) {
     // single-FoV steps of conv_variant 9: 0 one dependent launch per conv; 1 the
     // same launches with the flagged hand-off compiled in; 2 the resident stack
     // (conv32ps: one launch for all convs).  Same bits in every mode.
-    if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "flow: 0, 1 or 2");
+    if (value < 0 || value > 3) return fail(FFN_ERR_ARG, "flow: 0 .. 3");
+    if (value == 3 && !e->h_ok)
+      return fail(FFN_ERR_ARG, "flow 3: the 64-voxel workgroups do not fit this FoV / device");
     if (value && !e->t_ok)
       return fail(FFN_ERR_ARG, "flow needs conv32mt's geometry (conv_variant 9)");
     if (value && e->depth < 2) return fail(FFN_ERR_ARG, "flow needs depth >= 2");

@@ -79,4 +79,5 @@ struct StepItem {
 #include "ffn_conv_exact.h"      // conv_variant 0, 2: exact f32
 #include "ffn_conv_split.h"      // conv_variant 6 .. 9: fp16 split products, FLOW hand-off
 #include "ffn_conv_resident.h"   // conv32ps: the stack as one launch
+#include "ffn_conv_half.h"       // conv32h / conv32hs: 64-voxel workgroups, two chains per SIMD
 #include "ffn_canvas_kernels.h"  // box I/O, commit, segment turn

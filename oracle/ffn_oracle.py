@@ -196,6 +196,41 @@ def forward_torch(image, seed, variables, depth, threads=None, f64=False):
   return out[0] if squeeze else out
 
 
+_LIB64 = None
+
+
+def forward_f64c(image, seed, blob, depth, threads=0):
+  """The forward pass in double precision throughout (convstack_f64.c: built on
+  request for this host, `make -C oracle libffn_oracle_f64.so`): what
+  forward_torch(f64=True) computes, ~5x faster.  One FoV or a batch of them."""
+  global _LIB64
+  if _LIB64 is None:
+    path = os.path.join(_HERE, 'libffn_oracle_f64.so')
+    if not os.path.exists(path):
+      subprocess.check_call(['make', '-C', _HERE, 'libffn_oracle_f64.so'])
+    lib = ctypes.CDLL(path)
+    lib.ffn_oracle_forward_f64.restype = ctypes.c_int
+    lib.ffn_oracle_forward_f64.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    _LIB64 = lib
+  image = np.ascontiguousarray(image, dtype=np.float32)
+  seed = np.ascontiguousarray(seed, dtype=np.float32)
+  squeeze = image.ndim == 3
+  if squeeze:
+    image, seed = image[None], seed[None]
+  blob = np.ascontiguousarray(blob, dtype=np.float32)
+  out = np.empty_like(seed)
+  for k in range(image.shape[0]):
+    z, y, x = image.shape[1:]
+    rc = _LIB64.ffn_oracle_forward_f64(image[k].ctypes.data, seed[k].ctypes.data, z, y, x,
+                                       depth, blob.ctypes.data, out[k].ctypes.data,
+                                       int(threads or 0))
+    if rc != 0:
+      raise RuntimeError('ffn_oracle_forward_f64 failed: %d' % rc)
+  return out[0] if squeeze else out
+
+
 # ---------------------------------------------------------------------------
 # Move scoring  (movement.py:42-100)
 # ---------------------------------------------------------------------------

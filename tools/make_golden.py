@@ -410,6 +410,15 @@ def make_masks(blob, depth):
         {k: v for k, v in cdict.items() if k.startswith('skip')})
 
 
+def _forward_fn(forward, blob, variables, depth, threads):
+  import functools
+  if forward == 'f64c':
+    return functools.partial(ffn_oracle.forward_f64c, blob=blob, depth=depth,
+                             threads=threads)
+  return functools.partial(ffn_oracle.forward_torch, variables=variables, depth=depth,
+                           threads=threads, f64=forward == 'f64')
+
+
 def make_cells250(blob, depth, forward='oracle', variables=None, num_seeds=14,
                   threads=None, tag='', volume_seed=1234):
   """BASELINE configs[1] at its full size: the 250^3 cells phantom of bench.py
@@ -433,11 +442,11 @@ def make_cells250(blob, depth, forward='oracle', variables=None, num_seeds=14,
     # the same run with another CORRECT implementation of the conv stack:
     # 'onednn' = torch-CPU f32 (blocked / vectorised sums, the kind of kernel
     # TensorFlow's CPU path also uses), 'f64' = double precision throughout
-    import functools
-    forward_fn = functools.partial(ffn_oracle.forward_torch, variables=variables,
-                                   depth=depth, threads=threads,
-                                   f64=forward == 'f64')
-    suffix = '_' + forward
+    # (torch), 'f64c' = the same double-precision arithmetic from
+    # oracle/convstack_f64.c (its f32-rounded logits equal torch's bit for bit
+    # on the sample FoV; 0.19 s instead of 1.8 s per FoV on 4 cores)
+    forward_fn = _forward_fn(forward, blob, variables, depth, threads)
+    suffix = '_' + ('f64' if forward == 'f64c' else forward)
   suffix += tag
   canvas, trace, counters = run_reference_canvas(image, blob, depth,
                                                  (33, 33, 33), (8, 8, 8), seeds,
@@ -472,7 +481,8 @@ def make_cells250(blob, depth, forward='oracle', variables=None, num_seeds=14,
         % wall, 'counters', keep)
 
 
-def make_phantoms(blob, depth, variables, vol_seeds, size, threads):
+def make_phantoms(blob, depth, variables, vol_seeds, size, threads, forward='onednn',
+                  tag=''):
   """An ENSEMBLE of whole-volume runs: `size`^3 cells phantoms of several seeds, every
   grid seed, through the reference's Canvas behind the torch-CPU / oneDNN f32
   forward (the configuration of the 250^3 whole-volume fixtures, at a size that
@@ -484,8 +494,7 @@ def make_phantoms(blob, depth, variables, vol_seeds, size, threads):
   import time
   out = {'vol_seeds': np.array(vol_seeds, np.int32), 'size': np.int32(size)}
   shape = (size,) * 3
-  forward_fn = functools.partial(ffn_oracle.forward_torch, variables=variables,
-                                 depth=depth, threads=threads)
+  forward_fn = _forward_fn(forward, blob, variables, depth, threads)
   for vs in vol_seeds:
     vol = synthetic.cells_volume(shape, seed=int(vs))
     seeds = ffn_oracle.grid_seeds(shape, (16, 16, 16))
@@ -503,14 +512,14 @@ def make_phantoms(blob, depth, variables, vol_seeds, size, threads):
     print('phantom seed %d: %d steps, %d objects, %d voxels, %.0f s' % (
         vs, len(trace), len(canvas.origins), int((seg > 0).sum()), time.time() - t0),
           flush=True)
-  np.savez_compressed(os.path.join(GOLD, 'ref_canvas_phantoms%d.npz' % size), **out)
+  np.savez_compressed(os.path.join(GOLD, 'ref_canvas_phantoms%d%s.npz' % (size, tag)), **out)
 
 
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--only', default='')
   ap.add_argument('--forward', default='oracle',
-                  choices=['oracle', 'onednn', 'f64'],
+                  choices=['oracle', 'onednn', 'f64', 'f64c'],
                   help='cells250: the conv-stack implementation behind the '
                   "reference Canvas (default: the C oracle's sequential f32 "
                   'fmaf chain)')
@@ -554,7 +563,8 @@ def main():
   if args.only == 'phantoms':  # ~40 minutes: only on request
     v = tf_checkpoint.load_checkpoint(CKPT)
     make_phantoms(ffn_oracle.weights_blob(v, 12), 12, v, args.phantom_seeds,
-                  args.phantom_size, args.threads or 8)
+                  args.phantom_size, args.threads or 8,
+                  'onednn' if args.forward == 'oracle' else args.forward, args.tag)
   if args.only == 'cells250':  # slow: only on request
     v = tf_checkpoint.load_checkpoint(CKPT)
     make_cells250(ffn_oracle.weights_blob(v, 12), 12, args.forward, v,
