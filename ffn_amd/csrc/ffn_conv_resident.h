@@ -38,6 +38,7 @@ struct ConvStackTab {
   unsigned epoch0;        // conv l publishes epoch0 + l + 1 and waits for epoch0 + l
   int pace;               // 10-ns ticks between two convs of a workgroup (0: free-running)
   int pace_tail;          // conv32ps: the tail workgroups' offset inside a period
+  int pace_spread;        // phi of the FoV's last voxel, in ticks (0: every workgroup at once)
 };
 
 __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
@@ -77,12 +78,13 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
   const char* sp_out = (tb.l_begin & 1) ? tb.sp_t : tb.sp_s;
   const int l_first = tb.l_begin, l_dbg = tb.dbg_layer;
   // Pacing (tb.pace > 0; engine option flow_pace): conv l of a workgroup does not start
-  // before  t0 + l pace + phi,  phi = pace x (its first voxel / V) for a main workgroup and
-  // half a period more for a tail one -- a tail's taps then fall into the wait / stage /
-  // drain of the main workgroup it shares a CU with instead of wherever the free-running
-  // hand-off leaves them.  Timing only: the arithmetic does not know about it.
+  // before  t0 + l pace + phi,  phi = pace_spread x (its first voxel / V), + pace_tail for a
+  // tail workgroup: the free-running hand-off lets the lower planes run ahead and every
+  // consumer wait for the latest of its ~20 producers; a common beat a little above the
+  // chain's own length takes that jitter out (measured: -2.5 % per stack at 7.0 us per
+  // conv, profiles/r06_pacing.txt).  Timing only: the arithmetic does not know about it.
   const long long t_pace0 =
-      wall_clock64() + (long long)tb.pace * v0 / a.V + (main_wg ? 0 : tb.pace_tail);
+      wall_clock64() + (long long)tb.pace_spread * v0 / a.V + (main_wg ? 0 : tb.pace_tail);
   for (int l = tb.l_begin; l < tb.l_end; ++l) {
     if (tb.pace > 0) {
       const long long target = t_pace0 + (long long)(l - l_first) * tb.pace;

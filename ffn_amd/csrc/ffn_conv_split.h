@@ -213,7 +213,8 @@ constexpr bool kPollMerged = FFN_POLL_MERGED != 0;
 constexpr int kFlowStride = 64;  // words between two producers' words
 
 __device__ __forceinline__ int flow_unit(const ConvDArgs& a, int d) {
-  if (a.flow_n_main < 0) return d >> 6;  // conv32h: uniform 64-voxel producers
+  if (a.flow_n_main < 0)  // conv32h: uniform 80-voxel producers (d / 80)
+    return (int)__umulhi((unsigned)d, 53687092u);
   const int m = a.flow_n_main * 128;  // (= kMChunk)
   return d < m ? d >> 7 : a.flow_n_main + ((d - m) >> 5);
 }

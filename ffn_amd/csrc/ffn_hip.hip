@@ -177,12 +177,23 @@ struct ffn_engine {
   bool d_weights_ok = true;      // every |weight| x 2^11 inside the fp16 range
   uint16_t* wpackd = nullptr;    // [28][khalf][plane hi, res][64][8] fp16 per layer
   size_t wpackd_layer = 0;       // halves per layer
-  // conv32h (flow = 3): 64-voxel workgroups on 16x16x32 tiles
+  // conv32h / conv32hs (variant 10): 80-voxel workgroups on 16x16x32 tiles, two
+  // hand-off chains per SIMD for a single FoV; several FoVs run conv32m as under 9
   uint16_t* wpackh = nullptr;    // [28][out half][plane hi, res][64][8] fp16 per layer
   bool h_ok = false;             // geometry + residency
-  int n_half = 0;                // 64-voxel chunks of the FoV
-  int flow_pace = 0;             // ConvStackTab::pace (10-ns ticks)
+  bool h_now = false;            // the stack being queued is conv32h's
+  int n_half = 0;                // 80-voxel chunks of the FoV
+  // Pacing of the resident stack (ConvStackTab::pace, 10-ns ticks between two convs of a
+  // workgroup).  flow_pace: -1 = the beat measured by tune_pace() when the weights were
+  // set (conv_variant 9; 0 if no beat beat the free-running stack), 0 = off, > 0 = that
+  // beat.  flow_pace_spread: -1 = as wide as the beat (the FoV's last voxel one beat behind
+  // its first), else ticks.
+  int flow_pace = -1;
   int flow_pace_tail = 0;        // ConvStackTab::pace_tail
+  int flow_pace_spread = -1;
+  int pace_auto = 0;             // tune_pace()'s beat (0: none)
+  float pace_auto_us[2] = {0.f, 0.f};  // us per stack it measured: free-running, at the beat
+  int cus = 0;                   // compute units of the device
   size_t lds_bytes_d = 0;        // 3 slots x 8 planes x Rc_k rows x 16 B
   int dsched_aoff[4 * 8] = {};
   int dsched_btap[4 * 8] = {};
@@ -515,6 +526,18 @@ int set_lds_attr_m() {
   FFN_MTF_ATTR(1, true, false);
   FFN_MTF_ATTR(1, true, true);
 #undef FFN_MTF_ATTR
+#define FFN_H_ATTR(KIND, SK, HEADV)                                               \
+  HIP_TRY(hipFuncSetAttribute(                                                    \
+      reinterpret_cast<const void*>(&conv32h_kernel<KIND, SK, HEADV>),            \
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHLdsBytes))
+  FFN_H_ATTR(0, false, false);
+  FFN_H_ATTR(1, false, false);
+  FFN_H_ATTR(1, true, false);
+  FFN_H_ATTR(1, true, true);
+#undef FFN_H_ATTR
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32hs_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kHLdsBytes));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32ps_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kMLdsBytes));
@@ -930,8 +953,9 @@ int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr) {
   tb.bias0 = e->weights + e->bias_off[0];
   tb.bias_stride = e->depth > 1 ? (long)(e->bias_off[1] - e->bias_off[0]) : 0;
   tb.epoch0 = e->flow_epoch;
-  tb.pace = e->flow_pace;
+  tb.pace = e->flow_pace < 0 ? e->pace_auto : e->flow_pace;
   tb.pace_tail = e->flow_pace_tail;
+  tb.pace_spread = e->flow_pace_spread < 0 ? tb.pace : e->flow_pace_spread;
   e->flow_epoch += (unsigned)tb.nlayers;
   const dim3 grid(8 * (mp.mains_per_xcd + mp.tails_per_xcd)), block(kDThreads);
   tb.l_begin = 0;
@@ -942,9 +966,34 @@ int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr) {
 
 // The same stack on 64-voxel workgroups, two per CU (conv32hs, ffn_conv_half.h).
 void half_map(const ffn_engine* e, ConvHalfMap& mp) {
+  // (the dispatcher hands an XCD's first blocks to its empty CUs: cus / 8 first slots)
   mp.n_chunks = e->n_half;
-  mp.n_first = (e->n_half + 1) / 2;
-  mp.per_slot = (mp.n_first + 7) / 8;
+  mp.per_first = std::max(1, e->cus / 8);
+  mp.n_first = std::min(e->n_half, 8 * mp.per_first);
+  mp.per_second = (e->n_half - mp.n_first + 7) / 8;
+}
+
+// one conv of the 80-voxel family as its own launch: what a resident step that came
+// back void is repeated with (the same bits), and flow = 0
+template <int KIND, bool SK>
+int launch_conv32h(ffn_engine* e, const float* raw_in, float* raw_out, int layer,
+                   const HeadFusion& head = HeadFusion()) {
+  ConvDArgs a;
+  conv32d_args(e, 1, raw_in, raw_out, layer, head, a);
+  a.L.wpack = reinterpret_cast<const char*>(e->wpackh + (size_t)layer * e->wpackd_layer);
+  a.flow_n_main = -1;
+  ConvHalfMap mp;
+  half_map(e, mp);
+  const dim3 grid(8 * (mp.per_first + mp.per_second)), block(kDThreads);
+  if (head.on) {
+    if constexpr (KIND == 1)
+      hipLaunchKernelGGL((conv32h_kernel<KIND, SK, true>), grid, block, kHLdsBytes, e->stream,
+                         a, mp);
+  } else {
+    hipLaunchKernelGGL((conv32h_kernel<KIND, SK, false>), grid, block, kHLdsBytes, e->stream,
+                       a, mp);
+  }
+  return FFN_OK;
 }
 
 int launch_conv32hs(ffn_engine* e, float pad_value, float move_thr) {
@@ -971,9 +1020,10 @@ int launch_conv32hs(ffn_engine* e, float pad_value, float move_thr) {
   e->flow_epoch += (unsigned)tb.nlayers;
   tb.l_begin = 0;
   tb.l_end = tb.nlayers;
-  tb.pace = e->flow_pace;
+  tb.pace = e->flow_pace < 0 ? 0 : e->flow_pace;  // (no measured beat for this family)
   tb.pace_tail = 0;
-  const dim3 grid(8 * 2 * mp.per_slot), block(kDThreads);
+  tb.pace_spread = e->flow_pace_spread < 0 ? tb.pace : e->flow_pace_spread;
+  const dim3 grid(8 * (mp.per_first + mp.per_second)), block(kDThreads);
   hipLaunchKernelGGL(conv32hs_kernel, grid, block, kHLdsBytes, e->stream, a, mp, tb);
   return FFN_OK;
 }
@@ -1021,14 +1071,32 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   // with several FoVs run plain conv32m (cost per voxel: the K-split tail costs
   // 5-10 % there) unless tail_batched asks for the single-FoV bits
   e->t_now = e->conv_variant == 9 && (n == 1 || e->tail_batched != 0);
+  // variant 10: a single FoV on 80-voxel workgroups (conv32hs / conv32h); steps with
+  // several FoVs run plain conv32m, as under 9
+  e->h_now = e->conv_variant == 10 && n == 1;
   if (e->conv_variant >= 6) {
     if (e->depth == 1)
       return fail(FFN_ERR_ARG, "conv_variant 6 needs depth >= 2 (fused head)");
     // T' -> (X, X') -> T' -> ... ; the head is always fused into the last conv_b
     auto chain = [&]() -> int {
-      if (e->t_now && n == 1 && e->flow == 3) {
-        e->last_stack_resident = true;
-        return launch_conv32hs(e, pad_value, move_thr);
+      if (e->h_now) {
+        if (e->flow == 2 && e->flow_skip > 0) {
+          e->flow_skip -= 1;  // the repeat of a voided resident step
+        } else if (e->flow == 2) {
+          e->last_stack_resident = true;
+          return launch_conv32hs(e, pad_value, move_thr);
+        }
+        int r = launch_conv32h<1, false>(e, e->rawT, e->rawS, 0);
+        for (int i = 1; i < e->depth && !r; ++i) {
+          r = launch_conv32h<0, false>(e, e->rawS, e->rawT, 2 * i - 1);
+          if (r) break;
+          HeadFusion hf;
+          hf.on = i == e->depth - 1;
+          hf.pad_value = pad_value;
+          hf.move_thr = move_thr;
+          r = launch_conv32h<1, true>(e, e->rawT, e->rawS, 2 * i, hf);
+        }
+        return r;
       }
       if (e->t_now && n == 1 && e->flow == 2) {
         if (e->flow_skip > 0) {
@@ -1088,7 +1156,8 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   }
   if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   if (head_fused) {
-    e->count_blocks = e->t_now ? e->n_main + (n == 1 ? e->n_tail : e->n_tail3)
+    e->count_blocks = e->h_now ? e->n_half
+                      : e->t_now ? e->n_main + (n == 1 ? e->n_tail : e->n_tail3)
                       : e->m_now ? e->nchunks_m : e->small_now ? e->nchunks_e
                       : e->conv_variant >= 6 ? e->nchunks_k : e->nchunks_c;
   } else {
@@ -1467,21 +1536,22 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
       e->flow_fits = cus >= e->n_main && (long)cus * per_cu >= grid;
     }
     e->flow = e->flow_fits ? 2 : 0;
-    // conv32hs: 64-voxel workgroups, two per CU, all resident at once
+    // conv32hs (variant 10): 80-voxel workgroups, two per CU, all resident at once
     if (e->t_ok && depth >= 2) {
       const Geom& q = e->gp;
       e->n_half = FFN_H_VCLIP ? FFN_H_VCLIP / kHChunk : (q.V + kHChunk - 1) / kHChunk;
       const int span_h = chunk_span(q, 0, kHChunk, e->n_half);
       int cus = 0, per_cu = 0;
       E_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id));
+      e->cus = cus;
       E_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv32hs_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kHLdsBytes));
       E_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv32hs_kernel, kDThreads,
                                                          kHLdsBytes));
       ConvHalfMap mp;
       half_map(e, mp);
-      e->h_ok = (FFN_H_VCLIP || span_h + 2 * (q.XS + 1) <= kHRows) &&
-                (long)cus * per_cu >= 8 * 2 * mp.per_slot;
+      e->h_ok = e->n_half >= 2 && span_h + 2 * (q.XS + 1) <= kHRows &&
+                (long)cus * per_cu >= 8 * (mp.per_first + mp.per_second);
     }
   }
 
@@ -1615,6 +1685,76 @@ void ffn_engine_destroy(ffn_engine* e) {
   delete e;
 }
 
+// The beat of the paced resident stack is measured, not assumed: the chain a conv of the
+// stack has to get through (words seen -> rows staged -> taps -> stores drained -> word
+// published) is 6.2 - 6.9 us depending on the box and its clocks, a beat below it leaves
+// the stack free-running (no loss), a beat above it costs 24 x the excess.  So: time the
+// stack on noise inputs at a ladder of beats and keep the best one plus a margin of 0.1 us
+// -- if it beats the free-running stack by more than 1.5 %.  ~80 ms per set_weights.
+int tune_pace(ffn_engine* e) {
+  e->pace_auto = 0;
+  e->pace_auto_us[0] = e->pace_auto_us[1] = 0.f;
+  if (!(e->t_ok && e->flow_fits && e->flow == 2 && e->conv_variant == 9 && e->depth >= 2))
+    return FFN_OK;
+  const size_t V = (size_t)e->g.V;
+  {
+    std::vector<float> noise(2 * V);
+    unsigned x = 12345u;
+    for (auto& v : noise) {
+      x = x * 1664525u + 1013904223u;
+      v = ((int)(x >> 8) % 2001 - 1000) * 1e-3f;
+    }
+    HIP_TRY(hipMemcpy(e->up_image, noise.data(), V * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->up_seed, noise.data() + V, V * sizeof(float), hipMemcpyHostToDevice));
+  }
+  StepItems si;
+  int rc = dense_items(e, 1, &si);
+  if (rc) return rc;
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  const int user_pace = e->flow_pace;
+  auto stacks_us = [&](int pace, int reps, float* us) -> int {
+    e->flow_pace = pace;
+    int r = FFN_OK;
+    for (int k = 0; k < 6 && !r; ++k) r = run_stack(e, 1, si, std::nanf(""), INFINITY);
+    if (!r && hipEventRecord(ev0, e->stream) != hipSuccess) r = FFN_ERR_HIP;
+    for (int k = 0; k < reps && !r; ++k) r = run_stack(e, 1, si, std::nanf(""), INFINITY);
+    if (!r && (hipEventRecord(ev1, e->stream) != hipSuccess ||
+               hipEventSynchronize(ev1) != hipSuccess))
+      r = FFN_ERR_HIP;
+    float ms = 0.f;
+    if (!r && hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) r = FFN_ERR_HIP;
+    *us = ms * 1e3f / (float)reps;
+    return r;
+  };
+  float warm = 0.f, free_us = 0.f, best_us = 0.f;
+  int best = 0;
+  rc = stacks_us(0, 120, &warm);  // clocks up
+  if (!rc) rc = stacks_us(0, 40, &free_us);
+  best_us = free_us;
+  for (int pace = 560; pace <= 800 && !rc; pace += 20) {
+    float us = 0.f;
+    rc = stacks_us(pace, 24, &us);
+    if (!rc && us < best_us) {
+      best_us = us;
+      best = pace;
+    }
+  }
+  e->flow_pace = user_pace;
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  if (rc) return rc;
+  unsigned errs = 0;
+  HIP_TRY(hipMemcpy(&errs, e->flow_err, sizeof(errs), hipMemcpyDeviceToHost));
+  const bool timed_out = errs != e->flow_err_seen;
+  e->flow_err_seen = errs;
+  e->pace_auto_us[0] = free_us;
+  e->pace_auto_us[1] = best_us;
+  if (!timed_out && best > 0 && best_us < 0.985f * free_us) e->pace_auto = best + 10;
+  return FFN_OK;
+}
+
 int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   EngineLock lock_(e);
   if (!e || !blob) return fail(FFN_ERR_ARG, "null argument");
@@ -1717,6 +1857,10 @@ int ffn_engine_set_weights(ffn_engine* e, const float* blob, size_t count) {
   HIP_TRY(hipMemcpy(e->weights, host.data(),
                     sizeof(float) * (e->wl_off + F + 1), hipMemcpyHostToDevice));
   e->weights_set = true;
+  if (e->flow_pace < 0) {
+    int rc = tune_pace(e);
+    if (rc) return rc;
+  }
   return FFN_OK;
 }
 
@@ -1791,9 +1935,12 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
 
   if (std::strcmp(name, "conv_variant") == 0) {
     if (value == -1) value = e->exact_variant;  // "the exact-f32 kernel of this FoV"
-    if (value != 0 && value != 2 && !(value >= 6 && value <= 9))
-      return fail(FFN_ERR_ARG, "conv_variant must be 0, 2, 6, 7, 8 or 9 (1, 3, 4, 5 "
+    if (value != 0 && value != 2 && !(value >= 6 && value <= 10))
+      return fail(FFN_ERR_ARG, "conv_variant must be 0, 2, 6, 7, 8, 9 or 10 (1, 3, 4, 5 "
                                "were removed in ABI 7)");
+    if (value == 10 && !e->h_ok)
+      return fail(FFN_ERR_ARG, "conv_variant 10 unsupported for this fov / depth / device "
+                               "(80-voxel workgroups, two per CU, all resident)");
     if (value >= 6 && e->weights_set && !e->fp16_ok)
       return fail(FFN_ERR_ARG, "conv_variant %d: a weight is outside the fp16 range",
                   value);
@@ -1845,8 +1992,14 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     return FFN_OK;
   }
   if (std::strcmp(name, "flow_pace") == 0) {
-    if (value < 0 || value > 5000) return fail(FFN_ERR_ARG, "flow_pace: 0 .. 5000 (10-ns ticks)");
+    if (value < -1 || value > 5000)
+      return fail(FFN_ERR_ARG, "flow_pace: -1 (measured), 0 (off) .. 5000 (10-ns ticks)");
     e->flow_pace = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "flow_pace_spread") == 0) {
+    if (value < -1 || value > 5000) return fail(FFN_ERR_ARG, "flow_pace_spread: -1 .. 5000");
+    e->flow_pace_spread = value;
     return FFN_OK;
   }
   if (std::strcmp(name, "flow_pace_tail") == 0) {
@@ -1858,9 +2011,7 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     // single-FoV steps of conv_variant 9: 0 one dependent launch per conv; 1 the
     // same launches with the flagged hand-off compiled in; 2 the resident stack
     // (conv32ps: one launch for all convs).  Same bits in every mode.
-    if (value < 0 || value > 3) return fail(FFN_ERR_ARG, "flow: 0 .. 3");
-    if (value == 3 && !e->h_ok)
-      return fail(FFN_ERR_ARG, "flow 3: the 64-voxel workgroups do not fit this FoV / device");
+    if (value < 0 || value > 2) return fail(FFN_ERR_ARG, "flow: 0, 1 or 2");
     if (value && !e->t_ok)
       return fail(FFN_ERR_ARG, "flow needs conv32mt's geometry (conv_variant 9)");
     if (value && e->depth < 2) return fail(FFN_ERR_ARG, "flow needs depth >= 2");
@@ -1941,6 +2092,11 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "flow") == 0) *value = e->flow;
   else if (std::strcmp(name, "flow_auto_off") == 0) *value = e->flow_auto_off;
   else if (std::strcmp(name, "stat_flow_voids") == 0) *value = (int)e->stat_flow_voids;
+  else if (std::strcmp(name, "flow_pace") == 0) *value = e->flow_pace;
+  else if (std::strcmp(name, "flow_pace_now") == 0)
+    *value = e->flow_pace < 0 ? e->pace_auto : e->flow_pace;
+  else if (std::strcmp(name, "flow_pace_free_ns") == 0) *value = (int)(e->pace_auto_us[0] * 1e3f);
+  else if (std::strcmp(name, "flow_pace_best_ns") == 0) *value = (int)(e->pace_auto_us[1] * 1e3f);
   else if (std::strcmp(name, "stat_flow_timeouts") == 0) {
     unsigned v = 0;
     HIP_TRY(hipSetDevice(e->device));

@@ -34,10 +34,21 @@ def stack_us(eng, reps=400):
 
 def mate_overlap(raw, n, nl=23):
   """How long a workgroup's taps take against how much of them runs while the OTHER
-  workgroup of its CU (chunk c +- n/2) is in its taps too."""
+  workgroup of its CU is in its taps too."""
   tr = raw[:, :nl, :6]
-  half = n // 2
-  a, b = tr[:half], tr[half:n]
+  ids = (raw[:, 1, 6] * 100.0).astype(np.int64)
+  xcc = (raw[:, 1, 7] * 100.0).astype(np.int64)
+  cu = ((ids >> 8) & 0xff) | (xcc << 8)
+  by_cu = {}
+  for c in range(n):
+    if tr[c, 1, 0] > 0:
+      by_cu.setdefault(int(cu[c]), []).append(c)
+  pairs = [v for v in by_cu.values() if len(v) == 2]
+  if not pairs:
+    return
+  a = tr[[v[0] for v in pairs]]
+  b = tr[[v[1] for v in pairs]]
+  half = len(pairs)
   durs, ovs = [], []
   for x, y in ((a, b), (b, a)):
     for l in range(1, nl - 1):
@@ -77,29 +88,31 @@ def main():
   ref = eng.predict(seed, img)
   lib = os.path.basename(os.environ.get('FFN_AMD_LIB', 'libffn_hip.so'))
   if args.check:
-    eng.set_option('flow', 3)
+    eng.set_option('conv_variant', 10)
     got = eng.predict(seed, img)
     print('%s: flow 3 against flow 2: max |d logit| %.3g, identical %s, timeouts %d' % (
         lib, np.abs(got - ref).max(), np.array_equal(got, ref),
         eng.get_option('stat_flow_timeouts')))
   eng.set_option('flow_debug', args.flow_debug)
   for r in range(args.rounds):
-    eng.set_option('flow', 2)
+    eng.set_option('conv_variant', 9)
     a = stack_us(eng)
-    eng.set_option('flow', 3)
+    eng.set_option('conv_variant', 10)
     b = stack_us(eng)
-    print('%s round %d: us per stack (conv0_a + resident launch)  flow 2: %.2f   flow 3: %.2f  '
+    print('%s round %d: us per stack (conv0_a + resident launch)  variant 9: %.2f   variant 10: %.2f  '
           '(%+.1f %%)' % (lib, r, a, b, (b / a - 1) * 100), flush=True)
   for pv in [int(x) for x in args.pace.split(',') if x]:
     eng.set_option('flow_pace', pv)
-    print('%s flow 3 paced at %d ticks (%.2f us per conv; 24 x = %.1f us): %.2f us per stack' % (
+    eng.set_option('flow_pace_spread', pv)
+    print('%s variant 10 paced at %d ticks (%.2f us per conv; 24 x = %.1f us): %.2f us per stack' % (
         lib, pv, pv / 100.0, 24 * pv / 100.0, stack_us(eng, 200)), flush=True)
   eng.set_option('flow_pace', args.trace_pace)
+  eng.set_option('flow_pace_spread', args.trace_pace)
   print('timeouts', eng.get_option('stat_flow_timeouts'), '; traced stack: flow_pace', args.trace_pace)
   eng.set_option('debug_clock', 4)
   eng.forward_resident(1, 1)
   eng.synchronize()
-  n = int(os.environ.get('FFN_H_SLOTS', '512'))
+  n = int(os.environ.get('FFN_H_SLOTS', '450'))
   raw = eng.debug_flow_trace(n).astype(np.float64) / 100.0  # us
   eng.set_option('debug_clock', 0)
   if args.dump:
@@ -109,7 +122,7 @@ def main():
   live = tr[:, 1, 0] > 0
   t00 = tr[live][:, 0, 0].min()
   tr = np.where(tr > 0, tr - t00, np.nan)
-  print('flow 3, flow_debug %d: %d workgroups stamped; span %.1f us' % (
+  print('variant 10, flow_debug %d: %d workgroups stamped; span %.1f us' % (
       args.flow_debug, live.sum(), np.nanmax(tr[:, nl - 1, 5])))
   per = np.diff(np.nanmedian(tr[:, :, 0], axis=0))
   print('median entry-to-entry period per layer: %s; mean (layers 2..) %.2f us' % (
@@ -117,8 +130,8 @@ def main():
   names = ['wait', 'stage', 'taps', 'epilogue+drain', 'publish']
   half = n // 2
   for name, rows in (('first slots ', slice(0, half)), ('second slots', slice(half, n)),
-                     ('chunks   0- 63', slice(0, 64)), ('chunks 192-255', slice(192, 256)),
-                     ('chunks 256-319', slice(256, 320)), ('chunks 448-511', slice(448, 512))):
+                     ('first  64 chunks', slice(0, 64)), ('last 64 of the first half', slice(half - 64, half)),
+                     ('first 64 of the second half', slice(half, half + 64)), ('last 64 chunks', slice(n - 64, n))):
     x = tr[rows, 2:nl - 1, :]
     d = np.diff(x, axis=2)
     p = np.nanmedian(np.diff(tr[rows, 1:nl - 1, 0], axis=1))
@@ -137,8 +150,8 @@ def main():
       by_cu.setdefault(int(cu[c]), []).append(c)
   sizes = np.bincount([len(v) for v in by_cu.values()])
   print('CUs used %d; workgroups per CU histogram %s' % (len(by_cu), sizes.tolist()))
-  meant = sum(1 for v in by_cu.values() if len(v) == 2 and abs(v[0] - v[1]) == half)
-  print('CUs whose two workgroups are chunks c and c + %d: %d' % (half, meant))
+  meant = sum(1 for v in by_cu.values() if len(v) == 2 and abs(v[0] - v[1]) >= n // 3)
+  print('CUs whose two workgroups are chunks at least %d apart: %d' % (n // 3, meant))
   offs = []
   for v in by_cu.values():
     if len(v) == 2:

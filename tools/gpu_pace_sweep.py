@@ -31,7 +31,8 @@ def stack_us(eng, reps=300):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--pace', default='0,600,640,680,720,760')
-  ap.add_argument('--tail', default='0,150,300,450')
+  ap.add_argument('--tail', default='0')
+  ap.add_argument('--spread', default='0,100', help='flow_pace_spread as percent of the pace')
   ap.add_argument('--rounds', type=int, default=2)
   args = ap.parse_args()
   model = convstack_3d.ConvStack3DFFNModel(fov_size=[33, 33, 33], deltas=[8, 8, 8], depth=12)
@@ -41,6 +42,9 @@ def main():
   img = rng.normal(0, 1, [1, 33, 33, 33]).astype(np.float32)
   seed = rng.normal(0, 1, [1, 33, 33, 33]).astype(np.float32)
   ref = eng.predict(seed, img)
+  print('measured beat (flow_pace -1): %d ticks; the tuner saw %.2f us free-running, %.2f at its best beat'
+        % (eng.get_option('flow_pace_now'), eng.get_option('flow_pace_free_ns') / 1e3,
+           eng.get_option('flow_pace_best_ns') / 1e3))
   t_end = time.perf_counter() + 2.0
   while time.perf_counter() < t_end:
     eng.forward_resident(1, 20)
@@ -48,12 +52,19 @@ def main():
   paces = [int(x) for x in args.pace.split(',')]
   tails = [int(x) for x in args.tail.split(',')]
   for r in range(args.rounds):
+    eng.set_option('flow_pace', -1)
+    eng.set_option('flow_pace_spread', -1)
+    eng.set_option('flow_pace_tail', 0)
+    print('round %d measured beat %d: %.2f us per stack' % (r, eng.get_option('flow_pace_now'),
+                                                            stack_us(eng)), flush=True)
     for p in paces:
       row = []
       for t in (tails if p else [0]):
-        eng.set_option('flow_pace', p)
-        eng.set_option('flow_pace_tail', t)
-        row.append('tail %4d: %6.2f' % (t, stack_us(eng)))
+        for sp in ([int(x) for x in args.spread.split(',')] if p else [0]):
+          eng.set_option('flow_pace', p)
+          eng.set_option('flow_pace_tail', t)
+          eng.set_option('flow_pace_spread', p * sp // 100)
+          row.append('tail %d spread %d %%: %6.2f' % (t, sp, stack_us(eng)))
       print('round %d pace %4d | %s' % (r, p, ' | '.join(row)), flush=True)
   eng.set_option('flow_pace', paces[-1])
   got = eng.predict(seed, img)
