@@ -242,6 +242,9 @@ __device__ __forceinline__ void flow_wait_tiles(const ConvDArgs& a, const ConvLa
   auto give_up = [&]() {
     if (lane == 0) {
       atomicAdd(a.flow_err, 1u);
+      // word 1 names the CAUSE for this very step (the faces launch / ffn_predict
+      // read it next to word 0): a time-out, not the fp16 range check
+      __hip_atomic_store(vflag + 1, a.range_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(vflag, a.range_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };

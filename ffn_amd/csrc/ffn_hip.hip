@@ -158,7 +158,6 @@ struct ffn_engine {
   // resident steps in a row turn the resident launch off for this engine
   // (flow_auto_off; option "flow" turns it on again).
   bool flow_fits = false;
-  unsigned flow_err_seen = 0;      // *flow_err as of the last voided step
   int flow_strikes = 0;            // voided resident steps since the last good one
   int flow_skip = 0;               // the next single-FoV stack runs per-layer launches
   int flow_auto_off = 0;
@@ -330,20 +329,17 @@ struct EngineLock {
 };
 constexpr int kFlowStrikes = 3;
 
-// A step came back void.  Was it the resident launch giving up on a producer
-// (conv32ps: a poll reached its bound -- some workgroup was not on the chip, or
-// far too late) rather than the fp16 range check?  Then the caller gets
+// A step came back void, and its own record says why (ffn_step_result.range_error
+// 3, written from word 1 of the step's range flag): the resident launch gave up on
+// a producer (conv32ps: a poll reached its bound -- some workgroup was not on the
+// chip, or far too late), not the fp16 range check.  Then the caller gets
 // FFN_ERR_FLOW instead of FFN_ERR_RANGE: same contract (nothing was pasted,
 // repeat the step), but the arithmetic stays -- the repeat runs the same convs as
 // per-layer launches (same bits) -- and after kFlowStrikes such steps in a row
 // the engine stops using the resident launch.  0: not a flow time-out.
-int flow_voided(ffn_engine* e, bool resident) {
-  if (!resident || !e->flow_err) return 0;
-  unsigned v = 0;
-  if (hipMemcpy(&v, e->flow_err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+int flow_voided(ffn_engine* e, bool timed_out) {
+  if (!timed_out) return 0;
   EngineLock lock_(e);
-  if (v == e->flow_err_seen) return 0;
-  e->flow_err_seen = v;
   e->stat_flow_voids += 1;
   e->flow_strikes += 1;
   e->flow_skip = 1;
@@ -1579,10 +1575,12 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
     E_TRY(hipMalloc(&e->wpackd, e->wpackd_layer * (2 * depth - 1) *
                                     sizeof(uint16_t)));
     E_TRY(hipMalloc(&e->wpackh, e->wpackd_layer * (2 * depth - 1) * sizeof(uint16_t)));
-    E_TRY(hipMalloc(&e->range_flag, sizeof(unsigned)));
-    E_TRY(hipMemset(e->range_flag, 0, sizeof(unsigned)));
-    E_TRY(hipMalloc(&e->range_flag_alt, sizeof(unsigned)));
-    E_TRY(hipMemset(e->range_flag_alt, 0, sizeof(unsigned)));
+    // two words each: [0] the tag of the last void run, [1] ... of the last run that
+    // was void because the resident launch timed out (the cause, per step)
+    E_TRY(hipMalloc(&e->range_flag, 2 * sizeof(unsigned)));
+    E_TRY(hipMemset(e->range_flag, 0, 2 * sizeof(unsigned)));
+    E_TRY(hipMalloc(&e->range_flag_alt, 2 * sizeof(unsigned)));
+    E_TRY(hipMemset(e->range_flag_alt, 0, 2 * sizeof(unsigned)));
     {
       const size_t words = ((size_t)(e->gp.V + 31) / 32 + 64) * kFlowStride;
       E_TRY(hipMalloc(&e->flow_flags, words * sizeof(unsigned)));
@@ -1707,6 +1705,8 @@ int tune_pace(ffn_engine* e) {
     HIP_TRY(hipMemcpy(e->up_image, noise.data(), V * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->up_seed, noise.data() + V, V * sizeof(float), hipMemcpyHostToDevice));
   }
+  unsigned errs0 = 0;
+  HIP_TRY(hipMemcpy(&errs0, e->flow_err, sizeof(errs0), hipMemcpyDeviceToHost));
   StepItems si;
   int rc = dense_items(e, 1, &si);
   if (rc) return rc;
@@ -1747,8 +1747,7 @@ int tune_pace(ffn_engine* e) {
   if (rc) return rc;
   unsigned errs = 0;
   HIP_TRY(hipMemcpy(&errs, e->flow_err, sizeof(errs), hipMemcpyDeviceToHost));
-  const bool timed_out = errs != e->flow_err_seen;
-  e->flow_err_seen = errs;
+  const bool timed_out = errs != errs0;
   e->pace_auto_us[0] = free_us;
   e->pace_auto_us[1] = best_us;
   if (!timed_out && best > 0 && best_us < 0.985f * free_us) e->pace_auto = best + 10;
@@ -1889,24 +1888,28 @@ int ffn_predict(ffn_engine* e, int n, const float* seed, const float* image,
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(h_logits, e->logits, bytes, hipMemcpyDeviceToHost,
                          e->stream));
-  unsigned flag = 0;
-  if (e->conv_variant >= 6)
-    HIP_TRY(hipMemcpyAsync(&flag, e->range_flag, sizeof(flag),
-                           hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  if (e->conv_variant >= 6 && flag == e->range_tag) {
-    // void: the resident launch gave up on a producer (the repeat runs per-layer
-    // launches: same bits), or an operand left the fp16 range (this engine then
-    // stays on the exact-f32 kernel)
-    if (flow_voided(e, e->last_stack_resident) == 0) {
+  // A void run is repeated: after a time-out of the resident launch with per-layer
+  // launches of the same kernels (same bits), after a range error -- also one that
+  // only shows in that repeat -- with the exact-f32 kernel.  At most two repeats.
+  for (int attempt = 0;; ++attempt) {
+    unsigned flag[2] = {0, 0};
+    if (e->conv_variant >= 6)
+      HIP_TRY(hipMemcpyAsync(flag, e->range_flag, sizeof(flag), hipMemcpyDeviceToHost,
+                             e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const bool is_void = e->conv_variant >= 6 && flag[0] == e->range_tag;
+    if (!is_void) {
+      if (e->last_stack_resident) e->flow_strikes = 0;
+      break;
+    }
+    if (attempt == 2) return fail(FFN_ERR_HIP, "ffn_predict: the step stayed void");
+    if (flow_voided(e, flag[1] == e->range_tag) == 0) {
       rc = switch_variant(e, e->exact_variant);
       if (rc) return rc;
     }
     rc = run_stack(e, n, si, std::nanf(""), INFINITY);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h_logits, e->logits, bytes, hipMemcpyDeviceToHost,
-                           e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpyAsync(h_logits, e->logits, bytes, hipMemcpyDeviceToHost, e->stream));
   }
   std::memcpy(logits_out, h_logits, bytes);
   return FFN_OK;
@@ -2678,12 +2681,9 @@ int step_wait_impl(ffn_engine* e, uint32_t ticket, ffn_step_result* results,
   bool any_void = false;
   for (int k = 0; k < n; ++k) any_void = any_void || results[k].range_error != 0;
   if (any_void) {
-    bool resident;
-    {
-      EngineLock lock_(e);
-      resident = e->slot_resident[slot];
-    }
-    const int frc = flow_voided(e, resident);
+    bool timed_out = false;  // the cause is per step: two steps may be in flight
+    for (int k = 0; k < n; ++k) timed_out = timed_out || results[k].range_error == 3;
+    const int frc = flow_voided(e, timed_out);
     if (frc) return frc;
   } else {
     EngineLock lock_(e);

@@ -670,7 +670,9 @@ __device__ __forceinline__ void faces_body(
       s_res.num_deleted = deleted;
       // (2: this step ran on a speculative conv0_a launch that chose another
       // position than the host did: nothing is pasted, the library repeats it)
-      s_res.range_error = (*range_flag == range_tag) ? 1
+      // (3: the void came from the resident launch giving up on a producer --
+      // range_flag[1] carries this step's tag then -- not from the range check)
+      s_res.range_error = (*range_flag == range_tag) ? (range_flag[1] == range_tag ? 3 : 1)
                           : (spec_expected >= 0 && *spec_choice != spec_expected) ? 2
                                                                                   : 0;
     }

@@ -119,21 +119,24 @@ class BoxDealer:
   Iterating yields the SubBox objects this rank was dealt; `taken` keeps them.
 
   Every deal of a process group has its OWN counter in the store: `key` + '/' +
-  a job number that rank 0 draws from a second counter in the store and
-  broadcasts (one small collective per deal: every rank of the job constructs
-  its dealer, as it must anyway to be dealt anything), so a second job over the
+  a job number that rank 0 draws from a second counter in the store and hands
+  to the others THROUGH THE STORE (no process-group collective: constructing a
+  dealer blocks nobody and touches no device), so a second job over the
   same process group -- or a process that restarts against a store that is
   still alive -- starts at zero instead of at an earlier job's final count, and
   dealers that only SOME ranks construct (a local tiling with world == 1, a rank
   that takes deal='static' once) cannot shift the ranks' keys apart.  `job`: an
   explicit tag instead (any value all ranks agree on; no collective then).
 
-  `check_complete()` (collective, after the job): every box was taken exactly
-  once over all ranks, else RuntimeError.
+  `check_complete(failed)` (collective, after the job; on `device`): every box
+  was taken exactly once over all ranks and no rank reports a failure of its
+  own, else RuntimeError ON EVERY RANK.
   """
 
   def __init__(self, boxes: Sequence[SubBox], rank: int = 0, world: int = 1,
-               store=None, key: str = 'ffn_amd/next_box', cost=None, job=None):
+               store=None, key: str = 'ffn_amd/next_box', cost=None, job=None,
+               device=None):
+    self.device = device
     if cost is None:
       cost = lambda b: int(np.prod(b.size))
     # stable: equal costs keep the tiler's z-major order
@@ -155,30 +158,37 @@ class BoxDealer:
     import torch  # pylint:disable=g-import-not-at-top
     import torch.distributed as dist  # pylint:disable=g-import-not-at-top
     n = int(self._store.add(key + '/jobs', 1)) if self.rank == 0 else 0
-    if dist.is_initialized() and dist.get_world_size() == self.world:
-      dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-      t = torch.tensor([n], dtype=torch.int64, device=dev)
-      dist.broadcast(t, src=0)
-      return int(t.item())
-    # no process group of this size (a bare store): rank 0 publishes the number
+    # rank 0 publishes the number under the count of dealers THIS rank has made
+    # (every rank of a job makes its dealer, as it must to be dealt anything)
     tag = key + '/job_of_round/%d' % int(self._store.add(key + '/round/%d' % self.rank, 1))
     if self.rank == 0:
       self._store.set(tag, str(n))
       return n
     return int(self._store.get(tag))
 
-  def check_complete(self):
+  def _collective_device(self):
+    import torch.distributed as dist  # pylint:disable=g-import-not-at-top
+    if dist.get_backend() != 'nccl':
+      return 'cpu'
+    return self.device if self.device is not None else 'cuda'
+
+  def check_complete(self, failed: bool = False):
     """Collective over the job's ranks: every box of the deal was taken exactly
-    once (a rank that used another key would have been dealt every box)."""
+    once (a rank that used another key would have been dealt every box), and no
+    rank comes with a failure of its own (`failed`: e.g. a sub-box it had to skip)
+    -- the error is raised on EVERY rank, none is left waiting in a collective."""
     if self.world == 1:
-      n = len(self.taken)
+      n, bad = len(self.taken), int(bool(failed))
     else:
       import torch  # pylint:disable=g-import-not-at-top
       import torch.distributed as dist  # pylint:disable=g-import-not-at-top
-      dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-      t = torch.tensor([len(self.taken)], dtype=torch.int64, device=dev)
+      t = torch.tensor([len(self.taken), int(bool(failed))], dtype=torch.int64,
+                       device=self._collective_device())
       dist.all_reduce(t)
-      n = int(t.item())
+      n, bad = int(t[0].item()), int(t[1].item())
+    if bad:
+      raise RuntimeError('BoxDealer: %d rank(s) of the job report a failed or skipped '
+                         'sub-box (see their own message)' % bad)
     if n != len(self.order):
       raise RuntimeError('BoxDealer: %d sub-boxes were taken over all ranks, the job '
                          'has %d (did every rank deal from the same key %r?)'
@@ -244,15 +254,28 @@ class _HostAssembly:
     return out
 
   def broadcast_cores(self, out, boxes, owner, rank):
-    """One broadcast per sub-box core from the rank that segmented it."""
+    """One broadcast per OWNER: the cores a rank segmented, packed into one
+    contiguous buffer in sub-box order (thousands of small sub-boxes would make a
+    broadcast per core latency-bound)."""
     import torch  # pylint:disable=g-import-not-at-top
     import torch.distributed as dist  # pylint:disable=g-import-not-at-top
-    for b in boxes:
-      sel = tuple(slice(l, h) for l, h in zip(b.core_lo, b.core_hi))
-      t = torch.from_numpy(np.ascontiguousarray(out[sel]))
-      dist.broadcast(t, src=int(owner[b.index]))
-      if int(owner[b.index]) != rank:
-        out[sel] = t.numpy()
+    for src in sorted(set(int(o) for o in owner)):
+      theirs = [b for b in boxes if int(owner[b.index]) == src]
+      sels = [tuple(slice(l, h) for l, h in zip(b.core_lo, b.core_hi)) for b in theirs]
+      sizes = [int(np.prod([h - l for l, h in zip(b.core_lo, b.core_hi)])) for b in theirs]
+      buf = np.empty(sum(sizes), out.dtype)
+      if src == rank:
+        pos = 0
+        for sel, n in zip(sels, sizes):
+          buf[pos:pos + n] = out[sel].ravel()
+          pos += n
+      t = torch.from_numpy(buf)
+      dist.broadcast(t, src=src)
+      if src != rank:
+        pos = 0
+        for sel, n in zip(sels, sizes):
+          out[sel] = buf[pos:pos + n].reshape(out[sel].shape)
+          pos += n
     return out
 
   def margin_pairs(self, box, seg, off, merged):
@@ -339,16 +362,26 @@ class _DeviceAssembly:
     return out
 
   def broadcast_cores(self, out, boxes, owner, rank):
-    """One RCCL broadcast per sub-box core from the rank that segmented it
-    (through a contiguous staging tensor: a core is a strided box of `out`)."""
+    """One RCCL broadcast per OWNER: the cores a rank segmented, packed into one
+    contiguous device buffer in sub-box order (a core is a strided box of `out`;
+    one broadcast per core would be latency-bound with thousands of sub-boxes)."""
     import torch.distributed as dist  # pylint:disable=g-import-not-at-top
-    for b in boxes:
-      sel = tuple(slice(l, h) for l, h in zip(b.core_lo, b.core_hi))
-      t = out[sel].contiguous()
-      dist.broadcast(t, src=int(owner[b.index]))
-      if int(owner[b.index]) != rank:
-        out[sel] = t
-    self.torch.cuda.synchronize(self.device)
+    torch = self.torch
+    for src in sorted(set(int(o) for o in owner)):
+      theirs = [b for b in boxes if int(owner[b.index]) == src]
+      sels = [tuple(slice(l, h) for l, h in zip(b.core_lo, b.core_hi)) for b in theirs]
+      sizes = [int(np.prod([h - l for l, h in zip(b.core_lo, b.core_hi)])) for b in theirs]
+      if src == rank:
+        buf = torch.cat([out[sel].reshape(-1) for sel in sels])
+      else:
+        buf = torch.empty(sum(sizes), dtype=out.dtype, device=out.device)
+      dist.broadcast(buf, src=src)
+      if src != rank:
+        pos = 0
+        for sel, n in zip(sels, sizes):
+          out[sel] = buf[pos:pos + n].view(out[sel].shape)
+          pos += n
+    torch.cuda.synchronize(self.device)
     return out
 
   def margin_pairs(self, box, seg, off, merged):
@@ -427,8 +460,8 @@ def merge_segmentations(local_results, shape_zyx, rank: int, world: int,
       None: offsets by (rank, position in local_results), the static scheme.
     collective: 'all_reduce' = every rank writes its cores into a zero-filled
       volume, one all_reduce(MAX) (what north_star names; 2 (N-1)/N volumes
-      over each ring link); 'broadcast' = one broadcast per sub-box core from
-      its owner (needs num_boxes; (N-1)/N volumes in total, and no zero-filled
+      over each ring link); 'broadcast' = one broadcast per owning rank of the
+      cores it segmented, packed (needs num_boxes; (N-1)/N volumes in total, and no zero-filled
       buffer is reduced) -- for volumes of 1024^3 and more.
     allow_missing: with num_boxes, a sub-box that NO rank holds is an error
       (the job lost it) unless this is set (a deliberately partial assembly:
@@ -696,7 +729,7 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
   # FoV could not host a single seed
   boxes = tile_volume(size_zyx, sub_size_zyx, overlap_zyx, back_shift=True)
   if deal == 'dynamic':
-    dealer = BoxDealer(boxes, rank, world, store=store, job=deal_job)
+    dealer = BoxDealer(boxes, rank, world, store=store, job=deal_job, device=device)
   elif deal == 'static':
     dealer = iter(assign_round_robin(boxes, rank, world))
   else:
@@ -717,15 +750,31 @@ def segment_volume(runner, corner_zyx, size_zyx, sub_size_zyx, overlap_zyx,
     results[index] = (mine[index], asm.labels(canvas.segmentation))
 
   t0 = time.perf_counter()
-  runner.run_many(subvolumes(), batch_size=batch_size, save=save,
-                  on_done=collect)
+  failure = None
+  try:
+    runner.run_many(subvolumes(), batch_size=batch_size, save=save,
+                    on_done=collect)
+  except Exception as err:  # pylint:disable=broad-except
+    if deal != 'dynamic' or world == 1:
+      raise
+    failure = err  # the peers are told below, then it is raised again
   t_seg = time.perf_counter() - t0
+  skipped = [b for b, r in zip(mine, results) if r is None]
   if deal == 'dynamic':
-    dealer.check_complete()  # (collective) every sub-box was dealt exactly once
-  for b, r in zip(mine, results):
-    if r is None:
-      raise RuntimeError('sub-box %r was skipped (output exists / masked); '
-                         'assemble from the saved files instead' % (b,))
+    # (collective) every sub-box was dealt exactly once AND no rank failed: a rank
+    # that raised before this point would leave its peers blocked in here
+    try:
+      dealer.check_complete(failed=failure is not None or bool(skipped))
+    except RuntimeError:
+      if failure is not None:
+        raise failure
+      if not skipped:
+        raise
+  if failure is not None:
+    raise failure
+  for b in skipped:
+    raise RuntimeError('sub-box %r was skipped (output exists / masked); '
+                       'assemble from the saved files instead' % (b,))
   info = {'boxes': boxes, 'mine': mine}
   t0 = time.perf_counter()
   if reconcile:

@@ -84,7 +84,9 @@ typedef struct ffn_step_result {
                              the step was NOT pasted (FFN_ERR_RANGE); 2 = the
                              step's conv0_a was a launch made ahead for another
                              position (option "speculate"): NOT pasted either,
-                             ffn_canvas_step repeats such a step itself         */
+                             ffn_canvas_step repeats such a step itself; 3 = the
+                             resident conv launch gave up waiting for one of its
+                             own workgroups: NOT pasted (FFN_ERR_FLOW)          */
 } ffn_step_result;
 
 /* Result of the per-segment commit reduction (inference.py:614-646). */
