@@ -150,6 +150,26 @@ def _dist_env():
   return rank, local_rank, world
 
 
+def rank_devices(args, local_rank):
+  """-> (index of the GPU this rank computes on, device its collectives run on).
+  --ranks-share-gpus: rank r computes on GPU r % device_count (several ranks on one GPU:
+  the launcher, the deal and the rank bookkeeping of an N > 1 job exercised on a one-GPU
+  box -- not a scaling point); --collective-backend gloo: collectives on host tensors."""
+  import torch
+  dev_index = local_rank % torch.cuda.device_count() if args.ranks_share_gpus else local_rank
+  coll = torch.device('cuda', dev_index) if args.collective_backend == 'nccl' else None
+  return dev_index, coll
+
+
+def init_group(args, dev_index):
+  import torch
+  import torch.distributed as dist
+  if args.collective_backend == 'nccl':
+    dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+  else:
+    dist.init_process_group('gloo')
+
+
 class Comm:
   """The ranks of the job as far as the bench talks to them: a barrier and
   small reductions over `torch.distributed` (backend nccl = RCCL on the GPUs;
@@ -225,6 +245,9 @@ def stream_totals(comm, local):
   out['voxels_run'], out['steps_run'], out['voxels'] = comm.all_sum(
       [local['voxels_run'], local['steps_run'], local['voxels']])
   out['seconds_run'] = comm.all_max([local['seconds_run']])[0]
+  # resident launches that timed out (several ranks on ONE GPU cannot all be resident)
+  out['flow_voids'], out['flow_auto_off'] = comm.all_sum(
+      [local.get('flow_voids', 0), local.get('flow_auto_off', 0)])
   return out
 
 
@@ -267,12 +290,137 @@ def load_model():
   return model
 
 
-def full_fixture(workload_seed):
+def full_fixture(workload_seed, forward='onednn'):
   """The reference-minted run of the WHOLE 250^3 phantom of this seed (tools/
-  make_golden.py --only cells250 --forward onednn --num-seeds 0 [--volume-seed S])."""
+  make_golden.py --only cells250 --forward onednn|f64c --num-seeds 0 [--volume-seed S])."""
   tag = '' if workload_seed == 1234 else '_s%d' % workload_seed
   return os.path.join(ROOT, 'tests', 'golden',
-                      'ref_canvas_cells250_onednn_full%s.npz' % tag)
+                      'ref_canvas_cells250_%s_full%s.npz' % (forward, tag))
+
+
+def run_agreement(seg, seen, fixture_path, forward_name):
+  """A finished GPU pass (labels `seg`, FoV positions `seen`) against a run the
+  reference's own Canvas made of the same volume: the headline is the FOREGROUND IoU
+  (labelled in both / labelled in either: what the segmentation covers), the id-for-id
+  figure stands beside it (void as soon as the two runs number their objects apart)."""
+  fixture = np.load(fixture_path)
+  agree = segmentation_agreement(seg, fixture['segmentation'])
+  ref_steps = [tuple(int(v) for v in p) for p in fixture['steps']]
+  n = min(len(seen), len(ref_steps))
+  first_bad = next((k for k in range(n) if seen[k] != ref_steps[k]), None)
+  return {
+      'fixture': '%s (the reference\'s Canvas behind %s)' % (
+          os.path.relpath(fixture_path, ROOT), forward_name),
+      'iou': agree['iou_foreground'],
+      'iou_what': 'iou = iou_foreground: labelled in both / labelled in either; '
+                  'iou_id_for_id: same id in both / labelled in either (ids must agree: '
+                  'void once the runs count their objects apart); iou_best_match: per '
+                  'reference object, size-weighted',
+      'iou_foreground': agree['iou_foreground'],
+      'iou_id_for_id': agree['iou_labelled'],
+      'iou_best_match': agree['iou_best_match'],
+      'objects': agree['objects'],
+      'objects_matched_at_0999': agree['objects_matched_at_0999'],
+      'reference_steps': len(ref_steps),
+      'reference_objects': len(json.loads(str(fixture['origins']))),
+      'first_position_mismatch': first_bad,
+      'positions_compared': n,
+  }
+
+
+SHADER_CLOCK_SPREAD = {}  # batch -> min / median / max of sample_shader_clock's samples
+
+
+class BoardSampler:
+  """Socket power and shader clock of the GPU this process runs on, read from the
+  driver's hwmon files (power1_input: microwatts of the package power tracker, freq1_input:
+  sclk in Hz; what rocm-smi --showpower --showclocks prints) by a thread every few
+  milliseconds WHILE a kernel loop runs: the figures that tell a power-capped clock from
+  an idle one.  Read-only; everything is None where the files are not there."""
+
+  def __init__(self, device_index=0, period_s=0.004):
+    import glob
+    import threading
+    self.period_s = period_s
+    self.hwmon = None
+    self.cap_w = None
+    self._stop = threading.Event()
+    self._thread = None
+    self.power_w, self.sclk_mhz = [], []
+    try:
+      import torch
+      pr = torch.cuda.get_device_properties(device_index)
+      tail = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+      for d in glob.glob('/sys/class/drm/card*/device'):
+        if os.path.realpath(d).endswith(tail):
+          hw = glob.glob(os.path.join(d, 'hwmon', 'hwmon*'))
+          if hw and os.path.exists(os.path.join(hw[0], 'power1_input')):
+            self.hwmon = hw[0]
+      if self.hwmon:
+        self.cap_w = int(open(os.path.join(self.hwmon, 'power1_cap')).read()) / 1e6
+    except Exception:  # pylint:disable=broad-except
+      self.hwmon = None
+
+  def _read(self, name):
+    with open(os.path.join(self.hwmon, name)) as f:
+      return int(f.read())
+
+  def _loop(self):
+    while not self._stop.is_set():
+      try:
+        self.power_w.append(self._read('power1_input') / 1e6)
+        self.sclk_mhz.append(self._read('freq1_input') / 1e6)
+      except Exception:  # pylint:disable=broad-except
+        pass
+      self._stop.wait(self.period_s)
+
+  def __enter__(self):
+    import threading
+    if self.hwmon:
+      self._thread = threading.Thread(target=self._loop, daemon=True)
+      self._thread.start()
+    return self
+
+  def __exit__(self, *exc):
+    self._stop.set()
+    if self._thread:
+      self._thread.join()
+
+  def summary(self, what):
+    if not self.power_w:
+      return None
+    # (the first samples still show the idle state: the tracker averages over ~ms)
+    pw = np.array(self.power_w[len(self.power_w) // 4:] or self.power_w)
+    ck = np.array(self.sclk_mhz[len(self.sclk_mhz) // 4:] or self.sclk_mhz)
+    return {'what': what, 'samples': int(len(pw)),
+            'board_w': {'median': round(float(np.median(pw)), 1),
+                        'max': round(float(pw.max()), 1)},
+            'power_cap_w': self.cap_w,
+            'sclk_mhz': {'min': round(float(ck.min()), 0),
+                         'median': round(float(np.median(ck)), 0),
+                         'max': round(float(ck.max()), 0)},
+            'source': 'hwmon power1_input (package power tracker) / freq1_input (sclk) of this '
+                      'GPU, polled every %d ms while the loop ran' % int(self.period_s * 1e3)}
+
+
+def board_under_stack(eng, batch, seconds=1.2):
+  """BoardSampler over ~`seconds` of resident conv stacks at this batch (timing only)."""
+  try:
+    eng.forward_resident(batch, 3)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    eng.forward_resident(batch, 5)
+    eng.synchronize()
+    per = max((time.perf_counter() - t0) / 5, 1e-5)
+    with BoardSampler() as bs:
+      t_end = time.perf_counter() + seconds
+      while time.perf_counter() < t_end:
+        eng.forward_resident(batch, max(1, int(0.05 / per)))
+        eng.synchronize()
+    return bs.summary('%.1f s of back-to-back resident conv stacks, %d FoV(s) per launch'
+                      % (seconds, batch))
+  except Exception:  # pylint:disable=broad-except
+    return None
 
 
 def sample_shader_clock(eng, batch=1):
@@ -293,7 +441,12 @@ def sample_shader_clock(eng, batch=1):
       c = eng.debug_clocks().astype(np.float64)
       ghz += [(c[w, 3] - c[w, 0]) / ((c[w, 5] - c[w, 4]) * 10.0)
               for w in range(4) if c[w, 5] > c[w, 4] and c[w, 3] > c[w, 0]]
-    return round(float(np.median(ghz)), 3) if ghz else None
+    if not ghz:
+      return None
+    SHADER_CLOCK_SPREAD[batch] = {'samples': len(ghz), 'min': round(float(np.min(ghz)), 3),
+                                  'median': round(float(np.median(ghz)), 3),
+                                  'max': round(float(np.max(ghz)), 3)}
+    return round(float(np.median(ghz)), 3)
   except Exception:  # pylint:disable=broad-except
     return None
   finally:
@@ -337,6 +490,26 @@ def segmentation_agreement(seg, want):
       'objects_matched_at_0999': int(sum(1 for w in ref_ids
                                          if best.get(int(w), 0.0) >= 0.999)),
   }
+
+
+def recorded_pass(make, policy):
+  """One more complete pass (untimed) with the FoV positions kept."""
+  from ffn_amd.inference import inference_utils
+  canvas = make(inference_utils.Counters(), keep_history=True)
+  seen = []
+  inner = canvas._segment_at_native
+
+  def recording(start_pos, *a, **kw):
+    n = inner(start_pos, *a, **kw)
+    if n:
+      seen.extend(tuple(int(v) for v in p) for p in canvas.history[-n:])
+    return n
+
+  canvas._segment_at_native = recording
+  canvas.segment_all(seed_policy=policy)
+  again = np.array(np.asarray(canvas.segmentation))
+  canvas.close()
+  return seen, again
 
 
 def full_volume_pass(args, comm, model, exe, request, image, barrier):
@@ -390,42 +563,45 @@ def full_volume_pass(args, comm, model, exe, request, image, barrier):
   seg = np.array(np.asarray(canvas.segmentation))
   canvas.close()
   if fixture is not None and comm.rank == 0:
-    agree = segmentation_agreement(seg, fixture['segmentation'])
-    ref_steps = [tuple(int(v) for v in p) for p in fixture['steps']]
-    # untimed: the same pass with the positions kept
-    canvas = make(inference_utils.Counters(), keep_history=True)
-    seen = []
-    inner = canvas._segment_at_native
-
-    def recording(start_pos, *a, **kw):
-      n = inner(start_pos, *a, **kw)
-      if n:
-        seen.extend(tuple(int(v) for v in p) for p in canvas.history[-n:])
-      return n
-
-    canvas._segment_at_native = recording
-    canvas.segment_all(seed_policy=policy)
-    again = np.array(np.asarray(canvas.segmentation))
+    seen, again = recorded_pass(make, policy)
+    out['vs_reference_run'] = run_agreement(seg, seen, fixture_path,
+                                            'the torch-CPU / oneDNN f32 forward')
+    out['vs_reference_run']['repeat_pass_identical'] = bool(np.array_equal(again, seg))
+    f64_path = full_fixture(args.workload_seed, 'f64')
+    if os.path.exists(f64_path):
+      out['vs_f64_run'] = run_agreement(seg, seen, f64_path, 'a double-precision forward')
+  # the OTHER whole volume the suite holds a reference-minted run of (one more build of
+  # a 250^3 phantom and two passes, ~15 s): rank 0, N = 1, untimed for `value`
+  other = 4321 if args.workload_seed == 1234 else 1234
+  if (fixture is not None and comm.rank == 0 and comm.world == 1 and
+      not args.no_second_volume and os.path.exists(full_fixture(other))):
+    from ffn_amd import synthetic
+    image2 = synthetic.normalize(bench_volume(tuple(VOLUME_ZYX), other))
+    fx2 = np.load(full_fixture(other))
+    policy2 = functools.partial(seed_lib.PolicyFixed, coords=fx2['seeds'])
+    make2 = lambda counters, **kw: inference.DeviceCanvas(  # noqa: E731
+        model.info, exe.get_client(counters, direct=True), image2,
+        request.inference_options, counters=counters,
+        movement_policy_fn=movement.get_policy_fn(request, model.info), **kw)
+    c2 = inference_utils.Counters()
+    canvas = make2(c2)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    canvas.segment_all(seed_policy=policy2)
+    eng.synchronize()
+    t2 = time.perf_counter() - t0
+    seg2 = np.array(np.asarray(canvas.segmentation))
     canvas.close()
-    n = min(len(seen), len(ref_steps))
-    first_bad = next((k for k in range(n) if seen[k] != ref_steps[k]), None)
-    out['vs_reference_run'] = {
-        'fixture': '%s (the reference\'s Canvas behind the torch-CPU / oneDNN f32 '
-                   'forward)' % os.path.relpath(fixture_path, ROOT),
-        'iou': agree['iou_labelled'],
-        'iou_what': 'same id in both / labelled in either (ids must agree); '
-                    'iou_foreground and iou_best_match (per reference object, '
-                    'size-weighted) do not depend on the numbering',
-        'iou_foreground': agree['iou_foreground'],
-        'iou_best_match': agree['iou_best_match'],
-        'objects': agree['objects'],
-        'objects_matched_at_0999': agree['objects_matched_at_0999'],
-        'reference_steps': len(ref_steps),
-        'reference_objects': len(json.loads(str(fixture['origins']))),
-        'first_position_mismatch': first_bad,
-        'positions_compared': n,
-        'repeat_pass_identical': bool(np.array_equal(again, seg)),
-    }
+    seen2, _ = recorded_pass(make2, policy2)
+    rec = {'workload_seed': other, 'fov_steps': int(c2['update_at-calls'].value),
+           'seconds': round(t2, 4),
+           'fov_steps_per_s': round(c2['update_at-calls'].value / t2, 1),
+           'vs_reference_run': run_agreement(seg2, seen2, full_fixture(other),
+                                             'the torch-CPU / oneDNN f32 forward')}
+    if os.path.exists(full_fixture(other, 'f64')):
+      rec['vs_f64_run'] = run_agreement(seg2, seen2, full_fixture(other, 'f64'),
+                                        'a double-precision forward')
+    out['second_volume'] = rec
   eng.set_option('profile_every', mode)
   eng.set_profiling(args.profile_mode)
   return out
@@ -443,10 +619,11 @@ def run_gpu(args, rank, local_rank, world):
 
   if not torch.cuda.is_available():
     raise RuntimeError('bench.py needs an MI355X: no CPU fallback exists')
-  torch.cuda.set_device(local_rank)
+  dev_index, coll_device = rank_devices(args, local_rank)
+  torch.cuda.set_device(dev_index)
   if world > 1:
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-  comm = Comm(rank, world, torch.device('cuda', local_rank))
+    init_group(args, dev_index)
+  comm = Comm(rank, world, coll_device)
 
   def barrier():
     comm.barrier()
@@ -457,7 +634,7 @@ def run_gpu(args, rank, local_rank, world):
   counters = inference_utils.Counters()
   exe = executor.HipBatchExecutor(executor.ExecutorInterface(), model,
                                   model.info, None, counters, 1,
-                                  device_id=local_rank)
+                                  device_id=dev_index)
   eng = exe.engine
   if args.conv_variant is not None:
     eng.set_option('conv_variant', args.conv_variant)
@@ -611,7 +788,7 @@ def run_gpu(args, rank, local_rank, world):
     tm = time.perf_counter()
     merged, _ = ffn_dist.merge_segmentations(
         [(boxes[rank], seg)], full, rank, world,
-        device=torch.device('cuda', local_rank))
+        device=coll_device)
     barrier()
     merge_ms = (time.perf_counter() - tm) * 1e3
     merged_ids = int(merged.max())
@@ -620,6 +797,15 @@ def run_gpu(args, rank, local_rank, world):
     print('merge skipped: %r' % (e,), file=sys.stderr)
   canvas._flush_hot()
   shader_ghz = sample_shader_clock(eng, 1)
+  board = board_under_stack(eng, 1) if rank == 0 else None
+  pace = {'ticks_10ns': eng.get_option('flow_pace_now'),
+          'tuner_free_running_us': eng.get_option('flow_pace_free_ns') / 1e3,
+          'tuner_at_its_beat_us': eng.get_option('flow_pace_best_ns') / 1e3,
+          'what': 'the resident stack is PACED: conv l of a workgroup does not start before '
+                  't0 + l x beat + beat x (its first voxel / V); the beat is measured when the '
+                  'weights are set (a ladder of beats on noise inputs, the best one + 0.1 us '
+                  'if it beats the free-running stack by > 1.5 %, else 0 = free-running); '
+                  'timing only, bit-identical results (DESIGN.md section 3.3)'}
   cvals = {k: c.value for k, c in counters}
   cvals['gate_rejects'] = canvas.gate_rejects
   full_volume = None
@@ -628,6 +814,10 @@ def run_gpu(args, rank, local_rank, world):
   result = {
       'full_volume': full_volume,
       'shader_clock_ghz': shader_ghz,
+      'board': board,
+      'pace': pace,
+      'flow_voids': eng.get_option('stat_flow_voids'),
+      'flow_auto_off': eng.get_option('flow_auto_off'),
       'merge_ms': merge_ms,
       'merged_ids': merged_ids,
       'counters': cvals,
@@ -689,10 +879,10 @@ def run_sharded(args, rank, local_rank, world):
 
   if not torch.cuda.is_available():
     raise RuntimeError('bench.py needs an MI355X: no CPU fallback exists')
-  torch.cuda.set_device(local_rank)
-  device = torch.device('cuda', local_rank)
+  dev_index, device = rank_devices(args, local_rank)  # device: where collectives run
+  torch.cuda.set_device(dev_index)
   if world > 1:
-    dist.init_process_group('nccl', device_id=device)
+    init_group(args, dev_index)
   comm = Comm(rank, world, device)
 
   def barrier():
@@ -722,7 +912,7 @@ def run_sharded(args, rank, local_rank, world):
   else:
     request.model_checkpoint_path = os.path.join(out_dir, 'weights.npz')
     np.savez(request.model_checkpoint_path, **model_variables())
-  run = runner_lib.Runner(device_id=local_rank)
+  run = runner_lib.Runner(device_id=dev_index)
   run.start(request, batch_size=args.sharded_batch, direct=True,
             image_volume=vol)
   eng = run.executor.engine
@@ -737,7 +927,8 @@ def run_sharded(args, rank, local_rank, world):
   # sub-boxes are taken by the ranks as their canvas slots free up (the cost of
   # a box is heavy-tailed); ids follow the box index, so the assembled volume
   # does not depend on the deal
-  dealer = (ffn_dist.BoxDealer(boxes, rank, world) if args.sharded_deal == 'dynamic'
+  dealer = (ffn_dist.BoxDealer(boxes, rank, world, device=device)
+            if args.sharded_deal == 'dynamic'
             else iter(ffn_dist.assign_round_robin(boxes, rank, world)))
   asm = ffn_dist._assembly_for(device)
   asm.job_boxes = boxes
@@ -770,7 +961,10 @@ def run_sharded(args, rank, local_rank, world):
   if CONFIG != 'c1':  # (dense_random_blob: why)
     eng.set_weights(dense_random_blob())
     stack_us = time_stack()
+    board = board_under_stack(eng, args.sharded_batch)
     eng.set_weights(load_model().weights_blob())
+  else:
+    board = board_under_stack(eng, args.sharded_batch)
   t_setup = time.perf_counter() - t_setup0
   eng.set_option('stat_reset', 0)
   barrier()
@@ -803,7 +997,7 @@ def run_sharded(args, rank, local_rank, world):
       results, shape, rank, world, device, assembly=asm, keep_on_device=True, **kw)
   barrier()
   merge_ms = (time.perf_counter() - tm) * 1e3
-  plain_ids = int(torch.unique(merged).numel()) - 1
+  plain_ids = int(len(np.unique(asm.to_host(merged)))) - 1
   del merged
   barrier()
   tr = time.perf_counter()
@@ -811,7 +1005,7 @@ def run_sharded(args, rank, local_rank, world):
       results, shape, rank, world, device, keep_on_device=True, assembly=asm, **kw)
   barrier()
   reconcile_total_ms = (time.perf_counter() - tr) * 1e3
-  final_ids = int(torch.unique(merged).numel()) - 1
+  final_ids = int(len(np.unique(asm.to_host(merged)))) - 1
   totals = sharded_totals(comm, steps, voxels, t_seg_local, len(mine))
   merge_bytes = dict(ffn_dist.merge_collective_bytes(shape, boxes, world),
                      used=args.sharded_collective)
@@ -828,12 +1022,12 @@ def run_sharded(args, rank, local_rank, world):
     # checker leg (untimed): the assembly against its numpy specification
     t_check = time.perf_counter()
     from oracle import labels_oracle
-    host_results = [(b, seg.cpu().numpy()) for b, seg in held]
+    host_results = [(b, np.asarray(asm.to_host(seg))) for b, seg in held]
     host_results.sort(key=lambda r: r[0].index)  # ids follow the box index
     want, want_edges, _ = labels_oracle.reconcile(
         host_results, shape, ffn_dist.MIN_OVERLAP_VOXELS,
         ffn_dist.MIN_OVERLAP_FRACTION)
-    got = merged.cpu().numpy()
+    got = np.asarray(asm.to_host(merged))
     check = {'ids_expected': int(len(np.unique(want)) - 1),
              'ids_got': int(len(np.unique(got)) - 1),
              'volume_equal': bool(np.array_equal(got, want)),
@@ -859,7 +1053,8 @@ def run_sharded(args, rank, local_rank, world):
            driver_calls=run.last_driver.calls,
            driver_library_seconds=run.last_driver.library_seconds,
            driver_segments_ended=run.last_driver.segments_ended,
-           merge_bytes=merge_bytes, batched_ghz=batched_ghz)
+           merge_bytes=merge_bytes, batched_ghz=batched_ghz, board=board,
+           clock_spread=SHADER_CLOCK_SPREAD.get(args.sharded_batch))
   print(json.dumps(sharded_line(args, world, totals, m)))
 
 
@@ -976,6 +1171,28 @@ def sharded_line(args, world, totals, m):
   # convs, the fused head) over its wall time -- NOT 2 depth equal launches
   batched_tflops = args.sharded_batch * STEP_FLOPS / (stack_us * 1e-6) / 1e12
   batched_peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+  roofline = {
+      'bound': 'mfma',
+      'kernel': 'conv32m (conv_variant %s): the batched conv stack, %d FoVs per launch, one '
+                'launch per conv; %s' % (
+                    conv_variant, args.sharded_batch,
+                    'FIB-25 weights' if CONFIG == 'c1' else
+                    'dense seeded random weights loaded for the timing (the run\'s '
+                    'constructed network is mostly zeros: less power, higher clock)'),
+      'achieved': round(batched_tflops, 1),
+      'peak': round(batched_peak, 1),
+      'unit': 'TFLOP/s',
+      'frac': round(batched_tflops / batched_peak, 4),
+      'traffic': None,
+      'flops_per_stack': args.sharded_batch * STEP_FLOPS,
+      'avg_stack_us': round(stack_us, 1),
+      'timing': 'wall clock over %d resident stacks of %d FoVs between device '
+                'synchronisations (conv0_a + %d conv launches each, every flop of a step '
+                'counted)' % (kernel_reps, args.sharded_batch, 2 * DEPTH - 1),
+      'shader_clock_ghz': m.get('batched_ghz'),
+      'shader_clock_samples': m.get('clock_spread'),
+      'board': m.get('board'),
+  }
   out = {
       'metric': 'FoV-steps/sec (one %s volume sharded by sub-box over %d GPU(s))'
                 % ('x'.join(str(v) for v in shape), world),
@@ -1011,6 +1228,8 @@ def sharded_line(args, world, totals, m):
           'sub_boxes': len(boxes),
           'conv_variant': conv_variant,
           'engine_options': dict(_engine_options(args)),
+          'launch': {'collective_backend': args.collective_backend,
+                     'ranks_share_gpus': bool(args.ranks_share_gpus)},
           'max_steps_per_canvas': args.sharded_max_steps or None,
           'parallelism': 'sub-boxes sharded over ranks; collectives only in the '
                          'final assembly (RCCL)',
@@ -1035,6 +1254,7 @@ def sharded_line(args, world, totals, m):
                   'rate: steps with fewer FoVs than the batch (canvases between '
                   'segments, the tail of the job) and host turn-around',
       },
+      'roofline': roofline,
       'batched_kernel': {
           'batch': args.sharded_batch,
           'us_per_stack': round(stack_us, 1),
@@ -1424,13 +1644,49 @@ def batched_leg(args):
       'unit': d['unit'],
       'steps': d['steps'],
       'seconds': d['segmentation_seconds'],
-      'roofline': d['batched_kernel'],
+      'roofline': dict(d['batched_kernel'], board=d['roofline'].get('board')),
       'check_vs_specification': d['assembly']['check_vs_specification'],
       'voxels_segmented_per_s': d['voxels_segmented_per_s'],
       'assembly_ms': d['assembly']['merge_plus_reconcile_ms'],
       'engine_calls': d['engine_calls'],
       'host_loop': d['host_loop'],
       'setup_seconds': d['setup_seconds'],
+      'wall_seconds_of_this_leg': round(time.perf_counter() - t0, 1),
+  }
+
+
+def c5_leg(args):
+  """BASELINE configs[4]'s model (depth 18, FoV zyx 21 x 41 x 41, deltas 5 x 10 x 10) next
+  to the headline, bounded: this script once more with --mode sharded --config c5 on a
+  96 x 512 x 512 volume (32 anisotropic sub-boxes, 16 canvases open) in a process of its
+  own.  The run uses the constructed flood-fill network (no checkpoint of that shape
+  exists) and is checked against the numpy specification; the kernel `roofline` is
+  timed on dense random weights (68.44 GFLOP per FoV step against 2,500 / 3 TFLOP/s).
+  Never `value`."""
+  import subprocess
+  cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'sharded', '--config', 'c5',
+         '--sharded-volume-zyx', '96', '512', '512', '--sharded-sub-zyx', '64', '192', '192',
+         '--sharded-batch', '8', '--sharded-groups', '2', '--no-cpu-baseline']
+  t0 = time.perf_counter()
+  try:
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=args.c5_timeout)
+    d = json.loads(run.stdout.strip().splitlines()[-1])
+  except Exception as e:  # pylint:disable=broad-except
+    return {'error': repr(e), 'seconds': round(time.perf_counter() - t0, 1)}
+  return {
+      'what': 'bench.py --mode sharded --config c5 on one 96x512x512 volume in %d '
+              'sub-boxes of 64x192x192, 16 canvases open' % d['config']['sub_boxes'],
+      'workload': d['config']['workload'],
+      'conv_variant': d['config']['conv_variant'],
+      'value': d['value'],
+      'unit': d['unit'],
+      'steps': d['steps'],
+      'seconds': d['segmentation_seconds'],
+      'roofline': d['roofline'],
+      'whole_run': d['batched_kernel']['whole_run'],
+      'check_vs_specification': d['assembly']['check_vs_specification'],
+      'voxels_segmented_per_s': d['voxels_segmented_per_s'],
+      'assembly_ms': d['assembly']['merge_plus_reconcile_ms'],
       'wall_seconds_of_this_leg': round(time.perf_counter() - t0, 1),
   }
 
@@ -1481,15 +1737,16 @@ def stream_line(args, world, res):
   # this same command, when present.
   traffic = None
   traffic_source = None
+  traffic_stale = None
   pmc_commit = None
   pmc_busy_cycles = None
   try:
     resident = res.get('flow') == 2 and res.get('conv_variant') == 9
-    tname = (('r05_conv32ps_pmc.json' if resident else
+    tname = (('r06_conv32ps_pmc.json' if resident else
               'conv32_pmc_traffic.json') if CONFIG == 'c1' else
              'r03_conv32mt_c5_pmc_traffic.json')
     if not os.path.exists(os.path.join(ROOT, 'profiles', tname)) and resident:
-      tname = 'r04_conv32ps_pmc_traffic.json'
+      tname = 'r05_conv32ps_pmc.json'
     with open(os.path.join(ROOT, 'profiles', tname)) as f:
       tj = json.load(f)
     if (tj.get('conv_variant', 9) == res.get('conv_variant', 9) and
@@ -1500,6 +1757,9 @@ def stream_line(args, world, res):
                         '(NOT measured in this run)' % (tname, tj.get('commit') or
                                                         '(not recorded)'))
       pmc_commit = tj.get('commit')
+      from ffn_amd import _lib as lib_mod
+      pmc_sha = tj.get('csrc_sha')
+      traffic_stale = pmc_sha != lib_mod.csrc_sha()
       busy = (tj.get('sq_per_launch') or {}).get('SQ_VALU_MFMA_BUSY_CYCLES')
       if busy:
         pmc_busy_cycles = float(busy)
@@ -1599,6 +1859,16 @@ def stream_line(args, world, res):
           'engine_options': dict(_engine_options(args)),
           'env': {k: os.environ[k] for k in ('HIP_FORCE_DEV_KERNARG',)
                   if k in os.environ},
+          'launch': {'collective_backend': args.collective_backend,
+                     'ranks_share_gpus': bool(args.ranks_share_gpus)},
+      },
+      'resident_launch_fallbacks': {
+          'steps_repeated_per_layer': int(res.get('flow_voids', 0)),
+          'ranks_that_turned_the_resident_launch_off': int(res.get('flow_auto_off', 0)),
+          'note': 'all ranks; 0 on a GPU of its own -- ranks that SHARE a GPU cannot all keep '
+                  'their 356 workgroups resident: FFN_ERR_FLOW, the step repeated with '
+                  'per-layer launches (same bits), three in a row turn the resident launch '
+                  'off for that engine',
       },
       # the second half of BASELINE.json's metric: from the complete pass below
       # (`full_volume`) when it ran, else from the partial run (`voxels_leg`)
@@ -1651,6 +1921,9 @@ def stream_line(args, world, res):
           'traffic': traffic,
           'traffic_source': traffic_source,
           'traffic_commit': pmc_commit,
+          # True: ffn_amd/csrc has changed since that capture (its csrc_sha differs from
+          # this tree's): the figure describes an EARLIER kernel
+          'traffic_stale': traffic_stale,
           # matrix-pipe occupancy: SQ_VALU_MFMA_BUSY_CYCLES of one launch (summed
           # over the chip's 1,024 SIMDs, from the same committed PMC capture) over
           # the SIMD-cycles of THIS run's mean launch at the 2.1 GHz the chip holds
@@ -1661,6 +1934,9 @@ def stream_line(args, world, res):
           # the clock this box held under the kernel (sample_shader_clock): the peak
           # above is at the 2.4 GHz boost clock
           'shader_clock_ghz': res.get('shader_clock_ghz'),
+          'shader_clock_samples': SHADER_CLOCK_SPREAD.get(1),
+          'board': res.get('board'),
+          'pace': res.get('pace'),
           'frac_of_peak_at_that_clock': (
               round(achieved / (peak * res['shader_clock_ghz'] / 2.4), 4)
               if res.get('shader_clock_ghz') else None),
@@ -1706,6 +1982,10 @@ def stream_line(args, world, res):
 def build_parser():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--collective-backend', choices=['nccl', 'gloo'], default='nccl',
+                  help='nccl = RCCL on the GPUs (default); gloo = collectives on host tensors')
+  ap.add_argument('--ranks-share-gpus', action='store_true',
+                  help='rank r computes on GPU r %% device_count (N ranks on fewer GPUs)')
   ap.add_argument('--steps', type=int, default=1500)
   ap.add_argument('--warmup', type=int, default=100)
   ap.add_argument('--prewarm-max-steps', type=int, default=2500)
@@ -1784,6 +2064,11 @@ def build_parser():
   ap.add_argument('--no-batched-leg', action='store_true',
                   help='skip the time-boxed batched (configs[2]) leg of the '
                   'default run')
+  ap.add_argument('--no-second-volume', action='store_true',
+                  help='skip the pass over the other reference-minted 250^3 volume')
+  ap.add_argument('--no-c5-leg', action='store_true',
+                  help='skip the configs[4] leg (depth 18, FoV 21x41x41) of the default line')
+  ap.add_argument('--c5-timeout', type=float, default=240.0)
   ap.add_argument('--batched-max-steps', type=int, default=0)
   ap.add_argument('--batched-timeout', type=float, default=420.0)
   ap.add_argument('--host-loop', choices=['native', 'python'], default='native',
@@ -1825,6 +2110,8 @@ def main():
                   'parity_error': repr(e)})
   if world == 1 and CONFIG == 'c1' and not args.no_batched_leg:
     out['batched'] = batched_leg(args)
+  if world == 1 and CONFIG == 'c1' and not args.no_c5_leg:
+    out['c5'] = c5_leg(args)
   print(json.dumps(out))
 
 

@@ -323,3 +323,17 @@ def check(rc: int):
 
 def i3(values):
   return (ctypes.c_int32 * 3)(*[int(v) for v in values])
+
+
+def csrc_sha() -> str:
+  """sha256 over the kernel / host sources of the library (ffn_amd/csrc/*.hip, *.h), in
+  name order: what a committed profile was taken on (profiles/*_pmc.json `csrc_sha`) against
+  what this tree builds (bench.py: roofline.traffic_stale)."""
+  import hashlib
+  h = hashlib.sha256()
+  for name in sorted(os.listdir(CSRC)):
+    if name.endswith(('.hip', '.h')):
+      h.update(name.encode())
+      with open(os.path.join(CSRC, name), 'rb') as f:
+        h.update(f.read())
+  return h.hexdigest()[:16]

@@ -35,7 +35,8 @@ def main():
   ap.add_argument('--commit', default='', help='git revision of the tree the capture ran on')
   ap.add_argument('--sq-csv', default='', help='counter dump of an SQ pass '
                   '(SQ_VALU_MFMA_BUSY_CYCLES ...): per-launch means go into the JSON')
-  ap.add_argument('--script', default='tools/gpu_profile_r5.sh')
+  ap.add_argument('--script', default='tools/gpu_profile_r6.sh')
+  ap.add_argument('--csrc-sha', default='', help='ffn_amd._lib.csrc_sha() of the tree')
   args = ap.parse_args()
   fetch = per_kernel(args.fetch_csv, 'FETCH_SIZE')
   write = per_kernel(args.write_csv, 'WRITE_SIZE')
@@ -61,6 +62,7 @@ def main():
       'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, '
                 '--kernel-trace only; %s; %s' % (args.script, args.command),
       'commit': args.commit or None,
+      'csrc_sha': args.csrc_sha or None,
       'units': 'KiB per dispatch; fetched bytes = 2 x FETCH_SIZE x 1024 on gfx950 '
                '(MI355X_MICROARCH.md, HBM section)',
       'conv_variant': 9,
