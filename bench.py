@@ -816,6 +816,18 @@ def run_gpu(args, rank, local_rank, world):
       'shader_clock_ghz': shader_ghz,
       'board': board,
       'pace': pace,
+      'turn_around': {
+          'gpu_us': round(eng.get_option('stat_turn_gpu_ns') / 1e3, 2),
+          'host_us': round(eng.get_option('stat_turn_host_ns') / 1e3, 2),
+          'launch_call_us': round(eng.get_option('stat_launch_host_ns') / 1e3, 2),
+          'steps': eng.get_option('stat_turn_count'),
+          'what': 'between two single-FoV steps, mean over the run: gpu_us = from the faces '
+                  'block publishing a step\'s record (in-kernel wall clock) to the first '
+                  'instruction of the NEXT resident launch; host_us = from the host seeing '
+                  'that record to the next hipLaunchKernelGGL(conv32ps) having returned; '
+                  'launch_call_us = inside that call alone.  gpu_us - host_us = the record\'s '
+                  'trip over PCIe + doorbell -> first wave.',
+      },
       'flow_voids': eng.get_option('stat_flow_voids'),
       'flow_auto_off': eng.get_option('flow_auto_off'),
       'merge_ms': merge_ms,
@@ -1885,6 +1897,7 @@ def stream_line(args, world, res):
                     'seed set-up and segment commits included); the K timed '
                     'steps alone held %d voxels' % int(res['voxels']),
       },
+      'turn_around_us': res.get('turn_around'),
       'host_breakdown_us_per_step': {
           'c_abi_step_call': round(1e3 * res['counters'].get(
               'inference-time-ms', 0) / max(res['counters'].get(

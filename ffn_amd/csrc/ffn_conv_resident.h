@@ -39,6 +39,9 @@ struct ConvStackTab {
   int pace;               // 10-ns ticks between two convs of a workgroup (0: free-running)
   int pace_tail;          // conv32ps: the tail workgroups' offset inside a period
   int pace_spread;        // phi of the FoV's last voxel, in ticks (0: every workgroup at once)
+  // [0] when the last step's record was published (faces block), [1] sum over the launches
+  // of (this launch's first instruction - [0]) in 10-ns ticks, [2] their count; or NULL
+  long long* stamps;
 };
 
 __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
@@ -51,6 +54,19 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
   const int c = xcd * (main_wg ? mp.mains_per_xcd : mp.tails_per_xcd) + r;
   if (c >= (main_wg ? mp.n_main : mp.n_tail)) return;
   const long long t0 = a.dbg_wgs ? wall_clock64() : 0;
+  const long long t_entry = (tb.stamps && tb.stamps[15] != 0) ? wall_clock64() : 0;
+  if (tb.stamps && blockIdx.x == 0 && threadIdx.x == 0 && tb.stamps[0]) {
+    // publish of the last step -> first instruction of this stack: the host's turn-around
+    // + the launch, as the GPU saw it (engine options stat_turn_gpu_ns / stat_turn_count)
+    // (steps INSIDE a segment: a turn between two segments -- commit, seed policy, the
+    // next init_seed -- takes milliseconds and is not what this figure is about)
+    const long long dt = wall_clock64() - tb.stamps[0];
+    if (dt < 10000) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(tb.stamps + 1), (unsigned long long)dt);
+      atomicAdd(reinterpret_cast<unsigned long long*>(tb.stamps + 2), 1ull);
+    }
+    tb.stamps[0] = 0;
+  }
   const int v0 = main_wg ? c * kMChunk : mp.n_main * kMChunk + c * 32;
   const int gc = main_wg ? c : mp.n_main + c;
   ConvLayer Ldbg = a.L;
@@ -139,6 +155,12 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
     }
   }
   stamp_workgroup(a, Ldbg, t0);
+  // (debug_fused_trace: [7] first entry, [11] last end of this launch's workgroups)
+  if (tb.stamps && tb.stamps[15] != 0 && threadIdx.x == 0) {
+    atomicMin(reinterpret_cast<unsigned long long*>(tb.stamps + 7), (unsigned long long)t_entry);
+    atomicMax(reinterpret_cast<unsigned long long*>(tb.stamps + 11),
+              (unsigned long long)wall_clock64());
+  }
 }
 
 }  // namespace ffn

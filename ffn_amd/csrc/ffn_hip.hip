@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -257,6 +258,14 @@ struct ffn_engine {
   // and a histogram of FoVs per call (index min(n, 64))
   long stat_calls = 0, stat_items = 0;
   long stat_hist[65] = {};
+  // the turn-around between two single-FoV steps: the GPU's view (d_stamps, see
+  // ConvStackTab::stamps) and the host's (steady-clock ns from "record arrived" to
+  // "the next resident launch is queued", and inside that hipLaunchKernelGGL alone)
+  long long* d_stamps = nullptr;
+  long long t_arrived_ns = 0;
+  int fused_trace_in = 0;        // debug_fused_trace: steps until the traced one
+  long long stat_turn_host_ns = 0, stat_launch_host_ns = 0;
+  long stat_turn_host_count = 0;
 
   void* d_scratch = nullptr;
   void* h_scratch = nullptr;
@@ -313,6 +322,10 @@ struct ffn_canvas {
 };
 
 namespace {
+inline long long steady_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(
+             std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 inline unsigned next_tag(unsigned t) { return t + 1 ? t + 1 : 1; }  // never 0
 // A speculative conv0_a launch that no step will use: its range tag is spent.
 inline void drop_spec(ffn_engine* e) {
@@ -956,7 +969,18 @@ int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr) {
   const dim3 grid(8 * (mp.mains_per_xcd + mp.tails_per_xcd)), block(kDThreads);
   tb.l_begin = 0;
   tb.l_end = tb.nlayers;
+  tb.stamps = e->d_stamps;
+  const long long t_l0 = e->t_arrived_ns ? steady_ns() : 0;
   hipLaunchKernelGGL(conv32ps_kernel, grid, block, kMLdsBytes, e->stream, a, mp, tb);
+  if (e->t_arrived_ns) {
+    const long long t_l1 = steady_ns();
+    if (t_l1 - e->t_arrived_ns < 100000) {  // (inside a segment: see ConvStackTab::stamps)
+      e->stat_turn_host_ns += t_l1 - e->t_arrived_ns;
+      e->stat_launch_host_ns += t_l1 - t_l0;
+      e->stat_turn_host_count += 1;
+    }
+    e->t_arrived_ns = 0;
+  }
   return FFN_OK;
 }
 
@@ -1019,6 +1043,7 @@ int launch_conv32hs(ffn_engine* e, float pad_value, float move_thr) {
   tb.pace = e->flow_pace < 0 ? 0 : e->flow_pace;  // (no measured beat for this family)
   tb.pace_tail = 0;
   tb.pace_spread = e->flow_pace_spread < 0 ? tb.pace : e->flow_pace_spread;
+  tb.stamps = nullptr;
   const dim3 grid(8 * (mp.per_first + mp.per_second)), block(kDThreads);
   hipLaunchKernelGGL(conv32hs_kernel, grid, block, kHLdsBytes, e->stream, a, mp, tb);
   return FFN_OK;
@@ -1594,6 +1619,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
         E_TRY(hipMemset(e->flow_trace, 0, bytes));
       }
     }
+    E_TRY(hipMalloc(&e->d_stamps, 16 * sizeof(long long)));
+    E_TRY(hipMemset(e->d_stamps, 0, 16 * sizeof(long long)));
     E_TRY(hipMalloc(&e->d_spec_choice, sizeof(int)));
     E_TRY(hipMemset(e->d_spec_choice, 0xff, sizeof(int)));
     E_TRY(hipMalloc(&e->d_spec_choice_alt, sizeof(int)));
@@ -1668,6 +1695,7 @@ void ffn_engine_destroy(ffn_engine* e) {
   (void)hipFree(e->flow_err);
   (void)hipFree(e->flow_trace);
   (void)hipFree(e->d_spec_choice);
+  (void)hipFree(e->d_stamps);
   (void)hipFree(e->valid);
   (void)hipFree(e->validbits);
   (void)hipFree(e->pidx);
@@ -2052,6 +2080,18 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->stat_spec_launched = e->stat_spec_hits = e->stat_spec_mismatch = 0;
     e->stat_calls = e->stat_items = 0;
     std::memset(e->stat_hist, 0, sizeof(e->stat_hist));
+    e->stat_turn_host_ns = e->stat_launch_host_ns = 0;
+    e->stat_turn_host_count = 0;
+    e->t_arrived_ns = 0;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemset(e->d_stamps, 0, 16 * sizeof(long long)));
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "debug_fused_trace") == 0) {
+    // the N-th single-FoV step from now stamps when its launches' roles ran
+    // (ConvStackTab::stamps [4 .. 11]; read with debug_fused_stamp_K)
+    e->fused_trace_in = value;
     return FFN_OK;
   }
   if (std::strcmp(name, "debug_layer") == 0) {
@@ -2095,6 +2135,30 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "flow") == 0) *value = e->flow;
   else if (std::strcmp(name, "flow_auto_off") == 0) *value = e->flow_auto_off;
   else if (std::strcmp(name, "stat_flow_voids") == 0) *value = (int)e->stat_flow_voids;
+  else if (std::strcmp(name, "stat_turn_host_ns") == 0)
+    *value = e->stat_turn_host_count
+                 ? (int)(e->stat_turn_host_ns / e->stat_turn_host_count) : 0;
+  else if (std::strcmp(name, "stat_launch_host_ns") == 0)
+    *value = e->stat_turn_host_count
+                 ? (int)(e->stat_launch_host_ns / e->stat_turn_host_count) : 0;
+  else if (std::strcmp(name, "stat_turn_count") == 0) *value = (int)e->stat_turn_host_count;
+  else if (std::strcmp(name, "stat_turn_gpu_ns") == 0) {
+    long long st[4] = {0, 0, 0, 0};
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(st, e->d_stamps, sizeof(st), hipMemcpyDeviceToHost));
+    *value = st[2] ? (int)(st[1] * 10 / st[2]) : 0;
+  }
+  else if (std::strncmp(name, "debug_fused_stamp_", 18) == 0) {
+    // stamp k (4 .. 11) minus the stack's first entry [7], in 10-ns ticks
+    const int k = std::atoi(name + 18);
+    long long st[16];
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(st, e->d_stamps, sizeof(st), hipMemcpyDeviceToHost));
+    if (k < 4 || k > 14) return fail(FFN_ERR_ARG, "debug_fused_stamp_4 .. 14");
+    *value = (int)(st[k] - st[7]);
+  }
   else if (std::strcmp(name, "flow_pace") == 0) *value = e->flow_pace;
   else if (std::strcmp(name, "flow_pace_now") == 0)
     *value = e->flow_pace < 0 ? e->pace_auto : e->flow_pace;
@@ -2494,6 +2558,12 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     e->spec_force_mismatch -= 1;
     spec_expected = kSpecMax;  // an index the device cannot have chosen
   }
+  const bool traced = n == 1 && e->fused_trace_in > 0 && --e->fused_trace_in == 0;
+  if (traced) {  // arm: minima at +inf, maxima at 0, the switch on
+    HIP_TRY(hipMemsetAsync(e->d_stamps + 4, 0x7f, 4 * sizeof(long long), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_stamps + 8, 0, 4 * sizeof(long long), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_stamps + 15, 1, sizeof(long long), e->stream));
+  }
   int rc = run_stack(e, n, si, params->pad_value, params->move_threshold,
                      spec_expected >= 0);
   if (rc) return rc;
@@ -2545,7 +2615,7 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
                        e->count_blocks, params->move_threshold,
                        params->disco_seed_threshold, params->deleted_threshold,
                        e->range_flag, e->range_tag, h_pub, step_id, e->d_spec_choice,
-                       spec_expected, nx);
+                       spec_expected, nx, e->d_stamps);
   } else if (n == 1 && e->fuse_paste) {
     hipLaunchKernelGGL(faces_paste_kernel, dim3(1 + 71), dim3(512), 0, e->stream, si,
                        g, e->logits, e->seed_raw, e->count, e->count_blocks,
@@ -2575,6 +2645,7 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
       e->stat_spec_launched += 1;
     }
   }
+  if (traced) HIP_TRY(hipMemsetAsync(e->d_stamps + 15, 0, sizeof(long long), e->stream));
   HIP_TRY(hipGetLastError());
   e->stat_calls += 1;
   e->stat_items += n;
@@ -2662,6 +2733,7 @@ int step_wait_impl(ffn_engine* e, uint32_t ticket, ffn_step_result* results,
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (!arrived()) return fail(FFN_ERR_HIP, "step %u did not complete", step_id);
   }
+  if (n == 1) e->t_arrived_ns = steady_ns();
   {
     uint32_t* out = reinterpret_cast<uint32_t*>(results);
     for (int k = 0; k < n * kPubWords; ++k)

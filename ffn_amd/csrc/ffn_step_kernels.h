@@ -539,19 +539,96 @@ __device__ __forceinline__ void faces_body(
     const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
     float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
     unsigned range_tag, unsigned long long* __restrict__ pub, unsigned step_id,
-    const int* __restrict__ spec_choice, int spec_expected) {
+    const int* __restrict__ spec_choice, int spec_expected, long long* tr = nullptr) {
+  // (tr: debug_fused_trace stamps [12] count known, [13] faces reduced, [14] record built)
   __shared__ unsigned s_cnt[8];
   __shared__ ffn_step_result s_res;
   const ItemView it = item_view(si, item);
   const float* lg = logits + (size_t)item * g.V;
   const float* old = in_seed + (size_t)item * g.V;
-  const unsigned cnt = step_count(g, lg, move_thr, block_count, head_blocks, item, s_cnt);
-  const bool disco = disco_on(cnt, g.Vp, disco_thr);
+  // Every global load of the block is in flight before any is waited for: the block
+  // counts, the face values (logits, old seed, segmentation ids under the faces) and the
+  // candidates' point values are ONE round trip to a memory the launch boundary left cold
+  // (3.5 + 2.6 + 0.9 us when they follow each other: profiles/r06_step_roles.txt), and the
+  // host's turn-around starts when this block's record leaves.
   const int z0 = it.pos[0] - g.fz / 2;
   const int y0 = it.pos[1] - g.fy / 2;
   const int x0 = it.pos[2] - g.fx / 2;
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
+  unsigned cnt_part = 0;
+  if (!g.crop)
+    for (int e = threadIdx.x; e < head_blocks; e += blockDim.x)
+      cnt_part += block_count[item * head_blocks + e];
+  // face geometry of this wave (waves 0 .. 5)
+  const int f_axis = wave >> 1;
+  const int f_sign = (wave & 1) ? 1 : -1;
+  const int f_cz = g.c0[0] + (g.c1[0] - g.c0[0]) / 2;
+  const int f_cy = g.c0[1] + (g.c1[1] - g.c0[1]) / 2;
+  const int f_cx = g.c0[2] + (g.c1[2] - g.c0[2]) / 2;
+  const int f_nr = f_axis == 0 ? 2 * g.dy + 1 : 2 * g.dz + 1;
+  const int f_nc = f_axis == 2 ? 2 * g.dy + 1 : 2 * g.dx + 1;
+  const int f_total = f_nr * f_nc;
+  auto face_zyx = [&](int e, int& z, int& y, int& x) {
+    const int fi = e / f_nc, fj = e - fi * f_nc;
+    z = f_axis == 0 ? f_cz + f_sign * g.dz : f_cz - g.dz + fi;
+    y = f_axis == 1 ? f_cy + f_sign * g.dy
+                    : (f_axis == 0 ? f_cy - g.dy + fi : f_cy - g.dy + fj);
+    x = f_axis == 2 ? f_cx + f_sign * g.dx : f_cx - g.dx + fj;
+  };
+  constexpr int kFaceSweep = 8;  // elements per lane and sweep
+  const bool one_sweep = f_total <= kFaceSweep * 64;
+  float fa[kFaceSweep], fb[kFaceSweep];
+  int fs[kFaceSweep];
+  if (wave < 6 && one_sweep) {
+#pragma unroll
+    for (int k = 0; k < kFaceSweep; ++k) {
+      const int e = k * 64 + lane;
+      int z, y, x;
+      face_zyx(e < f_total ? e : 0, z, y, x);
+      const int v = (z * g.fy + y) * g.fx + x;
+      fa[k] = lg[v];
+      fb[k] = old[v];
+      fs[k] = it.seg[((size_t)(z0 + z) * it.cy + (y0 + y)) * it.cx + (x0 + x)];
+    }
+  }
+  // the candidates' point values (wave 6)
+  float c_lg = 0.f, c_old = 0.f, c_seed = 0.f;
+  int c_seg = 0, c_kind = 0;  // 1: a voxel this step writes, 2: outside its box
+  if (wave == 6) {
+    const int n = it.req->num_candidates;
+    if (lane <= n && lane <= FFN_MAX_CANDIDATES) {
+      const int32_t* q = lane == 0 ? it.req->start_pos : it.req->candidates[lane - 1];
+      const int z = q[0], y = q[1], x = q[2];
+      if (z >= 0 && z < it.cz && y >= 0 && y < it.cy && x >= 0 && x < it.cx) {
+        const int lz = z - z0, ly = y - y0, lx = x - x0;
+        const size_t ci = ((size_t)z * it.cy + y) * it.cx + x;
+        if (in_pred_box(g, lz, ly, lx)) {
+          const int v = (lz * g.fy + ly) * g.fx + lx;
+          c_lg = lg[v];
+          c_old = old[v];
+          c_kind = 1;
+        } else {
+          c_seed = it.seed[ci];
+          c_kind = 2;
+        }
+        c_seg = it.seg[ci];
+      }
+    }
+  }
+  unsigned cnt;
+  if (!g.crop) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt_part += __shfl_xor(cnt_part, off);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt_part;
+    __syncthreads();
+    cnt = 0;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) cnt += s_cnt[wv];
+  } else {
+    cnt = step_count(g, lg, move_thr, block_count, head_blocks, item, s_cnt);
+  }
+  if (tr && threadIdx.x == 0) tr[12] = wall_clock64();
+  const bool disco = disco_on(cnt, g.Vp, disco_thr);
 
   if (wave < 6) {
     const int axis = wave >> 1;
@@ -581,6 +658,11 @@ __device__ __forceinline__ void faces_body(
 #pragma unroll
       for (int k = 0; k < 8; ++k) {  // all loads of the sweep in flight at once
         const int e = base + k * 64 + lane;
+        if (one_sweep) {  // (loaded in front of the block-count barrier)
+          a[k] = fa[k];
+          b[k] = fb[k];
+          continue;
+        }
         const int v = dense_index(e < total ? e : 0);
         a[k] = lg[v];
         b[k] = old[v];
@@ -612,11 +694,12 @@ __device__ __forceinline__ void faces_body(
         besti = oi;
       }
     }
+    if (tr && threadIdx.x == 0) tr[13] = wall_clock64();
     if (lane == 0) {
       s_res.face_score[wave] = best;
       s_res.face_index[wave] = besti;
       int sg = 0;
-      if (besti != 0x7fffffff) {
+      if (besti != 0x7fffffff && !one_sweep) {
         const int fi = besti / nc, fj = besti - fi * nc;
         const int z = axis == 0 ? cz + sign * g.dz : cz - g.dz + fi;
         const int y = axis == 1 ? cy + sign * g.dy
@@ -626,24 +709,23 @@ __device__ __forceinline__ void faces_body(
       }
       s_res.face_seg[wave] = sg;
     }
+    if (one_sweep) {
+      // the id under the arg-max: element besti sits in register besti >> 6 of lane
+      // besti & 63
+      int mine = 0;
+#pragma unroll
+      for (int k = 0; k < kFaceSweep; ++k) mine = (besti >> 6) == k ? fs[k] : mine;
+      const int sgv = __shfl(mine, besti == 0x7fffffff ? 0 : (besti & 63));
+      if (lane == 0) s_res.face_seg[wave] = besti == 0x7fffffff ? 0 : sgv;
+    }
   } else if (wave == 6) {
     const int n = it.req->num_candidates;
     if (lane <= n && lane <= FFN_MAX_CANDIDATES) {
-      const int32_t* q = lane == 0 ? it.req->start_pos : it.req->candidates[lane - 1];
-      const int z = q[0], y = q[1], x = q[2];
-      float sv = __builtin_nanf("");
-      int gv = 0;
-      if (z >= 0 && z < it.cz && y >= 0 && y < it.cy && x >= 0 && x < it.cx) {
-        const int lz = z - z0, ly = y - y0, lx = x - x0;
-        const size_t ci = ((size_t)z * it.cy + y) * it.cx + x;
-        if (in_pred_box(g, lz, ly, lx)) {  // a voxel this step writes
-          const int v = (lz * g.fy + ly) * g.fx + lx;
-          sv = post_disco(lg[v], old[v], disco);
-        } else {
-          sv = it.seed[ci];
-        }
-        gv = it.seg[ci];
-      }
+      // (a voxel this step writes: recomputed as the paste will write it)
+      const float sv = c_kind == 1   ? post_disco(c_lg, c_old, disco)
+                       : c_kind == 2 ? c_seed
+                                     : __builtin_nanf("");
+      const int gv = c_seg;
       if (lane == 0) {
         s_res.start_logit = sv;
         s_res.num_above_move = cnt;
@@ -678,6 +760,7 @@ __device__ __forceinline__ void faces_body(
     }
   }
   __syncthreads();
+  if (tr && threadIdx.x == 0) tr[14] = wall_clock64();
   // Publish from ONE wave, in ONE trip over PCIe: every 32-bit word of the record
   // goes to pinned host memory as an 8-byte word that carries the step number in
   // its upper half (8-byte stores are atomic: a word is either the old step's or
@@ -797,20 +880,44 @@ __global__ __launch_bounds__(512) void faces_paste_conv0a_kernel(
     const unsigned* __restrict__ block_count, int head_blocks, float move_thr,
     float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
     unsigned range_tag, unsigned long long* __restrict__ pub, unsigned step_id,
-    const int* __restrict__ spec_choice, int spec_expected, Conv0Next nx) {
+    const int* __restrict__ spec_choice, int spec_expected, Conv0Next nx,
+    long long* __restrict__ stamps) {
   static_assert(kC0Threads == 512, "one block size for the three roles");
+  // engine option debug_fused_trace (stamps[15] != 0): when each role of this launch ran --
+  // first entry (min over the blocks) [4] faces, [5] paste, [6] conv0_a; last end (max) [8]
+  // faces = record published, [9] paste, [10] conv0_a; ([7], [11]: the stack before it)
+  const bool tr_on = stamps && stamps[15] != 0;
+  struct RoleStamp {
+    long long* lo;
+    long long* hi;
+    bool on;
+    __device__ RoleStamp(long long* l, long long* h, bool o) : lo(l), hi(h), on(o) {
+      if (on && threadIdx.x == 0)
+        atomicMin(reinterpret_cast<unsigned long long*>(lo), (unsigned long long)wall_clock64());
+    }
+    __device__ ~RoleStamp() {
+      if (on && threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned long long*>(hi), (unsigned long long)wall_clock64());
+    }
+  };
   if (blockIdx.x == 0) {
+    RoleStamp rs(stamps + 4, stamps + 8, tr_on);
     faces_body(0, si, g, logits, in_seed, block_count, head_blocks, move_thr,
                disco_thr, deleted_thr, range_flag, range_tag, pub, step_id,
-               spec_choice, spec_expected);
+               spec_choice, spec_expected, tr_on ? stamps : nullptr);
+    // (stat_turn_*: when this step's record left for the host -- the next resident
+    // launch measures how long the GPU then waited for it, conv32ps_kernel)
+    if (stamps && threadIdx.x == 0) stamps[0] = wall_clock64();
     return;
   }
   if (blockIdx.x <= kPasteBlocks) {
+    RoleStamp rs(stamps + 5, stamps + 9, tr_on);
     paste_body(0, blockIdx.x - 1, kPasteBlocks, si, g, logits, in_seed, block_count,
                head_blocks, move_thr, disco_thr, range_flag, range_tag, spec_choice,
                spec_expected);
     return;
   }
+  RoleStamp rs(stamps + 6, stamps + 10, tr_on);
   __shared__ unsigned s_cnt[8];
   const ItemView it = item_view(si, 0);
   SeedOverlay ov;
