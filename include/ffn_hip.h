@@ -376,6 +376,11 @@ int ffn_engine_set_pred_size(ffn_engine* engine, const int32_t pred_zyx[3]);
  *   9 (default where the FoV has 257 .. 512 chunks of 128 voxels, e.g. 33^3) =
  *       a step of ONE FoV runs conv32mt (conv32m for the first 256 chunks +
  *       32-voxel K-split tail workgroups), a step of several runs conv32m,
+ *  10 = a step of ONE FoV on 80-voxel workgroups, two per CU (conv32hs / conv32h:
+ *       four 16-position tiles on 16x16x32 MFMAs + a fifth tile split over the
+ *       waves by tap; another summation order than 9, the same tolerance); a step
+ *       of several FoVs runs conv32m as under 9.  Measured SLOWER than 9 at 33^3
+ *       (profiles/r06_gate_two_chains.txt): selectable, not a default,
  *  -1 = this FoV's exact-f32 kernel ("exact_variant": 2 where it fits, else 0).
  * (1, 3, 4, 5 -- conv32p, the bf16x3 and the earlier fp16 kernels -- were removed
  * in ABI 7; they are in the history up to commit af82310.)
@@ -404,12 +409,28 @@ int ffn_engine_set_pred_size(ffn_engine* engine, const int32_t pred_zyx[3]);
  *   steps in a row the engine sets "flow" = 0 itself ("flow_auto_off" reads 1;
  *   setting "flow" again re-arms).  "flow_debug" 2048: fault injection for
  *   tests (a producer stops publishing); its other bits and "debug_clock" 4 act
- *   only in -DFFN_EXPERIMENTS=1 builds. */
+ *   only in -DFFN_EXPERIMENTS=1 builds.
+ * "flow_pace": the beat of the resident launch, in 10-ns ticks: conv l of a
+ *   workgroup does not start before t0 + l x beat + "flow_pace_spread" x (its first
+ *   voxel / V).  -1 (default) = the beat ffn_engine_set_weights MEASURED for this
+ *   device (a ladder of beats on noise inputs, ~80 ms; 0 if none beats the
+ *   free-running launch by 1.5 %), 0 = free-running, > 0 = that beat;
+ *   "flow_pace_spread" -1 (default) = as wide as the beat.  Timing only: results are
+ *   bit-identical under any beat (profiles/r06_pacing.txt).
+ * "debug_fused_trace" N: the N-th next single-FoV step stamps when each role of its
+ *   two launches ran ("debug_fused_stamp_4" .. "_14", 10-ns ticks after the stack's
+ *   first workgroup: tools/gpu_step_trace.py). */
 int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
 /* Current value of an option ("conv_variant", "exact_variant", "fuse_head",
  * "store_policy", "sync_mode", "profile_every", "speculate", "fuse_paste",
- * "fuse_conv0a", "flow", "flow_auto_off"), "stat_flow_timeouts" (polls of the
- * resident launch that gave up, ever) / "stat_flow_voids" (steps voided by one), or
+ * "fuse_conv0a", "flow", "flow_auto_off", "flow_pace", "flow_pace_now" (the beat in
+ * use), "flow_pace_free_ns" / "flow_pace_best_ns" (what the measurement saw per
+ * stack: free-running, at its best beat)), "stat_flow_timeouts" (polls of the
+ * resident launch that gave up, ever) / "stat_flow_voids" (steps voided by one),
+ * "stat_turn_gpu_ns" / "stat_turn_host_ns" / "stat_launch_host_ns" / "stat_turn_count"
+ * (between two single-FoV steps inside a segment, mean since "stat_reset": record
+ * published -> first instruction of the next resident launch as the GPU saw it;
+ * record seen -> that launch queued, and the launch call alone, on the host), or
  * a statistic of the step calls since set_option("stat_reset", 0):
  * "stat_step_calls", "stat_step_items" (FoVs in them), "stat_hist_<n>" (calls
  * with n FoVs), "stat_spec_launched" / "stat_spec_hits" / "stat_spec_mismatch"

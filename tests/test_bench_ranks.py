@@ -116,7 +116,7 @@ def test_stream_mode_rank_aggregation(tmp_path, world):
   assert fv['steps'] == steps and fv['voxels_segmented'] == voxels
   assert fv['rank0']['steps'] == int(ranks[0][0])
   t_all = max(float(r[3]) for r in ranks)
-  assert fv['seconds'] >= max(float(r[2]) for r in ranks) - 1e-3
+  assert fv['seconds'] >= max(float(r[2]) for r in ranks) - 0.05  # (other ranks' clocks)
   assert abs(fv['seconds'] - t_all) < 0.25
   assert line['value'] == fv['fov_steps_per_s'] == round(steps / fv['seconds'], 1)
   assert line['voxels_segmented_per_s'] == fv['voxels_segmented_per_s']

@@ -255,6 +255,8 @@ def test_phantom_ensemble(hip_exe, fib25_model):  # noqa: F811
   if not os.path.exists(path):
     pytest.skip('fixture not minted')
   g = np.load(path)
+  p64 = os.path.join(GOLDEN, 'ref_canvas_phantoms128_f64.npz')
+  g64 = np.load(p64) if os.path.exists(p64) else None
   size = int(g['size'])
   _assert_shipped_default(hip_exe.engine)
   rows = []
@@ -268,8 +270,24 @@ def test_phantom_ensemble(hip_exe, fib25_model):  # noqa: F811
     first_bad = next((j for j in range(n) if got_steps[j] != want_steps[j]), None)
     agree = bench.segmentation_agreement(np.asarray(canvas.segmentation),
                                          g[k + 'segmentation'])
+    seg_gpu = np.array(np.asarray(canvas.segmentation))
     canvas.close()
     rows.append((vs, len(want_steps), len(got_steps), first_bad, agree))
+    if g64 is not None and k + 'steps' in g64.files:
+      # the reference's Canvas behind a DOUBLE-PRECISION forward on the same volume:
+      # the GPU run against it, and the reference's two runs against each other
+      w64 = [tuple(int(v) for v in p) for p in g64[k + 'steps']]
+      n64 = min(len(got_steps), len(w64))
+      bad64 = next((j for j in range(n64) if got_steps[j] != w64[j]), None)
+      a64 = bench.segmentation_agreement(seg_gpu, g64[k + 'segmentation'])
+      r64 = bench.segmentation_agreement(g[k + 'segmentation'], g64[k + 'segmentation'])
+      nrr = min(len(want_steps), len(w64))
+      badrr = next((j for j in range(nrr) if want_steps[j] != w64[j]), None)
+      print('  seed %d against the f64-minted run: GPU first mismatch %s, IoU foreground %.6f, '
+            'best match %.6f, id for id %.6f | the oneDNN-f32-minted run against the f64 one: '
+            'first mismatch %s, foreground %.6f, best match %.6f, id for id %.6f' % (
+                vs, bad64, a64['iou_foreground'], a64['iou_best_match'], a64['iou_labelled'],
+                badrr, r64['iou_foreground'], r64['iou_best_match'], r64['iou_labelled']))
     print('phantom %d^3 seed %d: reference %d steps, GPU %d; first position mismatch %s; '
           'objects %d / %d (matched at >= 0.999: %d); IoU foreground %.6f, best match '
           '%.6f, id for id %.6f' % (

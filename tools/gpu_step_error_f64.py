@@ -84,17 +84,33 @@ def main():
   print('step   pos              same pos as the reference run   max|logit|   '
         'max|GPU - f64|   max|oneDNN f32 - f64|   max|GPU - oneDNN f32|')
   worst = [0.0, 0.0]
+  sq = {'GPU split products (conv_variant 9)': [], 'GPU exact f32, sequential (conv_variant 2)': [],
+        'torch-CPU / oneDNN f32': [], 'C oracle f32, sequential': []}
+  blob = ffn_oracle.weights_blob(variables, 12)
   for k, pos, img, seed in samples:
     s = np.where(np.isnan(seed), pad_logit, seed).astype(np.float32)
     gpu = eng.predict(s[None], img[None])[0]
+    eng.set_option('conv_variant', 2)
+    gpu2 = eng.predict(s[None], img[None])[0]
+    eng.set_option('conv_variant', 9)
     f32 = ffn_oracle.forward_torch(img, s, variables, 12, threads=16)
     f64 = ffn_oracle.forward_torch(img, s, variables, 12, threads=16, f64=True)
+    c32 = ffn_oracle.forward(img, s, blob, 12)
+    for name, arr in zip(sq, (gpu, gpu2, f32, c32)):
+      sq[name].append((arr.astype(np.float64) - f64).ravel())
     e_gpu, e_f32 = float(np.abs(gpu - f64).max()), float(np.abs(f32 - f64).max())
     worst = [max(worst[0], e_gpu), max(worst[1], e_f32)]
     print('%5d  %-16s %-30s %8.2f     %.3g        %.3g                %.3g' % (
         k, pos, k < len(want_steps) and want_steps[k] == pos, np.abs(f64).max(), e_gpu,
         e_f32, float(np.abs(gpu - f32).max())))
   print('worst over the samples: GPU vs f64 %.3g, oneDNN f32 vs f64 %.3g' % tuple(worst))
+  print('error against the f64 forward (its logits rounded to f32) over all %d x 35,937 logits:'
+        % len(samples))
+  for name, errs in sq.items():
+    e = np.concatenate(errs)
+    print('  %-44s rms %.3g   mean %+.3g   99.9 %% %.3g   max %.3g   exactly equal %.1f %%' % (
+        name, np.sqrt(np.mean(e * e)), e.mean(), np.percentile(np.abs(e), 99.9),
+        np.abs(e).max(), 100.0 * np.mean(e == 0)))
   eng.close()
 
 
