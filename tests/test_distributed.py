@@ -323,3 +323,46 @@ def test_merge_reports_a_sub_box_nobody_holds():
   out, _ = ffn_dist.merge_segmentations([(boxes[0], seg)], shape, 0, 1,
                                         num_boxes=len(boxes), allow_missing=True)
   assert out.max() == 1 and (out == 0).any()
+
+
+# ---------------------------------------------------------------------------
+# a rank's own failure reaches every rank through check_complete
+# ---------------------------------------------------------------------------
+def _failing_worker(rank, world, port, tmpdir):
+  import torch.distributed as dist
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  boxes = ffn_dist.tile_volume(_DEAL_SHAPE, _DEAL_SUB, _DEAL_OV, back_shift=True)
+  # (constructing the dealer is no collective: rank 1 makes its own a little later)
+  if rank == 1:
+    import time
+    time.sleep(0.3)
+  dealer = ffn_dist.BoxDealer(boxes, rank, world)
+  taken = [b.index for b in dealer]
+  msg = ''
+  try:
+    dealer.check_complete(failed=rank == 1)  # rank 1 "had to skip a sub-box"
+  except RuntimeError as e:
+    msg = str(e)
+  with open(os.path.join(tmpdir, 'fail_%d.txt' % rank), 'w') as f:
+    f.write('%d|%s' % (len(taken), msg))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_a_ranks_failure_is_raised_on_every_rank(tmp_path):
+  """`check_complete(failed)`: ONE all-reduce carries the boxes taken and the ranks'
+  own failures; a rank that failed no longer leaves its peers blocked in a collective
+  it never reaches (distributed.segment_volume)."""
+  import socket
+  import torch.multiprocessing as mp
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  mp.spawn(_failing_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  rows = [open(tmp_path / ('fail_%d.txt' % r)).read().split('|') for r in range(2)]
+  boxes = ffn_dist.tile_volume(_DEAL_SHAPE, _DEAL_SUB, _DEAL_OV, back_shift=True)
+  assert sum(int(r[0]) for r in rows) == len(boxes)  # dealt exactly once over the ranks
+  for r in rows:
+    assert 'report a failed or skipped sub-box' in r[1], r
