@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1713,15 +1714,40 @@ void ffn_engine_destroy(ffn_engine* e) {
 
 // The beat of the paced resident stack is measured, not assumed: the chain a conv of the
 // stack has to get through (words seen -> rows staged -> taps -> stores drained -> word
-// published) is 6.2 - 6.9 us depending on the box and its clocks, a beat below it leaves
-// the stack free-running (no loss), a beat above it costs 24 x the excess.  So: time the
-// stack on noise inputs at a ladder of beats and keep the best one plus a margin of 0.1 us
-// -- if it beats the free-running stack by more than 1.5 %.  ~80 ms per set_weights.
+// published) is 6.2 - 7.0 us depending on the box and its clocks; a beat below it leaves
+// the stack free-running (no loss), a beat above it costs 24 x the excess -- and on a box
+// whose free-running stack already runs at its chain's length pacing gains nothing at all
+// (profiles/r06_pacing.txt: -5 % on three boxes, 0 on a fourth).  So: bring the clocks up
+// (~150 ms of stacks), time the free-running stack before AND after a ladder of beats on
+// noise inputs, take the best beat + 0.1 us, and CONFIRM it against the free-running stack
+// in two alternating rounds; it is kept only if it wins both by more than 1.5 %.  The
+// answer is cached per (device, depth, FoV) for the process: ~0.3 s once.
+struct PaceKey {
+  int device, depth, V;
+  bool operator<(const PaceKey& o) const {
+    return device != o.device ? device < o.device : depth != o.depth ? depth < o.depth : V < o.V;
+  }
+};
+struct PaceVal { int beat; float free_us, best_us; };
+std::mutex g_pace_mu;
+std::map<PaceKey, PaceVal> g_pace_cache;
+
 int tune_pace(ffn_engine* e) {
   e->pace_auto = 0;
   e->pace_auto_us[0] = e->pace_auto_us[1] = 0.f;
   if (!(e->t_ok && e->flow_fits && e->flow == 2 && e->conv_variant == 9 && e->depth >= 2))
     return FFN_OK;
+  const PaceKey key{e->device, e->depth, e->g.V};
+  {
+    std::lock_guard<std::mutex> lk(g_pace_mu);
+    auto it = g_pace_cache.find(key);
+    if (it != g_pace_cache.end()) {
+      e->pace_auto = it->second.beat;
+      e->pace_auto_us[0] = it->second.free_us;
+      e->pace_auto_us[1] = it->second.best_us;
+      return FFN_OK;
+    }
+  }
   const size_t V = (size_t)e->g.V;
   {
     std::vector<float> noise(2 * V);
@@ -1756,18 +1782,34 @@ int tune_pace(ffn_engine* e) {
     *us = ms * 1e3f / (float)reps;
     return r;
   };
-  float warm = 0.f, free_us = 0.f, best_us = 0.f;
+  float us = 0.f, free_us = 0.f, best_us = 0.f;
   int best = 0;
-  rc = stacks_us(0, 120, &warm);  // clocks up
+  {  // clocks up: the board needs ~100 ms under load to settle
+    const long long t_end = steady_ns() + 150000000LL;
+    while (!rc && steady_ns() < t_end) rc = stacks_us(0, 60, &us);
+  }
   if (!rc) rc = stacks_us(0, 40, &free_us);
-  best_us = free_us;
+  best_us = 1e30f;
   for (int pace = 560; pace <= 800 && !rc; pace += 20) {
-    float us = 0.f;
     rc = stacks_us(pace, 24, &us);
     if (!rc && us < best_us) {
       best_us = us;
       best = pace;
     }
+  }
+  if (!rc) {
+    rc = stacks_us(0, 40, &us);
+    free_us = std::min(free_us, us);
+  }
+  bool keep = !rc && best > 0 && best_us < 0.985f * free_us;
+  float conf_free = free_us, conf_paced = best_us;
+  for (int round = 0; round < 2 && keep && !rc; ++round) {  // confirm, alternating
+    float f = 0.f, p = 0.f;
+    rc = stacks_us(0, 40, &f);
+    if (!rc) rc = stacks_us(best + 10, 40, &p);
+    keep = !rc && p < 0.985f * f;
+    conf_free = f;
+    conf_paced = p;
   }
   e->flow_pace = user_pace;
   (void)hipEventDestroy(ev0);
@@ -1776,9 +1818,13 @@ int tune_pace(ffn_engine* e) {
   unsigned errs = 0;
   HIP_TRY(hipMemcpy(&errs, e->flow_err, sizeof(errs), hipMemcpyDeviceToHost));
   const bool timed_out = errs != errs0;
-  e->pace_auto_us[0] = free_us;
-  e->pace_auto_us[1] = best_us;
-  if (!timed_out && best > 0 && best_us < 0.985f * free_us) e->pace_auto = best + 10;
+  e->pace_auto_us[0] = conf_free;
+  e->pace_auto_us[1] = keep ? conf_paced : best_us;
+  if (!timed_out && keep) e->pace_auto = best + 10;
+  if (!timed_out) {
+    std::lock_guard<std::mutex> lk(g_pace_mu);
+    g_pace_cache[key] = PaceVal{e->pace_auto, e->pace_auto_us[0], e->pace_auto_us[1]};
+  }
   return FFN_OK;
 }
 

@@ -48,8 +48,8 @@ def test_pacing_is_timing_only():
   assert beat == 0 or 560 <= beat <= 820, beat
   free_us = eng.get_option('flow_pace_free_ns') / 1e3
   best_us = eng.get_option('flow_pace_best_ns') / 1e3
-  assert 100 < best_us <= free_us < 400, (best_us, free_us)
-  if beat:
+  assert 100 < best_us < 400 and 100 < free_us < 400, (best_us, free_us)
+  if beat:  # kept only where it beat the free-running stack twice in a row
     assert best_us < 0.985 * free_us
   paced = eng.predict(seed, img)
   for pace, spread in ((0, -1), (700, -1), (700, 0), (640, 320)):
