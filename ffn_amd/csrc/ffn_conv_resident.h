@@ -42,11 +42,18 @@ struct ConvStackTab {
   // [0] when the last step's record was published (faces block), [1] sum over the launches
   // of (this launch's first instruction - [0]) in 10-ns ticks, [2] their count; or NULL
   long long* stamps;
+  // A stack queued AHEAD of the host (engine option stack_ahead), behind the speculative
+  // conv0_a of its step: that launch's choice word (-1: the device found no valid
+  // position and computed nothing -- this launch then ends after its first conv, which
+  // ran on the last step's planes; nobody reads what it wrote).  NULL: an ordinary launch.
+  const int* ahead_choice;
+  int trace;  // debug_fused_trace: stamp [7] first entry, [11] last end of this launch
 };
 
 __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
                                                                 ConvTailMap mp,
                                                                 ConvStackTab tb) {
+  warm_kernargs<sizeof(ConvDArgs) + sizeof(ConvTailMap) + sizeof(ConvStackTab)>();
   const int xcd = blockIdx.x & 7;
   const int r0 = blockIdx.x >> 3;
   const bool main_wg = r0 < mp.mains_per_xcd;
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
   const int c = xcd * (main_wg ? mp.mains_per_xcd : mp.tails_per_xcd) + r;
   if (c >= (main_wg ? mp.n_main : mp.n_tail)) return;
   const long long t0 = a.dbg_wgs ? wall_clock64() : 0;
-  const long long t_entry = (tb.stamps && tb.stamps[15] != 0) ? wall_clock64() : 0;
+  const long long t_entry = (tb.stamps && tb.trace) ? wall_clock64() : 0;
   if (tb.stamps && blockIdx.x == 0 && threadIdx.x == 0 && tb.stamps[0]) {
     // publish of the last step -> first instruction of this stack: the host's turn-around
     // + the launch, as the GPU saw it (engine options stat_turn_gpu_ns / stat_turn_count)
@@ -67,6 +74,8 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
     }
     tb.stamps[0] = 0;
   }
+  // (a scalar load in flight under the first conv: no wait of its own)
+  const int ahead_ch = tb.ahead_choice ? *tb.ahead_choice : 0;
   const int v0 = main_wg ? c * kMChunk : mp.n_main * kMChunk + c * 32;
   const int gc = main_wg ? c : mp.n_main + c;
   ConvLayer Ldbg = a.L;
@@ -125,6 +134,7 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
       sp_out = t;
     }
     if (L.dbg) Ldbg = L;
+    if (l == l_first + 1 && ahead_ch < 0) break;  // (every workgroup alike)
     const bool last = l == tb.nlayers - 1;
     if (main_wg) {
       const bool dbg_here = blockIdx.x == 0 && a.dbg_wgs != 2;
@@ -156,10 +166,24 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
   }
   stamp_workgroup(a, Ldbg, t0);
   // (debug_fused_trace: [7] first entry, [11] last end of this launch's workgroups)
-  if (tb.stamps && tb.stamps[15] != 0 && threadIdx.x == 0) {
+  if (tb.stamps && tb.trace == 1 && threadIdx.x == 0) {
     atomicMin(reinterpret_cast<unsigned long long*>(tb.stamps + 7), (unsigned long long)t_entry);
     atomicMax(reinterpret_cast<unsigned long long*>(tb.stamps + 11),
               (unsigned long long)wall_clock64());
+  }
+  // ([25] last end, [26] first entry of the stack IN FRONT of a traced step under stack_ahead)
+  // (one plain store per workgroup into its own slot, reduced by the host: 356 atomics on one
+  // word at the END of a launch would stand between it and the launch behind it)
+  if (tb.stamps && tb.trace == 2 && threadIdx.x == 0) {
+    tb.stamps[32 + blockIdx.x] = wall_clock64();
+    if (blockIdx.x == 0) tb.stamps[26] = t_entry;
+    // ... and where the workgroup ran: (main?, XCC, SE, SH, CU) -- two main workgroups on
+    // one CU is what a dispatch onto a chip that is not yet empty can produce
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    tb.stamps[32 + 512 + blockIdx.x] =
+        (long long)(((main_wg ? 1u : 0u) << 31) | ((xcc & 15u) << 16) | ((hw >> 8) & 0xffu)) + 1;
   }
 }
 

@@ -217,6 +217,17 @@ struct ffn_engine {
   int fuse_conv0a = 1;      // option: ... and the next step's conv0_a in it as well
   int* d_spec_choice = nullptr;
   long stat_spec_launched = 0, stat_spec_hits = 0;
+  // The NEXT step's resident stack queued right behind the launch that holds its
+  // speculative conv0_a, before the host has seen this step's record (engine option
+  // stack_ahead): the stack reads only what that conv0_a wrote (and gives up after its
+  // first conv when the device found no valid position), so the host's turn-around and
+  // the launch latency of the stack leave the step's critical path.
+  int stack_ahead = 1;
+  int paste_blocks = 0;  // fused step launch: paste blocks (0: one block per CU, see kPasteBlocks)
+  int debug_submit_delay_ns = 0;  // experiment: the host idles this long in front of a step's launches
+  bool trace_now = false;     // debug_fused_trace: the launches being queued stamp
+  bool ahead_valid = false;   // such a stack is in the stream, for the step e->spec describes
+  long stat_ahead_used = 0, stat_ahead_wasted = 0;
   unsigned range_tag = 0;        // tag of the run being queued
   bool fp16_ok = true;           // every weight inside the fp16 range
   int conv_variant = 0;       // 0 conv32 (any FoV), 2 conv32c (exact f32), 6 conv32d, 7 = 6
@@ -330,10 +341,11 @@ inline long long steady_ns() {
 inline unsigned next_tag(unsigned t) { return t + 1 ? t + 1 : 1; }  // never 0
 // A speculative conv0_a launch that no step will use: its range tag is spent.
 inline void drop_spec(ffn_engine* e) {
-  if (e->spec.valid) {
-    e->spec.valid = false;
-    e->range_tag = next_tag(e->range_tag);
-  }
+  if (e->spec.valid && !e->ahead_valid) e->range_tag = next_tag(e->range_tag);
+  // (a stack queued ahead has taken the tag already: run_stack)
+  if (e->ahead_valid) e->stat_ahead_wasted += 1;
+  e->spec.valid = false;
+  e->ahead_valid = false;
 }
 struct EngineLock {
   std::unique_lock<std::recursive_mutex> lk;
@@ -942,7 +954,8 @@ void launch_conv0a(ffn_engine* e, int n, const StepItems& si, float pad_value,
 // The 2 depth - 1 convs of ONE FoV as a single resident launch (conv32ps,
 // ffn_conv_resident.h): conv32mt's workgroups keep their voxels through the stack and
 // hand rows to each other through the tile words instead of kernel boundaries.
-int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr) {
+int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr,
+                    const int* ahead_choice = nullptr) {
   HeadFusion hf;
   hf.on = true;
   hf.pad_value = pad_value;
@@ -971,6 +984,9 @@ int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr) {
   tb.l_begin = 0;
   tb.l_end = tb.nlayers;
   tb.stamps = e->d_stamps;
+  tb.ahead_choice = ahead_choice;
+  // (2: the stack in front of the traced step, queued ahead one call earlier: its end only)
+  tb.trace = e->trace_now ? 1 : (ahead_choice && e->fused_trace_in == 1) ? 2 : 0;
   const long long t_l0 = e->t_arrived_ns ? steady_ns() : 0;
   hipLaunchKernelGGL(conv32ps_kernel, grid, block, kMLdsBytes, e->stream, a, mp, tb);
   if (e->t_arrived_ns) {
@@ -1045,6 +1061,8 @@ int launch_conv32hs(ffn_engine* e, float pad_value, float move_thr) {
   tb.pace_tail = 0;
   tb.pace_spread = e->flow_pace_spread < 0 ? tb.pace : e->flow_pace_spread;
   tb.stamps = nullptr;
+  tb.ahead_choice = nullptr;
+  tb.trace = 0;
   const dim3 grid(8 * (mp.per_first + mp.per_second)), block(kDThreads);
   hipLaunchKernelGGL(conv32hs_kernel, grid, block, kHLdsBytes, e->stream, a, mp, tb);
   return FFN_OK;
@@ -1052,12 +1070,16 @@ int launch_conv32hs(ffn_engine* e, float pad_value, float move_thr) {
 
 // conv0a_done: the step's conv0_a has been queued already (a speculative launch
 // that chose its position)
+// ahead: the stack of the step AFTER the one being submitted, behind the speculative
+// conv0_a just queued for it (engine option stack_ahead; conv0a_done with it)
 int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
-              float move_thr, bool conv0a_done = false) {
+              float move_thr, bool conv0a_done = false, bool ahead = false) {
   const Geom& g = e->g;
   const float* W = e->weights;
   if (!conv0a_done) drop_spec(e);
+  if (e->ahead_valid) e->stat_ahead_wasted += 1;  // (a caller that steps past it)
   e->spec.valid = false;
+  e->ahead_valid = false;
   e->last_stack_resident = false;
   e->range_tag = next_tag(e->range_tag);
   // this step's set of conv0_a outputs: what a launch made ahead for it wrote,
@@ -1125,9 +1147,10 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
           e->flow_skip -= 1;  // the repeat of a voided resident step
         } else {
           e->last_stack_resident = true;
-          return launch_conv32ps(e, pad_value, move_thr);
+          return launch_conv32ps(e, pad_value, move_thr, ahead ? e->d_spec_choice : nullptr);
         }
       }
+      if (ahead) return fail(FFN_ERR_STATE, "stack_ahead without the resident launch");
       int r = launch_conv32d<1, false>(e, n, e->rawT, e->rawS, 0);
       for (int i = 1; i < e->depth && !r; ++i) {
         r = launch_conv32d<0, false>(e, n, e->rawS, e->rawT, 2 * i - 1);
@@ -1620,8 +1643,8 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
         E_TRY(hipMemset(e->flow_trace, 0, bytes));
       }
     }
-    E_TRY(hipMalloc(&e->d_stamps, 16 * sizeof(long long)));
-    E_TRY(hipMemset(e->d_stamps, 0, 16 * sizeof(long long)));
+    E_TRY(hipMalloc(&e->d_stamps, (32 + 1024) * sizeof(long long)));
+    E_TRY(hipMemset(e->d_stamps, 0, (32 + 1024) * sizeof(long long)));
     E_TRY(hipMalloc(&e->d_spec_choice, sizeof(int)));
     E_TRY(hipMemset(e->d_spec_choice, 0xff, sizeof(int)));
     E_TRY(hipMalloc(&e->d_spec_choice_alt, sizeof(int)));
@@ -2115,6 +2138,21 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->fuse_conv0a = value != 0;
     return FFN_OK;
   }
+  if (std::strcmp(name, "paste_blocks") == 0) {
+    if (value < 0 || value > 1024) return fail(FFN_ERR_ARG, "paste_blocks out of range");
+    e->paste_blocks = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "debug_submit_delay_ns") == 0) {
+    e->debug_submit_delay_ns = value;
+    return FFN_OK;
+  }
+  if (std::strcmp(name, "stack_ahead") == 0) {
+    // the next step's resident stack behind its speculative conv0_a, ahead of the host
+    drop_spec(e);
+    e->stack_ahead = value != 0;
+    return FFN_OK;
+  }
   if (std::strcmp(name, "speculate") == 0) {
     // single-FoV steps of ffn_canvas_segment_at: queue the next step's conv0_a
     // behind the paste, ahead of the host's turn-around (SpecArgs)
@@ -2124,6 +2162,7 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   }
   if (std::strcmp(name, "stat_reset") == 0) {
     e->stat_spec_launched = e->stat_spec_hits = e->stat_spec_mismatch = 0;
+    e->stat_ahead_used = e->stat_ahead_wasted = 0;
     e->stat_calls = e->stat_items = 0;
     std::memset(e->stat_hist, 0, sizeof(e->stat_hist));
     e->stat_turn_host_ns = e->stat_launch_host_ns = 0;
@@ -2131,12 +2170,19 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->t_arrived_ns = 0;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemset(e->d_stamps, 0, 16 * sizeof(long long)));
+    HIP_TRY(hipMemset(e->d_stamps, 0, 32 * sizeof(long long)));
     return FFN_OK;
   }
   if (std::strcmp(name, "debug_fused_trace") == 0) {
     // the N-th single-FoV step from now stamps when its launches' roles ran
     // (ConvStackTab::stamps [4 .. 11]; read with debug_fused_stamp_K)
+    // (minima at +inf, maxima at 0 -- here, not in the stream of the traced step)
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemset(e->d_stamps + 4, 0x7f, 4 * sizeof(long long)));
+    HIP_TRY(hipMemset(e->d_stamps + 8, 0, 4 * sizeof(long long)));
+    HIP_TRY(hipMemset(e->d_stamps + 12, 0, 20 * sizeof(long long)));
+    HIP_TRY(hipMemset(e->d_stamps + 32, 0, 1024 * sizeof(long long)));
     e->fused_trace_in = value;
     return FFN_OK;
   }
@@ -2169,6 +2215,9 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "stat_step_calls") == 0) *value = (int)e->stat_calls;
   else if (std::strcmp(name, "stat_step_items") == 0) *value = (int)e->stat_items;
   else if (std::strcmp(name, "speculate") == 0) *value = e->speculate;
+  else if (std::strcmp(name, "stack_ahead") == 0) *value = e->stack_ahead;
+  else if (std::strcmp(name, "stat_ahead_used") == 0) *value = (int)e->stat_ahead_used;
+  else if (std::strcmp(name, "stat_ahead_wasted") == 0) *value = (int)e->stat_ahead_wasted;
   else if (std::strcmp(name, "fuse_paste") == 0) *value = e->fuse_paste;
   else if (std::strcmp(name, "fuse_conv0a") == 0) *value = e->fuse_conv0a;
   else if (std::strcmp(name, "stat_spec_launched") == 0)
@@ -2198,12 +2247,26 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strncmp(name, "debug_fused_stamp_", 18) == 0) {
     // stamp k (4 .. 11) minus the stack's first entry [7], in 10-ns ticks
     const int k = std::atoi(name + 18);
-    long long st[16];
+    long long st[32 + 1024];
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(st, e->d_stamps, sizeof(st), hipMemcpyDeviceToHost));
-    if (k < 4 || k > 14) return fail(FFN_ERR_ARG, "debug_fused_stamp_4 .. 14");
-    *value = (int)(st[k] - st[7]);
+    for (int w = 0; w < 512; ++w) st[25] = std::max(st[25], st[32 + w]);  // (per-workgroup ends)
+    {  // [27]: main workgroups that share their CU with another main workgroup
+      std::map<unsigned, int> per_cu;
+      for (int w = 0; w < 512; ++w) {
+        const unsigned v = (unsigned)st[32 + 512 + w];
+        if (st[32 + 512 + w] != 0 && ((v - 1) >> 31)) per_cu[(v - 1) & 0x7fffffffu] += 1;
+      }
+      long long shared = 0;
+      for (const auto& kv : per_cu) if (kv.second > 1) shared += kv.second;
+      st[27] = st[4] + shared;  // (the getter subtracts the origin)
+      if (!e->stack_ahead) st[27] = st[7] + shared;
+    }
+    if (k < 4 || k > 27 || k == 15) return fail(FFN_ERR_ARG, "debug_fused_stamp_4 .. 27");
+    // (stack_ahead: the stack inside the traced window is the NEXT step's; the fused
+    // launch's first faces entry [4] is the origin then)
+    *value = (int)(st[k] - (e->stack_ahead ? st[4] : st[7]));
   }
   else if (std::strcmp(name, "flow_pace") == 0) *value = e->flow_pace;
   else if (std::strcmp(name, "flow_pace_now") == 0)
@@ -2605,14 +2668,24 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     spec_expected = kSpecMax;  // an index the device cannot have chosen
   }
   const bool traced = n == 1 && e->fused_trace_in > 0 && --e->fused_trace_in == 0;
-  if (traced) {  // arm: minima at +inf, maxima at 0, the switch on
-    HIP_TRY(hipMemsetAsync(e->d_stamps + 4, 0x7f, 4 * sizeof(long long), e->stream));
-    HIP_TRY(hipMemsetAsync(e->d_stamps + 8, 0, 4 * sizeof(long long), e->stream));
-    HIP_TRY(hipMemsetAsync(e->d_stamps + 15, 1, sizeof(long long), e->stream));
+  e->trace_now = traced;  // (the launches of this call stamp: a kernel argument)
+  if (e->debug_submit_delay_ns > 0) {
+    const long long t_d = steady_ns();
+    while (steady_ns() - t_d < e->debug_submit_delay_ns) {}
   }
-  int rc = run_stack(e, n, si, params->pad_value, params->move_threshold,
-                     spec_expected >= 0);
+  int rc = FFN_OK;
+  if (e->ahead_valid && spec_expected >= 0) {
+    // this step's stack is in the stream already, behind the conv0_a made for it
+    // (what run_stack would have done was done when it was queued)
+    e->ahead_valid = false;
+    e->spec.valid = false;
+    e->stat_ahead_used += 1;
+  } else {
+    rc = run_stack(e, n, si, params->pad_value, params->move_threshold,
+                   spec_expected >= 0);
+  }
   if (rc) return rc;
+  const bool this_stack_resident = e->last_stack_resident;
   const unsigned step_id = ++e->step_id ? e->step_id : ++e->step_id;  // never 0
   // One FoV: faces first -- the host's turn-around is on the critical path and
   // the paste runs under it.  Several: paste first, so that the completion flag
@@ -2656,12 +2729,15 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     Conv0Next nx;
     const int tiles = conv0a_split_args(e, params->pad_value, next_tag(e->range_tag), sp,
                                         true, nx);
-    hipLaunchKernelGGL(faces_paste_conv0a_kernel, dim3(1 + kPasteBlocks + tiles),
+    const int paste_blocks = e->paste_blocks > 0
+        ? e->paste_blocks
+        : std::max(kPasteBlocksMin, std::min(kPasteBlocks, e->cus - 1 - tiles));
+    hipLaunchKernelGGL(faces_paste_conv0a_kernel, dim3(1 + paste_blocks + tiles),
                        dim3(512), 0, e->stream, si, g, e->logits, e->seed_raw, e->count,
                        e->count_blocks, params->move_threshold,
                        params->disco_seed_threshold, params->deleted_threshold,
                        e->range_flag, e->range_tag, h_pub, step_id, e->d_spec_choice,
-                       spec_expected, nx, e->d_stamps);
+                       spec_expected, nx, e->d_stamps, e->trace_now ? 1 : 0, paste_blocks);
   } else if (n == 1 && e->fuse_paste) {
     hipLaunchKernelGGL(faces_paste_kernel, dim3(1 + 71), dim3(512), 0, e->stream, si,
                        g, e->logits, e->seed_raw, e->count, e->count_blocks,
@@ -2681,6 +2757,16 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     if (sp.n > 0) {
       if (!fused_next)
         launch_conv0a(e, 1, si, params->pad_value, next_tag(e->range_tag), sp, true);
+      // ... and that step's stack behind it (stack_ahead): only where this step's own
+      // stack was a resident launch that is still trusted, and the loop made the step
+      bool ahead = false;
+      if (fused_next && e->stack_ahead && from_loop && this_stack_resident &&
+          e->flow == 2 && e->flow_skip == 0 && e->conv_variant == 9) {
+        rc = run_stack(e, 1, si, params->pad_value, params->move_threshold, true, true);
+        if (rc) return rc;
+        ahead = true;
+      }
+      e->ahead_valid = ahead;
       e->spec.valid = true;
       e->spec.canvas = c;
       e->spec.n = sp.n;
@@ -2691,13 +2777,13 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
       e->stat_spec_launched += 1;
     }
   }
-  if (traced) HIP_TRY(hipMemsetAsync(e->d_stamps + 15, 0, sizeof(long long), e->stream));
+  e->trace_now = false;
   HIP_TRY(hipGetLastError());
   e->stat_calls += 1;
   e->stat_items += n;
   e->stat_hist[n < 64 ? n : 64] += 1;
   e->slot_n[slot] = n;
-  e->slot_resident[slot] = e->last_stack_resident;
+  e->slot_resident[slot] = this_stack_resident;
   e->slot_ticket[slot] = step_id;
   e->slot_canvas[slot].assign(canvases, canvases + n);
   e->next_slot = other;
@@ -2763,12 +2849,24 @@ int step_wait_impl(ffn_engine* e, uint32_t ticket, ffn_step_result* results,
     // Poll the records the faces blocks write into pinned memory: lower wake-up
     // latency than a blocking stream synchronise.  Bounded spin, then fall back
     // to the stream so that device faults still surface as errors.
+    // (the stream is asked only after 2 ms without the record, then every 2 ms: a
+    // hipStreamQuery on a busy stream puts a system-scope barrier packet into the queue --
+    // one per step when it was asked every 4096 spins, sitting between the step's last
+    // launch and the next step's first: a full cache release + acquire the next launch
+    // waited behind, 3 us per step where launches are queued ahead; profiles/r06_turn_around.txt)
     bool done = false;
-    for (long spin = 0; spin < 200000000L && !done; ++spin) {
+    long long t_first = 0, t_query = 0;
+    for (long spin = 0; !done; ++spin) {
       done = arrived();
-      if (!done && (spin & 0xfff) == 0xfff &&
-          hipStreamQuery(e->stream) == hipSuccess) {
-        done = true;  // stream drained: the records must be there (or the kernel died)
+      if (!done && (spin & 0xfff) == 0xfff) {
+        const long long now = steady_ns();
+        if (t_first == 0) t_first = t_query = now;
+        if (now - t_first > 10000000000LL) break;  // 10 s: let the stream say what happened
+        if (now - t_query > 2000000) {
+          t_query = now;
+          if (hipStreamQuery(e->stream) == hipSuccess)
+            done = true;  // stream drained: the records must be there (or the kernel died)
+        }
       }
     }
     if (!done) HIP_TRY(hipStreamSynchronize(e->stream));

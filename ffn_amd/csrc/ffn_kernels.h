@@ -61,6 +61,27 @@ __device__ __forceinline__ bool in_pred_box(const Geom& g, int z, int y, int x) 
          x < g.c1[2];
 }
 
+// The kernel arguments of a launch that has just crossed a boundary are cold (the scalar
+// cache was invalidated, the host wrote them to device memory), and a kernel with roles and
+// branches reads them in STAGES: every s_load behind a branch is its own miss, 0.5 - 1 us
+// each, one behind the other (the fused step launch: six stages before its first data load).
+// This touches every 64-byte line of the first BYTES of the segment at once and waits for
+// them once: one miss, the stages after it hit the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs() {
+  const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+  unsigned sink;
+  static_assert(BYTES > 0 && BYTES <= 1024, "");
+  // (line L is touched when the segment reaches it: assembler conditionals on BYTES)
+#define FFN_KA(OFF) ".if %2 > " #OFF "\n\ts_load_dword %0, %1, " #OFF "\n\t.endif\n\t"
+  asm volatile(FFN_KA(0x0) FFN_KA(0x40) FFN_KA(0x80) FFN_KA(0xc0) FFN_KA(0x100) FFN_KA(0x140)
+               FFN_KA(0x180) FFN_KA(0x1c0) FFN_KA(0x200) FFN_KA(0x240) FFN_KA(0x280)
+               FFN_KA(0x2c0) FFN_KA(0x300) FFN_KA(0x340) FFN_KA(0x380) FFN_KA(0x3c0)
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(sink) : "s"(ka), "n"(BYTES) : "memory");
+#undef FFN_KA
+}
+
 // Per-FoV step descriptor read by the gather / paste kernels.
 struct StepItem {
   const float* image;        // f32 canvas image (already normalised), or NULL:

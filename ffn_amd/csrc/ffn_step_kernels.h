@@ -40,6 +40,9 @@ struct ItemView {
   int pos[3];
   const ffn_step_request* req;  // start_pos / candidates (read per lane)
 };
+// INLINE_ONLY: a launch that is only ever made for one FoV (the fused step launch) reads the
+// kernel-argument copy without looking at use_inline -- one dependent argument load less
+template <bool INLINE_ONLY = false>
 __device__ __forceinline__ ItemView item_view(const StepItems& si, int item) {
   ItemView v;
 #define FFN_VIEW_FROM(S)                                                        \
@@ -53,7 +56,7 @@ __device__ __forceinline__ ItemView item_view(const StepItems& si, int item) {
   v.req = &(S).req;
   // (the position is pinned on its side of the select, so that it is read from
   // the kernel arguments there and not through the merged `req` pointer)
-  if (si.use_inline) {
+  if (INLINE_ONLY || si.use_inline) {
     FFN_VIEW_FROM(si.inline_item)
     asm volatile("" : "+s"(v.pos[0]), "+s"(v.pos[1]), "+s"(v.pos[2]));
   } else {
@@ -129,13 +132,30 @@ __device__ __forceinline__ int overlay_index(const SeedOverlay& ov, int Z, int Y
   return in ? (lz * ov.fy + ly) * ov.fx + lx : -1;
 }
 
-template <bool SPLIT>
+// ov_in.on says whether an overlay MAY apply: its loads are then issued with all the others;
+// resolve(ov) is called once, by every thread of the block, when they are in flight, and
+// settles ov.on / ov.disco (the fused launch: the step's void flags and its count, whose own
+// loads have been in flight since the block started -- one round trip to a memory the launch
+// boundary left cold instead of three in a row).
+struct Conv0NoResolve {
+  __device__ void operator()(SeedOverlay&) const {}
+};
+template <bool SPLIT, class Resolve = Conv0NoResolve>
 __device__ __forceinline__ void conv0a_body(
     const int tile_block, const int item, const StepItems& si, float pad_value,
     const float* __restrict__ w /*[27][2][32]*/,
     const float* __restrict__ bias, float* __restrict__ out,
     float* __restrict__ seed_raw, const Geom& g, int tiles_y, int tiles_x,
-    const Conv0SplitOut& so, const SpecArgs& sp, const SeedOverlay& ov) {
+    const Conv0SplitOut& so, const SpecArgs& sp, const SeedOverlay& ov_in,
+    long long* tr = nullptr, Resolve resolve = Resolve()) {
+  SeedOverlay ov = ov_in;
+  // (tr: debug_fused_trace stamps, last of every eighth block to get there: [16] position
+  // chosen, [17] tile staged in LDS, [18] MFMAs done -- a sample, so that the stamps'
+  // atomics do not stand in the way of what they time)
+  auto stamp = [&](int k) {
+    if (tr && threadIdx.x == 0 && (tile_block & 7) == 0)
+      atomicMax(reinterpret_cast<unsigned long long*>(tr + k), (unsigned long long)wall_clock64());
+  };
   constexpr int HZ = kC0Z + 2, HY = kC0Y + 2, HX = kC0X + 2;
   __shared__ float tile[HZ * HY * HX * 2];  // (image, seed) interleaved
   __shared__ float s_lut[256];              // uint8 canvases: normalisation table
@@ -234,6 +254,20 @@ __device__ __forceinline__ void conv0a_body(
     }
   };
 
+  // B fragments: k = 4 s + grp -> w[k][16 nhalf + i]; k >= 54 is zero padding
+  // (loaded in front of everything that is waited for: they depend on nothing)
+  float bw[2][14];
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int kk = 4 * s + grp;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      bw[h][s] = kk < 54 ? w[kk * kFeatures + 16 * h + i] : 0.0f;
+  }
+  const float bias0 = bias[i], bias1 = bias[16 + i];
+  float lut_v = 0.0f;  // in flight with the canvas loads
+  if (u8 && threadIdx.x < 256) lut_v = it.image_lut[threadIdx.x];
+
   if (sp.n > 0) {  // every block makes the same choice from the same loads
     // (all of them in flight at once)
     float sv[kSpecMax];
@@ -254,9 +288,12 @@ __device__ __forceinline__ void conv0a_body(
     // position of the list: it is the one chosen unless the step about to end
     // has invalidated it, and then its round trip is the choice's own
     issue_gather(sp.pos[0]);
+    if (tr && threadIdx.x == 0 && tile_block == 0) tr[20] = wall_clock64();  // (loads issued)
+    resolve(ov);
+    if (tr && threadIdx.x == 0 && tile_block == 0) tr[21] = wall_clock64();  // (count known)
 #pragma unroll
     for (int k = 0; k < kSpecMax; ++k)
-      if (ovi[k] >= 0) sv[k] = post_disco(ol[k], oo[k], ov.disco != 0);
+      if (ov.on && ovi[k] >= 0) sv[k] = post_disco(ol[k], oo[k], ov.disco != 0);
 #pragma unroll
     for (int k = 0; k < kSpecMax; ++k)  // (no short-circuit into dependent loads)
       asm volatile("" : "+v"(sv[k]), "+v"(gv[k]));
@@ -266,6 +303,8 @@ __device__ __forceinline__ void conv0a_body(
       if (k < sp.n && !(sv[k] < sp.move_thr) && gv[k] <= 0) ch = k;
     if (tile_block == 0 && threadIdx.x == 0) *sp.choice = ch;
     if (ch < 0) return;
+    stamp(16);
+    if (tr && threadIdx.x == 0 && tile_block == 0) tr[22] = wall_clock64();
 #pragma unroll
     for (int k = 0; k < kSpecMax; ++k)
       if (k == ch) {
@@ -276,20 +315,9 @@ __device__ __forceinline__ void conv0a_body(
     if (ch != 0) issue_gather(pos);  // (every block and lane alike)
   } else {
     issue_gather(pos);
+    resolve(ov);
   }
 
-  // B fragments: k = 4 s + grp -> w[k][16 nhalf + i]; k >= 54 is zero padding
-  float bw[2][14];
-#pragma unroll
-  for (int s = 0; s < 14; ++s) {
-    const int kk = 4 * s + grp;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-      bw[h][s] = kk < 54 ? w[kk * kFeatures + 16 * h + i] : 0.0f;
-  }
-  const float bias0 = bias[i], bias1 = bias[16 + i];
-  float lut_v = 0.0f;  // in flight with the canvas loads
-  if (u8 && threadIdx.x < 256) lut_v = it.image_lut[threadIdx.x];
   if (ov.on) {
 #pragma unroll
     for (int k = 0; k < kC0Per; ++k)
@@ -312,6 +340,7 @@ __device__ __forceinline__ void conv0a_body(
     tile[2 * e + 1] = vs;
   }
   __syncthreads();
+  stamp(17);
 
   const int ch = grp & 1;
 #pragma unroll
@@ -352,10 +381,13 @@ __device__ __forceinline__ void conv0a_body(
       o[16 + i] = fmaxf(acc1[r], 0.0f);
     }
   }
+  stamp(18);
   if constexpr (SPLIT) {
     __syncthreads();
     unsigned range_max = 0;
     char* ob = so.out_sp + (long)item * so.item_bytes;
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc(ob, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int e = threadIdx.x + kC0Threads * k;  // (chunk plane c, position op)
@@ -388,9 +420,16 @@ __device__ __forceinline__ void conv0a_body(
           res[4 * h + cc] = r4[cc];
         }
       }
-      *reinterpret_cast<f16x8_c0*>(ob + (long)c * so.sp_plane_bytes + p * 16) = hi;
-      *reinterpret_cast<f16x8_c0*>(ob + (long)(4 + c) * so.sp_plane_bytes + p * 16) =
-          res;
+      // write-through (sc1), as the split-product kernels' own epilogues: no dirty L2
+      // lines for the launch boundary in front of the stack to write back (4.6 MB here:
+      // +0.5 us of boundary, tools/probes/boundary_probe.hip)
+      typedef unsigned u32x4_c0 __attribute__((ext_vector_type(4)));
+      __builtin_amdgcn_raw_buffer_store_b128(
+          __builtin_bit_cast(u32x4_c0, hi), rs_out,
+          (unsigned)((long)c * so.sp_plane_bytes + p * 16), 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(
+          __builtin_bit_cast(u32x4_c0, res), rs_out,
+          (unsigned)((long)(4 + c) * so.sp_plane_bytes + p * 16), 0, 16);
     }
     if (__ballot(range_max > 0x477fe000u) && lane == 0)  // > 65504 (or NaN)
       *so.range_flag = so.range_tag;
@@ -616,6 +655,7 @@ __device__ __forceinline__ void faces_body(
       }
     }
   }
+  if (tr && threadIdx.x == 0) tr[19] = wall_clock64();  // (every load of the block issued)
   unsigned cnt;
   if (!g.crop) {
 #pragma unroll
@@ -861,7 +901,12 @@ __global__ __launch_bounds__(512) void faces_paste_kernel(
 // boundary less per step, the conv0_a under the faces' PCIe round trips.  The
 // next step's raw seed copy, range flag and choice word are the OTHER of two
 // sets (StepSlot): this step's are still being read.
+// (how many: the host picks them so that the launch has one block per CU -- 1 faces block +
+// paste blocks + conv0_a tiles = the CU count where that leaves at least kPasteBlocksMin -- a
+// conv0_a block that shares its CU with another block reaches its position choice 2.7 us
+// after the others, and the next stack waits for the last of them)
 constexpr int kPasteBlocks = 71;
+constexpr int kPasteBlocksMin = 16;
 struct Conv0Next {
   float pad_value;
   const float* w;
@@ -881,17 +926,22 @@ __global__ __launch_bounds__(512) void faces_paste_conv0a_kernel(
     float disco_thr, float deleted_thr, const unsigned* __restrict__ range_flag,
     unsigned range_tag, unsigned long long* __restrict__ pub, unsigned step_id,
     const int* __restrict__ spec_choice, int spec_expected, Conv0Next nx,
-    long long* __restrict__ stamps) {
+    long long* __restrict__ stamps, int trace, int paste_blocks) {
   static_assert(kC0Threads == 512, "one block size for the three roles");
-  // engine option debug_fused_trace (stamps[15] != 0): when each role of this launch ran --
+  const long long t_in = wall_clock64();
+  warm_kernargs<832>();
+  const long long t_warm = wall_clock64();
+  // engine option debug_fused_trace (trace != 0): when each role of this launch ran --
   // first entry (min over the blocks) [4] faces, [5] paste, [6] conv0_a; last end (max) [8]
   // faces = record published, [9] paste, [10] conv0_a; ([7], [11]: the stack before it)
-  const bool tr_on = stamps && stamps[15] != 0;
+  const bool tr_on = stamps && trace != 0;
   struct RoleStamp {
     long long* lo;
     long long* hi;
     bool on;
-    __device__ RoleStamp(long long* l, long long* h, bool o) : lo(l), hi(h), on(o) {
+    // (every eighth block of a role stamps: the stamps' atomics on one word serialise)
+    __device__ RoleStamp(long long* l, long long* h, bool o)
+        : lo(l), hi(h), on(o && (blockIdx.x <= 1 || (blockIdx.x & 7) == 0)) {
       if (on && threadIdx.x == 0)
         atomicMin(reinterpret_cast<unsigned long long*>(lo), (unsigned long long)wall_clock64());
     }
@@ -910,23 +960,37 @@ __global__ __launch_bounds__(512) void faces_paste_conv0a_kernel(
     if (stamps && threadIdx.x == 0) stamps[0] = wall_clock64();
     return;
   }
-  if (blockIdx.x <= kPasteBlocks) {
+  if ((int)blockIdx.x <= paste_blocks) {
     RoleStamp rs(stamps + 5, stamps + 9, tr_on);
-    paste_body(0, blockIdx.x - 1, kPasteBlocks, si, g, logits, in_seed, block_count,
+    paste_body(0, blockIdx.x - 1, paste_blocks, si, g, logits, in_seed, block_count,
                head_blocks, move_thr, disco_thr, range_flag, range_tag, spec_choice,
                spec_expected);
     return;
   }
   RoleStamp rs(stamps + 6, stamps + 10, tr_on);
+  if (tr_on && threadIdx.x == 0) {  // ([23] last sampled block's entry, [24] block 0: arguments in)
+    if (((blockIdx.x - 1 - paste_blocks) & 7) == 0)
+      atomicMax(reinterpret_cast<unsigned long long*>(stamps + 23), (unsigned long long)t_in);
+    if ((int)blockIdx.x == 1 + paste_blocks) stamps[24] = t_warm;
+  }
   __shared__ unsigned s_cnt[8];
-  const ItemView it = item_view(si, 0);
+  const ItemView it = item_view<true>(si, 0);
+  // What decides how the canvas looks once this step has pasted -- its void flags (fp16
+  // range / a speculative conv0_a made for another position: it pastes nothing, the canvas
+  // stays as it is) and its count (the disco test) -- is LOADED here, without a branch and
+  // without a look at the values, and looked at when the conv0_a body has its own loads in
+  // flight (resolve): per-lane loads, so that no scalar wait of the body's stands behind
+  // them.  (A loop or a compare here and the compiler waits for the load on the spot: each
+  // of those was a cold round trip of its own, profiles/r06_step_roles.txt.)
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  unsigned rf = range_flag[z];
+  int sc = spec_choice[z];
+  const int e0 = (int)threadIdx.x < head_blocks ? (int)threadIdx.x : 0;
+  unsigned part = block_count[e0];
   SeedOverlay ov;
-  // a void step (fp16 range, or a speculative conv0_a made for another position)
-  // pastes nothing: the canvas stays as it is
-  ov.on = !(*range_flag == range_tag ||
-            (spec_expected >= 0 && *spec_choice != spec_expected));
-  const unsigned cnt = step_count(g, logits, move_thr, block_count, head_blocks, 0, s_cnt);
-  ov.disco = disco_on(cnt, g.Vp, disco_thr) ? 1 : 0;
+  ov.on = 1;
+  ov.disco = 0;
   ov.lg = logits;
   ov.old = in_seed;
   ov.z0 = it.pos[0] - g.fz / 2;
@@ -939,8 +1003,30 @@ __global__ __launch_bounds__(512) void faces_paste_conv0a_kernel(
     ov.c0[a] = g.c0[a];
     ov.c1[a] = g.c1[a];
   }
-  conv0a_body<true>(blockIdx.x - 1 - kPasteBlocks, 0, si, nx.pad_value, nx.w, nx.bias,
-                    nx.out, nx.seed_raw, nx.q, nx.tiles_y, nx.tiles_x, nx.so, nx.sp, ov);
+  auto resolve = [&](SeedOverlay& o) {
+    // (the values are looked at from here on: everything above has been issued)
+    asm volatile("" : "+v"(rf), "+v"(sc), "+v"(part) : : "memory");
+    unsigned cnt;
+    if (g.crop) {
+      cnt = step_count(g, logits, move_thr, block_count, head_blocks, 0, s_cnt);
+    } else {
+      unsigned p2 = (int)threadIdx.x < head_blocks ? part : 0u;
+      for (int e = kC0Threads + (int)threadIdx.x; e < head_blocks; e += kC0Threads)
+        p2 += block_count[e];  // (more partials than threads: no geometry has them today)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) p2 += __shfl_xor(p2, off);
+      if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = p2;
+      __syncthreads();
+      cnt = 0;
+#pragma unroll
+      for (int wv = 0; wv < kC0Threads / 64; ++wv) cnt += s_cnt[wv];
+    }
+    o.on = !(rf == range_tag || (spec_expected >= 0 && sc != spec_expected));
+    o.disco = disco_on(cnt, g.Vp, disco_thr) ? 1 : 0;
+  };
+  conv0a_body<true>(blockIdx.x - 1 - paste_blocks, 0, si, nx.pad_value, nx.w, nx.bias,
+                    nx.out, nx.seed_raw, nx.q, nx.tiles_y, nx.tiles_x, nx.so, nx.sp, ov,
+                    tr_on ? stamps : nullptr, resolve);
 }
 
 }  // namespace ffn

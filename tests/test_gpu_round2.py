@@ -47,13 +47,14 @@ def hip_exe(fib25_model):
 def _assert_shipped_default(eng):
   """The engine is in the state a fresh one ships in for the 33^3 FIB-25 model:
   conv32mt for a single FoV, run as ONE resident launch (flow 2), nothing chosen
-  explicitly, next conv0_a launched ahead, faces + paste fused."""
+  explicitly, next conv0_a (and the stack behind it) launched ahead, faces + paste fused."""
   assert eng.get_option('conv_variant') == 9
   assert not eng.variant_is_explicit
   assert eng.get_option('flow') == 2
   assert eng.get_option('speculate') == 1
   assert eng.get_option('fuse_paste') == 1
   assert eng.get_option('fuse_conv0a') == 1
+  assert eng.get_option('stack_ahead') == 1  # (round 6: the next stack queued ahead too)
 
 
 def _device_canvas(exe, model, image, **kwargs):
@@ -676,15 +677,20 @@ def test_speculative_conv0a_leaves_the_run_unchanged(hip_exe, fib25_model):
   _assert_shipped_default(eng)
   steps = len(g['steps'])
   stats = {}
+  stack_ahead_default = eng.get_option('stack_ahead')
   try:
     # (speculate, fuse_paste: faces + paste of a step as ONE launch, fuse_conv0a:
     # the next step's conv0_a in that launch too -- it then gathers the canvas as
     # the paste next to it is leaving it)
     # fuse 2 / 3: five steps whose launch is declared a mismatch (test hook) --
     # they paste nothing and are made again
-    for spec, fuse, f0a in ((1, 0, 0), (0, 0, 0), (1, 1, 0), (0, 1, 0), (1, 2, 0),
-                            (1, 1, 1), (0, 1, 1), (1, 3, 1)):
+    # ahead (round 6, engine option stack_ahead): the next step's resident stack queued
+    # behind that launch too, before the host has seen this step's record
+    for spec, fuse, f0a, ahead in ((1, 0, 0, 0), (0, 0, 0, 0), (1, 1, 0, 0), (0, 1, 0, 0),
+                                   (1, 2, 0, 0), (1, 1, 1, 0), (0, 1, 1, 0), (1, 3, 1, 0),
+                                   (1, 1, 1, 1), (1, 3, 1, 1), (0, 1, 1, 1)):
       eng.set_option('speculate', spec)
+      eng.set_option('stack_ahead', ahead)
       eng.set_option('fuse_paste', fuse & 1)
       eng.set_option('fuse_conv0a', f0a)
       eng.set_option('stat_reset', 0)
@@ -707,6 +713,14 @@ def test_speculative_conv0a_leaves_the_run_unchanged(hip_exe, fib25_model):
       assert canvas.counters['update_at-calls'].value == steps
       if seen:
         assert np.array_equal(np.array(seen), g['steps'])
+      if ahead:
+        stats['ahead', spec, fuse] = (eng.get_option('stat_ahead_used'),
+                                      eng.get_option('stat_ahead_wasted'))
+        spec_stats = (eng.get_option('stat_spec_launched'), eng.get_option('stat_spec_hits'))
+        canvas.close()
+        assert eng.get_option('stat_spec_mismatch') == (5 if fuse >= 2 else 0)
+        stats['ahead_spec', spec, fuse] = spec_stats
+        continue
       stats[spec, fuse, f0a] = (eng.get_option('stat_spec_launched'),
                                 eng.get_option('stat_spec_hits'))
       assert eng.get_option('stat_spec_mismatch') == (5 if fuse >= 2 else 0)
@@ -716,8 +730,15 @@ def test_speculative_conv0a_leaves_the_run_unchanged(hip_exe, fib25_model):
     eng.set_option('fuse_paste', 1)
     eng.set_option('fuse_conv0a', 1)
     eng.set_option('spec_force_mismatch', 0)
+    eng.set_option('stack_ahead', stack_ahead_default)
   print('cells72, %d steps: conv0_a launched ahead %d times, used by %d steps'
         % ((steps,) + stats[1, 0, 0]))
+  print('  stack_ahead: %d stacks queued ahead were used, %d were not (with 5 forced '
+        'mismatches: %d / %d)' % (stats['ahead', 1, 1] + stats['ahead', 1, 3]))
+  # every step that ran on a conv0_a made ahead also found its stack queued
+  assert stats['ahead_spec', 1, 1] == stats[1, 1, 1]
+  assert stats['ahead', 1, 1][0] == stats[1, 1, 1][1] > 0
+  assert stats['ahead', 0, 1] == (0, 0)
   assert stats[0, 0, 0] == stats[0, 1, 0] == stats[0, 1, 1] == (0, 0)
   assert stats[1, 0, 0] == stats[1, 1, 0] == stats[1, 1, 1]
   # (a repeated step carries no hint: the step after it runs without a launch)

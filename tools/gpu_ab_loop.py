@@ -53,7 +53,9 @@ def main():
       movement_policy_fn=movement.get_policy_fn(request, model.info))
   assert canvas._native_loop_ok()
   times = [[] for _ in arms]
-  seed_iter = iter([tuple(int(v) for v in s) for s in seeds])
+  board = [[] for _ in arms]
+  import itertools
+  seed_iter = itertools.cycle([tuple(int(v) for v in s) for s in seeds])
   state = {'active': False, 'start': None}
 
   def leg(n):
@@ -79,14 +81,22 @@ def main():
     for k, arm in enumerate(arms):
       for name, value in arm:
         eng.set_option(name, value)
-      dt, done = leg(args.leg_steps)
+      with bench.BoardSampler(0, period_s=0.002) as bs:
+        dt, done = leg(args.leg_steps)
       times[k].append(dt / done * 1e6)
+      if bs.power_w:
+        half = len(bs.power_w) // 2
+        board[k].append((float(np.median(bs.power_w[half:])), float(np.median(bs.sclk_mhz[half:]))))
   for k, arm in enumerate(arms):
     t = np.array(times[k])
     print('arm %d %s: median %.2f us/step (min %.2f, max %.2f, mean %.2f) over %d '
           'legs of %d steps  = %.0f FoV-steps/s' % (
               k, dict(arm), np.median(t), t.min(), t.max(), t.mean(), len(t),
               args.leg_steps, 1e6 / np.median(t)))
+    if board[k]:
+      b = np.array(board[k])
+      print('      board %.0f W, sclk %.0f MHz (medians of the legs\' second halves; hwmon)' % (
+          np.median(b[:, 0]), np.median(b[:, 1])))
   eng.close()
 
 

@@ -24,3 +24,14 @@ print('stack %.1f us (median), fused launch %.2f us; gap stack -> fused %.2f us 
       'fused -> next stack %.2f us (90 %%: %.2f); period %.1f us over %d steps' % (
           st.median(d1) / 1e3, st.median(d2) / 1e3, st.median(g1) / 1e3, q(g1, 0.9),
           st.median(g2) / 1e3, q(g2, 0.9), st.median(per) / 1e3, len(per)))
+# the same as MEANS over the steps whose three launches follow each other (medians of different
+# distributions do not add up to the period; means do)
+seq = []
+for a, b, c in zip(rows, rows[1:], rows[2:]):
+  if 'conv32ps' in a[2] and 'faces_paste_conv0a' in b[2] and 'conv32ps' in c[2] and c[0] - a[0] < 400000:
+    seq.append((a[1] - a[0], b[0] - a[1], b[1] - b[0], c[0] - b[1], c[0] - a[0]))
+if seq:
+  m = [sum(x[i] for x in seq) / len(seq) / 1e3 for i in range(5)]
+  print('means over %d stack -> fused -> stack triples: stack %.2f us + gap %.2f + fused %.2f + gap %.2f = '
+        'period %.2f us' % (len(seq), m[0], m[1], m[2], m[3], m[4]))
+
