@@ -829,8 +829,11 @@ def run_gpu(args, rank, local_rank, world):
                   'block publishing a step\'s record (in-kernel wall clock) to the first '
                   'instruction of the NEXT resident launch; host_us = from the host seeing '
                   'that record to the next hipLaunchKernelGGL(conv32ps) having returned; '
-                  'launch_call_us = inside that call alone.  gpu_us - host_us = the record\'s '
-                  'trip over PCIe + doorbell -> first wave.',
+                  'launch_call_us = inside that call alone.  Without stack_ahead gpu_us - '
+                  'host_us = the record\'s trip over PCIe + doorbell -> first wave; with it '
+                  '(the default) the next stack was queued before the record left and gpu_us '
+                  'is what remains of the fused launch behind its faces block + one launch '
+                  'boundary: the host\'s figures then describe work that runs UNDER the stack.',
       },
       'flow_voids': eng.get_option('stat_flow_voids'),
       'flow_auto_off': eng.get_option('flow_auto_off'),
@@ -844,9 +847,15 @@ def run_gpu(args, rank, local_rank, world):
           'conv0a_launched_ahead': eng.get_option('stat_spec_launched'),
           'steps_that_used_one': eng.get_option('stat_spec_hits'),
           'mismatches_repeated': eng.get_option('stat_spec_mismatch'),
+          'stack_ahead': eng.get_option('stack_ahead'),
+          'stacks_queued_ahead_and_used': eng.get_option('stat_ahead_used'),
+          'stacks_queued_ahead_not_used': eng.get_option('stat_ahead_wasted'),
           'note': 'the whole run of this rank; single-FoV steps of the '
                   'library segment loop queue the next conv0_a behind the paste '
-                  '(engine option speculate, DESIGN.md section 4)',
+                  '(engine option speculate) and the resident stack of that step behind '
+                  'it (stack_ahead): the host\'s turn-around leaves the critical path; a '
+                  'stack whose conv0_a found no valid position ends after its first conv '
+                  '(DESIGN.md section 4)',
       },
       'volume_passes_completed': state['volume_passes_completed'],
       'elapsed': elapsed,
