@@ -286,6 +286,11 @@ struct ffn_engine {
   int prof_mode = 0;
   std::vector<hipEvent_t> events;
   int events_used = 0;
+  // the event pair around a stack queued AHEAD (stack_ahead): it joins the samples when the
+  // stack is used by its step -- one that found no position to run at ends after its first
+  // conv, and its ~10 us would pass for a stack's duration
+  hipEvent_t ahead_ev[2] = {nullptr, nullptr};
+  bool ahead_ev_pending = false;
   double conv_ms = 0.0;
   int64_t conv_launches = 0;
   size_t lds_bytes = 0;
@@ -1095,7 +1100,10 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   int rc;
   const float* head_in;
   bool head_fused = false;
-  if (prof_chain) {
+  e->ahead_ev_pending = false;
+  if (prof_chain && ahead) {
+    HIP_TRY(hipEventRecord(e->ahead_ev[0], e->stream));
+  } else if (prof_chain) {
     if (e->events_used + 2 > (int)e->events.size()) {
       rc = flush_events(e);
       if (rc) return rc;
@@ -1199,7 +1207,12 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     }
     head_in = e->bufX;
   }
-  if (prof_chain) HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  if (prof_chain && ahead) {
+    HIP_TRY(hipEventRecord(e->ahead_ev[1], e->stream));
+    e->ahead_ev_pending = true;
+  } else if (prof_chain) {
+    HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+  }
   if (head_fused) {
     e->count_blocks = e->h_now ? e->n_half
                       : e->t_now ? e->n_main + (n == 1 ? e->n_tail : e->n_tail3)
@@ -1653,6 +1666,7 @@ int ffn_engine_create(int device_id, const int32_t fov_zyx[3],
 
   e->events.resize(2 * 64);
   for (auto& ev : e->events) E_TRY(hipEventCreate(&ev));
+  for (auto& ev : e->ahead_ev) E_TRY(hipEventCreate(&ev));
 
   {
     int rc = set_lds_attr<false, false, false>(e->lds_bytes);
@@ -1702,6 +1716,8 @@ void ffn_engine_destroy(ffn_engine* e) {
   if (e->main_ev) (void)hipEventDestroy(e->main_ev);
   if (e->ustream) (void)hipStreamDestroy(e->ustream);
   for (auto& ev : e->events)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : e->ahead_ev)
     if (ev) (void)hipEventDestroy(ev);
   (void)hipFree(e->act_base);
   (void)hipFree(e->up_image);
@@ -2216,6 +2232,7 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "stat_step_items") == 0) *value = (int)e->stat_items;
   else if (std::strcmp(name, "speculate") == 0) *value = e->speculate;
   else if (std::strcmp(name, "stack_ahead") == 0) *value = e->stack_ahead;
+  else if (std::strcmp(name, "paste_blocks") == 0) *value = e->paste_blocks;
   else if (std::strcmp(name, "stat_ahead_used") == 0) *value = (int)e->stat_ahead_used;
   else if (std::strcmp(name, "stat_ahead_wasted") == 0) *value = (int)e->stat_ahead_wasted;
   else if (std::strcmp(name, "fuse_paste") == 0) *value = e->fuse_paste;
@@ -2680,6 +2697,16 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     e->ahead_valid = false;
     e->spec.valid = false;
     e->stat_ahead_used += 1;
+    if (e->ahead_ev_pending) {  // its event pair is a stack's: among the samples from now on
+      e->ahead_ev_pending = false;
+      if (e->events_used + 2 > (int)e->events.size()) {
+        rc = flush_events(e);
+        if (rc) return rc;
+      }
+      e->chain_launches_pending.push_back(2 * e->depth - 1);
+      std::swap(e->events[e->events_used++], e->ahead_ev[0]);
+      std::swap(e->events[e->events_used++], e->ahead_ev[1]);
+    }
   } else {
     rc = run_stack(e, n, si, params->pad_value, params->move_threshold,
                    spec_expected >= 0);

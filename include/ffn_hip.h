@@ -396,8 +396,15 @@ int ffn_engine_set_pred_size(ffn_engine* engine, const int32_t pred_zyx[3]);
  * the step result and then queues the rest of the step behind it; a step whose
  * launch chose otherwise pastes nothing and is made again).  "fuse_paste"
  * (default 1): faces and paste of a single-FoV step as one launch; "fuse_conv0a"
- * (default 1): ... and the next step's conv0_a in it as well.  None changes any
- * result.
+ * (default 1): ... and the next step's conv0_a in it as well.  "stack_ahead"
+ * (default 1): the resident conv stack of that next step is queued right behind the
+ * launch that holds its conv0_a, before the host has seen this step's record -- the
+ * host's turn-around and the launch latency leave the step's critical path (the stack
+ * reads only what that conv0_a wrote; if the device found no valid position it ends
+ * after its first conv and the step is made the ordinary way).  "paste_blocks" (0 =
+ * automatic: one block per compute unit in the fused step launch).  None changes any
+ * result.  "debug_submit_delay_ns": the host idles this long in front of every step's
+ * launches (an experiment: what a slower host costs with and without stack_ahead).
  * "flow": how the 2 depth - 1 convs of a single-FoV step of conv_variant 9 run:
  *   0 = one dependent launch per conv, 1 = the same launches with the flagged
  *   hand-off compiled in, 2 = ONE resident launch whose workgroups hand rows to
@@ -418,12 +425,13 @@ int ffn_engine_set_pred_size(ffn_engine* engine, const int32_t pred_zyx[3]);
  *   "flow_pace_spread" -1 (default) = as wide as the beat.  Timing only: results are
  *   bit-identical under any beat (profiles/r06_pacing.txt).
  * "debug_fused_trace" N: the N-th next single-FoV step stamps when each role of its
- *   two launches ran ("debug_fused_stamp_4" .. "_14", 10-ns ticks after the stack's
- *   first workgroup: tools/gpu_step_trace.py). */
+ *   two launches ran ("debug_fused_stamp_4" .. "_27", 10-ns ticks after the stack's
+ *   first workgroup -- under stack_ahead after the entry of the step's faces block:
+ *   tools/gpu_step_trace.py names the slots). */
 int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
 /* Current value of an option ("conv_variant", "exact_variant", "fuse_head",
  * "store_policy", "sync_mode", "profile_every", "speculate", "fuse_paste",
- * "fuse_conv0a", "flow", "flow_auto_off", "flow_pace", "flow_pace_now" (the beat in
+ * "fuse_conv0a", "stack_ahead", "paste_blocks", "flow", "flow_auto_off", "flow_pace", "flow_pace_now" (the beat in
  * use), "flow_pace_free_ns" / "flow_pace_best_ns" (what the measurement saw per
  * stack: free-running, at its best beat)), "stat_flow_timeouts" (polls of the
  * resident launch that gave up, ever) / "stat_flow_voids" (steps voided by one),
@@ -434,7 +442,9 @@ int ffn_engine_set_option(ffn_engine* engine, const char* name, int value);
  * a statistic of the step calls since set_option("stat_reset", 0):
  * "stat_step_calls", "stat_step_items" (FoVs in them), "stat_hist_<n>" (calls
  * with n FoVs), "stat_spec_launched" / "stat_spec_hits" / "stat_spec_mismatch"
- * (conv0_a launches made ahead, steps that ran on one, steps repeated). */
+ * (conv0_a launches made ahead, steps that ran on one, steps repeated),
+ * "stat_ahead_used" / "stat_ahead_wasted" (stacks queued ahead that their step used /
+ * that no step used). */
 int ffn_engine_get_option(ffn_engine* engine, const char* name, int* value);
 /* Debug: with option "debug_clock" = 1 the compact conv kernel records, for its
  * first workgroup, per wave {shader clock at entry, at main-loop start, at

@@ -34,4 +34,14 @@ if seq:
   m = [sum(x[i] for x in seq) / len(seq) / 1e3 for i in range(5)]
   print('means over %d stack -> fused -> stack triples: stack %.2f us + gap %.2f + fused %.2f + gap %.2f = '
         'period %.2f us' % (len(seq), m[0], m[1], m[2], m[3], m[4]))
+# a stack queued ahead whose conv0_a found no valid position ends after its first conv: those
+# launches are in rocprofv3's per-kernel average, they are not stacks
+d = [r[1] - r[0] for r in rows if 'conv32ps' in r[2]]
+short = [x for x in d if x < 60000]
+full = [x for x in d if x >= 60000]
+if d:
+  print('conv32ps launches: %d, of them %d shorter than 60 us (gave up after the first conv: mean %.1f us); '
+        'mean of the others %.2f us (rocprofv3 --stats averages over all of them: %.2f us)' % (
+            len(d), len(short), (sum(short) / len(short) / 1e3) if short else 0.0,
+            sum(full) / max(len(full), 1) / 1e3, sum(d) / len(d) / 1e3))
 
