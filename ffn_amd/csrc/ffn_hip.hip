@@ -6,6 +6,7 @@
 // The reference interfaces each entry point replaces are cited in the header.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -959,8 +960,13 @@ void launch_conv0a(ffn_engine* e, int n, const StepItems& si, float pad_value,
 // The 2 depth - 1 convs of ONE FoV as a single resident launch (conv32ps,
 // ffn_conv_resident.h): conv32mt's workgroups keep their voxels through the stack and
 // hand rows to each other through the tile words instead of kernel boundaries.
+// ev0 / ev1: a sampled launch -- the events carry the START and END of this very dispatch
+// (hipExtLaunchKernelGGL: the timestamps rocprofv3 reads), not markers queued around it: a
+// marker is a barrier packet with system-scope fences of its own, 2 - 3 us each, which the
+// sampled launch and the step around it would wait behind
 int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr,
-                    const int* ahead_choice = nullptr) {
+                    const int* ahead_choice = nullptr, hipEvent_t ev0 = nullptr,
+                    hipEvent_t ev1 = nullptr) {
   HeadFusion hf;
   hf.on = true;
   hf.pad_value = pad_value;
@@ -993,7 +999,11 @@ int launch_conv32ps(ffn_engine* e, float pad_value, float move_thr,
   // (2: the stack in front of the traced step, queued ahead one call earlier: its end only)
   tb.trace = e->trace_now ? 1 : (ahead_choice && e->fused_trace_in == 1) ? 2 : 0;
   const long long t_l0 = e->t_arrived_ns ? steady_ns() : 0;
-  hipLaunchKernelGGL(conv32ps_kernel, grid, block, kMLdsBytes, e->stream, a, mp, tb);
+  if (ev0)
+    hipExtLaunchKernelGGL(conv32ps_kernel, grid, block, kMLdsBytes, e->stream, ev0, ev1, 0, a,
+                          mp, tb);
+  else
+    hipLaunchKernelGGL(conv32ps_kernel, grid, block, kMLdsBytes, e->stream, a, mp, tb);
   if (e->t_arrived_ns) {
     const long long t_l1 = steady_ns();
     if (t_l1 - e->t_arrived_ns < 100000) {  // (inside a segment: see ConvStackTab::stamps)
@@ -1101,15 +1111,26 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
   const float* head_in;
   bool head_fused = false;
   e->ahead_ev_pending = false;
+  // a sampled stack that runs as ONE resident launch is timed by that dispatch's own
+  // start / end (launch_conv32ps); a chain of launches by markers around it
+  const bool one_launch = e->conv_variant == 9 && n == 1 && e->flow == 2 &&
+                          e->flow_skip == 0 && e->tail_batched == 0;
+  hipEvent_t k_ev0 = nullptr, k_ev1 = nullptr;
   if (prof_chain && ahead) {
-    HIP_TRY(hipEventRecord(e->ahead_ev[0], e->stream));
+    if (one_launch) k_ev0 = e->ahead_ev[0], k_ev1 = e->ahead_ev[1];
+    else HIP_TRY(hipEventRecord(e->ahead_ev[0], e->stream));
   } else if (prof_chain) {
     if (e->events_used + 2 > (int)e->events.size()) {
       rc = flush_events(e);
       if (rc) return rc;
     }
     e->chain_launches_pending.push_back(2 * e->depth - 1);
-    HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+    if (one_launch) {
+      k_ev0 = e->events[e->events_used], k_ev1 = e->events[e->events_used + 1];
+      e->events_used += 2;
+    } else {
+      HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
+    }
   }
   // conv32d: one workgroup per CU (160-voxel chunks) for a single FoV; with
   // several FoVs in flight the 96-voxel form (two workgroups per CU, the same
@@ -1155,7 +1176,8 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
           e->flow_skip -= 1;  // the repeat of a voided resident step
         } else {
           e->last_stack_resident = true;
-          return launch_conv32ps(e, pad_value, move_thr, ahead ? e->d_spec_choice : nullptr);
+          return launch_conv32ps(e, pad_value, move_thr, ahead ? e->d_spec_choice : nullptr,
+                                 k_ev0, k_ev1);
         }
       }
       if (ahead) return fail(FFN_ERR_STATE, "stack_ahead without the resident launch");
@@ -1208,9 +1230,9 @@ int run_stack(ffn_engine* e, int n, const StepItems& si, float pad_value,
     head_in = e->bufX;
   }
   if (prof_chain && ahead) {
-    HIP_TRY(hipEventRecord(e->ahead_ev[1], e->stream));
+    if (!k_ev0) HIP_TRY(hipEventRecord(e->ahead_ev[1], e->stream));
     e->ahead_ev_pending = true;
-  } else if (prof_chain) {
+  } else if (prof_chain && !k_ev0) {
     HIP_TRY(hipEventRecord(e->events[e->events_used++], e->stream));
   }
   if (head_fused) {
