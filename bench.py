@@ -850,6 +850,7 @@ def run_gpu(args, rank, local_rank, world):
           'stack_ahead': eng.get_option('stack_ahead'),
           'stacks_queued_ahead_and_used': eng.get_option('stat_ahead_used'),
           'stacks_queued_ahead_not_used': eng.get_option('stat_ahead_wasted'),
+          'of_them_ended_after_the_first_conv': eng.get_option('stat_ahead_aborted'),
           'note': 'the whole run of this rank; single-FoV steps of the '
                   'library segment loop queue the next conv0_a behind the paste '
                   '(engine option speculate) and the resident stack of that step behind '

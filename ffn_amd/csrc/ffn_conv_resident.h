@@ -134,7 +134,12 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
       sp_out = t;
     }
     if (L.dbg) Ldbg = L;
-    if (l == l_first + 1 && ahead_ch < 0) break;  // (every workgroup alike)
+    if (l == l_first + 1 && ahead_ch < 0) {  // (every workgroup alike)
+      // ([3]: launches that ended here -- engine statistic stat_ahead_aborted)
+      if (tb.stamps && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(tb.stamps + 3), 1ull);
+      break;
+    }
     const bool last = l == tb.nlayers - 1;
     if (main_wg) {
       const bool dbg_here = blockIdx.x == 0 && a.dbg_wgs != 2;

@@ -2276,6 +2276,13 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
     *value = e->stat_turn_host_count
                  ? (int)(e->stat_launch_host_ns / e->stat_turn_host_count) : 0;
   else if (std::strcmp(name, "stat_turn_count") == 0) *value = (int)e->stat_turn_host_count;
+  else if (std::strcmp(name, "stat_ahead_aborted") == 0) {
+    long long st[4] = {0, 0, 0, 0};
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(st, e->d_stamps, sizeof(st), hipMemcpyDeviceToHost));
+    *value = (int)st[3];
+  }
   else if (std::strcmp(name, "stat_turn_gpu_ns") == 0) {
     long long st[4] = {0, 0, 0, 0};
     HIP_TRY(hipSetDevice(e->device));

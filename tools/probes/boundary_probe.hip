@@ -3,6 +3,7 @@
 // the 100-MHz wall clock (every workgroup stores its own stamp; the host reduces).
 // Build: hipcc --offload-arch=gfx950 -O2 -o boundary_probe boundary_probe.hip
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -149,7 +150,36 @@ static void chain(const char* name, int iters, double a_us, double b_us, double 
   CK(hipStreamDestroy(s)); CK(hipFree(st));
 }
 
+// What hipExtLaunchKernelGGL's events measure: a 100-us kernel behind a 30-us one.
+static void event_semantics() {
+  long long* st; CK(hipMalloc(&st, 2 * kMaxBlocks * sizeof(long long)));
+  float4* buf; CK(hipMalloc(&buf, 1 << 20));
+  hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipEvent_t a, b, c; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); CK(hipEventCreate(&c));
+  for (int mode = 0; mode < 3; ++mode) {
+    std::vector<double> v;
+    for (int rep = 0; rep < 20; ++rep) {
+      hipLaunchKernelGGL(writer<0>, dim3(356), dim3(256), 0, s, buf, 0, st, 3000);
+      if (mode == 0) { CK(hipEventRecord(a, s)); hipLaunchKernelGGL(writer<0>, dim3(356), dim3(256), 0, s, buf, 0, st, 10000); CK(hipEventRecord(b, s)); }
+      if (mode == 1) hipExtLaunchKernelGGL(writer<0>, dim3(356), dim3(256), 0, s, a, b, 0, buf, 0, st, 10000);
+      if (mode == 2) hipExtLaunchKernelGGL(writer<0>, dim3(356), dim3(256), 0, s, nullptr, c, 0, buf, 0, st, 10000);
+      CK(hipStreamSynchronize(s));
+      float ms = 0.f;
+      hipError_t e = mode == 2 ? hipEventElapsedTime(&ms, c, c) : hipEventElapsedTime(&ms, a, b);
+      if (e != hipSuccess) { printf("mode %d: hipEventElapsedTime -> %s\n", mode, hipGetErrorString(e)); (void)hipGetLastError(); break; }
+      v.push_back(ms * 1e3);
+    }
+    if (!v.empty()) { std::sort(v.begin(), v.end());
+      printf("100-us kernel behind a 30-us one, %s: %.2f us (min %.2f)\n",
+             mode == 0 ? "hipEventRecord markers around it" : mode == 1 ? "hipExtLaunchKernelGGL(start, stop)" : "hipExtLaunchKernelGGL(NULL, stop), elapsed(stop, stop)",
+             v[v.size() / 2], v.front()); }
+  }
+  CK(hipStreamDestroy(s));
+}
+
 int main() {
+  event_semantics();
+
   printf("-- the queue never drains: [B_i, A_i+1] queued in one burst while A_i runs (hipMemcpy polls of a stamp in between)\n");
   chain("burst reaches the queue 60 us into A_i", 40, 160, 10, 60.0, false);
   chain("burst reaches the queue 5 us into A_i", 40, 160, 10, 5.0, false);
