@@ -847,6 +847,8 @@ def run_gpu(args, rank, local_rank, world):
           'conv0a_launched_ahead': eng.get_option('stat_spec_launched'),
           'steps_that_used_one': eng.get_option('stat_spec_hits'),
           'mismatches_repeated': eng.get_option('stat_spec_mismatch'),
+          'launched_but_step_elsewhere_hint_list_full': eng.get_option('stat_spec_miss_full'),
+          'launched_but_step_elsewhere_hint_list_short': eng.get_option('stat_spec_miss_short'),
           'stack_ahead': eng.get_option('stack_ahead'),
           'stacks_queued_ahead_and_used': eng.get_option('stat_ahead_used'),
           'stacks_queued_ahead_not_used': eng.get_option('stat_ahead_wasted'),

@@ -218,6 +218,7 @@ struct ffn_engine {
   int fuse_conv0a = 1;      // option: ... and the next step's conv0_a in it as well
   int* d_spec_choice = nullptr;
   long stat_spec_launched = 0, stat_spec_hits = 0;
+  long stat_spec_miss_full = 0, stat_spec_miss_short = 0;
   // The NEXT step's resident stack queued right behind the launch that holds its
   // speculative conv0_a, before the host has seen this step's record (engine option
   // stack_ahead): the stack reads only what that conv0_a wrote (and gives up after its
@@ -2201,6 +2202,7 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
   if (std::strcmp(name, "stat_reset") == 0) {
     e->stat_spec_launched = e->stat_spec_hits = e->stat_spec_mismatch = 0;
     e->stat_ahead_used = e->stat_ahead_wasted = 0;
+    e->stat_spec_miss_full = e->stat_spec_miss_short = 0;
     e->stat_calls = e->stat_items = 0;
     std::memset(e->stat_hist, 0, sizeof(e->stat_hist));
     e->stat_turn_host_ns = e->stat_launch_host_ns = 0;
@@ -2255,6 +2257,8 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "speculate") == 0) *value = e->speculate;
   else if (std::strcmp(name, "stack_ahead") == 0) *value = e->stack_ahead;
   else if (std::strcmp(name, "paste_blocks") == 0) *value = e->paste_blocks;
+  else if (std::strcmp(name, "stat_spec_miss_full") == 0) *value = (int)e->stat_spec_miss_full;
+  else if (std::strcmp(name, "stat_spec_miss_short") == 0) *value = (int)e->stat_spec_miss_short;
   else if (std::strcmp(name, "stat_ahead_used") == 0) *value = (int)e->stat_ahead_used;
   else if (std::strcmp(name, "stat_ahead_wasted") == 0) *value = (int)e->stat_ahead_wasted;
   else if (std::strcmp(name, "fuse_paste") == 0) *value = e->fuse_paste;
@@ -2709,6 +2713,13 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
       if (std::memcmp(e->spec.pos[j], requests[0].pos, sizeof(int) * 3) == 0)
         spec_expected = j;
   if (spec_expected >= 0) e->stat_spec_hits += 1;
+  else if (e->spec.valid && n == 1 && from_loop && e->spec.canvas == canvases[0]) {
+    // a launch made ahead that this step does not run on: was its hint list full (the
+    // queue held more candidates than a launch looks at) or short (the step comes from the
+    // moves the last step queued)?
+    if (e->spec.n >= kSpecMax) e->stat_spec_miss_full += 1;
+    else e->stat_spec_miss_short += 1;
+  }
   if (spec_expected >= 0 && e->spec_force_mismatch > 0) {  // test hook
     e->spec_force_mismatch -= 1;
     spec_expected = kSpecMax;  // an index the device cannot have chosen
