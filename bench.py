@@ -825,6 +825,14 @@ def run_gpu(args, rank, local_rank, world):
           'host_us': round(eng.get_option('stat_turn_host_ns') / 1e3, 2),
           'launch_call_us': round(eng.get_option('stat_launch_host_ns') / 1e3, 2),
           'steps': eng.get_option('stat_turn_count'),
+          'segment_turn': {
+              'calls': eng.get_option('stat_segturn_calls'),
+              'queue_us': round(eng.get_option('stat_segturn_queue_ns') / 1e3, 1),
+              'wait_us': round(eng.get_option('stat_segturn_wait_ns') / 1e3, 1),
+              'what': 'ffn_canvas_segment_turn (commit, the next seeds tested, init_seed: one '
+                      'call between two segments), host view: queueing its device sequence, '
+                      'then waiting for its record',
+          },
           'what': 'between two single-FoV steps, mean over the run: gpu_us = from the faces '
                   'block publishing a step\'s record (in-kernel wall clock) to the first '
                   'instruction of the NEXT resident launch; host_us = from the host seeing '

@@ -219,6 +219,9 @@ struct ffn_engine {
   int* d_spec_choice = nullptr;
   long stat_spec_launched = 0, stat_spec_hits = 0;
   long stat_spec_miss_full = 0, stat_spec_miss_short = 0;
+  // ffn_canvas_segment_turn on the host: queueing its sequence, waiting for its record
+  long long stat_segturn_queue_ns = 0, stat_segturn_wait_ns = 0;
+  long stat_segturn_calls = 0;
   // The NEXT step's resident stack queued right behind the launch that holds its
   // speculative conv0_a, before the host has seen this step's record (engine option
   // stack_ahead): the stack reads only what that conv0_a wrote (and gives up after its
@@ -2203,6 +2206,8 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->stat_spec_launched = e->stat_spec_hits = e->stat_spec_mismatch = 0;
     e->stat_ahead_used = e->stat_ahead_wasted = 0;
     e->stat_spec_miss_full = e->stat_spec_miss_short = 0;
+    e->stat_segturn_queue_ns = e->stat_segturn_wait_ns = 0;
+    e->stat_segturn_calls = 0;
     e->stat_calls = e->stat_items = 0;
     std::memset(e->stat_hist, 0, sizeof(e->stat_hist));
     e->stat_turn_host_ns = e->stat_launch_host_ns = 0;
@@ -2257,6 +2262,11 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
   else if (std::strcmp(name, "speculate") == 0) *value = e->speculate;
   else if (std::strcmp(name, "stack_ahead") == 0) *value = e->stack_ahead;
   else if (std::strcmp(name, "paste_blocks") == 0) *value = e->paste_blocks;
+  else if (std::strcmp(name, "stat_segturn_queue_ns") == 0)
+    *value = e->stat_segturn_calls ? (int)(e->stat_segturn_queue_ns / e->stat_segturn_calls) : 0;
+  else if (std::strcmp(name, "stat_segturn_wait_ns") == 0)
+    *value = e->stat_segturn_calls ? (int)(e->stat_segturn_wait_ns / e->stat_segturn_calls) : 0;
+  else if (std::strcmp(name, "stat_segturn_calls") == 0) *value = (int)e->stat_segturn_calls;
   else if (std::strcmp(name, "stat_spec_miss_full") == 0) *value = (int)e->stat_spec_miss_full;
   else if (std::strcmp(name, "stat_spec_miss_short") == 0) *value = (int)e->stat_spec_miss_short;
   else if (std::strcmp(name, "stat_ahead_used") == 0) *value = (int)e->stat_ahead_used;
@@ -3362,6 +3372,7 @@ int ffn_canvas_segment_turn(ffn_canvas* c, const ffn_turn_request* rq,
   ffn_engine* e = c->engine;
   if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
+  const long long t_turn0 = steady_ns();
   HIP_TRY(lock_.begin(e, c));
   // scratch: [record][histogram][flags, seeds, segs: n each][candidates: 3 n]
   const int32_t max_id = rq->do_commit ? std::max(rq->max_existing_id, 0) : 0;
@@ -3431,7 +3442,11 @@ int ffn_canvas_segment_turn(ffn_canvas* c, const ffn_turn_request* rq,
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hs, ds, o_cand, hipMemcpyDeviceToHost, e->ustream));
+  const long long t_turn1 = steady_ns();
   HIP_TRY(lock_.wait(e, c));
+  e->stat_segturn_queue_ns += t_turn1 - t_turn0;
+  e->stat_segturn_wait_ns += steady_ns() - t_turn1;
+  e->stat_segturn_calls += 1;
   const auto* hr = reinterpret_cast<const TurnRecord*>(hs);
   std::memset(out, 0, sizeof(*out));
   out->counts.raw_segmented_voxels = (int64_t)hr->counts[0];
