@@ -354,6 +354,26 @@ inline void drop_spec(ffn_engine* e) {
   if (e->spec.valid && !e->ahead_valid) e->range_tag = next_tag(e->range_tag);
   // (a stack queued ahead has taken the tag already: run_stack)
   if (e->ahead_valid) e->stat_ahead_wasted += 1;
+  {
+    static const bool dbg_ahead = std::getenv("FFN_DEBUG_AHEAD") != nullptr;
+    if (dbg_ahead && e->ahead_valid) {
+      int ch = -9;
+      (void)hipStreamSynchronize(e->stream);
+      (void)hipMemcpy(&ch, e->d_spec_choice, sizeof(int), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "ahead dropped: spec.n=%d choice=%d hints=", e->spec.n, ch);
+      for (int j = 0; j < e->spec.n; ++j) {
+        const ffn_canvas* cv = e->spec.canvas;
+        float sv = 0.f;
+        int gv = 0;
+        const size_t ci = ((size_t)e->spec.pos[j][0] * cv->cy + e->spec.pos[j][1]) * cv->cx + e->spec.pos[j][2];
+        (void)hipMemcpy(&sv, cv->seed + ci, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&gv, cv->seg + ci, 4, hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "(%d,%d,%d: seed %.4f seg %d) ", e->spec.pos[j][0], e->spec.pos[j][1],
+                     e->spec.pos[j][2], sv, gv);
+      }
+      std::fprintf(stderr, " move_thr %.4f\n", e->spec.move_thr);
+    }
+  }
   e->spec.valid = false;
   e->ahead_valid = false;
 }
@@ -408,8 +428,12 @@ struct UtilLock {
   }
   // Before the first utility operation of a call: the canvas' last step has
   // pasted (see ffn_engine::ustream).
-  hipError_t begin(ffn_engine* e, ffn_canvas* c) {
-    drop_spec(e);  // the canvas may change under a speculative conv0_a
+  // reads_only: the call looks at the canvas and changes nothing -- a speculative conv0_a
+  // (and the stack queued behind it) stays what it is; the segment loop's own point reads
+  // between two steps used to cost it its launch (0.5 % of the steps: a whole stack run for
+  // nothing + a step made the ordinary way)
+  hipError_t begin(ffn_engine* e, ffn_canvas* c, bool reads_only = false) {
+    if (!reads_only) drop_spec(e);  // the canvas may change under a speculative conv0_a
     if (!c->paste_after_flag) return hipSuccess;
     hipError_t err = hipEventRecord(e->main_ev, e->stream);
     if (err == hipSuccess) err = hipStreamWaitEvent(e->ustream, e->main_ev, 0);
@@ -2290,6 +2314,20 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
     *value = e->stat_turn_host_count
                  ? (int)(e->stat_launch_host_ns / e->stat_turn_host_count) : 0;
   else if (std::strcmp(name, "stat_turn_count") == 0) *value = (int)e->stat_turn_host_count;
+  else if (std::strcmp(name, "stat_turn_long_us") == 0) {
+    long long st[32];
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(st, e->d_stamps, sizeof(st), hipMemcpyDeviceToHost));
+    *value = (int)(st[31] / 100);
+  }
+  else if (std::strcmp(name, "stat_stack_to_record_ns") == 0) {
+    long long st[32];
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(st, e->d_stamps, sizeof(st), hipMemcpyDeviceToHost));
+    *value = st[30] ? (int)(st[29] * 10 / st[30]) : 0;
+  }
   else if (std::strcmp(name, "stat_ahead_aborted") == 0) {
     long long st[4] = {0, 0, 0, 0};
     HIP_TRY(hipSetDevice(e->device));
@@ -2722,6 +2760,21 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     for (int j = 0; j < e->spec.n && spec_expected < 0; ++j)
       if (std::memcmp(e->spec.pos[j], requests[0].pos, sizeof(int) * 3) == 0)
         spec_expected = j;
+  {
+    static const bool dbg_ahead = std::getenv("FFN_DEBUG_AHEAD") != nullptr;
+    if (dbg_ahead && e->ahead_valid && spec_expected < 0) {
+      int ch = -9;
+      (void)hipStreamSynchronize(e->stream);
+      (void)hipMemcpy(&ch, e->d_spec_choice, sizeof(int), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "ahead unused: n=%d from_loop=%d spec.valid=%d same_canvas=%d spec.n=%d "
+                   "choice=%d req=(%d,%d,%d) hints=", n, (int)from_loop, (int)e->spec.valid,
+                   (int)(e->spec.canvas == canvases[0]), e->spec.n, ch, requests[0].pos[0],
+                   requests[0].pos[1], requests[0].pos[2]);
+      for (int j = 0; j < e->spec.n; ++j)
+        std::fprintf(stderr, "(%d,%d,%d) ", e->spec.pos[j][0], e->spec.pos[j][1], e->spec.pos[j][2]);
+      std::fprintf(stderr, "\n");
+    }
+  }
   if (spec_expected >= 0) e->stat_spec_hits += 1;
   else if (e->spec.valid && n == 1 && from_loop && e->spec.canvas == canvases[0]) {
     // a launch made ahead that this step does not run on: was its hint list full (the
@@ -3181,7 +3234,7 @@ int ffn_canvas_read_points(ffn_canvas* c, int n, const int32_t* pos,
   ffn_engine* e = c->engine;
   if (!e) return fail(FFN_ERR_STATE, "canvas outlived its engine");
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(lock_.begin(e, c));
+  HIP_TRY(lock_.begin(e, c, true));
   const size_t pb = sizeof(int32_t) * 3 * n;
   const size_t pbr = (pb + 15) & ~(size_t)15;
   int rc = ensure_scratch(e, pbr + 8 * (size_t)n);

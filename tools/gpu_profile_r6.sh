@@ -17,7 +17,7 @@ CMD="python $R/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-batched-l
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $CMD > $O/stats.log 2>&1
 cd $R
-tail -1 $O/stats.log | cut -c1-600 > $O/bench_under_kernel_trace.json
+grep "^{" $O/stats.log | tail -1 > $O/bench_under_kernel_trace.json
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1)
 cp "$f" $O/kernel_stats.csv
 head -8 $O/kernel_stats.csv
