@@ -824,8 +824,6 @@ def run_gpu(args, rank, local_rank, world):
           'gpu_us': round(eng.get_option('stat_turn_gpu_ns') / 1e3, 2),
           'host_us': round(eng.get_option('stat_turn_host_ns') / 1e3, 2),
           'launch_call_us': round(eng.get_option('stat_launch_host_ns') / 1e3, 2),
-          'stack_to_record_us': round(eng.get_option('stat_stack_to_record_ns') / 1e3, 2),
-          'long_gaps_total_ms': round(eng.get_option('stat_turn_long_us') / 1e3, 2),
           'steps': eng.get_option('stat_turn_count'),
           'segment_turn': {
               'calls': eng.get_option('stat_segturn_calls'),
@@ -839,10 +837,7 @@ def run_gpu(args, rank, local_rank, world):
                   'block publishing a step\'s record (in-kernel wall clock) to the first '
                   'instruction of the NEXT resident launch; host_us = from the host seeing '
                   'that record to the next hipLaunchKernelGGL(conv32ps) having returned; '
-                  'launch_call_us = inside that call alone; stack_to_record_us = from the '
-                  'first instruction of a step\'s resident stack to its record leaving (the '
-                  'stack + one boundary + the faces block), so that stack_to_record_us + gpu_us '
-                  '= the period of a speculated in-segment step as the GPU clocks it.  Without stack_ahead gpu_us - '
+                  'launch_call_us = inside that call alone.  Without stack_ahead gpu_us - '
                   'host_us = the record\'s trip over PCIe + doorbell -> first wave; with it '
                   '(the default) the next stack was queued before the record left and gpu_us '
                   'is what remains of the fused launch behind its faces block + one launch '

@@ -71,16 +71,9 @@ __global__ __launch_bounds__(kDThreads, 2) void conv32ps_kernel(ConvDArgs a,
     if (dt < 10000) {
       atomicAdd(reinterpret_cast<unsigned long long*>(tb.stamps + 1), (unsigned long long)dt);
       atomicAdd(reinterpret_cast<unsigned long long*>(tb.stamps + 2), 1ull);
-    } else if (dt < 100000000) {
-      // ([31]: the long ones, summed -- turns between segments, a host that was away:
-      // stat_turn_long_us, microseconds in total)
-      atomicAdd(reinterpret_cast<unsigned long long*>(tb.stamps + 31), (unsigned long long)dt);
     }
     tb.stamps[0] = 0;
   }
-  // ([28]: when this launch's first workgroup started -- the faces block of its step adds
-  // "first instruction of the stack -> record published" to [29] / [30]: stat_stack_to_record_ns)
-  if (tb.stamps && blockIdx.x == 0 && threadIdx.x == 0) tb.stamps[28] = wall_clock64();
   // (a scalar load in flight under the first conv: no wait of its own)
   const int ahead_ch = tb.ahead_choice ? *tb.ahead_choice : 0;
   const int v0 = main_wg ? c * kMChunk : mp.n_main * kMChunk + c * 32;

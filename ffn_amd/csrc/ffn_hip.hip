@@ -354,26 +354,6 @@ inline void drop_spec(ffn_engine* e) {
   if (e->spec.valid && !e->ahead_valid) e->range_tag = next_tag(e->range_tag);
   // (a stack queued ahead has taken the tag already: run_stack)
   if (e->ahead_valid) e->stat_ahead_wasted += 1;
-  {
-    static const bool dbg_ahead = std::getenv("FFN_DEBUG_AHEAD") != nullptr;
-    if (dbg_ahead && e->ahead_valid) {
-      int ch = -9;
-      (void)hipStreamSynchronize(e->stream);
-      (void)hipMemcpy(&ch, e->d_spec_choice, sizeof(int), hipMemcpyDeviceToHost);
-      std::fprintf(stderr, "ahead dropped: spec.n=%d choice=%d hints=", e->spec.n, ch);
-      for (int j = 0; j < e->spec.n; ++j) {
-        const ffn_canvas* cv = e->spec.canvas;
-        float sv = 0.f;
-        int gv = 0;
-        const size_t ci = ((size_t)e->spec.pos[j][0] * cv->cy + e->spec.pos[j][1]) * cv->cx + e->spec.pos[j][2];
-        (void)hipMemcpy(&sv, cv->seed + ci, 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(&gv, cv->seg + ci, 4, hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "(%d,%d,%d: seed %.4f seg %d) ", e->spec.pos[j][0], e->spec.pos[j][1],
-                     e->spec.pos[j][2], sv, gv);
-      }
-      std::fprintf(stderr, " move_thr %.4f\n", e->spec.move_thr);
-    }
-  }
   e->spec.valid = false;
   e->ahead_valid = false;
 }
@@ -2314,20 +2294,6 @@ int ffn_engine_get_option(ffn_engine* e, const char* name, int* value) {
     *value = e->stat_turn_host_count
                  ? (int)(e->stat_launch_host_ns / e->stat_turn_host_count) : 0;
   else if (std::strcmp(name, "stat_turn_count") == 0) *value = (int)e->stat_turn_host_count;
-  else if (std::strcmp(name, "stat_turn_long_us") == 0) {
-    long long st[32];
-    HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(st, e->d_stamps, sizeof(st), hipMemcpyDeviceToHost));
-    *value = (int)(st[31] / 100);
-  }
-  else if (std::strcmp(name, "stat_stack_to_record_ns") == 0) {
-    long long st[32];
-    HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(st, e->d_stamps, sizeof(st), hipMemcpyDeviceToHost));
-    *value = st[30] ? (int)(st[29] * 10 / st[30]) : 0;
-  }
   else if (std::strcmp(name, "stat_ahead_aborted") == 0) {
     long long st[4] = {0, 0, 0, 0};
     HIP_TRY(hipSetDevice(e->device));
@@ -2760,21 +2726,6 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     for (int j = 0; j < e->spec.n && spec_expected < 0; ++j)
       if (std::memcmp(e->spec.pos[j], requests[0].pos, sizeof(int) * 3) == 0)
         spec_expected = j;
-  {
-    static const bool dbg_ahead = std::getenv("FFN_DEBUG_AHEAD") != nullptr;
-    if (dbg_ahead && e->ahead_valid && spec_expected < 0) {
-      int ch = -9;
-      (void)hipStreamSynchronize(e->stream);
-      (void)hipMemcpy(&ch, e->d_spec_choice, sizeof(int), hipMemcpyDeviceToHost);
-      std::fprintf(stderr, "ahead unused: n=%d from_loop=%d spec.valid=%d same_canvas=%d spec.n=%d "
-                   "choice=%d req=(%d,%d,%d) hints=", n, (int)from_loop, (int)e->spec.valid,
-                   (int)(e->spec.canvas == canvases[0]), e->spec.n, ch, requests[0].pos[0],
-                   requests[0].pos[1], requests[0].pos[2]);
-      for (int j = 0; j < e->spec.n; ++j)
-        std::fprintf(stderr, "(%d,%d,%d) ", e->spec.pos[j][0], e->spec.pos[j][1], e->spec.pos[j][2]);
-      std::fprintf(stderr, "\n");
-    }
-  }
   if (spec_expected >= 0) e->stat_spec_hits += 1;
   else if (e->spec.valid && n == 1 && from_loop && e->spec.canvas == canvases[0]) {
     // a launch made ahead that this step does not run on: was its hint list full (the

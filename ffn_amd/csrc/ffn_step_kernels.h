@@ -957,16 +957,7 @@ __global__ __launch_bounds__(512) void faces_paste_conv0a_kernel(
                spec_choice, spec_expected, tr_on ? stamps : nullptr);
     // (stat_turn_*: when this step's record left for the host -- the next resident
     // launch measures how long the GPU then waited for it, conv32ps_kernel)
-    if (stamps && threadIdx.x == 0) {
-      const long long now = wall_clock64();
-      stamps[0] = now;
-      const long long dt = now - stamps[28];
-      if (stamps[28] != 0 && dt > 0 && dt < 100000) {  // (< 1 ms: the stack of THIS step)
-        stamps[29] += dt;
-        stamps[30] += 1;
-      }
-      stamps[28] = 0;
-    }
+    if (stamps && threadIdx.x == 0) stamps[0] = wall_clock64();
     return;
   }
   if ((int)blockIdx.x <= paste_blocks) {
