@@ -229,7 +229,8 @@ struct ffn_engine {
   // the launch latency of the stack leave the step's critical path.
   int stack_ahead = 1;
   int paste_blocks = 0;  // fused step launch: paste blocks (0: one block per CU, see kPasteBlocks)
-  int debug_submit_delay_ns = 0;  // experiment: the host idles this long in front of a step's launches
+  int debug_submit_delay_ns = 0;
+  int debug_fused_twice = 0;  // experiment: the host idles this long in front of a step's launches
   bool trace_now = false;     // debug_fused_trace: the launches being queued stamp
   bool ahead_valid = false;   // such a stack is in the stream, for the step e->spec describes
   long stat_ahead_used = 0, stat_ahead_wasted = 0;
@@ -2189,6 +2190,10 @@ int ffn_engine_set_option(ffn_engine* e, const char* name, int value) {
     e->paste_blocks = value;
     return FFN_OK;
   }
+  if (std::strcmp(name, "debug_fused_twice") == 0) {
+    e->debug_fused_twice = value;
+    return FFN_OK;
+  }
   if (std::strcmp(name, "debug_submit_delay_ns") == 0) {
     e->debug_submit_delay_ns = value;
     return FFN_OK;
@@ -2813,6 +2818,15 @@ int ffn_canvas_step_submit(ffn_engine* e, int n, ffn_canvas* const* canvases,
     const int paste_blocks = e->paste_blocks > 0
         ? e->paste_blocks
         : std::max(kPasteBlocksMin, std::min(kPasteBlocks, e->cus - 1 - tiles));
+    // (experiment debug_fused_twice: the same launch made twice -- idempotent: same record,
+    // same paste, same conv0_a -- so that the second, traced one starts on warm caches)
+    if (e->debug_fused_twice)
+      hipLaunchKernelGGL(faces_paste_conv0a_kernel, dim3(1 + paste_blocks + tiles),
+                         dim3(512), 0, e->stream, si, g, e->logits, e->seed_raw, e->count,
+                         e->count_blocks, params->move_threshold,
+                         params->disco_seed_threshold, params->deleted_threshold,
+                         e->range_flag, e->range_tag, h_pub, step_id, e->d_spec_choice,
+                         spec_expected, nx, e->d_stamps, 0, paste_blocks);
     hipLaunchKernelGGL(faces_paste_conv0a_kernel, dim3(1 + paste_blocks + tiles),
                        dim3(512), 0, e->stream, si, g, e->logits, e->seed_raw, e->count,
                        e->count_blocks, params->move_threshold,

@@ -404,7 +404,9 @@ int ffn_engine_set_pred_size(ffn_engine* engine, const int32_t pred_zyx[3]);
  * after its first conv and the step is made the ordinary way).  "paste_blocks" (0 =
  * automatic: one block per compute unit in the fused step launch).  None changes any
  * result.  "debug_submit_delay_ns": the host idles this long in front of every step's
- * launches (an experiment: what a slower host costs with and without stack_ahead).
+ * launches (an experiment: what a slower host costs with and without stack_ahead);
+ * "debug_fused_twice": the fused step launch is made twice (idempotent), so that a trace of
+ * the second shows what warm caches are worth (nothing: profiles/r06_turn_around.txt).
  * "flow": how the 2 depth - 1 convs of a single-FoV step of conv_variant 9 run:
  *   0 = one dependent launch per conv, 1 = the same launches with the flagged
  *   hand-off compiled in, 2 = ONE resident launch whose workgroups hand rows to

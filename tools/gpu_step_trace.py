@@ -26,6 +26,8 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--samples', type=int, default=12)
   ap.add_argument('--ahead', type=int, default=0)
+  ap.add_argument('--twice', type=int, default=0,
+                  help='engine option debug_fused_twice: the fused launch made twice, the second one traced')
   args = ap.parse_args()
   from ffn_amd import synthetic
   from ffn_amd.inference import executor, inference, inference_utils, movement
@@ -38,6 +40,7 @@ def main():
                                   counters, 1)
   eng = exe.engine
   eng.set_option('stack_ahead', args.ahead)
+  eng.set_option('debug_fused_twice', args.twice)
   image = synthetic.normalize(bench.bench_volume((250, 250, 250), 1234))
   canvas = inference.DeviceCanvas(
       model.info, exe.get_client(counters, direct=True), image, request.inference_options,
