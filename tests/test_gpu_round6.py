@@ -180,3 +180,40 @@ def test_turn_around_figures(hip_exe, fib25_model):  # noqa: F811
   assert 1000 < launch_ns <= host_ns < 100000, (launch_ns, host_ns)
   assert 2000 < gpu_ns < 100000, gpu_ns
   _assert_shipped_default(eng)
+
+
+def test_stack_queued_ahead_bookkeeping(hip_exe, fib25_model):  # noqa: F811
+  """stack_ahead (the default): every step that runs on a conv0_a made ahead also finds its
+  resident stack queued behind it; a stack that no step used either ended after its first
+  conv (its conv0_a found no valid position) or is one of the few the loop stepped past; a
+  host that idles 20 us in front of every step's launches changes nothing -- and the run is
+  the reference-minted one either way."""
+  import functools
+  from ffn_amd import synthetic
+  g = np.load(os.path.join(GOLDEN, 'ref_canvas_cells72.npz'))  # 94 FoV steps
+  eng = hip_exe.engine
+  _assert_shipped_default(eng)
+  try:
+    for delay in (0, 20000):
+      eng.set_option('debug_submit_delay_ns', delay)
+      eng.set_option('stat_reset', 0)
+      canvas = _device_canvas(hip_exe, fib25_model, synthetic.normalize(g['volume']))
+      canvas.segment_all(seed_policy=functools.partial(seed_lib_fixed(),
+                                                       coords=g['seeds'].astype(np.int32)))
+      assert np.array_equal(np.asarray(canvas.segmentation), g['segmentation'])
+      assert canvas.counters['update_at-calls'].value == len(g['steps'])
+      canvas.close()
+      launched = eng.get_option('stat_spec_launched')
+      hits = eng.get_option('stat_spec_hits')
+      used = eng.get_option('stat_ahead_used')
+      wasted = eng.get_option('stat_ahead_wasted')
+      aborted = eng.get_option('stat_ahead_aborted')
+      print('delay %d ns: conv0_a launched ahead %d, used %d; stacks queued ahead used %d, not '
+            'used %d (ended after the first conv: %d)' % (delay, launched, hits, used, wasted,
+                                                          aborted))
+      assert used == hits > 0.6 * len(g['steps'])
+      assert used + wasted == launched  # every launch made ahead had its stack behind it
+      assert 0 <= aborted <= wasted
+      assert eng.get_option('stat_spec_mismatch') == 0
+  finally:
+    eng.set_option('debug_submit_delay_ns', 0)
